@@ -1,0 +1,203 @@
+"""Oracle restatement of reference internal/stepfun.py (TEST INFRASTRUCTURE ONLY).
+
+Conventions as the reference (stepfun.py:15-23): last axis runs along the ray,
+`t` has n+1 fence-posts, `w`/`y`/`p` have n bins.
+"""
+
+import numpy as np
+import torch
+
+from oracle import math as rmath
+
+
+def _eps(x):
+  return torch.finfo(x.dtype if x.dtype.is_floating_point else torch.float32).eps
+
+
+F32_EPS = float(np.finfo(np.float32).eps)
+
+
+def seq_cumsum(x):
+  """Strict left-to-right cumulative sum in x's own dtype (no grad).
+
+  torch.cumsum on CPU accumulates fp32 rows in double; numpy accumulates in the
+  array dtype, element by element -- the order the HIP kernel uses.
+  """
+  return torch.from_numpy(np.cumsum(x.detach().numpy(), axis=-1, dtype=x.detach().numpy().dtype))
+
+
+def searchsorted(a, v):
+  """stepfun.py:30-53 -- (idx_lo, idx_hi) with a[idx_lo] <= v < a[idx_hi]."""
+  i = torch.arange(a.shape[-1])
+  v_ge_a = v[..., None, :] >= a[..., :, None]
+  idx_lo = torch.where(v_ge_a, i[:, None], i[:1, None]).max(dim=-2).values
+  idx_hi = torch.where(~v_ge_a, i[:, None], i[-1:, None]).min(dim=-2).values
+  return idx_lo, idx_hi
+
+
+def query(tq, t, y, outside_value=0):
+  """stepfun.py:56-61."""
+  idx_lo, idx_hi = searchsorted(t, tq)
+  idx = torch.clamp(idx_lo, max=y.shape[-1] - 1)
+  y_b = y.expand(idx.shape[:-1] + y.shape[-1:])
+  yq = torch.where(idx_lo == idx_hi, torch.as_tensor(outside_value, dtype=y.dtype),
+                   torch.gather(y_b, -1, idx))
+  return yq
+
+
+def inner_outer(t0, t1, y1):
+  """stepfun.py:64-77 -- inner and outer measures of (t1, y1) on t0."""
+  cy1 = torch.cat([torch.zeros_like(y1[..., :1]), torch.cumsum(y1, dim=-1)], dim=-1)
+  idx_lo, idx_hi = searchsorted(t1, t0)
+  cy1_lo = torch.gather(cy1, -1, idx_lo)
+  cy1_hi = torch.gather(cy1, -1, idx_hi)
+  y0_outer = cy1_hi[..., 1:] - cy1_lo[..., :-1]
+  y0_inner = torch.where(idx_hi[..., :-1] <= idx_lo[..., 1:],
+                         cy1_lo[..., 1:] - cy1_hi[..., :-1],
+                         torch.zeros_like(y0_outer))
+  return y0_inner, y0_outer
+
+
+def lossfun_outer(t, w, t_env, w_env, eps=F32_EPS):
+  """stepfun.py:80-86 -- proposal weights must upper-bound the nerf weights."""
+  _, w_outer = inner_outer(t, t_env, w_env)
+  return torch.clamp(w - w_outer, min=0)**2 / (w + eps)
+
+
+def weight_to_pdf(t, w, eps=F32_EPS**2):
+  """stepfun.py:89-91."""
+  return w / torch.clamp(t[..., 1:] - t[..., :-1], min=eps)
+
+
+def pdf_to_weight(t, p):
+  """stepfun.py:94-96."""
+  return p * (t[..., 1:] - t[..., :-1])
+
+
+def max_dilate(t, w, dilation, domain=(-np.inf, np.inf)):
+  """stepfun.py:99-113 -- max-pool dilation of a non-negative step function."""
+  t0 = t[..., :-1] - dilation
+  t1 = t[..., 1:] + dilation
+  t_dilate = torch.sort(torch.cat([t, t0, t1], dim=-1), dim=-1).values
+  t_dilate = torch.clamp(t_dilate, domain[0], domain[1])
+  inside = ((t0[..., None, :] <= t_dilate[..., None]) &
+            (t1[..., None, :] > t_dilate[..., None]))
+  w_dilate = torch.where(inside, w[..., None, :],
+                         torch.zeros_like(w[..., None, :])).max(dim=-1).values[..., :-1]
+  return t_dilate, w_dilate
+
+
+def max_dilate_weights(t, w, dilation, domain=(-np.inf, np.inf),
+                       renormalize=False, eps=F32_EPS**2):
+  """stepfun.py:116-128."""
+  p = weight_to_pdf(t, w)
+  t_dilate, p_dilate = max_dilate(t, p, dilation, domain=domain)
+  w_dilate = pdf_to_weight(t_dilate, p_dilate)
+  if renormalize:
+    w_dilate = w_dilate / torch.clamp(w_dilate.sum(dim=-1, keepdim=True), min=eps)
+  return t_dilate, w_dilate
+
+
+def integrate_weights(w, sequential=True):
+  """stepfun.py:131-150 -- [0, min(1, cumsum(w[:-1])), 1].
+
+  `sequential` picks the documented left-to-right accumulation (no grad);
+  otherwise torch.cumsum (differentiable; used by weighted_percentile tests).
+  """
+  cs = seq_cumsum(w[..., :-1]) if sequential else torch.cumsum(w[..., :-1], dim=-1)
+  cw = torch.clamp(cs, max=1)
+  shape = cw.shape[:-1] + (1,)
+  return torch.cat([torch.zeros(shape, dtype=w.dtype), cw,
+                    torch.ones(shape, dtype=w.dtype)], dim=-1)
+
+
+def softmax_seq(logits):
+  """jax.nn.softmax (stepfun.py:156) with a left-to-right denominator."""
+  m = logits.max(dim=-1, keepdim=True).values
+  e = torch.exp(logits - m)
+  denom = seq_cumsum(e)[..., -1:]
+  return e / denom
+
+
+def invert_cdf(u, t, w_logits, use_gpu_resampling=False, return_index=False):
+  """stepfun.py:153-161."""
+  w = softmax_seq(w_logits)
+  cw = integrate_weights(w)
+  if use_gpu_resampling:
+    return rmath.interp(u, cw, t)
+  return rmath.sorted_interp(u, cw, t, return_index=return_index)
+
+
+def sample_u(u_jitter, batch_shape, num_samples, single_jitter=False,
+             deterministic_center=False, dtype=torch.float32):
+  """The `u` construction of stepfun.py:191-209 with the jitter as an INPUT.
+
+  `u_jitter` stands in for jax.random.uniform(rng, ...)/max_jitter, i.e. it is
+  uniform in [0,1) with shape [..., 1] (single_jitter) or [..., num_samples];
+  None means rng=None (deterministic).
+  """
+  eps = F32_EPS
+  if u_jitter is None:
+    if deterministic_center:
+      pad = 1 / (2 * num_samples)
+      u = torch.linspace(pad, 1. - pad - eps, num_samples, dtype=dtype)
+    else:
+      u = torch.linspace(0, 1. - eps, num_samples, dtype=dtype)
+    u = u.expand(tuple(batch_shape) + (num_samples,))
+  else:
+    u_max = eps + (1 - eps) / num_samples
+    max_jitter = (1 - u_max) / (num_samples - 1) - eps
+    d = 1 if single_jitter else num_samples
+    assert u_jitter.shape[-1] == d
+    u = (torch.linspace(0, 1 - u_max, num_samples, dtype=dtype) +
+         u_jitter.to(dtype) * max_jitter)
+  return u
+
+
+def sample(u_jitter, t, w_logits, num_samples, single_jitter=False,
+           deterministic_center=False, use_gpu_resampling=False,
+           return_index=False):
+  """stepfun.py:164-211 (rng replaced by the explicit `u_jitter` in [0,1))."""
+  u = sample_u(u_jitter, t.shape[:-1], num_samples, single_jitter,
+               deterministic_center, dtype=t.dtype)
+  return invert_cdf(u, t, w_logits, use_gpu_resampling=use_gpu_resampling,
+                    return_index=return_index)
+
+
+def sample_intervals(u_jitter, t, w_logits, num_samples, single_jitter=False,
+                     domain=(-np.inf, np.inf), use_gpu_resampling=False,
+                     return_index=False):
+  """stepfun.py:214-263 -- sample intervals (fence-posts between sampled centers)."""
+  if num_samples <= 1:
+    raise ValueError(f'num_samples must be > 1, is {num_samples}.')
+  out = sample(u_jitter, t, w_logits, num_samples, single_jitter,
+               deterministic_center=True, use_gpu_resampling=use_gpu_resampling,
+               return_index=return_index)
+  centers, idx = out if return_index else (out, None)
+  mid = (centers[..., 1:] + centers[..., :-1]) / 2
+  minval, maxval = domain
+  first = torch.clamp(2 * centers[..., :1] - mid[..., :1], min=minval)
+  last = torch.clamp(2 * centers[..., -1:] - mid[..., -1:], max=maxval)
+  t_samples = torch.cat([first, mid, last], dim=-1)
+  if return_index:
+    return t_samples, idx
+  return t_samples
+
+
+def lossfun_distortion(t, w):
+  """stepfun.py:266-276 -- iint w_i w_j |t_i - t_j| + intra-interval term."""
+  ut = (t[..., 1:] + t[..., :-1]) / 2
+  dut = torch.abs(ut[..., :, None] - ut[..., None, :])
+  loss_inter = torch.sum(w * torch.sum(w[..., None, :] * dut, dim=-1), dim=-1)
+  loss_intra = torch.sum(w**2 * (t[..., 1:] - t[..., :-1]), dim=-1) / 3
+  return loss_inter + loss_intra
+
+
+def weighted_percentile(t, w, ps):
+  """stepfun.py:298-308 -- np.interp of ps/100 into integrate_weights(w)."""
+  cw = integrate_weights(w)
+  cw_mat = cw.reshape(-1, cw.shape[-1]).detach().numpy()
+  t_mat = t.reshape(-1, t.shape[-1]).detach().numpy()
+  q = np.array(ps, dtype=cw_mat.dtype) / 100
+  out = np.stack([np.interp(q, cw_mat[i], t_mat[i]) for i in range(cw_mat.shape[0])])
+  return torch.as_tensor(out, dtype=t.dtype).reshape(cw.shape[:-1] + (len(ps),))
