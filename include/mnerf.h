@@ -1,0 +1,302 @@
+/* mnerf.h -- C ABI of libmnerf_hip.so: MI355X (gfx950) kernels for the MultiNeRF
+ * per-ray render/train hot path.
+ *
+ * The reference (google-research/multinerf) is pure Python/JAX and has no
+ * native operator interface; its hot path is the Python call surface
+ * Model.__call__ / MLP.__call__ / train_step.  This header is the boundary a
+ * host (ctypes here; cffi/pybind in a maintainer's tree)
+ * binds to replace the jax.numpy bodies of those functions.  Each entry point
+ * names the reference function(s) it replaces (file:line under the reference
+ * repository root).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (row-major,
+ *    contiguous unless a leading dimension is given); the library never
+ *    allocates, frees or retains them;
+ *  - `stream` is a hipStream_t passed as void*; calls only enqueue work;
+ *  - return value: 0 (MNR_OK) or a negative mnr_status; mnr_last_error()
+ *    returns a thread-local NUL-terminated description of the last failure;
+ *  - fp32 unless a name says bf16 (raw IEEE bfloat16, uint16_t storage);
+ *  - "B" = rays, "n" = intervals along a ray, fence-post arrays have n+1
+ *    entries (reference internal/stepfun.py:15-23).
+ */
+#ifndef MNERF_H_
+#define MNERF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MNR_OK = 0,
+  MNR_ERR_INVALID_ARGUMENT = -1,
+  MNR_ERR_HIP = -2,
+  MNR_ERR_UNSUPPORTED = -3
+} mnr_status;
+
+const char* mnr_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int mnr_abi_version(void);
+/* Device properties the host needs to size launches: fills cu_count, lds_bytes, gcn arch name. */
+int mnr_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------- *
+ * Sampling  (replaces models.py:153-204 = stepfun.max_dilate_weights
+ * stepfun.py:99-128, anneal/logits models.py:173-185, stepfun.sample_intervals
+ * stepfun.py:164-263 incl. invert_cdf :153-161, integrate_weights :131-150,
+ * math.sorted_interp math.py:108-127, and coord.construct_ray_warps s_to_t
+ * coord.py:63-99)
+ * ------------------------------------------------------------------------- */
+typedef enum { MNR_RAYDIST_IDENTITY = 0, MNR_RAYDIST_RECIPROCAL = 1, MNR_RAYDIST_PIECEWISE = 2,
+               MNR_RAYDIST_LOG = 3, MNR_RAYDIST_EXP = 4, MNR_RAYDIST_SQRT = 5, MNR_RAYDIST_SQUARE = 6 } mnr_raydist;
+
+typedef struct {
+  int n_prev;              /* intervals in the incoming step function (1 at level 0)  */
+  int n_samples;           /* intervals to draw (Model.num_prop_samples / num_nerf_samples) */
+  int use_dilation;        /* models.py:162-171 (level > 0 and dilation enabled)      */
+  float dilation;          /* models.py:153-154                                       */
+  float domain_lo, domain_hi; /* (init_s_near, init_s_far)                            */
+  float anneal;            /* Schlick bias of train_frac, models.py:174-179 (1 if slope==0) */
+  float resample_padding;  /* models.py:70                                            */
+  int single_jitter;       /* jitter shape [B] (1) or [B,n_samples] (0)               */
+  float max_jitter;        /* stepfun.py:204-205; ignored when jitter == NULL         */
+  int raydist_fn;          /* mnr_raydist for s_to_t                                  */
+} mnr_resample_cfg;
+
+/* One hierarchical-sampling level for B rays.
+ *  sdist_prev [B,n_prev+1], w_prev [B,n_prev]: incoming step function (s-space).
+ *  u_base [n_samples]: the linspace of stepfun.py:198 / :208 (host-computed).
+ *  jitter: NULL (rng=None) or uniform[0,1) draws, [B] or [B,n_samples].
+ *  near,far [B].  Outputs: sdist [B,n+1], tdist [B,n+1]; idx_out (optional,
+ *  may be NULL) [B,n] int32 = count(cw <= u) - 1, the bit-exact sample index. */
+int mnr_resample_level(const mnr_resample_cfg* cfg, int64_t B,
+                       const float* sdist_prev, const float* w_prev,
+                       const float* u_base, const float* jitter,
+                       const float* near, const float* far,
+                       float* sdist_out, float* tdist_out, int32_t* idx_out, void* stream);
+
+/* Leaf: math.sorted_interp(u, cw, t) (math.py:108-127) with the integer index.
+ * cw,t [B,nc]; u [B,nu] -> out [B,nu], idx [B,nu] (may be NULL). */
+int mnr_sorted_interp(int64_t B, int nc, int nu, const float* u, const float* cw, const float* t,
+                      float* out, int32_t* idx, void* stream);
+
+/* Leaf: stepfun.max_dilate_weights(t, w, dilation, domain, renormalize=True)
+ * (stepfun.py:116-128). t [B,n+1], w [B,n] -> t_out [B,3n+1], w_out [B,3n];
+ * scratch [B,n] floats. */
+int mnr_max_dilate_weights(int64_t B, int n, const float* t, const float* w, float dilation,
+                           float domain_lo, float domain_hi, float* t_out, float* w_out,
+                           float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Featurisation  (replaces render.cast_rays render.py:103-127 incl.
+ * conical_frustum_to_gaussian :44-78 / cylinder_to_gaussian :81-100 /
+ * lift_gaussian :21-41, coord.track_linearize(coord.contract) coord.py:21-60,
+ * coord.lift_and_diagonalize :129-133, coord.integrated_pos_enc :102-126 with
+ * math.safe_sin math.py:26-38; and coord.pos_enc :136-147 for view directions)
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  int ray_shape;       /* 0 cone, 1 cylinder (Model.ray_shape)                */
+  int warp_contract;   /* 1: MLP.warp_fn = coord.contract                     */
+  int disable_integration; /* Model.disable_integration: zero covariances     */
+  int basis_k;         /* K columns of pos_basis_t (21 icosa-2, 3 octa-1)     */
+  int min_deg, max_deg;
+} mnr_ipe_cfg;
+
+/* tdist [B,n+1]; origins, directions [B,3]; radii [B]; basis [K,3] (rows =
+ * geopoly.generate_basis rows, geopoly.py:78-124).  feat_out: bf16
+ * [B*n, ld_feat], columns [0, 2*K*(max_deg-min_deg)) = IPE features in the
+ * reference order, remaining columns zero.  means_out / covs_out (optional,
+ * fp32 [B*n,3] / [B*n,9]) are the POST-warp Gaussians, for parity tests. */
+int mnr_cast_rays_ipe(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist,
+                      const float* origins, const float* directions, const float* radii,
+                      const float* basis, uint16_t* feat_out, int ld_feat,
+                      float* means_out, float* covs_out, void* stream);
+
+/* Same, fp32 features [B*n, 2*K*L] (no padding): parity-test leaf for
+ * coord.integrated_pos_enc. */
+int mnr_cast_rays_ipe_f32(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist,
+                          const float* origins, const float* directions, const float* radii,
+                          const float* basis, float* feat_out, void* stream);
+
+/* coord.pos_enc(viewdirs, 0, deg_view, append_identity=True) per ray, written
+ * (bf16) into columns [col0, col0+3+6*deg_view) of every one of the ray's n
+ * rows of `dst` [B*n, ld]; columns up to col_end are zero-filled
+ * (models.py:550-557 broadcast + concat). */
+int mnr_viewdir_enc_fill(int64_t B, int n, const float* viewdirs, int deg_view,
+                         uint16_t* dst, int ld, int col0, int col_end, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Dense layers  (replaces flax.linen.Dense at models.py:436-437,456,460,495,
+ * 515,518,521,527,577,585: y = x @ kernel[in,out] + bias, and their VJPs)
+ * bf16 operands, fp32 accumulation on the MFMA units.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  /* A = [A1 | A2] : [M, K1+K2] bf16; K1,K2 multiples of 64; A2 may be NULL (K2=0).
+   * The second segment is the skip concat of models.py:458-459. */
+  const uint16_t* A1; int lda1; int K1;
+  const uint16_t* A2; int lda2; int K2;
+  const uint16_t* Bt; int ldb;        /* [N, K1+K2] bf16: row n = output column n */
+  int64_t M;                          /* multiple of 128 */
+  int N;                              /* multiple of 128 (padded rows of Bt are zero) */
+  const float* bias; int n_bias;      /* bias[n] added for n < n_bias (may be NULL) */
+  int relu;                           /* nn.relu epilogue                          */
+  const uint16_t* mask; int ldmask;   /* optional: out *= (mask[m,n] > 0)  (ReLU VJP) */
+  uint16_t* Cb; int ldcb; int nb;     /* bf16 output for columns n < nb (may be NULL) */
+  float* Cf; int ldcf; int f0; int nf;/* fp32 output for f0 <= n < f0+nf at column n-f0 */
+} mnr_gemm_nt_args;
+
+/* C[M,N] = epilogue([A1|A2] * Bt^T). */
+int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* args, void* stream);
+
+typedef struct {
+  const uint16_t* A; int lda; int K;   /* A [M, lda] bf16, K columns used, K multiple of 128 */
+  const uint16_t* B; int ldb; int N;   /* B [M, ldb] bf16, N columns used, N multiple of 128 */
+  int64_t M;                           /* multiple of 64 */
+  float* C; int ldc;                   /* fp32 [k_valid, ldc]: C[k,n] += sum_m A[m,k] B[m,n] */
+  int k_valid, n_valid;                /* only k < k_valid, n < n_valid are written */
+} mnr_gemm_tn_args;
+
+/* Weight gradient: C += A^T B (fp32 atomics; C must be initialised by the caller). */
+int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* args, void* stream);
+
+/* out[n] += sum_m X[m,n] for n < n_valid (bias gradient). X bf16 [M, ld]. */
+int mnr_colsum_bf16(const uint16_t* X, int ld, int64_t M, int n_valid, float* out, void* stream);
+
+/* One entry of the weight-packing table: copy an fp32 [rows_in, cols_out] flax
+ * kernel (params + src_off) into a bf16 matrix at dst_off, as itself
+ * (transpose=0: dst[r*ld + c]) or transposed (transpose=1: dst[c*ld + r]),
+ * starting at (row0, col0) of the destination. */
+typedef struct {
+  int64_t src_off; int rows_in; int cols_out;
+  int64_t dst_off; int ld; int row0; int col0; int transpose;
+} mnr_pack_desc;
+int mnr_pack_weights_bf16(const float* params, const mnr_pack_desc* descs_device, int n_desc,
+                          int max_elems, uint16_t* dst, void* stream);
+
+/* dst[k*ld_dst + c] (fp32, flat-gradient layout) += src[(row0+k)*ld_src + col0 + c] for
+ * k < rows, c < cols: scatter a (padded / merged) weight-gradient block into
+ * the flat gradient vector. */
+int mnr_scatter_add_f32(const float* src, int ld_src, int row0, int col0, int rows, int cols,
+                        float* dst, int ld_dst, void* stream);
+
+/* fp32 -> bf16 cast of a strided matrix [M, n] (ld_src) into dst [M, ld_dst] at col0. */
+int mnr_cast_f32_to_bf16(const float* src, int ld_src, int64_t M, int n, uint16_t* dst, int ld_dst,
+                         int col0, void* stream);
+
+/* Small-N dense VJP pieces (heads with 1..4 outputs, e.g. the rgb Dense(3)):
+ *  dX[m,k] = relu'(H[m,k]) * sum_c g[m,c] W[k,c]          (bf16 out)
+ *  dW[k,c] += sum_m H[m,k] g[m,c];  db[c] += sum_m g[m,c]  (fp32 atomics)
+ * H bf16 [M, ldh] (K columns), g fp32 [M, C], W fp32 [K, C] (flax kernel). */
+int mnr_small_head_bwd(int64_t M, int K, int C, const uint16_t* H, int ldh, const float* g,
+                       const float* W, uint16_t* dX, int lddx, int apply_relu_mask,
+                       float* dW, float* db, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Compositing  (replaces the density/rgb activations models.py:506,584-602,
+ * render.compute_alpha_weights render.py:130-151, render.volumetric_rendering
+ * render.py:154-213 and stepfun.weighted_percentile stepfun.py:298-308)
+ * ------------------------------------------------------------------------- */
+typedef enum { MNR_ACT_SIGMOID = 0, MNR_ACT_SAFE_EXP = 1, MNR_ACT_SOFTPLUS = 2, MNR_ACT_EXP = 3,
+               MNR_ACT_RELU = 4 } mnr_act;
+
+typedef struct {
+  int n;                   /* intervals per ray                                      */
+  int opaque_background;   /* Model.opaque_background                                */
+  int density_act;         /* mnr_act (softplus default)                             */
+  float density_bias;      /* MLP.density_bias                                       */
+  float density_noise_std; /* MLP.density_noise (0: none)                            */
+  int has_rgb;             /* 0: MLP.disable_rgb (rgb = 0)                           */
+  int rgb_act;             /* mnr_act                                                */
+  float rgb_premultiplier, rgb_bias, rgb_padding;
+  int bg_mode;             /* 0: scalar bg_value; 1: per-ray bg [B,3]                */
+  float bg_value;
+} mnr_composite_cfg;
+
+/* raw_density [B,n] (Dense(1) output incl. its bias), density_noise [B,n] or
+ * NULL, raw_rgb [B,n,3] or NULL, tdist [B,n+1], dirs [B,3], bg [B,3] or NULL,
+ * exposure_scale [B,3] or NULL (RawNeRF models.py:257-267, already combined).
+ * Outputs: density [B,n], rgb [B,n,3] (NULL if !has_rgb), weights [B,n],
+ * rgb_out [B,3], acc [B]. */
+int mnr_composite_fwd(const mnr_composite_cfg* cfg, int64_t B, const float* raw_density,
+                      const float* density_noise, const float* raw_rgb, const float* tdist,
+                      const float* dirs, const float* bg, const float* exposure_scale,
+                      float* density, float* rgb, float* weights, float* rgb_out, float* acc,
+                      void* stream);
+
+/* VJP of mnr_composite_fwd.  g_rgb_out [B,3] or NULL, g_weights [B,n] or NULL
+ * (from the interlevel / distortion losses).  Outputs: g_raw_density [B,n]
+ * fp32 (and, if g_raw_density_bf16 != NULL, the same value as bf16 at
+ * g_raw_density_bf16[row*ld_bf16], the density column of the head-gradient
+ * matrix), g_raw_rgb [B,n,3] or NULL. */
+int mnr_composite_bwd(const mnr_composite_cfg* cfg, int64_t B, const float* raw_density,
+                      const float* density_noise, const float* raw_rgb, const float* tdist,
+                      const float* dirs, const float* bg, const float* exposure_scale,
+                      const float* weights, const float* g_rgb_out, const float* g_weights,
+                      float* g_raw_density, uint16_t* g_raw_density_bf16, int ld_bf16,
+                      float* g_raw_rgb, void* stream);
+
+/* The compute_extras outputs of render.volumetric_rendering (render.py:184-211):
+ * distance_mean, distance_percentile_5 / median / percentile_95 -> out [B,4]. */
+int mnr_render_extras(int64_t B, int n, const float* weights, const float* tdist, const float* t_far,
+                      float* out, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Losses  (replaces train_utils.compute_data_loss train_utils.py:72-136,
+ * interlevel_loss :139-150 with stepfun.lossfun_outer stepfun.py:30-86,
+ * distortion_loss :153-159 with stepfun.lossfun_distortion stepfun.py:266-276)
+ * Scalars accumulate into `stats` (fp32 device array, zeroed by the caller).
+ * ------------------------------------------------------------------------- */
+typedef enum { MNR_LOSS_MSE = 0, MNR_LOSS_CHARB = 1, MNR_LOSS_RAWNERF = 2 } mnr_data_loss_type;
+
+/* out[0] += sum(lossmult broadcast to [B,3]) over the first B_valid rays. lossmult [B,lm_c], lm_c in {1,3}. */
+int mnr_lossmult_sum(int64_t B_valid, const float* lossmult, int lm_c, float* out, void* stream);
+
+/* One level of compute_data_loss.  rgb [B,3] rendered, gt [B,3], denom = device
+ * scalar from mnr_lossmult_sum.  stats[0] += mse numerator/denom, stats[1] +=
+ * loss_mult * data loss.  g_rgb [B,3] (may be NULL) = d(loss_mult*loss)/d rgb. */
+int mnr_data_loss(int loss_type, float charb_padding, float loss_mult, int64_t B, int64_t B_valid,
+                  const float* rgb, const float* gt, const float* lossmult, int lm_c,
+                  const float* denom, float* stats, float* g_rgb, void* stream);
+
+/* interlevel: t [B,n+1], w [B,n] (final level, constants); t_env [B,ne+1], w_env
+ * [B,ne] (proposal).  stats[0] += mult * mean(lossfun_outer); g_w_env [B,ne]
+ * (+=, may be NULL) = d/d w_env. */
+int mnr_interlevel_loss(float mult, int64_t B, int64_t B_valid, int n, const float* t, const float* w,
+                        int ne, const float* t_env, const float* w_env, float* stats, float* g_w_env,
+                        void* stream);
+
+/* distortion on (t = sdist, w): stats[0] += mult * mean(lossfun_distortion); g_w [B,n] += d/d w. */
+int mnr_distortion_loss(float mult, int64_t B, int64_t B_valid, int n, const float* t, const float* w,
+                        float* stats, float* g_w, void* stream);
+
+/* Leaf for parity: per-ray lossfun_outer [B,n] and lossfun_distortion [B]. */
+int mnr_lossfun_outer(int64_t B, int n, const float* t, const float* w, int ne, const float* t_env,
+                      const float* w_env, float* out, void* stream);
+int mnr_lossfun_distortion(int64_t B, int n, const float* t, const float* w, float* out, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Optimiser  (replaces train_utils.clip_gradients train_utils.py:200-218,
+ * jnp.nan_to_num :328 and optax.adam state.apply_gradients :330,372)
+ * ------------------------------------------------------------------------- */
+/* out[0] += sum of squares of grad[begin:end] (each element first clipped to
+ * +-max_val when max_val > 0): one call per top-level module. */
+int mnr_grad_sqnorm(const float* grad, int64_t begin, int64_t end, float max_val, float* out, void* stream);
+
+typedef struct {
+  float lr, b1, b2, eps;
+  float bias_corr1, bias_corr2;  /* 1 - b1^t, 1 - b2^t                          */
+  float grad_max_val;            /* 0: off                                      */
+  float grad_max_norm;           /* 0: off                                      */
+} mnr_adam_cfg;
+
+/* For one segment [begin,end): g = clip_value(g); g *= min(1, max_norm/(eps32+sqrt(sqnorm[seg])));
+ * g = nan_to_num(g); Adam moments and parameter update in place. */
+int mnr_clip_adam(const mnr_adam_cfg* cfg, int64_t begin, int64_t end, const float* sqnorm_seg,
+                  const float* grad, float* params, float* mu, float* nu, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNERF_H_ */

@@ -1,0 +1,147 @@
+"""ctypes binding of include/mnerf.h (cffi is not installed in this image).
+
+The product path has NO CPU fallback: if libmnerf_hip.so is missing or a symbol
+declared in the header is absent, importing/using the ops raises.
+"""
+
+import ctypes as C
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libmnerf_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(HERE), 'include', 'mnerf.h')
+
+MNR_OK = 0
+MNR_ERR_INVALID_ARGUMENT = -1
+
+# enums of mnerf.h
+RAYDIST = {None: 0, 'identity': 0, 'reciprocal': 1, 'piecewise': 2, 'log': 3, 'exp': 4, 'sqrt': 5,
+           'square': 6}
+ACT = {'sigmoid': 0, 'safe_exp': 1, 'softplus': 2, 'exp': 3, 'relu': 4}
+DATA_LOSS = {'mse': 0, 'charb': 1, 'rawnerf': 2}
+
+c_f32p = C.POINTER(C.c_float)
+c_u16p = C.POINTER(C.c_uint16)
+c_i32p = C.POINTER(C.c_int32)
+vp = C.c_void_p
+
+
+class ResampleCfg(C.Structure):
+  _fields_ = [('n_prev', C.c_int), ('n_samples', C.c_int), ('use_dilation', C.c_int),
+              ('dilation', C.c_float), ('domain_lo', C.c_float), ('domain_hi', C.c_float),
+              ('anneal', C.c_float), ('resample_padding', C.c_float), ('single_jitter', C.c_int),
+              ('max_jitter', C.c_float), ('raydist_fn', C.c_int)]
+
+
+class IpeCfg(C.Structure):
+  _fields_ = [('ray_shape', C.c_int), ('warp_contract', C.c_int), ('disable_integration', C.c_int),
+              ('basis_k', C.c_int), ('min_deg', C.c_int), ('max_deg', C.c_int)]
+
+
+class GemmNTArgs(C.Structure):
+  _fields_ = [('A1', vp), ('lda1', C.c_int), ('K1', C.c_int),
+              ('A2', vp), ('lda2', C.c_int), ('K2', C.c_int),
+              ('Bt', vp), ('ldb', C.c_int),
+              ('M', C.c_int64), ('N', C.c_int),
+              ('bias', vp), ('n_bias', C.c_int), ('relu', C.c_int),
+              ('mask', vp), ('ldmask', C.c_int),
+              ('Cb', vp), ('ldcb', C.c_int), ('nb', C.c_int),
+              ('Cf', vp), ('ldcf', C.c_int), ('f0', C.c_int), ('nf', C.c_int)]
+
+
+class GemmTNArgs(C.Structure):
+  _fields_ = [('A', vp), ('lda', C.c_int), ('K', C.c_int),
+              ('B', vp), ('ldb', C.c_int), ('N', C.c_int),
+              ('M', C.c_int64), ('C', vp), ('ldc', C.c_int),
+              ('k_valid', C.c_int), ('n_valid', C.c_int)]
+
+
+class PackDesc(C.Structure):
+  _fields_ = [('src_off', C.c_int64), ('rows_in', C.c_int), ('cols_out', C.c_int),
+              ('dst_off', C.c_int64), ('ld', C.c_int), ('row0', C.c_int), ('col0', C.c_int),
+              ('transpose', C.c_int)]
+
+
+class CompositeCfg(C.Structure):
+  _fields_ = [('n', C.c_int), ('opaque_background', C.c_int), ('density_act', C.c_int),
+              ('density_bias', C.c_float), ('density_noise_std', C.c_float), ('has_rgb', C.c_int),
+              ('rgb_act', C.c_int), ('rgb_premultiplier', C.c_float), ('rgb_bias', C.c_float),
+              ('rgb_padding', C.c_float), ('bg_mode', C.c_int), ('bg_value', C.c_float)]
+
+
+class AdamCfg(C.Structure):
+  _fields_ = [('lr', C.c_float), ('b1', C.c_float), ('b2', C.c_float), ('eps', C.c_float),
+              ('bias_corr1', C.c_float), ('bias_corr2', C.c_float), ('grad_max_val', C.c_float),
+              ('grad_max_norm', C.c_float)]
+
+
+i64, i32, f32 = C.c_int64, C.c_int, C.c_float
+_PROTOS = {
+    'mnr_abi_version': ([], i32),
+    'mnr_device_info': ([i32, C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32], i32),
+    'mnr_resample_level': ([C.POINTER(ResampleCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
+    'mnr_sorted_interp': ([i64, i32, i32, vp, vp, vp, vp, vp, vp], i32),
+    'mnr_max_dilate_weights': ([i64, i32, vp, vp, f32, f32, f32, vp, vp, vp, vp], i32),
+    'mnr_cast_rays_ipe': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp], i32),
+    'mnr_cast_rays_ipe_f32': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp], i32),
+    'mnr_viewdir_enc_fill': ([i64, i32, vp, i32, vp, i32, i32, i32, vp], i32),
+    'mnr_gemm_nt_bf16': ([C.POINTER(GemmNTArgs), vp], i32),
+    'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
+    'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),
+    'mnr_pack_weights_bf16': ([vp, vp, i32, i32, vp, vp], i32),
+    'mnr_scatter_add_f32': ([vp, i32, i32, i32, i32, i32, vp, i32, vp], i32),
+    'mnr_cast_f32_to_bf16': ([vp, i32, i64, i32, vp, i32, i32, vp], i32),
+    'mnr_small_head_bwd': ([i64, i32, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp], i32),
+    'mnr_composite_fwd': ([C.POINTER(CompositeCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
+    'mnr_composite_bwd': ([C.POINTER(CompositeCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32,
+                           vp, vp], i32),
+    'mnr_render_extras': ([i64, i32, vp, vp, vp, vp, vp], i32),
+    'mnr_lossmult_sum': ([i64, vp, i32, vp, vp], i32),
+    'mnr_data_loss': ([i32, f32, f32, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp], i32),
+    'mnr_interlevel_loss': ([f32, i64, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp], i32),
+    'mnr_distortion_loss': ([f32, i64, i64, i32, vp, vp, vp, vp, vp], i32),
+    'mnr_lossfun_outer': ([i64, i32, vp, vp, i32, vp, vp, vp, vp], i32),
+    'mnr_lossfun_distortion': ([i64, i32, vp, vp, vp, vp], i32),
+    'mnr_grad_sqnorm': ([vp, i64, i64, f32, vp, vp], i32),
+    'mnr_clip_adam': ([C.POINTER(AdamCfg), i64, i64, vp, vp, vp, vp, vp, vp], i32),
+}
+
+_lib = None
+
+
+def header_symbols():
+  """Every function name include/mnerf.h declares."""
+  with open(HEADER_PATH) as f:
+    text = f.read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(mnr_[a-z0-9_]+)\s*\(', text)))
+
+
+def load():
+  """Load libmnerf_hip.so; raises (never falls back) when it is unavailable."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f'{LIB_PATH} is missing: the HIP extension has not been built. Run '
+        '`python -m multinerf_amd.build` (needs hipcc, ROCm >= 7.0). There is no CPU fallback.')
+  lib = C.CDLL(LIB_PATH)
+  lib.mnr_last_error.restype = C.c_char_p
+  lib.mnr_last_error.argtypes = []
+  for name, (argtypes, restype) in _PROTOS.items():
+    fn = getattr(lib, name)      # AttributeError if the symbol is missing
+    fn.argtypes = argtypes
+    fn.restype = restype
+  _lib = lib
+  return lib
+
+
+def check(status):
+  if status == MNR_OK:
+    return
+  msg = load().mnr_last_error().decode()
+  if status == MNR_ERR_INVALID_ARGUMENT:
+    raise ValueError(msg)
+  raise RuntimeError(f'libmnerf_hip status {status}: {msg}')

@@ -1,0 +1,79 @@
+"""Build recipe for libmnerf_hip.so (hipcc, gfx950 only; cross-compiles without a GPU).
+
+    python -m multinerf_amd.build            # build if stale
+    python -m multinerf_amd.build --force
+
+The shared library is written IN-TREE (multinerf_amd/libmnerf_hip.so) so that it
+travels with the source snapshot to the GPU box; it is git-ignored.
+"""
+
+import concurrent.futures
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+LIB = os.path.join(HERE, 'libmnerf_hip.so')
+OBJ_DIR = os.path.join(HERE, 'build')
+SOURCES = ['api.hip', 'gemm.hip', 'resample.hip', 'features.hip', 'render.hip', 'losses.hip', 'optim.hip']
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'mnerf.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+  for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+    if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+      return c
+  raise RuntimeError('hipcc not found')
+
+
+def _digest():
+  h = hashlib.sha256()
+  for p in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+    with open(p, 'rb') as f:
+      h.update(f.read())
+  h.update(' '.join(FLAGS).encode())
+  return h.hexdigest()
+
+
+def is_stale():
+  stamp = LIB + '.stamp'
+  if not (os.path.exists(LIB) and os.path.exists(stamp)):
+    return True
+  with open(stamp) as f:
+    return f.read().strip() != _digest()
+
+
+def build(force=False, verbose=True):
+  """Compile every HIP translation unit for gfx950 and link the C-ABI library."""
+  if not force and not is_stale():
+    return LIB
+  os.makedirs(OBJ_DIR, exist_ok=True)
+  hipcc = _hipcc()
+
+  def compile_one(src):
+    obj = os.path.join(OBJ_DIR, src.replace('.hip', '.o'))
+    cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError(f'hipcc failed on {src}:\n{r.stdout}\n{r.stderr}')
+    return obj
+
+  with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+    objs = list(ex.map(compile_one, SOURCES))
+  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+  r = subprocess.run(cmd, capture_output=True, text=True)
+  if r.returncode != 0:
+    raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+  with open(LIB + '.stamp', 'w') as f:
+    f.write(_digest())
+  if verbose:
+    print(f'built {LIB} ({os.path.getsize(LIB)} bytes)')
+  return LIB
+
+
+if __name__ == '__main__':
+  build(force='--force' in sys.argv)

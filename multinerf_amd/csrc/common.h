@@ -1,0 +1,59 @@
+// Shared device/host helpers for the MI355X (gfx950) MultiNeRF hot-path kernels.
+// gfx950 only: 64-lane wavefronts, bf16 MFMA 32x32x16, LDS-DMA, LDS transpose reads.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mnerf.h"
+
+typedef __bf16 bf16;
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define MNR_F32_EPS 1.1920928955078125e-07f      // jnp.finfo(jnp.float32).eps
+#define MNR_F32_MAX 3.4028234663852886e+38f
+
+#define MNR_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define MNR_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// Error plumbing: thread-local message owned by the library (mnr_last_error()).
+void mnr_set_error(const char* fmt, ...);
+
+#define MNR_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      mnr_set_error(__VA_ARGS__);                \
+      return MNR_ERR_INVALID_ARGUMENT;           \
+    }                                            \
+  } while (0)
+
+#define MNR_CHECK_LAUNCH()                                                   \
+  do {                                                                       \
+    hipError_t e_ = hipGetLastError();                                       \
+    if (e_ != hipSuccess) {                                                  \
+      mnr_set_error("%s:%d: HIP launch failed: %s", __FILE__, __LINE__,      \
+                    hipGetErrorString(e_));                                  \
+      return MNR_ERR_HIP;                                                    \
+    }                                                                        \
+  } while (0)
+
+static inline int mnr_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// nan_to_num(x, nan=0) followed by clip to [0,1] (reference internal/math.py:125).
+__device__ __forceinline__ float mnr_nan0_clip01(float x) {
+  if (x != x) return 0.0f;
+  return fminf(fmaxf(x, 0.0f), 1.0f);
+}
+
+__device__ __forceinline__ float mnr_softplus(float x) {
+  // jax.nn.softplus = logaddexp(x, 0) = max(x,0) + log1p(exp(-|x|)).
+  return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
+}
+
+__device__ __forceinline__ float mnr_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -1,0 +1,286 @@
+// Ray casting + integrated positional encoding -> bf16 feature rows (gfx950).
+//
+// Per sample (interval of a ray) this fuses, in fp32:
+//   render.cast_rays            (render.py:103-127; conical frustum eq. 7 :62-70 or cylinder :97-99,
+//                                lift_gaussian full covariance :35-41)
+//   coord.track_linearize(coord.contract)   (coord.py:21-27, 39-60; closed-form Jacobian)
+//   coord.lift_and_diagonalize  (coord.py:129-133)
+//   coord.integrated_pos_enc    (coord.py:102-126) with math.safe_sin (math.py:26-38)
+// and writes the [2*K*L] features of the sample as one bf16 row of the first
+// Dense layer's A operand.  The reference materialises means [B,n,3], covs
+// [B,n,3,3], lifted [B,n,K] x2 and the fp32 features [B,n,2KL] in HBM; here only
+// the bf16 row leaves the CU, staged through LDS so the global stores are full
+// 16-byte-per-lane row segments.
+//
+// Work split inside a 256-thread block handling SPB consecutive samples:
+//   phase 1: one thread per sample: Gaussian (mean, cov), warp -> LDS
+//   phase 2: one thread per (sample, basis direction): projection, then the L degrees
+//   phase 3: all threads: coalesced copy of the [SPB, ld] bf16 rows to HBM
+#include "common.h"
+
+#define FE_THREADS 256
+#define FE_PI_2 1.57079632679489661923f
+#define FE_100PI 314.159265358979323846f
+
+__device__ __forceinline__ float fe_safe_sin(float x) {
+  // math.py:26-28: sin(x if |x| < 100*pi else x mod 100*pi); `%` takes the divisor's sign.
+  const float t = FE_100PI;
+  if (!(fabsf(x) < t)) {
+    float m = fmodf(x, t);
+    if (m != 0.0f && (m < 0.0f)) m += t;
+    x = m;
+  }
+  return sinf(x);
+}
+
+struct FeSample {
+  float mean[3];
+  float cov[6];   // xx, xy, xz, yy, yz, zz (symmetric)
+};
+
+__device__ __forceinline__ void fe_gaussian(const mnr_ipe_cfg& c, float t0, float t1, const float* o,
+                                            const float* d, float radius, FeSample& g) {
+  float t_mean, t_var, r_var;
+  if (c.ray_shape == 0) {
+    // render.py:62-70 (stable form of mip-NeRF eq. 7).
+    const float mu = (t0 + t1) / 2.0f;
+    const float hw = (t1 - t0) / 2.0f;
+    const float denom = fmaxf(MNR_F32_EPS, 3.0f * mu * mu + hw * hw);
+    const float hw2 = hw * hw, hw4 = hw2 * hw2;
+    t_mean = mu + (2.0f * mu * hw2) / denom;
+    t_var = hw2 / 3.0f - (4.0f / 15.0f) * hw4 * (12.0f * mu * mu - hw2) / (denom * denom);
+    r_var = (mu * mu) / 4.0f + (5.0f / 12.0f) * hw2 - (4.0f / 15.0f) * hw4 / denom;
+    r_var *= radius * radius;
+  } else {
+    // render.py:97-99.
+    t_mean = (t0 + t1) / 2.0f;
+    r_var = radius * radius / 4.0f;
+    t_var = (t1 - t0) * (t1 - t0) / 12.0f;
+  }
+  // render.py:23-41 lift_gaussian(diag=False) and :126 (+ origins).
+  const float dmag = fmaxf(1e-10f, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  float mean[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) mean[i] = o[i] + d[i] * t_mean;
+  float cov[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float dd = d[i] * d[j];
+      const float null_outer = (i == j ? 1.0f : 0.0f) - d[i] * (d[j] / dmag);
+      cov[i][j] = t_var * dd + r_var * null_outer;
+    }
+  if (c.disable_integration) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) cov[i][j] = 0.0f;
+  }
+  if (c.warp_contract) {
+    // coord.py:21-27 and its Jacobian: inside the unit ball identity; outside
+    // z = s x, J = s I + c x x^T, s = (2 sqrt(m) - 1)/m, c = 2 (1 - sqrt(m))/m^2.
+    const float m = fmaxf(MNR_F32_EPS, mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
+    if (!(m <= 1.0f)) {
+      const float sq = sqrtf(m);
+      const float s = (2.0f * sq - 1.0f) / m;
+      const float cc = 2.0f * (1.0f - sq) / (m * m);
+      float J[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) J[i][j] = (i == j ? s : 0.0f) + cc * mean[i] * mean[j];
+      float tmp[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          tmp[i][j] = J[i][0] * cov[0][j] + J[i][1] * cov[1][j] + J[i][2] * cov[2][j];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          cov[i][j] = tmp[i][0] * J[j][0] + tmp[i][1] * J[j][1] + tmp[i][2] * J[j][2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) mean[i] = s * mean[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g.mean[i] = mean[i];
+  // Symmetrise exactly the way diag(P^T C P) sees it: keep both triangles' average.
+  g.cov[0] = cov[0][0];
+  g.cov[1] = 0.5f * (cov[0][1] + cov[1][0]);
+  g.cov[2] = 0.5f * (cov[0][2] + cov[2][0]);
+  g.cov[3] = cov[1][1];
+  g.cov[4] = 0.5f * (cov[1][2] + cov[2][1]);
+  g.cov[5] = cov[2][2];
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
+    mnr_ipe_cfg c, int64_t total, int n, int spb, const float* __restrict__ tdist,
+    const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ radii,
+    const float* __restrict__ basis, void* __restrict__ feat_out, int ld_feat, float* __restrict__ means_out,
+    float* __restrict__ covs_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int K = c.basis_k;
+  const int L = c.max_deg - c.min_deg;
+  const int nfeat = 2 * K * L;
+  // LDS: samples [spb] FeSample | basis [K*3] | rows [spb][ld] (bf16 or f32)
+  FeSample* gs = (FeSample*)smem;
+  float* bs = (float*)(gs + spb);
+  char* rows = (char*)(bs + ((K * 3 + 3) & ~3));
+  const int64_t s0 = (int64_t)blockIdx.x * spb;
+  const int ns = (int)min((int64_t)spb, total - s0);
+
+  for (int i = threadIdx.x; i < K * 3; i += FE_THREADS) bs[i] = basis[i];
+  if (threadIdx.x < ns) {
+    const int64_t s = s0 + threadIdx.x;
+    const int64_t ray = s / n;
+    const int j = (int)(s % n);
+    const float t0 = tdist[ray * (n + 1) + j], t1 = tdist[ray * (n + 1) + j + 1];
+    float o[3], d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      o[i] = origins[ray * 3 + i];
+      d[i] = directions[ray * 3 + i];
+    }
+    FeSample g;
+    fe_gaussian(c, t0, t1, o, d, radii[ray], g);
+    gs[threadIdx.x] = g;
+    if (means_out) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) means_out[s * 3 + i] = g.mean[i];
+    }
+    if (covs_out) {
+      const float* cv = g.cov;
+      const float full[9] = {cv[0], cv[1], cv[2], cv[1], cv[3], cv[4], cv[2], cv[4], cv[5]};
+#pragma unroll
+      for (int i = 0; i < 9; ++i) covs_out[s * 9 + i] = full[i];
+    }
+  }
+  __syncthreads();
+
+  const int row_elems = OUT_F32 ? nfeat : ld_feat;
+  for (int pair = threadIdx.x; pair < ns * K; pair += FE_THREADS) {
+    const int si = pair / K, k = pair % K;
+    const FeSample g = gs[si];
+    const float px = bs[k * 3 + 0], py = bs[k * 3 + 1], pz = bs[k * 3 + 2];
+    // coord.py:131-132: mean . p_k ; p_k^T cov p_k.
+    const float lm = g.mean[0] * px + g.mean[1] * py + g.mean[2] * pz;
+    const float cx = g.cov[0] * px + g.cov[1] * py + g.cov[2] * pz;
+    const float cy = g.cov[1] * px + g.cov[3] * py + g.cov[4] * pz;
+    const float cz = g.cov[2] * px + g.cov[4] * py + g.cov[5] * pz;
+    const float lv = px * cx + py * cy + pz * cz;
+    for (int l = 0; l < L; ++l) {
+      const float sc = ldexpf(1.0f, c.min_deg + l);       // 2^deg, exact
+      const float y = lm * sc;
+      const float v = lv * sc * sc;
+      const float att = expf(-0.5f * v);
+      const float fs = att * fe_safe_sin(y);
+      const float fc = att * fe_safe_sin(y + FE_PI_2);
+      const int col = l * K + k;
+      if (OUT_F32) {
+        float* rowp = (float*)rows + (size_t)si * row_elems;
+        rowp[col] = fs;
+        rowp[K * L + col] = fc;
+      } else {
+        bf16* rowp = (bf16*)rows + (size_t)si * row_elems;
+        rowp[col] = (bf16)fs;
+        rowp[K * L + col] = (bf16)fc;
+      }
+    }
+  }
+  if (!OUT_F32) {
+    // zero the padding columns [nfeat, ld)
+    const int pad = ld_feat - nfeat;
+    for (int e = threadIdx.x; e < ns * pad; e += FE_THREADS) {
+      const int si = e / pad, cidx = nfeat + e % pad;
+      ((bf16*)rows)[(size_t)si * ld_feat + cidx] = (bf16)0.0f;
+    }
+  }
+  __syncthreads();
+  // Coalesced write-out: the block's rows are contiguous in HBM (16 B per lane).
+  const size_t row_bytes = (size_t)row_elems * (OUT_F32 ? 4 : 2);
+  const size_t nbytes = (size_t)ns * row_bytes;
+  char* dst = (char*)feat_out + (size_t)s0 * row_bytes;
+  for (size_t off = (size_t)threadIdx.x * 16; off < nbytes; off += (size_t)FE_THREADS * 16)
+    *(uint4*)(dst + off) = *(const uint4*)(rows + off);
+}
+
+static int fe_launch(bool f32, const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist, const float* origins,
+                     const float* directions, const float* radii, const float* basis, void* feat_out, int ld_feat,
+                     float* means_out, float* covs_out, void* stream) {
+  MNR_CHECK_ARG(cfg && B > 0 && n > 0 && tdist && origins && directions && radii && basis && feat_out,
+                "mnr_cast_rays_ipe: null argument");
+  MNR_CHECK_ARG(cfg->ray_shape == 0 || cfg->ray_shape == 1, "ray_shape must be 'cone' or 'cylinder'");  // render.py:124
+  const int K = cfg->basis_k, L = cfg->max_deg - cfg->min_deg;
+  MNR_CHECK_ARG(K >= 1 && K <= 128 && L >= 1 && L <= 32, "mnr_cast_rays_ipe: basis_k=%d / degrees=%d out of range", K, L);
+  const int nfeat = 2 * K * L;
+  const int row_elems = f32 ? nfeat : ld_feat;
+  MNR_CHECK_ARG(f32 || (ld_feat >= nfeat && ld_feat % 8 == 0), "mnr_cast_rays_ipe: ld_feat=%d must be >= %d and a multiple of 8", ld_feat, nfeat);
+  MNR_CHECK_ARG(!f32 || nfeat % 4 == 0, "mnr_cast_rays_ipe_f32: feature count must be a multiple of 4");
+  const size_t row_bytes = (size_t)row_elems * (f32 ? 4 : 2);
+  int spb = (int)((32 * 1024) / row_bytes);
+  if (spb > FE_THREADS) spb = FE_THREADS;
+  spb &= ~3;                       // keeps the row buffer 16-byte aligned behind the FeSample array
+  MNR_CHECK_ARG(spb >= 4, "mnr_cast_rays_ipe: feature row too long");
+  const size_t lds = (size_t)spb * sizeof(FeSample) + (size_t)((K * 3 + 3) & ~3) * 4 + (size_t)spb * row_bytes;
+  const int64_t total = B * n;
+  const int grid = mnr_cdiv(total, spb);
+  if (f32) {
+    hipLaunchKernelGGL(cast_rays_ipe_kernel<true>, dim3(grid), dim3(FE_THREADS), lds, (hipStream_t)stream, *cfg,
+                       total, n, spb, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out, covs_out);
+  } else {
+    hipLaunchKernelGGL(cast_rays_ipe_kernel<false>, dim3(grid), dim3(FE_THREADS), lds, (hipStream_t)stream, *cfg,
+                       total, n, spb, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out, covs_out);
+  }
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+extern "C" int mnr_cast_rays_ipe(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist,
+                                 const float* origins, const float* directions, const float* radii,
+                                 const float* basis, uint16_t* feat_out, int ld_feat, float* means_out,
+                                 float* covs_out, void* stream) {
+  return fe_launch(false, cfg, B, n, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out,
+                   covs_out, stream);
+}
+
+extern "C" int mnr_cast_rays_ipe_f32(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist,
+                                     const float* origins, const float* directions, const float* radii,
+                                     const float* basis, float* feat_out, void* stream) {
+  return fe_launch(true, cfg, B, n, tdist, origins, directions, radii, basis, feat_out, 0, nullptr, nullptr, stream);
+}
+
+// ---------------------------------------------------------------------------
+// View-direction positional encoding broadcast into the view-MLP input matrix.
+
+__global__ void viewdir_enc_fill_kernel(int64_t total_rows, int n, const float* __restrict__ viewdirs,
+                                        int deg_view, bf16* __restrict__ dst, int ld, int col0, int col_end) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= total_rows) return;
+  const int64_t ray = row / n;
+  const float x[3] = {viewdirs[ray * 3 + 0], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2]};
+  bf16* o = dst + row * ld + col0;
+  const int nenc = 3 + 6 * deg_view;
+  // coord.py:136-147: [x, sin(2^l x) (l-major), sin(2^l x + pi/2)], plain sin.
+  int c = 0;
+  for (int i = 0; i < 3; ++i) o[c++] = (bf16)x[i];
+  for (int l = 0; l < deg_view; ++l)
+    for (int i = 0; i < 3; ++i) o[c++] = (bf16)sinf(x[i] * ldexpf(1.0f, l));
+  for (int l = 0; l < deg_view; ++l)
+    for (int i = 0; i < 3; ++i) o[c++] = (bf16)sinf(x[i] * ldexpf(1.0f, l) + FE_PI_2);
+  for (int k = col0 + nenc; k < col_end; ++k) dst[row * ld + k] = (bf16)0.0f;
+}
+
+extern "C" int mnr_viewdir_enc_fill(int64_t B, int n, const float* viewdirs, int deg_view, uint16_t* dst, int ld,
+                                    int col0, int col_end, void* stream) {
+  MNR_CHECK_ARG(B > 0 && n > 0 && viewdirs && dst && deg_view >= 0 && deg_view <= 16, "mnr_viewdir_enc_fill: bad arguments");
+  MNR_CHECK_ARG(col0 + 3 + 6 * deg_view <= col_end && col_end <= ld, "mnr_viewdir_enc_fill: columns out of range");
+  const int64_t rows = B * n;
+  hipLaunchKernelGGL(viewdir_enc_fill_kernel, dim3(mnr_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, rows, n,
+                     viewdirs, deg_view, (bf16*)dst, ld, col0, col_end);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}

@@ -1,0 +1,532 @@
+// bf16 MFMA GEMMs for the Dense stacks (gfx950, v_mfma_f32_32x32x16_bf16).
+//
+//   gemm_nt : C[M,N] = epi([A1|A2][M,K] * Bt[N,K]^T)   forward layers and dX
+//   gemm_tn : C[K,N] += A[M,K]^T * B[M,N]               weight gradients
+//
+// Both: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, each wave a
+// 64x64 block = 2x2 MFMA tiles of 32x32, fp32 accumulators in 64 VGPRs),
+// operand tiles streamed HBM -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4,
+// double-buffered, one barrier per K step), XOR-swizzled through the SOURCE
+// address so the linear DMA image is conflict-free for the fragment reads.
+// Workgroup ids are remapped so that the tiles sharing an operand panel run
+// back to back on one XCD (block b lands on XCD b%8; each XCD has a private L2).
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// NT kernel.
+//
+// LDS image of one operand tile: [128 rows][64 k] bf16 = 128 B per row = eight
+// 16-B slots.  Slot s of row r is stored at slot position s ^ ((r >> 1) & 7):
+// a ds_read_b128 lane group covers 16 distinct rows at one k-slot, and
+// (r & 1, (r >> 1) & 7) is distinct for them, so the 16 reads hit 16 distinct
+// 16-B slots of the 256-B bank row.
+// MFMA roles are swapped (A-operand = weights rows n, B-operand = activations
+// rows m) so that a lane's 4 consecutive accumulators are 4 consecutive n of
+// one output row m: row-major stores of 8 B (bf16x4) per lane.
+
+#define NT_BM 128
+#define NT_BN 128
+#define NT_BK 64
+#define NT_TILE_BYTES (128 * 64 * 2)                 // 16 KiB per operand tile
+#define NT_STAGE_BYTES (2 * NT_TILE_BYTES)           // A + B
+#define NT_LDS_BYTES (2 * NT_STAGE_BYTES)            // double buffered: 64 KiB
+
+__device__ __forceinline__ void nt_stage_tile(const bf16* __restrict__ g, int ld, int64_t row0,
+                                              int k0, char* lds_tile, int wave, int lane) {
+  // 1024 chunks of 16 B; wave w issues chunks [(i*4+w)*64, +64) for i = 0..3.
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cbase = (i * 4 + wave) * 64;
+    const int c = cbase + lane;
+    const int r = c >> 3;
+    const int slot = (c & 7) ^ ((r >> 1) & 7);      // global k-slot stored at this position
+    const bf16* src = g + (row0 + r) * (int64_t)ld + k0 + slot * 8;
+    __builtin_amdgcn_global_load_lds(MNR_GLOBAL_PTR(src), MNR_LDS_PTR(lds_tile + cbase * 16), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ bf16x8 nt_read_frag(const char* lds_tile, int row, int kslot) {
+  const int off = row * 128 + ((kslot ^ ((row >> 1) & 7)) << 4);
+  return *(const bf16x8*)(lds_tile + off);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(mnr_gemm_nt_args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware mapping: the nt N-tiles of one M-tile run consecutively on one XCD.
+  const int nt = p.N / NT_BN;
+  const int64_t mt = p.M / NT_BM;
+  const int xcd = blockIdx.x & 7;
+  const int64_t q = blockIdx.x >> 3;
+  const int64_t m_tile = xcd + 8 * (q / nt);
+  const int n_tile = (int)(q % nt);
+  if (m_tile >= mt) return;
+  const int64_t m0 = m_tile * NT_BM;
+  const int n0 = n_tile * NT_BN;
+
+  const bf16* A1 = (const bf16*)p.A1;
+  const bf16* A2 = (const bf16*)p.A2;
+  const bf16* Bt = (const bf16*)p.Bt;
+  const int K = p.K1 + p.K2;
+  const int nk = K / NT_BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto stage = [&](int kt, int buf) {
+    const int k0 = kt * NT_BK;
+    char* base = smem + buf * NT_STAGE_BYTES;
+    if (k0 < p.K1) {
+      nt_stage_tile(A1, p.lda1, m0, k0, base, wave, lane);
+    } else {
+      nt_stage_tile(A2, p.lda2, m0, k0 - p.K1, base, wave, lane);
+    }
+    nt_stage_tile(Bt, p.ldb, n0, k0, base + NT_TILE_BYTES, wave, lane);
+  };
+
+  stage(0, 0);
+  __syncthreads();
+
+  const int frow = lane & 31;
+  const int khalf = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+    const char* As = smem + cur * NT_STAGE_BYTES;
+    const char* Bs = As + NT_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kslot = ks * 2 + khalf;
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = nt_read_frag(As, wm * 64 + i * 32 + frow, kslot);
+        fb[i] = nt_read_frag(Bs, wn * 64 + i * 32 + frow, kslot);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // Epilogue.  acc[j][i][r]: n = n0 + wn*64 + j*32 + (r&3) + 8*(r>>2) + 4*khalf,
+  //                           m = m0 + wm*64 + i*32 + frow.
+  bf16* Cb = (bf16*)p.Cb;
+  const bf16* mask = (const bf16*)p.mask;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = m0 + wm * 64 + i * 32 + frow;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int n4 = n0 + wn * 64 + j * 32 + rq * 8 + khalf * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[j][i][rq * 4 + e];
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n4 + e < p.n_bias) v[e] += p.bias[n4 + e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        }
+        if (mask) {
+          const bf16x4 mk = *(const bf16x4*)(mask + m * p.ldmask + n4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ((float)mk[e] > 0.0f) ? v[e] : 0.0f;
+        }
+        if (Cb) {
+          if (n4 + 3 < p.nb) {
+            f32x4 vv = {v[0], v[1], v[2], v[3]};
+            *(bf16x4*)(Cb + m * p.ldcb + n4) = __builtin_convertvector(vv, bf16x4);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n4 + e < p.nb) Cb[m * p.ldcb + n4 + e] = (bf16)v[e];
+          }
+        }
+        if (p.Cf) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int nn = n4 + e - p.f0;
+            if (nn >= 0 && nn < p.nf) p.Cf[m * p.ldcf + nn] = v[e];
+          }
+        }
+      }
+    }
+  }
+}
+
+extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
+  MNR_CHECK_ARG(a != nullptr, "mnr_gemm_nt_bf16: null args");
+  MNR_CHECK_ARG(a->M > 0 && a->M % NT_BM == 0, "mnr_gemm_nt_bf16: M=%lld must be a positive multiple of 128", (long long)a->M);
+  MNR_CHECK_ARG(a->N > 0 && a->N % NT_BN == 0, "mnr_gemm_nt_bf16: N=%d must be a positive multiple of 128", a->N);
+  MNR_CHECK_ARG(a->K1 > 0 && a->K1 % NT_BK == 0 && a->K2 >= 0 && a->K2 % NT_BK == 0,
+                "mnr_gemm_nt_bf16: K1=%d, K2=%d must be multiples of 64", a->K1, a->K2);
+  MNR_CHECK_ARG(a->A1 && a->Bt && (a->K2 == 0 || a->A2), "mnr_gemm_nt_bf16: null operand");
+  MNR_CHECK_ARG(a->lda1 % 8 == 0 && a->ldb % 8 == 0 && (a->K2 == 0 || a->lda2 % 8 == 0),
+                "mnr_gemm_nt_bf16: leading dimensions must be multiples of 8 elements (16 B)");
+  MNR_CHECK_ARG(!a->Cb || a->ldcb % 4 == 0, "mnr_gemm_nt_bf16: ldcb must be a multiple of 4");
+  MNR_CHECK_ARG(!a->mask || a->ldmask % 4 == 0, "mnr_gemm_nt_bf16: ldmask must be a multiple of 4");
+  MNR_CHECK_ARG(a->Cb || a->Cf, "mnr_gemm_nt_bf16: no output");
+  const int nt = a->N / NT_BN;
+  const int64_t mt = a->M / NT_BM;
+  const int64_t groups = (mt + 7) / 8;
+  const int64_t grid = groups * 8 * nt;
+  MNR_CHECK_ARG(grid < (1ll << 31), "mnr_gemm_nt_bf16: grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)grid), dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// TN kernel (weight gradients): C[k,n] += sum_m A[m,k] B[m,n].
+//
+// The reduction index m is the slow (row) index of both operands, so MFMA
+// fragments (8 consecutive reduction elements per lane) are produced with the
+// gfx950 LDS transpose read ds_read_b64_tr_b16: per 16-lane group it reads a
+// [4 m][16 cols] block (lane p supplies the address of row p>>2, 8-byte chunk
+// p&3) and hands lane c the 4 m-values of column c.  Two reads give the 8
+// m-values of one MFMA k-step half.  LDS image of a tile: [64 m][128 cols] bf16
+// = 256 B per row = four 64-B blocks; block b of row r is stored at block
+// position b ^ (r & 3), so the 4 rows of one transpose read (r & 3 = 0..3) use
+// four different 64-B bank ranges.
+
+#define TN_BK 128      // output rows (columns of A)
+#define TN_BN 128      // output cols (columns of B)
+#define TN_BM 64       // reduction rows per step
+#define TN_TILE_BYTES (64 * 128 * 2)
+#define TN_STAGE_BYTES (2 * TN_TILE_BYTES)
+#define TN_LDS_BYTES (2 * TN_STAGE_BYTES)
+
+__device__ __forceinline__ void tn_stage_tile(const bf16* __restrict__ g, int ld, int64_t row0,
+                                              int col0, char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cbase = (i * 4 + wave) * 64;
+    const int c = cbase + lane;
+    const int r = c >> 4;              // 16 chunks (256 B) per row
+    const int pos = c & 15;
+    const int blk = (pos >> 2) ^ (r & 3);
+    const bf16* src = g + (row0 + r) * (int64_t)ld + col0 + blk * 32 + (pos & 3) * 8;
+    __builtin_amdgcn_global_load_lds(MNR_GLOBAL_PTR(src), MNR_LDS_PTR(lds_tile + cbase * 16), 16, 0, 0);
+  }
+}
+
+// Fragment of 8 reduction elements for column (colbase + 16*g16 + c) of the tile.
+__device__ __forceinline__ bf16x8 tn_read_frag(const char* lds_tile, int mbase, int colbase, int lane) {
+  const int p = lane & 15;
+  const int g16 = (lane >> 4) & 1;
+  const int col = colbase + g16 * 16 + (p & 3) * 4;
+  const int r0 = mbase + (p >> 2);
+  const int r1 = r0 + 4;
+  const int off0 = r0 * 256 + ((((col >> 5) ^ (r0 & 3))) << 6) + (col & 31) * 2;
+  const int off1 = r1 * 256 + ((((col >> 5) ^ (r1 & 3))) << 6) + (col & 31) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_tile + off0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_tile + off1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave >> 1, wn = wave & 1;
+
+  const int ktiles = p.K / TN_BK, ntiles = p.N / TN_BN;
+  const int tiles = ktiles * ntiles;
+  // All tiles of one M-split run consecutively on one XCD (operand rows shared through its L2).
+  const int xcd = blockIdx.x & 7;
+  const int q = blockIdx.x >> 3;
+  const int split = xcd + 8 * (q / tiles);
+  const int tile = q % tiles;
+  if (split >= splits) return;
+  const int k0 = (tile / ntiles) * TN_BK;
+  const int n0 = (tile % ntiles) * TN_BN;
+  const int total_steps = (int)(p.M / TN_BM);
+  const int s_begin = split * steps_per_split;
+  const int s_end = min(total_steps, s_begin + steps_per_split);
+  if (s_begin >= s_end) return;
+
+  const bf16* A = (const bf16*)p.A;
+  const bf16* B = (const bf16*)p.B;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto stage = [&](int step, int buf) {
+    char* base = smem + buf * TN_STAGE_BYTES;
+    const int64_t row0 = (int64_t)step * TN_BM;
+    tn_stage_tile(A, p.lda, row0, k0, base, wave, lane);
+    tn_stage_tile(B, p.ldb, row0, n0, base + TN_TILE_BYTES, wave, lane);
+  };
+
+  stage(s_begin, 0);
+  __syncthreads();
+  const int khalf = lane >> 5;
+  for (int s = s_begin; s < s_end; ++s) {
+    const int cur = (s - s_begin) & 1;
+    if (s + 1 < s_end) stage(s + 1, cur ^ 1);
+    const char* As = smem + cur * TN_STAGE_BYTES;
+    const char* Bs = As + TN_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int mbase = ks * 16 + khalf * 8;
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = tn_read_frag(As, mbase, wk * 64 + i * 32, lane);
+        fb[i] = tn_read_frag(Bs, mbase, wn * 64 + i * 32, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // acc[i][j][r]: k = k0 + wk*64 + i*32 + (r&3) + 8*(r>>2) + 4*khalf; n = n0 + wn*64 + j*32 + (lane&31).
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (k < p.k_valid && n < p.n_valid) unsafeAtomicAdd(p.C + (int64_t)k * p.ldc + n, acc[i][j][r]);
+      }
+    }
+}
+
+extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
+  MNR_CHECK_ARG(a != nullptr, "mnr_gemm_tn_bf16: null args");
+  MNR_CHECK_ARG(a->M > 0 && a->M % TN_BM == 0, "mnr_gemm_tn_bf16: M=%lld must be a positive multiple of 64", (long long)a->M);
+  MNR_CHECK_ARG(a->K > 0 && a->K % TN_BK == 0 && a->N > 0 && a->N % TN_BN == 0,
+                "mnr_gemm_tn_bf16: K=%d, N=%d must be multiples of 128", a->K, a->N);
+  MNR_CHECK_ARG(a->A && a->B && a->C, "mnr_gemm_tn_bf16: null operand");
+  MNR_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0, "mnr_gemm_tn_bf16: lda/ldb must be multiples of 8");
+  const int tiles = (a->K / TN_BK) * (a->N / TN_BN);
+  const int total_steps = (int)(a->M / TN_BM);
+  // Enough M-splits for >= ~768 workgroups, in multiples of 8 (one group of tiles per XCD).
+  int splits = ((768 + tiles - 1) / tiles + 7) / 8 * 8;
+  if (splits < 8) splits = 8;
+  while (splits > 8 && (total_steps + splits - 1) / splits < 4) splits -= 8;
+  const int steps_per_split = (total_steps + splits - 1) / splits;
+  const int64_t grid = (int64_t)splits * tiles;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(256), TN_LDS_BYTES, (hipStream_t)stream, *a,
+                     splits, steps_per_split);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Bias gradient: out[n] += sum_m X[m,n].
+
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, int ld, int64_t M,
+                                                      int n_valid, int rows_per_block, float* out) {
+  __shared__ float red[256 * 8];
+  const int groups = (n_valid + 7) / 8;              // 16-B column groups
+  const int lanes_per_row = groups;                  // threads across columns
+  const int row_lanes = 256 / lanes_per_row;         // >= 1 (host guarantees groups <= 256)
+  const int cg = threadIdx.x % lanes_per_row;
+  const int rl = threadIdx.x / lanes_per_row;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.0f;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(M, r0 + rows_per_block);
+  if (rl < row_lanes) {
+    for (int64_t r = r0 + rl; r < r1; r += row_lanes) {
+      const bf16x8 v = *(const bf16x8*)(X + r * ld + cg * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < row_lanes; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += red[(k * lanes_per_row + cg) * 8 + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (cg * 8 + e < n_valid) unsafeAtomicAdd(out + cg * 8 + e, s[e]);
+  }
+}
+
+extern "C" int mnr_colsum_bf16(const uint16_t* X, int ld, int64_t M, int n_valid, float* out, void* stream) {
+  MNR_CHECK_ARG(X && out && M > 0 && n_valid > 0, "mnr_colsum_bf16: bad arguments");
+  MNR_CHECK_ARG(ld % 8 == 0 && (n_valid + 7) / 8 <= 256 && ((n_valid + 7) / 8) * 8 <= ld,
+                "mnr_colsum_bf16: need ld %% 8 == 0 and n_valid <= min(ld, 2048)");
+  const int rows_per_block = 1024;
+  const int grid = mnr_cdiv(M, rows_per_block);
+  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)X, ld, M,
+                     n_valid, rows_per_block, out);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Weight packing: fp32 flax kernels -> padded bf16 GEMM operands (one launch for the whole table).
+
+__global__ void pack_weights_kernel(const float* __restrict__ params, const mnr_pack_desc* __restrict__ descs,
+                                    bf16* __restrict__ dst) {
+  const mnr_pack_desc d = descs[blockIdx.y];
+  const int total = d.rows_in * d.cols_out;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    int r, c;
+    if (d.transpose) {          // consecutive threads walk the destination row (= source column)
+      c = e / d.rows_in;
+      r = e % d.rows_in;
+    } else {
+      r = e / d.cols_out;
+      c = e % d.cols_out;
+    }
+    const float v = params[d.src_off + (int64_t)r * d.cols_out + c];
+    const int64_t o = d.transpose ? d.dst_off + (int64_t)(d.row0 + c) * d.ld + d.col0 + r
+                                  : d.dst_off + (int64_t)(d.row0 + r) * d.ld + d.col0 + c;
+    dst[o] = (bf16)v;
+  }
+}
+
+extern "C" int mnr_pack_weights_bf16(const float* params, const mnr_pack_desc* descs_device, int n_desc,
+                                     int max_elems, uint16_t* dst, void* stream) {
+  MNR_CHECK_ARG(params && descs_device && dst && n_desc > 0 && max_elems > 0, "mnr_pack_weights_bf16: bad arguments");
+  int gx = mnr_cdiv(max_elems, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(gx, n_desc), dim3(256), 0, (hipStream_t)stream, params,
+                     descs_device, (bf16*)dst);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+__global__ void scatter_add_kernel(const float* __restrict__ src, int ld_src, int row0, int col0, int rows,
+                                   int cols, float* __restrict__ dst, int ld_dst) {
+  const int total = rows * cols;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int k = e / cols, c = e % cols;
+    dst[(int64_t)k * ld_dst + c] += src[(int64_t)(row0 + k) * ld_src + col0 + c];
+  }
+}
+
+extern "C" int mnr_scatter_add_f32(const float* src, int ld_src, int row0, int col0, int rows, int cols,
+                                   float* dst, int ld_dst, void* stream) {
+  MNR_CHECK_ARG(src && dst && rows > 0 && cols > 0, "mnr_scatter_add_f32: bad arguments");
+  int grid = mnr_cdiv((long long)rows * cols, 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(scatter_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, ld_src, row0,
+                     col0, rows, cols, dst, ld_dst);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, int ld_src, int64_t M, int n,
+                                     bf16* __restrict__ dst, int ld_dst, int col0) {
+  const int64_t total = M * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / n;
+    const int c = (int)(e % n);
+    dst[r * ld_dst + col0 + c] = (bf16)src[r * ld_src + c];
+  }
+}
+
+extern "C" int mnr_cast_f32_to_bf16(const float* src, int ld_src, int64_t M, int n, uint16_t* dst, int ld_dst,
+                                    int col0, void* stream) {
+  MNR_CHECK_ARG(src && dst && M > 0 && n > 0, "mnr_cast_f32_to_bf16: bad arguments");
+  int grid = mnr_cdiv(M * n, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, ld_src, M, n,
+                     (bf16*)dst, ld_dst, col0);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Small-N head VJP (e.g. rgb Dense(3)): dX = relu'(H) * (g W^T), dW += H^T g, db += sum g.
+
+__global__ __launch_bounds__(256) void small_head_bwd_kernel(int64_t M, int K, int C, const bf16* __restrict__ H,
+                                                              int ldh, const float* __restrict__ g,
+                                                              const float* __restrict__ W, bf16* __restrict__ dX,
+                                                              int lddx, int relu_mask, float* dW, float* db,
+                                                              int rows_per_block) {
+  // Thread t owns columns k = t, t+256, ... ; loops over the block's rows.
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(M, r0 + rows_per_block);
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float w[4], aw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      w[c] = (c < C) ? W[(int64_t)k * C + c] : 0.0f;
+      aw[c] = 0.0f;
+    }
+    for (int64_t r = r0; r < r1; ++r) {
+      const float h = (float)H[r * ldh + k];
+      float gx = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < C) {
+          const float gc = g[r * C + c];
+          gx += gc * w[c];
+          aw[c] += h * gc;
+        }
+      }
+      if (dX) dX[r * lddx + k] = (bf16)((relu_mask && !(h > 0.0f)) ? 0.0f : gx);
+    }
+    if (dW)
+      for (int c = 0; c < C; ++c) unsafeAtomicAdd(dW + (int64_t)k * C + c, aw[c]);
+  }
+  if (db && threadIdx.x < C) {
+    float s = 0.0f;
+    for (int64_t r = r0; r < r1; ++r) s += g[r * C + threadIdx.x];
+    unsafeAtomicAdd(db + threadIdx.x, s);
+  }
+}
+
+extern "C" int mnr_small_head_bwd(int64_t M, int K, int C, const uint16_t* H, int ldh, const float* g,
+                                  const float* W, uint16_t* dX, int lddx, int apply_relu_mask, float* dW,
+                                  float* db, void* stream) {
+  MNR_CHECK_ARG(M > 0 && K > 0 && C >= 1 && C <= 4 && H && g && W, "mnr_small_head_bwd: bad arguments (1 <= C <= 4)");
+  const int rows_per_block = 128;
+  const int grid = mnr_cdiv(M, rows_per_block);
+  hipLaunchKernelGGL(small_head_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, C,
+                     (const bf16*)H, ldh, g, W, (bf16*)dX, lddx, apply_relu_mask, dW, db, rows_per_block);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}

@@ -1,0 +1,335 @@
+// Alpha compositing along rays, forward and VJP (gfx950).
+//
+// Replaces the head activations (models.py:506, 584-602), RawNeRF exposure
+// scaling (models.py:257-267), render.compute_alpha_weights (render.py:130-151)
+// and render.volumetric_rendering (render.py:154-213).  The reference runs these
+// as whole-batch tensor ops with an exclusive cumsum; here one lane owns one ray
+// and the scan stays in registers: a forward running sum of density*delta and, in
+// the VJP, one reverse running sum (formulas: SURVEY.md Appendix A "Backward").
+// A workgroup's rows are staged through LDS so that global loads/stores are
+// coalesced although each lane walks its own row.
+#include "common.h"
+
+#define CP_THREADS 64
+
+__device__ __forceinline__ float cp_act(int kind, float x) {
+  switch (kind) {
+    case MNR_ACT_SIGMOID: return mnr_sigmoid(x);
+    case MNR_ACT_SAFE_EXP: return expf(fminf(x, 88.0f));     // math.py:41-44
+    case MNR_ACT_SOFTPLUS: return mnr_softplus(x);
+    case MNR_ACT_EXP: return expf(x);
+    case MNR_ACT_RELU: return fmaxf(x, 0.0f);
+    default: return x;
+  }
+}
+
+// d act(x) / dx given x and y = act(x).
+__device__ __forceinline__ float cp_act_grad(int kind, float x, float y) {
+  switch (kind) {
+    case MNR_ACT_SIGMOID: return y * (1.0f - y);
+    case MNR_ACT_SAFE_EXP: return y;                          // math.py:47-54 custom JVP
+    case MNR_ACT_SOFTPLUS: return mnr_sigmoid(x);
+    case MNR_ACT_EXP: return y;
+    case MNR_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+    default: return 1.0f;
+  }
+}
+
+// Stage `rows` rows of `len` floats (contiguous in HBM from `src`) into LDS as [elem][ray].
+__device__ __forceinline__ void cp_load_rows(float* lds, const float* src, int rows, int len, int stride) {
+  for (int e = threadIdx.x; e < rows * len; e += CP_THREADS) {
+    const int r = e / len, i = e % len;
+    lds[i * stride + r] = src[e];
+  }
+}
+
+__device__ __forceinline__ void cp_store_rows(const float* lds, float* dst, int rows, int len, int stride) {
+  for (int e = threadIdx.x; e < rows * len; e += CP_THREADS) {
+    const int r = e / len, i = e % len;
+    dst[e] = lds[i * stride + r];
+  }
+}
+
+// LDS plan (floats per ray): raw density n | tdist n+1 | raw rgb 3n | weights n (out) | rgb 3n (out)
+__global__ __launch_bounds__(CP_THREADS) void composite_fwd_kernel(
+    mnr_composite_cfg c, int64_t B, int S, const float* __restrict__ raw_density, const float* __restrict__ noise,
+    const float* __restrict__ raw_rgb, const float* __restrict__ tdist, const float* __restrict__ dirs,
+    const float* __restrict__ bg, const float* __restrict__ expo, float* __restrict__ density,
+    float* __restrict__ rgb, float* __restrict__ weights, float* __restrict__ rgb_out, float* __restrict__ acc_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n = c.n;
+  float* l_den = lds;                       // n  (raw in, activated out)
+  float* l_t = l_den + n * S;               // n+1
+  float* l_w = l_t + (n + 1) * S;           // n
+  float* l_rgb = l_w + n * S;               // 3n (raw in, activated out)
+  const int64_t ray0 = (int64_t)blockIdx.x * S;
+  const int rows = (int)min((int64_t)S, B - ray0);
+  cp_load_rows(l_den, raw_density + ray0 * n, rows, n, S);
+  cp_load_rows(l_t, tdist + ray0 * (n + 1), rows, n + 1, S);
+  if (c.has_rgb) cp_load_rows(l_rgb, raw_rgb + ray0 * n * 3, rows, 3 * n, S);
+  if (noise && c.density_noise_std > 0.0f) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * n; e += CP_THREADS) {
+      const int r = e / n, i = e % n;
+      l_den[i * S + r] += c.density_noise_std * noise[ray0 * n + e];     // models.py:462-464
+    }
+  }
+  __syncthreads();
+  const int r = threadIdx.x;
+  if (r < rows) {
+    const int64_t ray = ray0 + r;
+    const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    float ex[3] = {1.0f, 1.0f, 1.0f};
+    if (expo) { ex[0] = expo[ray * 3]; ex[1] = expo[ray * 3 + 1]; ex[2] = expo[ray * 3 + 2]; }
+    float run = 0.0f, acc = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    for (int i = 0; i < n; ++i) {
+      const float sigma = cp_act(c.density_act, l_den[i * S + r] + c.density_bias);   // models.py:506
+      l_den[i * S + r] = sigma;
+      const float delta = (l_t[(i + 1) * S + r] - l_t[i * S + r]) * dnorm;           // render.py:132-133
+      float x = sigma * delta;
+      if (c.opaque_background && i == n - 1) x = INFINITY;                            // render.py:136-142
+      const float alpha = 1.0f - expf(-x);
+      const float trans = expf(-run);
+      const float w = alpha * trans;
+      run += x;
+      l_w[i * S + r] = w;
+      acc += w;
+      if (c.has_rgb) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          // models.py:584-586, 602, then exposure scaling :257-267.
+          float v = cp_act(c.rgb_act, c.rgb_premultiplier * l_rgb[(3 * i + ch) * S + r] + c.rgb_bias);
+          v = v * (1.0f + 2.0f * c.rgb_padding) - c.rgb_padding;
+          v *= ex[ch];
+          l_rgb[(3 * i + ch) * S + r] = v;
+          if (ch == 0) cr += w * v; else if (ch == 1) cg += w * v; else cb += w * v;
+        }
+      }
+    }
+    const float bgw = fmaxf(0.0f, 1.0f - acc);                                         // render.py:180
+    float b0 = c.bg_value, b1 = c.bg_value, b2 = c.bg_value;
+    if (c.bg_mode == 1) { b0 = bg[ray * 3]; b1 = bg[ray * 3 + 1]; b2 = bg[ray * 3 + 2]; }
+    rgb_out[ray * 3 + 0] = cr + bgw * b0;                                              // render.py:181
+    rgb_out[ray * 3 + 1] = cg + bgw * b1;
+    rgb_out[ray * 3 + 2] = cb + bgw * b2;
+    if (acc_out) acc_out[ray] = acc;
+  }
+  __syncthreads();
+  cp_store_rows(l_den, density + ray0 * n, rows, n, S);
+  cp_store_rows(l_w, weights + ray0 * n, rows, n, S);
+  if (c.has_rgb && rgb) cp_store_rows(l_rgb, rgb + ray0 * n * 3, rows, 3 * n, S);
+}
+
+// Rays per block: 64 if the staging fits in LDS, else halved until it does.
+static int cp_rays_per_block(int n) {
+  int s = CP_THREADS;
+  while (s > 1 && (size_t)(6 * n + 1) * s * 4 > 150 * 1024) s >>= 1;
+  return s;
+}
+static size_t cp_lds_bytes(int n, int s) { return (size_t)(6 * n + 1) * s * 4; }
+
+extern "C" int mnr_composite_fwd(const mnr_composite_cfg* cfg, int64_t B, const float* raw_density,
+                                 const float* density_noise, const float* raw_rgb, const float* tdist,
+                                 const float* dirs, const float* bg, const float* exposure_scale, float* density,
+                                 float* rgb, float* weights, float* rgb_out, float* acc, void* stream) {
+  MNR_CHECK_ARG(cfg && B > 0 && raw_density && tdist && dirs && density && weights && rgb_out,
+                "mnr_composite_fwd: null argument");
+  MNR_CHECK_ARG(cfg->n >= 1 && cfg->n <= 1024, "mnr_composite_fwd: n out of range");
+  MNR_CHECK_ARG(!cfg->has_rgb || raw_rgb, "mnr_composite_fwd: has_rgb needs raw_rgb");
+  MNR_CHECK_ARG(cfg->bg_mode == 0 || bg, "mnr_composite_fwd: bg_mode 1 needs bg");
+  const int S = cp_rays_per_block(cfg->n);
+  const size_t lds = cp_lds_bytes(cfg->n, S);
+  MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_composite_fwd: n=%d too long for LDS staging", cfg->n);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)composite_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(composite_fwd_kernel, dim3(mnr_cdiv(B, S)), dim3(CP_THREADS), lds, (hipStream_t)stream,
+                     *cfg, B, S, raw_density, density_noise, raw_rgb, tdist, dirs, bg, exposure_scale, density, rgb,
+                     weights, rgb_out, acc);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// VJP.  With x_i = sigma_i * delta_i, T_i = exp(-sum_{k<i} x_k), w_i = (1 - exp(-x_i)) T_i:
+//   g^_i = g_w[i] + g_rgb . c_i - [acc < 1] (g_rgb . bg)
+//   dL/dx_i = g^_i (T_i - w_i) - sum_{k>i} g^_k w_k ;  dL/dsigma_i = delta_i dL/dx_i ; dL/dc_i = w_i g_rgb.
+__global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
+    mnr_composite_cfg c, int64_t B, int S, const float* __restrict__ raw_density, const float* __restrict__ noise,
+    const float* __restrict__ raw_rgb, const float* __restrict__ tdist, const float* __restrict__ dirs,
+    const float* __restrict__ bg, const float* __restrict__ expo, const float* __restrict__ weights,
+    const float* __restrict__ g_rgb_out, const float* __restrict__ g_weights, float* __restrict__ g_raw_density,
+    bf16* __restrict__ g_den_bf16, int ld_bf16, float* __restrict__ g_raw_rgb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n = c.n;
+  float* l_den = lds;                       // n   raw density in, g_raw_density out
+  float* l_t = l_den + n * S;               // n+1
+  float* l_w = l_t + (n + 1) * S;           // n   weights in (g_weights added on the fly from HBM)
+  float* l_rgb = l_w + n * S;               // 3n  raw rgb in, g_raw_rgb out
+  const int64_t ray0 = (int64_t)blockIdx.x * S;
+  const int rows = (int)min((int64_t)S, B - ray0);
+  cp_load_rows(l_den, raw_density + ray0 * n, rows, n, S);
+  cp_load_rows(l_t, tdist + ray0 * (n + 1), rows, n + 1, S);
+  cp_load_rows(l_w, weights + ray0 * n, rows, n, S);
+  if (c.has_rgb) cp_load_rows(l_rgb, raw_rgb + ray0 * n * 3, rows, 3 * n, S);
+  if (noise && c.density_noise_std > 0.0f) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * n; e += CP_THREADS) {
+      const int r = e / n, i = e % n;
+      l_den[i * S + r] += c.density_noise_std * noise[ray0 * n + e];
+    }
+  }
+  __syncthreads();
+  const int r = threadIdx.x;
+  if (r < rows) {
+    const int64_t ray = ray0 + r;
+    const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    float ex[3] = {1.0f, 1.0f, 1.0f};
+    if (expo) { ex[0] = expo[ray * 3]; ex[1] = expo[ray * 3 + 1]; ex[2] = expo[ray * 3 + 2]; }
+    float go[3] = {0.0f, 0.0f, 0.0f};
+    if (g_rgb_out) { go[0] = g_rgb_out[ray * 3]; go[1] = g_rgb_out[ray * 3 + 1]; go[2] = g_rgb_out[ray * 3 + 2]; }
+    float b[3] = {c.bg_value, c.bg_value, c.bg_value};
+    if (c.bg_mode == 1) { b[0] = bg[ray * 3]; b[1] = bg[ray * 3 + 1]; b[2] = bg[ray * 3 + 2]; }
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) acc += l_w[i * S + r];
+    const float g_bgw = (1.0f - acc > 0.0f) ? (go[0] * b[0] + go[1] * b[1] + go[2] * b[2]) : 0.0f;
+    // Exclusive prefix of x at the last sample, then walk backwards:
+    // run_i = sum_{k<i} x_k, T_i = exp(-run_i), T_{i+1} = exp(-(run_i + x_i)).
+    float run = 0.0f;
+    for (int i = 0; i + 1 < n; ++i) {
+      const float sigma = cp_act(c.density_act, l_den[i * S + r] + c.density_bias);
+      run += sigma * (l_t[(i + 1) * S + r] - l_t[i * S + r]) * dnorm;
+    }
+    float suffix = 0.0f;                    // sum_{k>i} g^_k w_k
+    for (int i = n - 1; i >= 0; --i) {
+      const float w = l_w[i * S + r];
+      const float raw = l_den[i * S + r] + c.density_bias;
+      const float sigma = cp_act(c.density_act, raw);
+      const float delta = (l_t[(i + 1) * S + r] - l_t[i * S + r]) * dnorm;
+      const bool opaque_last = c.opaque_background && i == n - 1;
+      const float x = opaque_last ? INFINITY : sigma * delta;
+      const float t_next = expf(-(run + x));              // T_{i+1} = T_i - w_i
+      float ghat = g_weights ? g_weights[ray * n + i] : 0.0f;
+      ghat -= g_bgw;
+      float gc[3] = {0.0f, 0.0f, 0.0f};
+      if (c.has_rgb) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float z = c.rgb_premultiplier * l_rgb[(3 * i + ch) * S + r] + c.rgb_bias;
+          const float y = cp_act(c.rgb_act, z);
+          const float col = (y * (1.0f + 2.0f * c.rgb_padding) - c.rgb_padding) * ex[ch];
+          ghat += go[ch] * col;
+          // d col / d raw = ex * (1+2pad) * act'(z) * premult
+          gc[ch] = w * go[ch] * ex[ch] * (1.0f + 2.0f * c.rgb_padding) * cp_act_grad(c.rgb_act, z, y) *
+                   c.rgb_premultiplier;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) l_rgb[(3 * i + ch) * S + r] = gc[ch];
+      }
+      float gx = ghat * t_next - suffix;
+      if (opaque_last) gx = 0.0f;           // x = +inf is a constant
+      suffix += ghat * w;
+      l_den[i * S + r] = gx * delta * cp_act_grad(c.density_act, raw, sigma);
+      if (i > 0) {
+        const float sp = cp_act(c.density_act, l_den[(i - 1) * S + r] + c.density_bias);
+        run -= sp * (l_t[i * S + r] - l_t[(i - 1) * S + r]) * dnorm;
+      }
+    }
+  }
+  __syncthreads();
+  if (g_raw_density) cp_store_rows(l_den, g_raw_density + ray0 * n, rows, n, S);
+  if (g_den_bf16) {
+    for (int e = threadIdx.x; e < rows * n; e += CP_THREADS) {
+      const int rr = e / n, i = e % n;
+      g_den_bf16[(ray0 * n + e) * (int64_t)ld_bf16] = (bf16)l_den[i * S + rr];
+    }
+  }
+  if (c.has_rgb && g_raw_rgb) cp_store_rows(l_rgb, g_raw_rgb + ray0 * n * 3, rows, 3 * n, S);
+}
+
+extern "C" int mnr_composite_bwd(const mnr_composite_cfg* cfg, int64_t B, const float* raw_density,
+                                 const float* density_noise, const float* raw_rgb, const float* tdist,
+                                 const float* dirs, const float* bg, const float* exposure_scale,
+                                 const float* weights, const float* g_rgb_out, const float* g_weights,
+                                 float* g_raw_density, uint16_t* g_raw_density_bf16, int ld_bf16,
+                                 float* g_raw_rgb, void* stream) {
+  MNR_CHECK_ARG(cfg && B > 0 && raw_density && tdist && dirs && weights, "mnr_composite_bwd: null argument");
+  MNR_CHECK_ARG(g_raw_density || g_raw_density_bf16, "mnr_composite_bwd: no density-gradient output");
+  MNR_CHECK_ARG(!cfg->has_rgb || raw_rgb, "mnr_composite_bwd: has_rgb needs raw_rgb");
+  MNR_CHECK_ARG(cfg->bg_mode == 0 || bg, "mnr_composite_bwd: bg_mode 1 needs bg");
+  const int S = cp_rays_per_block(cfg->n);
+  const size_t lds = cp_lds_bytes(cfg->n, S);
+  MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_composite_bwd: n=%d too long for LDS staging", cfg->n);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)composite_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(mnr_cdiv(B, S)), dim3(CP_THREADS), lds, (hipStream_t)stream,
+                     *cfg, B, S, raw_density, density_noise, raw_rgb, tdist, dirs, bg, exposure_scale, weights,
+                     g_rgb_out, g_weights, g_raw_density, (bf16*)g_raw_density_bf16, ld_bf16, g_raw_rgb);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// compute_extras outputs (render.py:184-211): distance_mean and the 5/50/95 percentiles.
+
+__global__ void render_extras_kernel(int64_t B, int n, const float* __restrict__ weights,
+                                     const float* __restrict__ tdist, const float* __restrict__ t_far,
+                                     float* __restrict__ out) {
+  const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= B) return;
+  const float* w = weights + ray * n;
+  const float* t = tdist + ray * (n + 1);
+  float acc = 0.0f, e = 0.0f;
+  for (int i = 0; i < n; ++i) {
+    acc += w[i];
+    e += w[i] * logf(0.5f * (t[i] + t[i + 1]));              // render.py:192-197
+  }
+  float dm = expf(e / fmaxf(MNR_F32_EPS, acc));
+  if (dm != dm) dm = INFINITY;                                // nan_to_num(.., inf)
+  dm = fminf(fmaxf(dm, t[0]), t[n]);
+  out[ray * 4 + 0] = dm;
+  // stepfun.weighted_percentile on (t_aug = [tdist, t_far], w_aug = [w, bg_w]) (render.py:203-207,
+  // stepfun.py:298-308): np.interp of p/100 into cw = [0, min(1, cumsum(w_aug[:-1])), 1].
+  const float ps[3] = {0.05f, 0.5f, 0.95f};
+  const int nb = n + 1;                                       // bins of the augmented histogram
+  const float far = t_far[ray];
+  for (int q = 0; q < 3; ++q) {
+    const float p = ps[q];
+    float run = 0.0f, cw_lo = 0.0f;
+    float res = far;
+    bool found = false;
+    for (int k = 0; k < nb && !found; ++k) {
+      // fence-post k has cw_lo; fence-post k+1 has cw_hi.
+      float cw_hi;
+      if (k == nb - 1) cw_hi = 1.0f;
+      else { run += w[k]; cw_hi = fminf(1.0f, run); }
+      const float t_lo = t[k];
+      const float t_hi = (k + 1 <= n) ? t[k + 1] : far;
+      if (p < cw_hi || k == nb - 1) {
+        // np.interp: last segment [cw_lo, cw_hi] with cw_lo <= p < cw_hi (ties resolve to the
+        // right-most duplicate, as searchsorted(side='right') - 1 does).
+        const float d = cw_hi - cw_lo;
+        res = d > 0.0f ? t_lo + (p - cw_lo) / d * (t_hi - t_lo) : t_lo;
+        if (p >= 1.0f) res = far;
+        found = true;
+      }
+      cw_lo = cw_hi;
+    }
+    out[ray * 4 + 1 + q] = res;
+  }
+}
+
+extern "C" int mnr_render_extras(int64_t B, int n, const float* weights, const float* tdist, const float* t_far,
+                                 float* out, void* stream) {
+  MNR_CHECK_ARG(B > 0 && n > 0 && weights && tdist && t_far && out, "mnr_render_extras: bad arguments");
+  hipLaunchKernelGGL(render_extras_kernel, dim3(mnr_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, B, n, weights,
+                     tdist, t_far, out);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}

@@ -1,0 +1,845 @@
+"""Model / MLP host layer: the reference's Python surface over the HIP kernels.
+
+Mirrors reference internal/models.py: `Model` (models.py:47-312), `MLP` /
+`NerfMLP` / `PropMLP` (models.py:341-622) with the same gin-configurable
+hyper-parameter names and defaults, `construct_model` (models.py:315-338) and
+`render_image` (models.py:625-706).  The bodies do not contain arithmetic: the
+level loop enqueues kernels of libmnerf_hip.so (include/mnerf.h) on the current
+HIP stream and keeps every intermediate in device memory.
+
+Parameters live in ONE flat fp32 device vector (the buffer RCCL all-reduces and
+the fused clip+Adam kernel streams); `variables['params']` is a nested dict of
+views into it with flax's names ('NerfMLP_0'/'Dense_3'/'kernel' [in,out]).
+"""
+
+import ctypes as C
+import dataclasses
+import math
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from multinerf_amd import _lib as L
+from multinerf_amd import configs
+from multinerf_amd import geopoly
+from multinerf_amd import gin
+from multinerf_amd import ops
+from multinerf_amd import utils
+
+F32_EPS = float(np.finfo(np.float32).eps)
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+def _rup(x, m):
+  return (x + m - 1) // m * m
+
+
+# =============================================================================
+# Hyper-parameters (gin surface).
+
+
+@dataclasses.dataclass
+class MLP:
+  """A PosEnc MLP (fields/defaults: reference models.py:343-379)."""
+  net_depth: int = 8
+  net_width: int = 256
+  bottleneck_width: int = 256
+  net_depth_viewdirs: int = 1
+  net_width_viewdirs: int = 128
+  net_activation: str = 'relu'
+  min_deg_point: int = 0
+  max_deg_point: int = 12
+  weight_init: str = 'he_uniform'
+  skip_layer: int = 4
+  skip_layer_dir: int = 4
+  num_rgb_channels: int = 3
+  deg_view: int = 4
+  use_reflections: bool = False
+  use_directional_enc: bool = False
+  enable_pred_roughness: bool = False
+  roughness_activation: str = 'softplus'
+  roughness_bias: float = -1.
+  use_diffuse_color: bool = False
+  use_specular_tint: bool = False
+  use_n_dot_v: bool = False
+  bottleneck_noise: float = 0.0
+  density_activation: str = 'softplus'
+  density_bias: float = -1.
+  density_noise: float = 0.
+  rgb_premultiplier: float = 1.
+  rgb_activation: str = 'sigmoid'
+  rgb_bias: float = 0.
+  rgb_padding: float = 0.001
+  enable_pred_normals: bool = False
+  disable_density_normals: bool = False
+  disable_rgb: bool = False
+  warp_fn: Optional[str] = None
+  basis_shape: str = 'icosahedron'
+  basis_subdivisions: int = 2
+
+  def setup_checks(self):
+    """models.py:381-385."""
+    if self.use_reflections and not (self.enable_pred_normals or not self.disable_density_normals):
+      raise ValueError('Normals must be computed for reflection directions.')
+
+  def hip_supported(self):
+    """Which reference features the HIP path implements in this round (scope)."""
+    bad = []
+    if not self.disable_density_normals:
+      bad.append('density-gradient normals (disable_density_normals=False)')
+    for f in ('enable_pred_normals', 'use_reflections', 'use_directional_enc', 'enable_pred_roughness',
+              'use_diffuse_color', 'use_specular_tint', 'use_n_dot_v'):
+      if getattr(self, f):
+        bad.append(f)
+    if self.bottleneck_noise > 0:
+      bad.append('bottleneck_noise')
+    if self.net_activation != 'relu':
+      bad.append(f'net_activation={self.net_activation}')
+    if self.warp_fn not in (None, 'contract'):
+      bad.append(f'warp_fn={self.warp_fn}')
+    if self.net_width % 128 != 0:
+      bad.append('net_width not a multiple of 128')
+    if not self.disable_rgb and (self.bottleneck_width <= 0 or self.bottleneck_width % 64 != 0):
+      bad.append('bottleneck_width must be a positive multiple of 64')
+    if not self.disable_rgb and self.net_width_viewdirs % 128 != 0:
+      bad.append('net_width_viewdirs not a multiple of 128')
+    if self.num_rgb_channels != 3:
+      bad.append('num_rgb_channels != 3')
+    return bad
+
+
+@gin.configurable
+@dataclasses.dataclass
+class NerfMLP(MLP):
+  pass
+
+
+@gin.configurable
+@dataclasses.dataclass
+class PropMLP(MLP):
+  pass
+
+
+# =============================================================================
+# Static plan of one MLP: layer shapes, parameter offsets, packed bf16 operand layout.
+
+
+@dataclasses.dataclass
+class DenseSpec:
+  name: str            # 'Dense_k'
+  fan_in: int
+  fan_out: int
+  kernel_off: int = 0  # offsets into the flat fp32 parameter vector
+  bias_off: int = 0
+
+
+class MLPPlan:
+  """Everything about one MLP that does not depend on the batch."""
+
+  def __init__(self, hp: MLP, module_name: str, use_viewdirs: bool, num_glo_features: int, param_base: int):
+    hp.setup_checks()
+    self.hp = hp
+    self.module_name = module_name
+    self.basis = geopoly.generate_basis(hp.basis_shape, hp.basis_subdivisions)   # [K,3]
+    self.K = self.basis.shape[0]
+    self.L = hp.max_deg_point - hp.min_deg_point
+    self.F = 2 * self.K * self.L
+    self.ldF = _rup(self.F, 128)
+    self.W = hp.net_width
+    self.has_rgb = (not hp.disable_rgb)
+    self.use_viewdirs = use_viewdirs and self.has_rgb
+    self.dense: List[DenseSpec] = []
+    k = 0
+
+    def add(fi, fo):
+      nonlocal k
+      d = DenseSpec(f'Dense_{k}', fi, fo)
+      k += 1
+      self.dense.append(d)
+      return d
+
+    # trunk (models.py:455-459)
+    self.trunk: List[Tuple[DenseSpec, bool]] = []   # (spec, input_is_concat_with_features)
+    width, concat = self.F, False
+    first = True
+    for i in range(hp.net_depth):
+      fan_in = self.F if first else (self.W + (self.F if concat else 0))
+      self.trunk.append((add(fan_in, self.W), (not first) and concat))
+      first = False
+      concat = (i % hp.skip_layer == 0 and i > 0)
+    self.x_concat = concat                     # trunk output carries the features too (depth ending on a skip)
+    self.x_width = self.W + (self.F if concat else 0)
+    self.density = add(self.x_width, 1)        # models.py:460
+    self.view: List[Tuple[DenseSpec, bool]] = []
+    self.bottleneck = None
+    self.rgb = None
+    if self.has_rgb:
+      if self.use_viewdirs:
+        self.bottleneck = add(self.x_width, hp.bottleneck_width)     # models.py:527
+        self.dir_enc_dim = 3 + 2 * 3 * hp.deg_view                   # coord.pos_enc, append_identity
+        self.vi_width = hp.bottleneck_width + self.dir_enc_dim + num_glo_features
+        self.ldVI = _rup(self.vi_width, 128)
+        WV = hp.net_width_viewdirs
+        concat, first = False, True
+        for i in range(hp.net_depth_viewdirs):                       # models.py:576-580
+          fan_in = self.vi_width if first else (WV + (self.vi_width if concat else 0))
+          self.view.append((add(fan_in, WV), (not first) and concat))
+          first = False
+          concat = (i % hp.skip_layer_dir == 0 and i > 0)
+        self.v_concat = concat
+        rgb_in = WV + (self.vi_width if concat else 0)
+        if hp.net_depth_viewdirs == 0:
+          rgb_in = self.vi_width
+      else:
+        rgb_in = self.x_width
+      self.rgb = add(rgb_in, hp.num_rgb_channels)                    # models.py:585
+    # flat parameter offsets: kernel then bias, Dense_k in creation order
+    off = param_base
+    for d in self.dense:
+      d.kernel_off = off
+      off += d.fan_in * d.fan_out
+      d.bias_off = off
+      off += d.fan_out
+    self.param_begin, self.param_end = param_base, off
+
+  @property
+  def num_params(self):
+    return self.param_end - self.param_begin
+
+
+# =============================================================================
+# Model.
+
+
+@gin.configurable
+@dataclasses.dataclass
+class Model:
+  """A mip-NeRF 360 model containing all MLPs (fields/defaults: reference models.py:50-72)."""
+  config: Any = None
+  num_prop_samples: int = 64
+  num_nerf_samples: int = 32
+  num_levels: int = 3
+  bg_intensity_range: Tuple[float, float] = (1., 1.)
+  anneal_slope: float = 10
+  stop_level_grad: bool = True
+  use_viewdirs: bool = True
+  raydist_fn: Optional[str] = None
+  ray_shape: str = 'cone'
+  disable_integration: bool = False
+  single_jitter: bool = True
+  dilation_multiplier: float = 0.5
+  dilation_bias: float = 0.0025
+  num_glo_features: int = 0
+  num_glo_embeddings: int = 1000
+  learned_exposure_scaling: bool = False
+  near_anneal_rate: Optional[float] = None
+  near_anneal_init: float = 0.95
+  single_mlp: bool = False
+  resample_padding: float = 0.0
+  use_gpu_resampling: bool = False
+  opaque_background: bool = False
+
+  # ------------------------------------------------------------------ construction
+
+  def __post_init__(self):
+    self.nerf_hp = NerfMLP()
+    self.prop_hp = self.nerf_hp if self.single_mlp else PropMLP()
+    self._built = False
+
+  def hip_supported(self):
+    bad = []
+    for name, hp in (('NerfMLP', self.nerf_hp), ('PropMLP', self.prop_hp)):
+      bad += [f'{name}: {b}' for b in hp.hip_supported()]
+    if not self.stop_level_grad:
+      bad.append('stop_level_grad=False')
+    if self.num_glo_features > 0:
+      bad.append('GLO vectors (num_glo_features > 0)')
+    if self.learned_exposure_scaling:
+      bad.append('learned_exposure_scaling (RawNeRF)')
+    if self.ray_shape not in ('cone', 'cylinder'):
+      raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')
+    if self.raydist_fn not in L.RAYDIST:
+      bad.append(f'raydist_fn={self.raydist_fn}')
+    if self.num_prop_samples % 32 or self.num_nerf_samples % 32:
+      bad.append('sample counts must be multiples of 32')
+    return bad
+
+  def build(self, device='cuda'):
+    """Lay out parameters and device-side constant tables (flax `init` without the RNG part)."""
+    bad = self.hip_supported()
+    if bad:
+      raise NotImplementedError('not yet implemented on the HIP path: ' + '; '.join(bad))
+    self.device = torch.device(device)
+    self.nerf_plan = MLPPlan(self.nerf_hp, 'NerfMLP_0', self.use_viewdirs, self.num_glo_features, 0)
+    if self.single_mlp:
+      self.prop_plan = self.nerf_plan
+      end = self.nerf_plan.param_end
+    else:
+      self.prop_plan = MLPPlan(self.prop_hp, 'PropMLP_0', self.use_viewdirs, 0, self.nerf_plan.param_end)
+      end = self.prop_plan.param_end
+    self.num_params = end
+    self.modules = [(self.nerf_plan.module_name, self.nerf_plan.param_begin, self.nerf_plan.param_end)]
+    if not self.single_mlp:
+      self.modules.append((self.prop_plan.module_name, self.prop_plan.param_begin, self.prop_plan.param_end))
+    self._plans = [self.nerf_plan] + ([] if self.single_mlp else [self.prop_plan])
+    for p in self._plans:
+      p.basis_dev = torch.as_tensor(p.basis, dtype=f32, device=self.device).contiguous()
+      self._layout_packed(p)
+    self._ws: Dict[Any, torch.Tensor] = {}
+    self._built = True
+    return self
+
+  # Packed bf16 operands ------------------------------------------------------------
+  #
+  # For every Dense two bf16 images are kept, both zero-padded to the GEMM tile grid:
+  #   'f' (forward):  Bt[N_pad][K_pad] = kernel^T, K segments padded separately ([W | ldF])
+  #   'b' (backward): kernel[in_rows_pad][out_pad] as stored by flax (rows = dX outputs)
+  # The NeRF head (bottleneck + density) is merged into one operand pair so that x7 is read once.
+
+  def _layout_packed(self, p: MLPPlan):
+    descs: List[L.PackDesc] = []
+    off = 0
+    p.packed = {}
+
+    def alloc(rows, cols):
+      nonlocal off
+      o = off
+      off += rows * cols
+      return o
+
+    def seg_cols(concat, base_w, base_ld, feat=True):
+      """Column layout of an input that is [x (base_w, padded to base_ld) | features (F -> ldF)]."""
+      return base_ld + (p.ldF if concat else 0)
+
+    def pack_layer(key, d: DenseSpec, in_segments, n_pad):
+      """in_segments: list of (first kernel row, rows, first padded K column, padded width): where each
+      block of kernel rows lands among the padded K columns of the operand."""
+      kpad = max(s[2] + s[3] for s in in_segments)
+      fo = alloc(n_pad, kpad)                 # forward operand [n_pad][kpad]
+      for (r0, rows, c0, _) in in_segments:
+        descs.append(L.PackDesc(d.kernel_off + r0 * d.fan_out, rows, d.fan_out, fo, kpad, 0, c0, 1))
+      p.packed[key] = dict(f_off=fo, f_ld=kpad, n_pad=n_pad, kpad=kpad)
+      return p.packed[key]
+
+    # trunk
+    for i, (d, concat) in enumerate(p.trunk):
+      if i == 0:
+        segs = [(0, p.F, 0, p.ldF)]
+      elif concat:
+        segs = [(0, p.W, 0, p.W), (p.W, p.F, p.W, p.ldF)]
+      else:
+        segs = [(0, p.W, 0, p.W)]
+      e = pack_layer(('trunk', i), d, segs, _rup(d.fan_out, 128))
+      if i > 0:
+        # backward operand for dX_{i-1}: kernel rows [0, W) as [W][out_pad]
+        bo = alloc(_rup(p.W, 128), _rup(d.fan_out, 64))
+        descs.append(L.PackDesc(d.kernel_off, p.W, d.fan_out, bo, _rup(d.fan_out, 64), 0, 0, 0))
+        e.update(b_off=bo, b_ld=_rup(d.fan_out, 64))
+    assert not p.x_concat, 'net_depth ending on a skip layer is not supported on the HIP path'
+    # heads
+    if p.has_rgb and p.use_viewdirs:
+      bw = p.hp.bottleneck_width
+      nh = _rup(bw + 1, 128)
+      fo = alloc(nh, p.W)                                       # merged head fwd: rows [0,bw) bottleneck, row bw density
+      descs.append(L.PackDesc(p.bottleneck.kernel_off, p.W, bw, fo, p.W, 0, 0, 1))
+      descs.append(L.PackDesc(p.density.kernel_off, p.W, 1, fo, p.W, bw, 0, 1))
+      bo = alloc(_rup(p.W, 128), nh)                            # merged head bwd: [W][nh]
+      descs.append(L.PackDesc(p.bottleneck.kernel_off, p.W, bw, bo, nh, 0, 0, 0))
+      descs.append(L.PackDesc(p.density.kernel_off, p.W, 1, bo, nh, 0, bw, 0))
+      p.packed['head'] = dict(f_off=fo, f_ld=p.W, n_pad=nh, b_off=bo, b_ld=nh)
+      WV = p.hp.net_width_viewdirs
+      for i, (d, concat) in enumerate(p.view):
+        if i == 0:
+          segs = [(0, p.vi_width, 0, p.ldVI)]
+        elif concat:
+          segs = [(0, WV, 0, WV), (WV, p.vi_width, WV, p.ldVI)]
+        else:
+          segs = [(0, WV, 0, WV)]
+        e = pack_layer(('view', i), d, segs, _rup(d.fan_out, 128))
+        rows = bw if i == 0 else WV                             # dX target: bottleneck cols / previous hidden
+        bo = alloc(_rup(rows, 128), _rup(d.fan_out, 64))
+        descs.append(L.PackDesc(d.kernel_off, rows, d.fan_out, bo, _rup(d.fan_out, 64), 0, 0, 0))
+        e.update(b_off=bo, b_ld=_rup(d.fan_out, 64))
+      assert not getattr(p, 'v_concat', False), 'view MLP ending on a skip layer is not supported on the HIP path'
+      pack_layer('rgb', p.rgb, [(0, p.rgb.fan_in, 0, _rup(p.rgb.fan_in, 64))], 128)
+    elif p.has_rgb:
+      raise NotImplementedError('use_viewdirs=False with rgb is not yet on the HIP path')
+    else:
+      pack_layer('density', p.density, [(0, p.W, 0, p.W)], 128)
+    p.packed_elems = off
+    p.pack_descs = descs
+    arr = (L.PackDesc * len(descs))(*descs)
+    p.pack_descs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+    p.pack_max_elems = max(d.rows_in * d.cols_out for d in descs)
+    p.wbf = torch.zeros(off, dtype=bf16, device=self.device)     # padding stays zero forever
+    if p.has_rgb and p.use_viewdirs:
+      p.head_bias = torch.zeros(_rup(p.hp.bottleneck_width + 1, 128), dtype=f32, device=self.device)
+
+  def pack_weights(self, flat_params):
+    """fp32 master parameters -> bf16 GEMM operands (one launch per MLP)."""
+    for p in self._plans:
+      ops.pack_weights(flat_params, p.pack_descs_dev, len(p.pack_descs), p.pack_max_elems, p.wbf)
+      if p.has_rgb and p.use_viewdirs:
+        bw = p.hp.bottleneck_width
+        p.head_bias[:bw].copy_(flat_params[p.bottleneck.bias_off:p.bottleneck.bias_off + bw])
+        p.head_bias[bw:bw + 1].copy_(flat_params[p.density.bias_off:p.density.bias_off + 1])
+
+  # Parameters ------------------------------------------------------------------------
+
+  def init_flat_params(self, seed=0):
+    """Random init with flax semantics (he/glorot *_uniform kernels, zero biases; models.py:436-437)."""
+    assert self._built
+    gen = torch.Generator().manual_seed(seed)
+    flat = torch.zeros(self.num_params, dtype=f32)
+    for p in self._plans:
+      for d in p.dense:
+        kind = p.hp.weight_init
+        if kind == 'he_uniform':
+          lim = math.sqrt(6.0 / d.fan_in)
+        elif kind == 'glorot_uniform':
+          lim = math.sqrt(6.0 / (d.fan_in + d.fan_out))
+        else:
+          raise NotImplementedError(f'weight_init {kind}')
+        w = (torch.rand((d.fan_in, d.fan_out), generator=gen, dtype=torch.float64) * 2 - 1) * lim
+        flat[d.kernel_off:d.kernel_off + d.fan_in * d.fan_out] = w.reshape(-1).float()
+    return flat.to(self.device)
+
+  def params_tree(self, flat):
+    """Nested dict of views into `flat` with flax's names (train.py:194-195 layout)."""
+    tree = {}
+    for p in self._plans:
+      m = {}
+      for d in p.dense:
+        m[d.name] = {
+            'kernel': flat[d.kernel_off:d.kernel_off + d.fan_in * d.fan_out].view(d.fan_in, d.fan_out),
+            'bias': flat[d.bias_off:d.bias_off + d.fan_out],
+        }
+      tree[p.module_name] = m
+    return tree
+
+  def flat_from_tree(self, tree, device=None):
+    """Inverse of params_tree for externally supplied parameters (e.g. the oracle's)."""
+    flat = torch.zeros(self.num_params, dtype=f32)
+    for p in self._plans:
+      for d in p.dense:
+        flat[d.kernel_off:d.kernel_off + d.fan_in * d.fan_out] = tree[p.module_name][d.name]['kernel'].detach().reshape(-1).float().cpu()
+        flat[d.bias_off:d.bias_off + d.fan_out] = tree[p.module_name][d.name]['bias'].detach().float().cpu()
+    return flat.to(device or self.device)
+
+  # Workspace -------------------------------------------------------------------------
+
+  def _buf(self, key, shape, dtype, zero=False):
+    k = (key, tuple(shape), dtype)
+    t = self._ws.get(k)
+    if t is None:
+      t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+      self._ws[k] = t
+    return t
+
+  # ------------------------------------------------------------------ forward
+
+  def apply(self, variables, rng, rays, train_frac, compute_extras, zero_glo=True, **kw):
+    """flax-style entry: model.apply(variables, rng, rays, train_frac=..., compute_extras=...)."""
+    flat = variables['flat'] if isinstance(variables, dict) and 'flat' in variables else variables
+    return self._forward(flat, rng, rays, train_frac, compute_extras, zero_glo, **kw)
+
+  def __call__(self, rng, rays, train_frac, compute_extras, zero_glo=True, **kw):
+    """models.py:75-312 on the bound variables (set by construct_model / bind)."""
+    return self._forward(self._bound_flat, rng, rays, train_frac, compute_extras, zero_glo, **kw)
+
+  def bind(self, variables):
+    self._bound_flat = variables['flat'] if isinstance(variables, dict) else variables
+    return self
+
+  def _level_plan(self):
+    out = []
+    prod = 1
+    for i in range(self.num_levels):
+      is_prop = i < self.num_levels - 1
+      n = self.num_prop_samples if is_prop else self.num_nerf_samples
+      out.append((i, is_prop, n, prod))
+      prod *= n
+    return out
+
+  def _forward(self, flat, rng, rays, train_frac, compute_extras, zero_glo=True, noise=None,
+               keep_for_backward=False, repack=True):
+    """The level loop of models.py:147-297.  `noise` (parity tests) overrides `rng`:
+    noise['u_jitter'][level] uniform [0,1) of shape [B,1] / [B,n]."""
+    if not self._built:
+      self.build(flat.device)
+    if repack:
+      self.pack_weights(flat)
+    dev = self.device
+    lead = rays.origins.shape[:-1]
+    flat_rays = rays.map(lambda r: r.reshape(-1, r.shape[-1]).contiguous())
+    B0 = flat_rays.origins.shape[0]
+    # Pad to a multiple of 8 rays so every level's row count is a multiple of 256 (GEMM tiles).
+    Bp = _rup(B0, 8)
+    if Bp != B0:
+      pad = Bp - B0
+      flat_rays = flat_rays.map(lambda r: torch.cat([r, r[-1:].expand(pad, r.shape[-1])], 0).contiguous())
+    R = flat_rays
+    if R.exposure_idx is not None or self.learned_exposure_scaling:
+      raise NotImplementedError('RawNeRF exposure scaling is not yet on the HIP path')
+    near = R.near.reshape(-1).contiguous()
+    far = R.far.reshape(-1).contiguous()
+    radii = R.radii.reshape(-1).contiguous()
+
+    init_s_near = 0. if self.near_anneal_rate is None else float(
+        np.clip(1 - train_frac / self.near_anneal_rate, 0, self.near_anneal_init))
+    init_s_far = 1.
+    sdist = torch.tensor([init_s_near, init_s_far], dtype=f32, device=dev).repeat(Bp, 1)
+    weights = torch.ones((Bp, 1), dtype=f32, device=dev)
+
+    randomized = (rng is not None) or (noise is not None)
+    gen = None
+    if rng is not None and noise is None:
+      gen = rng if isinstance(rng, torch.Generator) else torch.Generator(device=dev).manual_seed(int(rng))
+
+    renderings, ray_history, saved = [], [], []
+    for (i_level, is_prop, n, prod_prev) in self._level_plan():
+      plan = self.prop_plan if is_prop else self.nerf_plan
+      hp = plan.hp
+      dilation = self.dilation_bias + self.dilation_multiplier * (init_s_far - init_s_near) / prod_prev
+      use_dilation = (self.dilation_bias > 0 or self.dilation_multiplier > 0) and i_level > 0
+      if self.anneal_slope > 0:
+        s = self.anneal_slope
+        anneal = (s * train_frac) / ((s - 1) * train_frac + 1)      # Schlick bias, models.py:176
+      else:
+        anneal = 1.
+
+      # --- sampling (stepfun.py:191-209 for u; the rest on device)
+      eps = F32_EPS
+      jitter = None
+      max_jitter = 0.0
+      if randomized:
+        u_max = eps + (1 - eps) / n
+        max_jitter = (1 - u_max) / (n - 1) - eps
+        u_base = torch.linspace(0, 1 - u_max, n, dtype=f32).to(dev)
+        d = 1 if self.single_jitter else n
+        if noise is not None:
+          jitter = noise['u_jitter'][i_level].to(dev).reshape(-1, d)
+          if jitter.shape[0] != Bp:
+            jitter = torch.cat([jitter, jitter[-1:].expand(Bp - jitter.shape[0], d)], 0)
+          jitter = jitter.contiguous().float()
+        else:
+          jitter = torch.rand((Bp, d), generator=gen, device=dev, dtype=f32)
+      else:
+        pad = 1 / (2 * n)
+        u_base = torch.linspace(pad, 1. - pad - eps, n, dtype=f32).to(dev)
+      sdist, tdist = ops.resample_level(
+          sdist, weights, u_base, jitter, near, far, n_samples=n, use_dilation=use_dilation, dilation=dilation,
+          domain=(init_s_near, init_s_far), anneal=anneal, resample_padding=self.resample_padding,
+          single_jitter=self.single_jitter, max_jitter=max_jitter, raydist_fn=self.raydist_fn)
+
+      # --- featurise + MLP
+      M = Bp * n
+      tag = ('lvl', i_level) if keep_for_backward else ('lvl', 'shared', is_prop)
+      feat = self._buf((tag, 'feat'), (M, plan.ldF), bf16)
+      ops.cast_rays_ipe(tdist, R.origins, R.directions, radii, plan.basis_dev, ray_shape=self.ray_shape,
+                        warp_contract=(hp.warp_fn == 'contract'), min_deg=hp.min_deg_point,
+                        max_deg=hp.max_deg_point, ld_feat=plan.ldF, disable_integration=self.disable_integration,
+                        out=feat)
+      mlp_out = self._mlp_forward(plan, flat, feat, M, n, R, tag, keep_for_backward)
+
+      # --- density noise (models.py:462-464), background colour (:241-254)
+      dnoise = None
+      if randomized and hp.density_noise > 0:
+        if noise is not None and 'density_noise' in noise:
+          dnoise = noise['density_noise'][i_level].to(dev).reshape(-1, n).float()
+          if dnoise.shape[0] != Bp:
+            dnoise = torch.cat([dnoise, dnoise[-1:].expand(Bp - dnoise.shape[0], n)], 0)
+          dnoise = dnoise.contiguous()
+        else:
+          dnoise = torch.randn((Bp, n), generator=gen, device=dev, dtype=f32)
+      lo, hi = self.bg_intensity_range
+      bg = None
+      if lo == hi:
+        bg_mode, bg_value = 0, lo
+      elif not randomized:
+        bg_mode, bg_value = 0, (lo + hi) / 2
+      else:
+        bg_mode, bg_value = 1, 0.0
+        if noise is not None and 'bg_rgbs' in noise:
+          u = noise['bg_rgbs'][i_level].to(dev).reshape(-1, 3).float()
+          if u.shape[0] != Bp:
+            u = torch.cat([u, u[-1:].expand(Bp - u.shape[0], 3)], 0)
+        else:
+          u = torch.rand((Bp, 3), generator=gen, device=dev, dtype=f32)
+        bg = (lo + (hi - lo) * u).contiguous()
+      ccfg = ops.composite_cfg(n, opaque_background=self.opaque_background, density_act=hp.density_activation,
+                               density_bias=hp.density_bias, density_noise_std=hp.density_noise if dnoise is not None else 0.0,
+                               has_rgb=plan.has_rgb, rgb_act=hp.rgb_activation,
+                               rgb_premultiplier=hp.rgb_premultiplier, rgb_bias=hp.rgb_bias,
+                               rgb_padding=hp.rgb_padding, bg_mode=bg_mode, bg_value=bg_value)
+      raw_density = mlp_out['raw_density'].view(Bp, n)
+      raw_rgb = mlp_out['raw_rgb'].view(Bp, n, 3) if plan.has_rgb else None
+      density, rgb, weights, rgb_out, acc = ops.composite_fwd(
+          ccfg, raw_density, tdist, R.directions, raw_rgb=raw_rgb, density_noise=dnoise, bg=bg)
+
+      rendering = {'rgb': rgb_out[:B0].reshape(lead + (3,))}
+      if compute_extras:
+        rendering['acc'] = acc[:B0].reshape(lead)
+        ex = ops.render_extras(weights, tdist, far)
+        for j, k in enumerate(['distance_mean', 'distance_percentile_5', 'distance_median',
+                               'distance_percentile_95']):
+          rendering[k] = ex[:B0, j].reshape(lead)
+        nvis = self.config.vis_num_rays if self.config is not None else 16
+        rendering['ray_sdist'] = sdist[:B0][:nvis]
+        rendering['ray_weights'] = weights[:B0][:nvis]
+        rendering['ray_rgbs'] = (rgb[:B0][:nvis] if rgb is not None
+                                 else torch.zeros((min(nvis, B0), n, 3), dtype=f32, device=dev))
+      renderings.append(rendering)
+      rgb_hist = rgb[:B0] if rgb is not None else torch.zeros((B0, n, 3), dtype=f32, device=dev)
+      ray_history.append(dict(
+          density=density[:B0].reshape(lead + (n,)), rgb=rgb_hist.reshape(lead + (n, 3)),
+          raw_grad_density=None, grad_pred=None, normals=None, normals_pred=None, roughness=None,
+          sdist=sdist[:B0].reshape(lead + (n + 1,)), weights=weights[:B0].reshape(lead + (n,)),
+          tdist=tdist[:B0].reshape(lead + (n + 1,))))
+      if keep_for_backward:
+        saved.append(dict(level=i_level, is_prop=is_prop, n=n, plan=plan, M=M, tag=tag, feat=feat, mlp=mlp_out,
+                          ccfg=ccfg, raw_density=raw_density, raw_rgb=raw_rgb, dnoise=dnoise, bg=bg,
+                          tdist=tdist, sdist=sdist, weights=weights, rgb_out=rgb_out))
+
+    if compute_extras:
+      # models.py:299-310: proposal levels show the final level's average colour.
+      final_rgb = torch.sum(renderings[-1]['ray_rgbs'] * renderings[-1]['ray_weights'][..., None], dim=-2)
+      for r in renderings[:-1]:
+        r['ray_rgbs'] = final_rgb[:, None, :].expand(r['ray_rgbs'].shape)
+
+    if keep_for_backward:
+      self._saved = dict(levels=saved, rays=R, B0=B0, Bp=Bp)
+    return renderings, ray_history
+
+  # ------------------------------------------------------------------ MLP forward / backward
+
+  def _w(self, plan, off, rows, ld):
+    """A [rows, ld] view into the packed bf16 operand buffer."""
+    return plan.wbf[off:off + rows * ld].view(rows, ld)
+
+  def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep):
+    hp = plan.hp
+    acts = []
+    x = None
+    for i, (d, concat) in enumerate(plan.trunk):
+      e = plan.packed[('trunk', i)]
+      out = self._buf((tag, 'act', i if keep else i % 2), (M, plan.W), bf16)
+      Bt = self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])
+      bias = flat[d.bias_off:d.bias_off + d.fan_out]
+      if i == 0:
+        ops.gemm_nt(feat, Bt, M=M, N=e['n_pad'], K1=plan.ldF, bias=bias, n_bias=d.fan_out, relu=True,
+                    Cb=out, ldcb=plan.W, nb=plan.W)
+      elif concat:
+        ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, A2=feat, K2=plan.ldF, bias=bias, n_bias=d.fan_out,
+                    relu=True, Cb=out, ldcb=plan.W, nb=plan.W)
+      else:
+        ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=bias, n_bias=d.fan_out, relu=True,
+                    Cb=out, ldcb=plan.W, nb=plan.W)
+      acts.append(out)
+      x = out
+    res = dict(acts=acts)
+    raw_density = self._buf((tag, 'raw_density'), (M,), f32)
+    if plan.has_rgb:
+      bw = hp.bottleneck_width
+      e = plan.packed['head']
+      VI = self._buf((tag, 'VI'), (M, plan.ldVI), bf16)
+      Bt = self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])
+      ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=bw + 1, relu=False,
+                  Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=raw_density, ldcf=1, f0=bw, nf=1)
+      ops.viewdir_enc_fill(R.viewdirs, n, hp.deg_view, VI, bw, plan.ldVI)
+      h = VI
+      vacts = []
+      WV = hp.net_width_viewdirs
+      for i, (d, concat) in enumerate(plan.view):
+        e = plan.packed[('view', i)]
+        out = self._buf((tag, 'vact', i if keep else i % 2), (M, WV), bf16)
+        Bt = self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])
+        bias = flat[d.bias_off:d.bias_off + d.fan_out]
+        if i == 0:
+          ops.gemm_nt(VI, Bt, M=M, N=e['n_pad'], K1=plan.ldVI, bias=bias, n_bias=d.fan_out, relu=True,
+                      Cb=out, ldcb=WV, nb=WV)
+        elif concat:
+          ops.gemm_nt(h, Bt, M=M, N=e['n_pad'], K1=WV, A2=VI, K2=plan.ldVI, bias=bias, n_bias=d.fan_out,
+                      relu=True, Cb=out, ldcb=WV, nb=WV)
+        else:
+          ops.gemm_nt(h, Bt, M=M, N=e['n_pad'], K1=WV, bias=bias, n_bias=d.fan_out, relu=True,
+                      Cb=out, ldcb=WV, nb=WV)
+        vacts.append(out)
+        h = out
+      e = plan.packed['rgb']
+      raw_rgb = self._buf((tag, 'raw_rgb'), (M, 3), f32)
+      d = plan.rgb
+      ops.gemm_nt(h, self._w(plan, e['f_off'], e['n_pad'], e['f_ld']), M=M, N=e['n_pad'], K1=e['kpad'],
+                  bias=flat[d.bias_off:d.bias_off + 3], n_bias=3, relu=False, Cf=raw_rgb, ldcf=3, f0=0, nf=3)
+      res.update(VI=VI, vacts=vacts, raw_rgb=raw_rgb)
+    else:
+      e = plan.packed['density']
+      d = plan.density
+      ops.gemm_nt(x, self._w(plan, e['f_off'], e['n_pad'], e['f_ld']), M=M, N=e['n_pad'], K1=plan.W,
+                  bias=flat[d.bias_off:d.bias_off + 1], n_bias=1, relu=False, Cf=raw_density, ldcf=1, f0=0, nf=1)
+    res['raw_density'] = raw_density
+    return res
+
+  def backward_level(self, lv, flat, grads, g_rgb_out, g_weights):
+    """VJP of one level w.r.t. the parameters: compositing -> heads -> trunk.
+    grads: flat fp32 gradient vector (accumulated into)."""
+    plan: MLPPlan = lv['plan']
+    hp = plan.hp
+    M, n, tag = lv['M'], lv['n'], lv['tag']
+    R = self._saved['rays']
+    mlp = lv['mlp']
+    acts = mlp['acts']
+    x_last = acts[-1]
+    W = plan.W
+    dA = self._buf(('bwd', 'dA', W), (M, W), bf16)       # ping-pong dY buffers (shared across levels)
+    dB = self._buf(('bwd', 'dB', W), (M, W), bf16)
+
+    def gslice(off, size):
+      return grads[off:off + size]
+
+    if plan.has_rgb:
+      bw = hp.bottleneck_width
+      e = plan.packed['head']
+      nh = e['n_pad']
+      dHB = self._buf(('bwd', 'dHB', nh), (M, nh), bf16, zero=True)   # cols > bw stay zero
+      _, g_raw_rgb = ops.composite_bwd(
+          lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], raw_rgb=lv['raw_rgb'],
+          density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights,
+          g_den_bf16=dHB.view(-1)[bw:], ld_bf16=nh, want_f32=False)
+      g_raw_rgb = g_raw_rgb.view(M, 3)
+      # rgb Dense(3): dH, dW, db
+      WV = hp.net_width_viewdirs
+      vacts = mlp['vacts']
+      d = plan.rgb
+      dV0 = self._buf(('bwd', 'dV0', WV), (M, WV), bf16)
+      dV1 = self._buf(('bwd', 'dV1', WV), (M, WV), bf16)
+      h_last = vacts[-1]
+      ops.small_head_bwd(h_last, WV, g_raw_rgb, flat[d.kernel_off:d.kernel_off + d.fan_in * 3].view(d.fan_in, 3),
+                         M=M, K=WV, Cn=3, dX=dV0, lddx=WV, relu_mask=True,
+                         dW=gslice(d.kernel_off, d.fan_in * 3), db=gslice(d.bias_off, 3))
+      dy, other = dV0, dV1
+      VI = mlp['VI']
+      for i in reversed(range(len(plan.view))):
+        d, concat = plan.view[i]
+        e = plan.packed[('view', i)]
+        inp = VI if i == 0 else vacts[i - 1]
+        in_w = plan.ldVI if i == 0 else WV
+        # dW (rows of the first input segment; then the skip-concat rows), db
+        ops.gemm_tn(inp, dy, gslice(d.kernel_off, d.fan_in * d.fan_out), M=M, K=in_w, N=WV,
+                    lda=inp.stride(0), ldb=WV, ldc=d.fan_out,
+                    k_valid=(plan.vi_width if i == 0 else WV), n_valid=d.fan_out)
+        if concat:
+          ops.gemm_tn(VI, dy, gslice(d.kernel_off + WV * d.fan_out, plan.vi_width * d.fan_out), M=M,
+                      K=plan.ldVI, N=WV, lda=plan.ldVI, ldb=WV, ldc=d.fan_out, k_valid=plan.vi_width,
+                      n_valid=d.fan_out)
+        ops.colsum(dy, M, d.fan_out, gslice(d.bias_off, d.fan_out), ld=WV)
+        Bw = self._w(plan, e['b_off'], _rup(bw if i == 0 else WV, 128), e['b_ld'])
+        if i == 0:
+          ops.gemm_nt(dy, Bw, M=M, N=_rup(bw, 128), K1=e['b_ld'], Cb=dHB, ldcb=nh, nb=bw)
+        else:
+          ops.gemm_nt(dy, Bw, M=M, N=WV, K1=e['b_ld'], mask=vacts[i - 1], ldmask=WV, Cb=other, ldcb=WV, nb=WV)
+          dy, other = other, dy
+      # merged head (bottleneck + density): dW, db, dX_last
+      e = plan.packed['head']
+      tmpW = self._buf(('bwd', 'tmpW', W, nh), (W, nh), f32)
+      tmpW.zero_()
+      ops.gemm_tn(x_last, dHB, tmpW, M=M, K=W, N=nh, lda=W, ldb=nh, ldc=nh)
+      ops.scatter_add(tmpW, nh, 0, 0, W, bw, gslice(plan.bottleneck.kernel_off, W * bw), bw)
+      ops.scatter_add(tmpW, nh, 0, bw, W, 1, gslice(plan.density.kernel_off, W), 1)
+      tmpb = self._buf(('bwd', 'tmpb', nh), (nh,), f32)
+      tmpb.zero_()
+      ops.colsum(dHB, M, bw + 1, tmpb, ld=nh)
+      ops.scatter_add(tmpb, nh, 0, 0, 1, bw, gslice(plan.bottleneck.bias_off, bw), bw)
+      ops.scatter_add(tmpb, nh, 0, bw, 1, 1, gslice(plan.density.bias_off, 1), 1)
+      Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
+      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=nh, mask=x_last, ldmask=W, Cb=dA, ldcb=W, nb=W)
+    else:
+      g_raw_density, _ = ops.composite_bwd(
+          lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], density_noise=lv['dnoise'],
+          bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights, want_f32=True)
+      d = plan.density
+      ops.small_head_bwd(x_last, W, g_raw_density.view(M, 1), flat[d.kernel_off:d.kernel_off + W].view(W, 1),
+                         M=M, K=W, Cn=1, dX=dA, lddx=W, relu_mask=True,
+                         dW=gslice(d.kernel_off, W), db=gslice(d.bias_off, 1))
+    # trunk
+    dy, other = dA, dB
+    feat = lv['feat']
+    for i in reversed(range(len(plan.trunk))):
+      d, concat = plan.trunk[i]
+      e = plan.packed[('trunk', i)]
+      if i == 0:
+        ops.gemm_tn(feat, dy, gslice(d.kernel_off, plan.F * W), M=M, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
+                    ldc=W, k_valid=plan.F, n_valid=W)
+      else:
+        ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W)
+        if concat:
+          ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
+                      lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
+      ops.colsum(dy, M, W, gslice(d.bias_off, W), ld=W)
+      if i > 0:
+        Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
+        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], mask=acts[i - 1], ldmask=W, Cb=other, ldcb=W, nb=W)
+        dy, other = other, dy
+
+
+# =============================================================================
+
+
+def construct_model(rng, rays, config, device='cuda'):
+  """models.py:315-338: returns (model, init_variables).  `rng`: int seed (flax init RNG)."""
+  model = Model(config=config)
+  model.build(device)
+  flat = model.init_flat_params(seed=0 if rng is None else int(rng))
+  variables = {'flat': flat, 'params': model.params_tree(flat)}
+  model.bind(variables)
+  return model, variables
+
+
+def render_image(render_fn, rays, rng, config, verbose=True, world_size=1, rank=0):
+  """models.py:625-706: render all pixels of an image in chunks of config.render_chunk_size.
+
+  `render_fn(rng, chunk_rays)` returns (renderings, ray_history) for this rank's slice, already
+  gathered across ranks (train_utils.create_render_fn does the all-gather of pixel buffers)."""
+  height, width = rays.origins.shape[:2]
+  num_rays = height * width
+  rays = rays.map(lambda r: r.reshape((num_rays, -1)))
+  chunks = []
+  idx0s = range(0, num_rays, config.render_chunk_size)
+  for i_chunk, idx0 in enumerate(idx0s):
+    if verbose and i_chunk % max(1, len(idx0s) // 10) == 0:
+      print(f'Rendering chunk {i_chunk}/{len(idx0s)-1}')
+    chunk_rays = rays.map(lambda r: r[idx0:idx0 + config.render_chunk_size])
+    actual = chunk_rays.origins.shape[0]
+    rem = actual % world_size
+    padding = 0
+    if rem != 0:
+      padding = world_size - rem
+      chunk_rays = chunk_rays.map(lambda r: torch.cat([r, r[-1:].expand(padding, r.shape[-1])], 0))  # mode='edge'
+    per = chunk_rays.origins.shape[0] // world_size
+    local = chunk_rays.map(lambda r: r[rank * per:(rank + 1) * per].contiguous())
+    chunk_renderings, _ = render_fn(rng, local)
+    if padding:
+      chunk_renderings = [{k: (v[:-padding] if not k.startswith('ray_') else v) for k, v in r.items()}
+                          for r in chunk_renderings]
+    chunk_rendering = dict(chunk_renderings[-1])
+    for k in chunk_renderings[0]:
+      if k.startswith('ray_'):
+        chunk_rendering[k] = [r[k] for r in chunk_renderings]
+    chunks.append(chunk_rendering)
+  rendering = {}
+  for k in chunks[0]:
+    if k.startswith('ray_'):
+      rendering[k] = [torch.cat([c[k][lv] for c in chunks], 0) for lv in range(len(chunks[0][k]))]
+    else:
+      z = torch.cat([c[k] for c in chunks], 0)
+      rendering[k] = z.reshape((height, width) + tuple(z.shape[1:]))
+  keys = [k for k in rendering if k.startswith('ray_')]
+  if keys:
+    nr = rendering[keys[0]][0].shape[0]
+    g = torch.Generator().manual_seed(0)          # the reference uses random.PRNGKey(0)
+    ray_idx = torch.randperm(nr, generator=g)[:config.vis_num_rays].to(rendering[keys[0]][0].device)
+    for k in keys:
+      rendering[k] = [r[ray_idx] for r in rendering[k]]
+  return rendering

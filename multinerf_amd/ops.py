@@ -1,0 +1,356 @@
+"""Torch-tensor front ends for the C ABI (include/mnerf.h).
+
+torch is plumbing here: it owns device memory and the stream; all arithmetic on
+the hot path happens inside libmnerf_hip.so.  Every function validates device,
+dtype and contiguity and then passes raw device pointers.
+"""
+
+import ctypes as C
+
+import torch
+
+from multinerf_amd import _lib as L
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+def _ptr(t):
+  return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name, allow_none=False):
+  if t is None:
+    if allow_none:
+      return
+    raise ValueError(f'{name} is None')
+  if not t.is_cuda:
+    raise ValueError(f'{name} must be a device tensor (the HIP path has no CPU fallback)')
+  if t.dtype != dtype:
+    raise ValueError(f'{name} must be {dtype}, is {t.dtype}')
+  if not t.is_contiguous():
+    raise ValueError(f'{name} must be contiguous')
+
+
+def lib():
+  return L.load()
+
+
+# ----------------------------------------------------------------------------- sampling
+
+
+def resample_level(sdist_prev, w_prev, u_base, jitter, near, far, *, n_samples, use_dilation,
+                   dilation, domain, anneal, resample_padding, single_jitter, max_jitter,
+                   raydist_fn, want_idx=False):
+  for t, nm in ((sdist_prev, 'sdist_prev'), (w_prev, 'w_prev'), (u_base, 'u_base'),
+                (near, 'near'), (far, 'far')):
+    _chk(t, f32, nm)
+  _chk(jitter, f32, 'jitter', allow_none=True)
+  B, n_prev = w_prev.shape
+  assert sdist_prev.shape == (B, n_prev + 1) and u_base.numel() == n_samples
+  assert near.numel() == B and far.numel() == B
+  if jitter is not None:
+    assert jitter.numel() == (B if single_jitter else B * n_samples)
+  cfg = L.ResampleCfg(n_prev, n_samples, int(use_dilation), float(dilation), float(domain[0]),
+                      float(domain[1]), float(anneal), float(resample_padding), int(single_jitter),
+                      float(max_jitter), L.RAYDIST[raydist_fn])
+  dev = w_prev.device
+  sdist = torch.empty((B, n_samples + 1), dtype=f32, device=dev)
+  tdist = torch.empty((B, n_samples + 1), dtype=f32, device=dev)
+  idx = torch.empty((B, n_samples), dtype=torch.int32, device=dev) if want_idx else None
+  L.check(lib().mnr_resample_level(C.byref(cfg), B, _ptr(sdist_prev), _ptr(w_prev), _ptr(u_base),
+                                   _ptr(jitter), _ptr(near), _ptr(far), _ptr(sdist), _ptr(tdist),
+                                   _ptr(idx), _stream()))
+  return (sdist, tdist, idx) if want_idx else (sdist, tdist)
+
+
+def sorted_interp(u, cw, t):
+  for x, nm in ((u, 'u'), (cw, 'cw'), (t, 't')):
+    _chk(x, f32, nm)
+  B, nc = cw.shape
+  nu = u.shape[1]
+  out = torch.empty_like(u)
+  idx = torch.empty(u.shape, dtype=torch.int32, device=u.device)
+  L.check(lib().mnr_sorted_interp(B, nc, nu, _ptr(u), _ptr(cw), _ptr(t), _ptr(out), _ptr(idx), _stream()))
+  return out, idx
+
+
+def max_dilate_weights(t, w, dilation, domain):
+  _chk(t, f32, 't')
+  _chk(w, f32, 'w')
+  B, n = w.shape
+  t_out = torch.empty((B, 3 * n + 1), dtype=f32, device=w.device)
+  w_out = torch.empty((B, 3 * n), dtype=f32, device=w.device)
+  scratch = torch.empty((B, n), dtype=f32, device=w.device)
+  L.check(lib().mnr_max_dilate_weights(B, n, _ptr(t), _ptr(w), float(dilation), float(domain[0]),
+                                       float(domain[1]), _ptr(t_out), _ptr(w_out), _ptr(scratch), _stream()))
+  return t_out, w_out
+
+
+# ----------------------------------------------------------------------------- features
+
+
+def _ipe_cfg(ray_shape, warp_contract, disable_integration, basis, min_deg, max_deg):
+  if ray_shape not in ('cone', 'cylinder'):
+    raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')   # render.py:124
+  return L.IpeCfg(0 if ray_shape == 'cone' else 1, int(bool(warp_contract)), int(bool(disable_integration)),
+                  basis.shape[0], int(min_deg), int(max_deg))
+
+
+def cast_rays_ipe(tdist, origins, directions, radii, basis, *, ray_shape, warp_contract, min_deg,
+                  max_deg, ld_feat, disable_integration=False, out=None, want_gaussians=False):
+  """-> bf16 features [B*n, ld_feat] (+ optional post-warp means [B*n,3], covs [B*n,9])."""
+  for x, nm in ((tdist, 'tdist'), (origins, 'origins'), (directions, 'directions'), (radii, 'radii'),
+                (basis, 'basis')):
+    _chk(x, f32, nm)
+  B, n1 = tdist.shape
+  n = n1 - 1
+  cfg = _ipe_cfg(ray_shape, warp_contract, disable_integration, basis, min_deg, max_deg)
+  dev = tdist.device
+  if out is None:
+    out = torch.empty((B * n, ld_feat), dtype=bf16, device=dev)
+  _chk(out, bf16, 'out')
+  assert out.shape == (B * n, ld_feat)
+  means = covs = None
+  if want_gaussians:
+    means = torch.empty((B * n, 3), dtype=f32, device=dev)
+    covs = torch.empty((B * n, 9), dtype=f32, device=dev)
+  L.check(lib().mnr_cast_rays_ipe(C.byref(cfg), B, n, _ptr(tdist), _ptr(origins), _ptr(directions),
+                                  _ptr(radii), _ptr(basis), _ptr(out), ld_feat, _ptr(means), _ptr(covs),
+                                  _stream()))
+  return (out, means, covs) if want_gaussians else out
+
+
+def cast_rays_ipe_f32(tdist, origins, directions, radii, basis, *, ray_shape, warp_contract, min_deg,
+                      max_deg, disable_integration=False):
+  for x, nm in ((tdist, 'tdist'), (origins, 'origins'), (directions, 'directions'), (radii, 'radii'),
+                (basis, 'basis')):
+    _chk(x, f32, nm)
+  B, n1 = tdist.shape
+  n = n1 - 1
+  cfg = _ipe_cfg(ray_shape, warp_contract, disable_integration, basis, min_deg, max_deg)
+  nfeat = 2 * basis.shape[0] * (max_deg - min_deg)
+  out = torch.empty((B * n, nfeat), dtype=f32, device=tdist.device)
+  L.check(lib().mnr_cast_rays_ipe_f32(C.byref(cfg), B, n, _ptr(tdist), _ptr(origins), _ptr(directions),
+                                      _ptr(radii), _ptr(basis), _ptr(out), _stream()))
+  return out
+
+
+def viewdir_enc_fill(viewdirs, n, deg_view, dst, col0, col_end):
+  _chk(viewdirs, f32, 'viewdirs')
+  _chk(dst, bf16, 'dst')
+  B = viewdirs.shape[0]
+  assert dst.shape[0] == B * n
+  L.check(lib().mnr_viewdir_enc_fill(B, n, _ptr(viewdirs), deg_view, _ptr(dst), dst.stride(0), col0, col_end,
+                                     _stream()))
+
+
+# ----------------------------------------------------------------------------- dense
+
+
+def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, bias=None, n_bias=0,
+            relu=False, mask=None, ldmask=0, Cb=None, ldcb=0, nb=0, Cf=None, ldcf=0, f0=0, nf=0):
+  """C[M,N] = epilogue([A1|A2] @ Bt^T).  Pointers may be views with explicit leading dimensions."""
+  _chk(A1, bf16, 'A1')
+  _chk(Bt, bf16, 'Bt')
+  _chk(A2, bf16, 'A2', allow_none=True)
+  _chk(mask, bf16, 'mask', allow_none=True)
+  _chk(bias, f32, 'bias', allow_none=True)
+  _chk(Cb, bf16, 'Cb', allow_none=True)
+  _chk(Cf, f32, 'Cf', allow_none=True)
+  a = L.GemmNTArgs()
+  a.A1, a.lda1, a.K1 = A1.data_ptr(), lda1 if lda1 else A1.stride(0), K1
+  a.A2, a.lda2, a.K2 = (A2.data_ptr() if A2 is not None else None), (lda2 if lda2 else (A2.stride(0) if A2 is not None else 0)), K2
+  a.Bt, a.ldb = Bt.data_ptr(), ldb if ldb else Bt.stride(0)
+  a.M, a.N = M, N
+  a.bias, a.n_bias, a.relu = (bias.data_ptr() if bias is not None else None), n_bias, int(relu)
+  a.mask, a.ldmask = (mask.data_ptr() if mask is not None else None), ldmask
+  a.Cb, a.ldcb, a.nb = (Cb.data_ptr() if Cb is not None else None), ldcb, nb
+  a.Cf, a.ldcf, a.f0, a.nf = (Cf.data_ptr() if Cf is not None else None), ldcf, f0, nf
+  L.check(lib().mnr_gemm_nt_bf16(C.byref(a), _stream()))
+
+
+def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, n_valid=None):
+  """Cout[k,n] += sum_m A[m,k] B[m,n]."""
+  _chk(A, bf16, 'A')
+  _chk(B, bf16, 'B')
+  _chk(Cout, f32, 'C')
+  a = L.GemmTNArgs()
+  a.A, a.lda, a.K = A.data_ptr(), lda if lda else A.stride(0), K
+  a.B, a.ldb, a.N = B.data_ptr(), ldb if ldb else B.stride(0), N
+  a.M = M
+  a.C, a.ldc = Cout.data_ptr(), ldc if ldc else Cout.stride(0)
+  a.k_valid = K if k_valid is None else k_valid
+  a.n_valid = N if n_valid is None else n_valid
+  L.check(lib().mnr_gemm_tn_bf16(C.byref(a), _stream()))
+
+
+def colsum(X, M, n_valid, out, ld=None):
+  _chk(X, bf16, 'X')
+  _chk(out, f32, 'out')
+  L.check(lib().mnr_colsum_bf16(_ptr(X), ld if ld else X.stride(0), M, n_valid, _ptr(out), _stream()))
+
+
+def pack_weights(params, descs_dev, n_desc, max_elems, dst):
+  _chk(params, f32, 'params')
+  _chk(dst, bf16, 'dst')
+  L.check(lib().mnr_pack_weights_bf16(_ptr(params), _ptr(descs_dev), n_desc, max_elems, _ptr(dst), _stream()))
+
+
+def scatter_add(src, ld_src, row0, col0, rows, cols, dst, ld_dst):
+  _chk(src, f32, 'src')
+  _chk(dst, f32, 'dst')
+  L.check(lib().mnr_scatter_add_f32(_ptr(src), ld_src, row0, col0, rows, cols, _ptr(dst), ld_dst, _stream()))
+
+
+def cast_f32_to_bf16(src, ld_src, M, n, dst, ld_dst, col0):
+  _chk(src, f32, 'src')
+  _chk(dst, bf16, 'dst')
+  L.check(lib().mnr_cast_f32_to_bf16(_ptr(src), ld_src, M, n, _ptr(dst), ld_dst, col0, _stream()))
+
+
+def small_head_bwd(H, ldh, g, W, *, M, K, Cn, dX=None, lddx=0, relu_mask=True, dW=None, db=None):
+  _chk(H, bf16, 'H')
+  _chk(g, f32, 'g')
+  _chk(W, f32, 'W')
+  L.check(lib().mnr_small_head_bwd(M, K, Cn, _ptr(H), ldh, _ptr(g), _ptr(W), _ptr(dX), lddx, int(relu_mask),
+                                   _ptr(dW), _ptr(db), _stream()))
+
+
+# ----------------------------------------------------------------------------- compositing
+
+
+def composite_cfg(n, *, opaque_background, density_act, density_bias, density_noise_std, has_rgb, rgb_act,
+                  rgb_premultiplier, rgb_bias, rgb_padding, bg_mode, bg_value):
+  return L.CompositeCfg(n, int(opaque_background), L.ACT[density_act], float(density_bias),
+                        float(density_noise_std), int(has_rgb), L.ACT[rgb_act], float(rgb_premultiplier),
+                        float(rgb_bias), float(rgb_padding), int(bg_mode), float(bg_value))
+
+
+def composite_fwd(cfg, raw_density, tdist, dirs, *, raw_rgb=None, density_noise=None, bg=None,
+                  exposure_scale=None, want_acc=True):
+  _chk(raw_density, f32, 'raw_density')
+  _chk(tdist, f32, 'tdist')
+  _chk(dirs, f32, 'dirs')
+  for x, nm in ((raw_rgb, 'raw_rgb'), (density_noise, 'density_noise'), (bg, 'bg'),
+                (exposure_scale, 'exposure_scale')):
+    _chk(x, f32, nm, allow_none=True)
+  B, n = raw_density.shape
+  dev = raw_density.device
+  density = torch.empty((B, n), dtype=f32, device=dev)
+  weights = torch.empty((B, n), dtype=f32, device=dev)
+  rgb = torch.empty((B, n, 3), dtype=f32, device=dev) if cfg.has_rgb else None
+  rgb_out = torch.empty((B, 3), dtype=f32, device=dev)
+  acc = torch.empty((B,), dtype=f32, device=dev) if want_acc else None
+  L.check(lib().mnr_composite_fwd(C.byref(cfg), B, _ptr(raw_density), _ptr(density_noise), _ptr(raw_rgb),
+                                  _ptr(tdist), _ptr(dirs), _ptr(bg), _ptr(exposure_scale), _ptr(density),
+                                  _ptr(rgb), _ptr(weights), _ptr(rgb_out), _ptr(acc), _stream()))
+  return density, rgb, weights, rgb_out, acc
+
+
+def composite_bwd(cfg, raw_density, tdist, dirs, weights, *, raw_rgb=None, density_noise=None, bg=None,
+                  exposure_scale=None, g_rgb_out=None, g_weights=None, g_den_bf16=None, ld_bf16=0,
+                  want_f32=True):
+  B, n = raw_density.shape
+  dev = raw_density.device
+  for x, nm in ((raw_density, 'raw_density'), (tdist, 'tdist'), (dirs, 'dirs'), (weights, 'weights')):
+    _chk(x, f32, nm)
+  for x, nm in ((g_rgb_out, 'g_rgb_out'), (g_weights, 'g_weights')):
+    _chk(x, f32, nm, allow_none=True)
+  _chk(g_den_bf16, bf16, 'g_den_bf16', allow_none=True)
+  g_raw_density = torch.empty((B, n), dtype=f32, device=dev) if want_f32 else None
+  g_raw_rgb = torch.empty((B, n, 3), dtype=f32, device=dev) if cfg.has_rgb else None
+  L.check(lib().mnr_composite_bwd(C.byref(cfg), B, _ptr(raw_density), _ptr(density_noise), _ptr(raw_rgb),
+                                  _ptr(tdist), _ptr(dirs), _ptr(bg), _ptr(exposure_scale), _ptr(weights),
+                                  _ptr(g_rgb_out), _ptr(g_weights), _ptr(g_raw_density), _ptr(g_den_bf16),
+                                  ld_bf16, _ptr(g_raw_rgb), _stream()))
+  return g_raw_density, g_raw_rgb
+
+
+def render_extras(weights, tdist, t_far):
+  for x, nm in ((weights, 'weights'), (tdist, 'tdist'), (t_far, 't_far')):
+    _chk(x, f32, nm)
+  B, n = weights.shape
+  out = torch.empty((B, 4), dtype=f32, device=weights.device)
+  L.check(lib().mnr_render_extras(B, n, _ptr(weights), _ptr(tdist), _ptr(t_far), _ptr(out), _stream()))
+  return out
+
+
+# ----------------------------------------------------------------------------- losses
+
+
+def lossmult_sum(lossmult, B_valid, out):
+  _chk(lossmult, f32, 'lossmult')
+  _chk(out, f32, 'out')
+  L.check(lib().mnr_lossmult_sum(B_valid, _ptr(lossmult), lossmult.shape[-1], _ptr(out), _stream()))
+
+
+def data_loss(loss_type, charb_padding, loss_mult, rgb, gt, lossmult, denom, stats, *, B_valid, want_grad=True):
+  for x, nm in ((rgb, 'rgb'), (gt, 'gt'), (lossmult, 'lossmult'), (denom, 'denom'), (stats, 'stats')):
+    _chk(x, f32, nm)
+  if loss_type not in L.DATA_LOSS:
+    raise ValueError(f'unsupported data_loss_type {loss_type!r}')
+  B = rgb.shape[0]
+  g = torch.empty_like(rgb) if want_grad else None
+  L.check(lib().mnr_data_loss(L.DATA_LOSS[loss_type], float(charb_padding), float(loss_mult), B, B_valid,
+                              _ptr(rgb), _ptr(gt), _ptr(lossmult), lossmult.shape[-1], _ptr(denom),
+                              _ptr(stats), _ptr(g), _stream()))
+  return g
+
+
+def interlevel_loss(mult, t, w, t_env, w_env, stats, g_w_env, *, B_valid):
+  for x, nm in ((t, 't'), (w, 'w'), (t_env, 't_env'), (w_env, 'w_env')):
+    _chk(x, f32, nm)
+  B, n = w.shape
+  ne = w_env.shape[1]
+  L.check(lib().mnr_interlevel_loss(float(mult), B, B_valid, n, _ptr(t), _ptr(w), ne, _ptr(t_env), _ptr(w_env),
+                                    _ptr(stats), _ptr(g_w_env), _stream()))
+
+
+def distortion_loss(mult, t, w, stats, g_w, *, B_valid):
+  _chk(t, f32, 't')
+  _chk(w, f32, 'w')
+  B, n = w.shape
+  L.check(lib().mnr_distortion_loss(float(mult), B, B_valid, n, _ptr(t), _ptr(w), _ptr(stats), _ptr(g_w),
+                                    _stream()))
+
+
+def lossfun_outer(t, w, t_env, w_env):
+  for x, nm in ((t, 't'), (w, 'w'), (t_env, 't_env'), (w_env, 'w_env')):
+    _chk(x, f32, nm)
+  B, n = w.shape
+  out = torch.empty((B, n), dtype=f32, device=w.device)
+  L.check(lib().mnr_lossfun_outer(B, n, _ptr(t), _ptr(w), w_env.shape[1], _ptr(t_env), _ptr(w_env), _ptr(out),
+                                  _stream()))
+  return out
+
+
+def lossfun_distortion(t, w):
+  _chk(t, f32, 't')
+  _chk(w, f32, 'w')
+  B, n = w.shape
+  out = torch.empty((B,), dtype=f32, device=w.device)
+  L.check(lib().mnr_lossfun_distortion(B, n, _ptr(t), _ptr(w), _ptr(out), _stream()))
+  return out
+
+
+# ----------------------------------------------------------------------------- optimiser
+
+
+def grad_sqnorm(grad, begin, end, max_val, out):
+  _chk(grad, f32, 'grad')
+  _chk(out, f32, 'out')
+  L.check(lib().mnr_grad_sqnorm(_ptr(grad), begin, end, float(max_val), _ptr(out), _stream()))
+
+
+def clip_adam(grad, params, mu, nu, begin, end, sqnorm, *, lr, b1, b2, eps, step, grad_max_val, grad_max_norm):
+  for x, nm in ((grad, 'grad'), (params, 'params'), (mu, 'mu'), (nu, 'nu')):
+    _chk(x, f32, nm)
+  cfg = L.AdamCfg(float(lr), float(b1), float(b2), float(eps), float(1 - b1**step), float(1 - b2**step),
+                  float(grad_max_val), float(grad_max_norm))
+  L.check(lib().mnr_clip_adam(C.byref(cfg), begin, end, _ptr(sqnorm), _ptr(grad), _ptr(params), _ptr(mu),
+                              _ptr(nu), _stream()))

@@ -1,0 +1,195 @@
+"""Training step and model creation (reference internal/train_utils.py).
+
+Keeps the reference's call surface -- `setup_model` (train_utils.py:399-419),
+`create_train_step` -> `train_pstep(rng, state, batch, cameras, train_frac,
+loss_threshold)` (:221-346), `create_optimizer` (:349-374), `create_render_fn`
+-> `render_eval_pfn(variables, train_frac, _, rays)` (:377-396) -- while the
+bodies enqueue HIP kernels.  `jax.pmap` + `pmean`/`all_gather` become one
+process per GPU with RCCL collectives over torch.distributed (multinerf_amd/dist.py).
+"""
+
+import dataclasses
+import math
+from typing import Any, Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from multinerf_amd import dist as mdist
+from multinerf_amd import models
+from multinerf_amd import ops
+from multinerf_amd import utils
+
+f32 = torch.float32
+
+
+def log_lerp(t, v0, v1):
+  """math.py:57-63."""
+  if v0 <= 0 or v1 <= 0:
+    raise ValueError(f'Interpolants {v0} and {v1} must be positive.')
+  lv0, lv1 = math.log(v0), math.log(v1)
+  return math.exp(min(max(t, 0.), 1.) * (lv1 - lv0) + lv0)
+
+
+def learning_rate_decay(step, lr_init, lr_final, max_steps, lr_delay_steps=0, lr_delay_mult=1):
+  """math.py:66-98 (host side: one scalar per step)."""
+  if lr_delay_steps > 0:
+    delay_rate = lr_delay_mult + (1 - lr_delay_mult) * math.sin(
+        0.5 * math.pi * min(max(step / lr_delay_steps, 0.), 1.))
+  else:
+    delay_rate = 1.
+  return delay_rate * log_lerp(step / max_steps, lr_init, lr_final)
+
+
+@dataclasses.dataclass
+class TrainState:
+  """flax.training.train_state.TrainState restated: step, params, optimiser moments."""
+  step: int
+  params: Dict[str, Any]          # {'flat': fp32 vector, 'params': nested views}
+  mu: torch.Tensor
+  nu: torch.Tensor
+
+
+def create_optimizer(config, variables):
+  """train_utils.py:349-374: Adam state (zeros) + the learning-rate schedule."""
+  flat = variables['flat']
+  lr_fn = lambda step: learning_rate_decay(step, config.lr_init, config.lr_final, config.max_steps,
+                                           config.lr_delay_steps, config.lr_delay_mult)
+  state = TrainState(step=0, params=variables, mu=torch.zeros_like(flat), nu=torch.zeros_like(flat))
+  return state, lr_fn
+
+
+def create_train_step(model: models.Model, config, dataset=None):
+  """train_utils.py:221-346.  Returns train_pstep(rng, state, batch, cameras, train_frac,
+  loss_threshold) -> (new_state, stats, rng).  `batch.rays` holds THIS rank's shard."""
+  if config.cast_rays_in_train_step:
+    raise NotImplementedError('cast_rays_in_train_step (camera_utils on device) is a "next" row (SURVEY 8f N2)')
+  if config.data_loss_type not in ('mse', 'charb', 'rawnerf'):
+    raise NotImplementedError(f'data_loss_type {config.data_loss_type!r} is out of scope')
+  if config.weight_decay_mults:
+    raise NotImplementedError('weight_decay_mults is not yet on the HIP path')
+  if (config.orientation_loss_mult > 0 or config.orientation_coarse_loss_mult > 0 or
+      config.predicted_normal_loss_mult > 0 or config.predicted_normal_coarse_loss_mult > 0):
+    raise NotImplementedError('Ref-NeRF normal losses are not yet on the HIP path')
+  lr_fn = lambda step: learning_rate_decay(step, config.lr_init, config.lr_final, config.max_steps,
+                                           config.lr_delay_steps, config.lr_delay_mult)
+
+  def train_step(rng, state: TrainState, batch, cameras, train_frac, loss_threshold, noise=None,
+                 return_grads=False):
+    flat = state.params['flat']
+    dev = flat.device
+    rays = batch.rays
+    compute_extras = config.compute_disp_metrics or config.compute_normal_metrics
+    use_rng = rng if config.randomized else None
+    renderings, ray_history = model._forward(flat, use_rng, rays, train_frac, compute_extras, zero_glo=False,
+                                             noise=noise if config.randomized else None,
+                                             keep_for_backward=True)
+    saved = model._saved
+    levels, Bp, B0 = saved['levels'], saved['Bp'], saved['B0']
+    R = saved['rays']
+
+    nlev = len(levels)
+    # stats layout: [mse_l, data_l]*nlev | interlevel | distortion | denom
+    stats = model._buf(('train', 'stats'), (2 * nlev + 3,), f32)
+    stats.zero_()
+    denom = stats[2 * nlev + 2:2 * nlev + 3]
+    lossmult = R.lossmult
+    if config.disable_multiscale_loss:
+      lossmult = torch.ones_like(lossmult)
+    gt = batch.rgb[..., :3].reshape(-1, 3).contiguous()
+    if gt.shape[0] != Bp:
+      gt = torch.cat([gt, gt[-1:].expand(Bp - gt.shape[0], 3)], 0).contiguous()
+    ops.lossmult_sum(lossmult, B0, denom)
+
+    grads = model._buf(('train', 'grads'), (model.num_params,), f32)
+    grads.zero_()
+
+    g_rgb, g_w = [None] * nlev, [None] * nlev
+    for li, lv in enumerate(levels):                                   # train_utils.py:85-111, 131-134
+      mult = config.data_loss_mult if li == nlev - 1 else config.data_coarse_loss_mult
+      g = ops.data_loss(config.data_loss_type, config.charb_padding, mult, lv['rgb_out'], gt, lossmult, denom,
+                        stats[2 * li:2 * li + 2], B_valid=B0, want_grad=mult > 0)
+      g_rgb[li] = g if mult > 0 else None
+    last = levels[-1]
+    if config.interlevel_loss_mult > 0:                                # train_utils.py:139-150
+      for li, lv in enumerate(levels[:-1]):
+        g_w[li] = model._buf(('train', 'g_w', li), (Bp, lv['n']), f32)
+        g_w[li].zero_()
+        ops.interlevel_loss(config.interlevel_loss_mult, last['sdist'], last['weights'], lv['sdist'],
+                            lv['weights'], stats[2 * nlev:2 * nlev + 1], g_w[li], B_valid=B0)
+    if config.distortion_loss_mult > 0:                                # train_utils.py:153-159
+      g_w[-1] = model._buf(('train', 'g_w', nlev - 1), (Bp, last['n']), f32)
+      g_w[-1].zero_()
+      ops.distortion_loss(config.distortion_loss_mult, last['sdist'], last['weights'],
+                          stats[2 * nlev + 1:2 * nlev + 2], g_w[-1], B_valid=B0)
+
+    for li, lv in enumerate(levels):
+      if g_rgb[li] is None and g_w[li] is None:
+        continue                                                       # this level receives no gradient
+      model.backward_level(lv, flat, grads, g_rgb[li], g_w[li])
+
+    # pmean over the 'batch' axis (train_utils.py:319-321): RCCL all-reduce of the flat buffers.
+    mdist.all_reduce_mean_(grads)
+    mdist.all_reduce_mean_(stats)
+
+    raw_grads = grads.clone() if return_grads else None
+    # clip per top-level module, nan_to_num, Adam (train_utils.py:326-330)
+    sq = model._buf(('train', 'sqnorm'), (len(model.modules),), f32)
+    sq.zero_()
+    step_count = state.step
+    lr = lr_fn(step_count)            # optax evaluates the schedule at the pre-increment count
+    for mi, (_, b, e) in enumerate(model.modules):
+      ops.grad_sqnorm(grads, b, e, config.grad_max_val, sq[mi:mi + 1])
+      ops.clip_adam(grads, flat, state.mu, state.nu, b, e, sq[mi:mi + 1], lr=lr, b1=config.adam_beta1,
+                    b2=config.adam_beta2, eps=config.adam_eps, step=step_count + 1,
+                    grad_max_val=config.grad_max_val, grad_max_norm=config.grad_max_norm)
+    new_state = TrainState(step=step_count + 1, params=state.params, mu=state.mu, nu=state.nu)
+
+    out_stats = {'_raw': stats, '_nlev': nlev, 'grad_sqnorms': sq}
+    if return_grads:
+      out_stats['_grads'] = raw_grads
+    return new_state, TrainStats(out_stats), rng
+
+  return train_step
+
+
+class TrainStats(dict):
+  """Lazy view of the device-side stats vector (no host sync until a value is read)."""
+
+  def materialize(self):
+    raw = self['_raw'].detach().cpu().numpy()
+    n = self['_nlev']
+    mses = raw[0:2 * n:2]
+    data = raw[1:2 * n:2]
+    out = {
+        'mses': mses,
+        'psnrs': -10. / math.log(10.) * np.log(mses),
+        'losses': {'data': float(data.sum()), 'interlevel': float(raw[2 * n]), 'distortion': float(raw[2 * n + 1])},
+    }
+    out['loss'] = sum(out['losses'].values())
+    out['psnr'] = float(out['psnrs'][-1])
+    out['grad_norms'] = np.sqrt(self['grad_sqnorms'].detach().cpu().numpy())
+    return out
+
+
+def create_render_fn(model: models.Model):
+  """train_utils.py:377-396: deterministic forward with extras; pixels all-gathered across ranks."""
+
+  def render_eval_fn(variables, train_frac, _, rays):
+    renderings, ray_history = model._forward(variables['flat'], None, rays, train_frac, True)
+    if mdist.world_size() > 1:
+      renderings = [{k: (mdist.all_gather_cat(v) if not k.startswith('ray_') else v) for k, v in r.items()}
+                    for r in renderings]
+    return renderings, ray_history
+
+  return render_eval_fn
+
+
+def setup_model(config, rng, dataset=None, device='cuda'):
+  """train_utils.py:399-419 -> (model, state, render_eval_pfn, train_pstep, lr_fn)."""
+  dummy_rays = utils.dummy_rays(include_exposure_idx=config.rawnerf_mode, include_exposure_values=True)
+  model, variables = models.construct_model(rng, dummy_rays, config, device=device)
+  state, lr_fn = create_optimizer(config, variables)
+  render_eval_pfn = create_render_fn(model)
+  train_pstep = create_train_step(model, config, dataset=dataset)
+  return model, state, render_eval_pfn, train_pstep, lr_fn

@@ -251,22 +251,31 @@ def param_count(params):
 
 
 class _DenseCursor:
-  """Hands out Dense_k in call order, like flax's auto-naming."""
+  """Hands out Dense_k in call order, like flax's auto-naming.
 
-  def __init__(self, p):
-    self.p, self.k = p, 0
+  `dense_dtype=torch.bfloat16` emulates the MFMA path (and the reference's own
+  TPU default precision, math.py:21-23): both Dense operands are rounded to bf16,
+  products accumulate in the working dtype, bias is added in the working dtype.
+  """
+
+  def __init__(self, p, dense_dtype=None):
+    self.p, self.k, self.dd = p, 0, dense_dtype
 
   def __call__(self, x):
     layer = self.p[f'Dense_{self.k}']
     self.k += 1
-    return rmath.matmul(x, layer['kernel']) + layer['bias']
+    kern = layer['kernel']
+    if self.dd is not None:
+      x = x.to(self.dd).to(kern.dtype)
+      kern = kern.to(self.dd).to(kern.dtype)
+    return rmath.matmul(x, kern) + layer['bias']
 
 
 def mlp_apply(mlp: MLP, p, gaussians, viewdirs=None, imageplane=None, glo_vec=None,
-              exposure=None, density_noise=None, bottleneck_noise=None):
+              exposure=None, density_noise=None, bottleneck_noise=None, dense_dtype=None):
   """MLP.__call__ -- returns the same dict as models.py:604-612."""
   mlp.check()
-  dense = _DenseCursor(p)
+  dense = _DenseCursor(p, dense_dtype)
   basis = mlp.pos_basis_t(gaussians[0].dtype)
   act = _ACT[mlp.net_activation]
 
@@ -380,7 +389,7 @@ def mlp_apply(mlp: MLP, p, gaussians, viewdirs=None, imageplane=None, glo_vec=No
 
 
 def model_apply(model: Model, nerf_mlp: MLP, prop_mlp: Optional[MLP], params, rays,
-                train_frac, compute_extras, zero_glo=True, noise=None):
+                train_frac, compute_extras, zero_glo=True, noise=None, dense_dtype=None):
   """Returns (renderings, ray_history) exactly as models.py:312.
 
   `rays` is any object with the utils.Rays fields (utils.py:44-57) as torch
@@ -469,7 +478,7 @@ def model_apply(model: Model, nerf_mlp: MLP, prop_mlp: Optional[MLP], params, ra
         imageplane=rays.imageplane,
         glo_vec=None if is_prop else glo_vec,
         exposure=rays.exposure_values,
-        density_noise=dn, bottleneck_noise=bn)
+        density_noise=dn, bottleneck_noise=bn, dense_dtype=dense_dtype)
 
     weights = render.compute_alpha_weights(
         ray_results['density'], tdist, rays.directions,

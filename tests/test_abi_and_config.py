@@ -1,0 +1,95 @@
+"""CPU checks of the boundary: the C-ABI library exports every symbol the header
+declares, the product path refuses to run without it, and the gin/Config surface
+loads the reference's config syntax."""
+
+import os
+
+import pytest
+import torch
+
+from multinerf_amd import _lib, configs, gin
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+  if not os.path.exists(_lib.LIB_PATH):
+    import __graft_entry__
+    __graft_entry__.build()
+  lib = _lib.load()
+  names = _lib.header_symbols()
+  assert len(names) >= 25
+  for n in names:
+    assert hasattr(lib, n), f'{n} declared in include/mnerf.h but not exported'
+  # and every exported prototype we bind is declared in the header
+  for n in _lib._PROTOS:
+    assert n in names
+  assert lib.mnr_abi_version() == 1
+
+
+def test_ops_refuse_cpu_tensors():
+  from multinerf_amd import ops
+  with pytest.raises(ValueError, match='device tensor'):
+    ops.sorted_interp(torch.zeros((1, 2)), torch.zeros((1, 2)), torch.zeros((1, 2)))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+  monkeypatch.setattr(_lib, '_lib', None)
+  monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    _lib.load()
+
+
+def test_gin_subset():
+  gin.clear_config()
+  gin.parse_config("""
+# comment
+Config.near = 0.2   # trailing comment
+Config.far = 1e6
+Config.weight_decay_mults = {
+    'NerfMLP_0': 0.00001,
+    'PropMLP_0/Dense_0': 0.001,
+}
+Model.raydist_fn = @jnp.reciprocal
+NerfMLP.warp_fn = @coord.contract
+NerfMLP.rgb_activation = @math.safe_exp
+Model.bg_intensity_range = (0., 1.)
+SomethingElse.x = 3
+""")
+  c = configs.Config()
+  assert c.near == 0.2 and c.far == 1e6
+  assert c.weight_decay_mults == {'NerfMLP_0': 1e-5, 'PropMLP_0/Dense_0': 1e-3}
+  from multinerf_amd import models
+  m = models.Model(config=c)
+  assert m.raydist_fn == 'reciprocal' and m.bg_intensity_range == (0., 1.)
+  assert models.NerfMLP().warp_fn == 'contract' and models.NerfMLP().rgb_activation == 'safe_exp'
+  assert 'Model.raydist_fn = @jnp.reciprocal' in gin.config_str()
+  with pytest.raises(gin.GinError):
+    gin.parse_config('Config.no_such_field = 1')
+  with pytest.raises(gin.GinError):
+    gin.parse_config('Unknown.x = 1', skip_unknown=False)
+  gin.clear_config()
+  assert configs.Config().near == 2.
+
+
+def test_gin_include_and_bindings(tmp_path):
+  gin.clear_config()
+  (tmp_path / 'base.gin').write_text("Config.batch_size = 1024\nModel.num_levels = 2\n")
+  (tmp_path / 'top.gin').write_text("include 'base.gin'\nConfig.lr_init = 1e-3\n")
+  c = configs.load_config([str(tmp_path / 'top.gin')], ['Config.batch_size = 4096'])
+  assert c.batch_size == 4096 and c.lr_init == 1e-3
+  assert gin.query_parameter('Model.num_levels') == 2
+  gin.clear_config()
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/configs'), reason='reference not mounted')
+@pytest.mark.parametrize('name', ['360', 'blender_256', 'blender_refnerf', 'llff_raw'])
+def test_presets_equal_reference_gin_files(name):
+  """The shipped presets bind exactly what the reference's .gin files bind."""
+  gin.clear_config()
+  gin.parse_config_file(f'/root/reference/configs/{name}.gin')
+  import copy
+  ref = copy.deepcopy(gin._BINDINGS)
+  configs.load_preset(name)
+  assert gin._BINDINGS == ref
+  gin.clear_config()

@@ -1,0 +1,519 @@
+"""Parity of every HIP kernel (through the C ABI) against the CPU oracle.  -m gpu.
+
+Tolerances are stated per test.  Integer artefacts (sample indices, searchsorted
+windows) are compared exactly.
+"""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import coord as ocoord
+from oracle import math as omath
+from oracle import models as omodels
+from oracle import render as orender
+from oracle import stepfun as ostepfun
+from oracle import train_utils as otrain
+
+
+@pytest.fixture(scope='module')
+def ops():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  from multinerf_amd import ops as _ops
+  _ops.lib()
+  return _ops
+
+
+def dev(x):
+  return x.contiguous().cuda()
+
+
+def rand_stepfun(gen, B, n, lo=0.0, hi=1.0):
+  t = torch.cumsum(torch.rand((B, n + 1), generator=gen) + 1e-3, -1)
+  t = (t - t[:, :1]) / (t[:, -1:] - t[:, :1]) * (hi - lo) + lo
+  w = torch.softmax(torch.randn((B, n), generator=gen) * 2, -1)
+  return t.float(), w.float()
+
+
+# ----------------------------------------------------------------------------- sampling
+
+
+def test_sorted_interp_bit_exact_indices(ops):
+  gen = torch.Generator().manual_seed(1)
+  B, nc, nu = 257, 191, 64
+  t, w = rand_stepfun(gen, B, nc - 1)
+  cw = ostepfun.integrate_weights(w)
+  u = torch.sort(torch.rand((B, nu), generator=gen) * (1 - 1e-6), -1).values
+  ref, ref_idx = omath.sorted_interp(u, cw, t, return_index=True)
+  out, idx = ops.sorted_interp(dev(u), dev(cw), dev(t))
+  assert torch.equal(idx.cpu(), ref_idx), 'sample indices must be bit-exact given identical (u, cw)'
+  # same (u, cw, t) and contraction off => identical fp32 arithmetic
+  np.testing.assert_array_equal(out.cpu().numpy(), ref.numpy())
+
+
+def test_sorted_interp_out_of_range_and_ties(ops):
+  xp = torch.tensor([[0.0, 0.2, 0.2, 0.2, 0.7, 1.0]])
+  fp = torch.tensor([[1.0, 2.0, 3.0, 4.0, 5.0, 6.0]])
+  x = torch.tensor([[-0.5, 0.0, 0.1, 0.2, 0.5, 1.0, 1.5]])
+  ref, ref_idx = omath.sorted_interp(x, xp, fp, return_index=True)
+  out, idx = ops.sorted_interp(dev(x), dev(xp), dev(fp))
+  assert torch.equal(idx.cpu(), ref_idx)
+  np.testing.assert_array_equal(out.cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize('n,dilation,domain', [(64, 0.0103125, (0., 1.)), (64, 0.00262207, (0., 1.)),
+                                               (8, 0.53, (-math.inf, math.inf)), (128, 0.0064, (0., 1.))])
+def test_max_dilate_weights(ops, n, dilation, domain):
+  gen = torch.Generator().manual_seed(2)
+  B = 131
+  t, w = rand_stepfun(gen, B, n)
+  w[3, 5:9] = 0.0
+  td_ref, wd_ref = ostepfun.max_dilate_weights(t, w, dilation, domain=domain, renormalize=True)
+  td, wd = ops.max_dilate_weights(dev(t), dev(w), dilation, domain)
+  np.testing.assert_array_equal(td.cpu().numpy(), td_ref.numpy())   # merge == sort, same fp32 ops
+  # weights: renormalisation sums in a different order (sequential vs pairwise): 1e-6 relative.
+  np.testing.assert_allclose(wd.cpu().numpy(), wd_ref.numpy(), rtol=2e-6, atol=1e-9)
+
+
+def _resample_ref(sd, w, u_jit, near, far, *, n, use_dil, dil, anneal, pad, single, raydist):
+  if use_dil:
+    sd, w = ostepfun.max_dilate_weights(sd, w, dil, domain=(0., 1.), renormalize=True)
+    sd, w = sd[..., 1:-1], w[..., 1:-1]
+  logits = torch.where(sd[..., 1:] > sd[..., :-1], anneal * torch.log(w + pad),
+                       torch.full_like(w, -float('inf')))
+  s, idx = ostepfun.sample_intervals(u_jit, sd, logits, n, single_jitter=single, domain=(0., 1.),
+                                     return_index=True)
+  _, s_to_t = ocoord.construct_ray_warps(raydist, near, far)
+  return s, s_to_t(s), idx
+
+
+def _u_base(n, jittered):
+  eps = float(np.finfo(np.float32).eps)
+  if jittered:
+    u_max = eps + (1 - eps) / n
+    return torch.linspace(0, 1 - u_max, n), (1 - u_max) / (n - 1) - eps
+  pad = 1 / (2 * n)
+  return torch.linspace(pad, 1. - pad - eps, n), 0.0
+
+
+@pytest.mark.parametrize('case', ['level0_det', 'level1_360_jit1', 'level2_360_jit1', 'nodil_jitn', 'b256_dil'])
+def test_resample_level(ops, case):
+  gen = torch.Generator().manual_seed(3)
+  B = 200
+  cfgs = {
+      'level0_det': dict(np_=1, n=64, use_dil=False, dil=0.5025, anneal=0.9090909, pad=0.0, single=True, jit=False, raydist='reciprocal', near=0.2, far=1e6),
+      'level1_360_jit1': dict(np_=64, n=64, use_dil=True, dil=0.0103125, anneal=0.9090909, pad=0.0, single=True, jit=True, raydist='reciprocal', near=0.2, far=1e6),
+      'level2_360_jit1': dict(np_=64, n=32, use_dil=True, dil=0.00262207, anneal=1.0, pad=0.0, single=True, jit=True, raydist='reciprocal', near=0.2, far=1e6),
+      'nodil_jitn': dict(np_=128, n=128, use_dil=False, dil=0.0, anneal=1.0, pad=0.01, single=False, jit=True, raydist=None, near=2.0, far=6.0),
+      'b256_dil': dict(np_=128, n=32, use_dil=True, dil=0.0064, anneal=0.5, pad=0.0, single=True, jit=True, raydist=None, near=2.0, far=6.0),
+  }
+  c = cfgs[case]
+  if c['np_'] == 1:
+    sd = torch.tensor([[0., 1.]]).repeat(B, 1)
+    w = torch.ones((B, 1))
+  else:
+    sd, w = rand_stepfun(gen, B, c['np_'])
+    w = w * 0.98   # alpha-compositing weights sum to <= 1
+  near = torch.full((B, 1), c['near'])
+  far = torch.full((B, 1), c['far'])
+  u_base, max_jitter = _u_base(c['n'], c['jit'])
+  u_jit = None
+  if c['jit']:
+    u_jit = torch.rand((B, 1 if c['single'] else c['n']), generator=gen)
+  s_ref, t_ref, idx_ref = _resample_ref(sd, w, u_jit, near, far, n=c['n'], use_dil=c['use_dil'], dil=c['dil'],
+                                        anneal=c['anneal'], pad=c['pad'], single=c['single'], raydist=c['raydist'])
+  s, t, idx = ops.resample_level(dev(sd), dev(w), dev(u_base), None if u_jit is None else dev(u_jit),
+                                 dev(near), dev(far), n_samples=c['n'], use_dilation=c['use_dil'],
+                                 dilation=c['dil'], domain=(0., 1.), anneal=c['anneal'], resample_padding=c['pad'],
+                                 single_jitter=c['single'], max_jitter=max_jitter, raydist_fn=c['raydist'],
+                                 want_idx=True)
+  mismatch = (idx.cpu() != idx_ref).float().mean().item()
+  # End-to-end the CDF depends on device expf/logf (<= 1 ulp from the host's): indices may flip
+  # only where u lands within an ulp of a CDF fence-post.  Report + bound the rate.
+  print(f'{case}: index mismatch rate {mismatch:.2e}')
+  assert mismatch < 2e-3
+  same = (idx.cpu() == idx_ref).all(-1)
+  np.testing.assert_allclose(s.cpu().numpy(), s_ref.numpy(), atol=2e-6, rtol=0)
+  rel = ((t.cpu() - t_ref).abs() / t_ref.abs().clamp_min(1e-6))
+  # reciprocal warp amplifies 1-ulp s differences near s=1 (t ~ 1e5..1e6): relative tolerance there.
+  assert rel[same].max().item() < 2e-2 if c['raydist'] == 'reciprocal' else rel.max().item() < 1e-5
+  assert torch.isfinite(t).all()
+
+
+def test_resample_rejects_single_sample(ops):
+  B = 4
+  z = torch.zeros((B, 2)).cuda()
+  with pytest.raises(ValueError, match='num_samples must be > 1'):
+    ops.resample_level(z, torch.ones((B, 1)).cuda(), torch.zeros(1).cuda(), None, torch.ones(B).cuda(),
+                       torch.ones(B).cuda(), n_samples=1, use_dilation=False, dilation=0., domain=(0., 1.),
+                       anneal=1., resample_padding=0., single_jitter=True, max_jitter=0., raydist_fn=None)
+
+
+# ----------------------------------------------------------------------------- features
+
+
+def _rays(gen, B):
+  o = torch.rand((B, 3), generator=gen) * 2 - 1
+  tgt = torch.randn((B, 3), generator=gen) * 0.3
+  d = tgt - o
+  d = d / d.norm(dim=-1, keepdim=True) * (1.0 + 0.2 * torch.rand((B, 1), generator=gen))
+  radii = 3e-4 + 7e-4 * torch.rand((B, 1), generator=gen)
+  return o.float(), d.float(), radii.float()
+
+
+@pytest.mark.parametrize('shape,contract,basis_name,maxdeg', [('cone', True, ('icosahedron', 2), 12),
+                                                              ('cone', False, ('octahedron', 1), 16),
+                                                              ('cylinder', False, ('octahedron', 1), 16)])
+def test_cast_rays_ipe(ops, shape, contract, basis_name, maxdeg):
+  from multinerf_amd import geopoly
+  gen = torch.Generator().manual_seed(4)
+  B, n = 96, 32
+  o, d, radii = _rays(gen, B)
+  if contract:
+    s = torch.sort(torch.rand((B, n + 1), generator=gen), -1).values
+    s[:, 0], s[:, -1] = 0.0, 1.0 - 2**-23
+    tdist = 1.0 / (s / 1e6 + (1 - s) / 0.2)
+  else:
+    tdist = 2.0 + 4.0 * torch.sort(torch.rand((B, n + 1), generator=gen), -1).values
+  basis = torch.as_tensor(geopoly.generate_basis(*basis_name), dtype=torch.float32)
+  means, covs = orender.cast_rays(tdist, o, d, radii, shape, diag=False)
+  if contract:
+    means, covs = ocoord.track_linearize(ocoord.contract, means, covs)
+  lm, lv = ocoord.lift_and_diagonalize(means, covs, basis.T.contiguous())
+  ref = ocoord.integrated_pos_enc(lm, lv, 0, maxdeg).reshape(B * n, -1)
+  ref64 = ocoord.integrated_pos_enc(lm.double(), lv.double(), 0, maxdeg).reshape(B * n, -1)
+
+  nfeat = 2 * basis.shape[0] * maxdeg
+  ld = (nfeat + 63) // 64 * 64
+  feat, gm, gc = ops.cast_rays_ipe(dev(tdist), dev(o), dev(d), dev(radii.reshape(-1)), dev(basis), ray_shape=shape,
+                                   warp_contract=contract, min_deg=0, max_deg=maxdeg, ld_feat=ld,
+                                   want_gaussians=True)
+  f32 = ops.cast_rays_ipe_f32(dev(tdist), dev(o), dev(d), dev(radii.reshape(-1)), dev(basis), ray_shape=shape,
+                              warp_contract=contract, min_deg=0, max_deg=maxdeg)
+  # Gaussians: fp32 round-off relative to the scale of each quantity.
+  m_ref = means.reshape(-1, 3)
+  np.testing.assert_allclose(gm.cpu().numpy(), m_ref.numpy(), rtol=2e-5, atol=2e-6)
+  c_ref = covs.reshape(-1, 9)
+  sc = c_ref.abs().max(-1, keepdim=True).values.clamp_min(1e-30)
+  assert ((gc.cpu() - c_ref).abs() / sc).max().item() < 5e-4
+  # Features: the fp32 oracle itself is only accurate to |mean| 2^deg 2^-24 in the sine argument
+  # (reference tests/coord_test.py:112-127 uses per-degree tolerances for the same reason), so the
+  # kernel is held to the oracle's own distance from fp64, per degree.
+  K = basis.shape[0]
+  got = f32.cpu().double()
+  for l in range(maxdeg):
+    cols = [h * K * maxdeg + l * K + k for h in (0, 1) for k in range(K)]
+    e_kernel = (got[:, cols] - ref64[:, cols]).abs().max().item()
+    e_oracle = (ref.double()[:, cols] - ref64[:, cols]).abs().max().item()
+    assert e_kernel <= max(4 * e_oracle, 2e-6 * 2**l + 1e-6), (l, e_kernel, e_oracle)
+  # bf16 rows = rounding of the fp32 features; padding columns are zero.
+  fb = feat.cpu().float()
+  np.testing.assert_allclose(fb[:, :nfeat].numpy(), f32.cpu().to(torch.bfloat16).float().numpy(), atol=0, rtol=0)
+  assert (fb[:, nfeat:] == 0).all()
+
+
+def test_cast_rays_rejects_bad_shape(ops):
+  z = torch.zeros((2, 3)).cuda()
+  with pytest.raises(ValueError, match='ray_shape'):
+    ops.cast_rays_ipe(torch.zeros((2, 3)).cuda(), z, z, torch.zeros(2).cuda(), torch.eye(3).cuda(),
+                      ray_shape='sphere', warp_contract=False, min_deg=0, max_deg=4, ld_feat=64)
+
+
+def test_viewdir_enc_fill(ops):
+  gen = torch.Generator().manual_seed(5)
+  B, n = 37, 8
+  v = torch.randn((B, 3), generator=gen)
+  v = (v / v.norm(dim=-1, keepdim=True)).float()
+  ref = ocoord.pos_enc(v, 0, 4, append_identity=True)
+  dst = torch.full((B * n, 320), 7.0, dtype=torch.bfloat16).cuda()
+  ops.viewdir_enc_fill(dev(v), n, 4, dst, 256, 320)
+  out = dst.cpu().float().reshape(B, n, 320)
+  assert (out[..., :256] == 7.0).all()
+  np.testing.assert_allclose(out[..., 256:283].numpy(), ref[:, None, :].expand(B, n, 27).to(torch.bfloat16).float().numpy(),
+                             atol=8e-3)   # device sinf vs host sinf may differ by 1 ulp before bf16 rounding
+  assert (out[..., 283:] == 0).all()
+
+
+# ----------------------------------------------------------------------------- dense
+
+
+def _bf(x):
+  return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('M,N,K1,K2', [(256, 128, 64, 0), (1024, 256, 512, 0), (512, 1024, 1024, 512),
+                                       (384, 128, 320, 0)])
+def test_gemm_nt(ops, M, N, K1, K2):
+  gen = torch.Generator().manual_seed(6)
+  A1 = _bf(torch.randn((M, K1), generator=gen))
+  A2 = _bf(torch.randn((M, K2), generator=gen)) if K2 else None
+  Bt = _bf(torch.randn((N, K1 + K2), generator=gen) / math.sqrt(K1 + K2))   # asymmetric, transpose-detecting
+  bias = torch.randn((N,), generator=gen)
+  A = A1.float() if A2 is None else torch.cat([A1.float(), A2.float()], -1)
+  ref = A.double() @ Bt.double().T + bias.double()
+  Cb = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
+  ops.gemm_nt(dev(A1), dev(Bt), M=M, N=N, K1=K1, A2=None if A2 is None else dev(A2), K2=K2, bias=dev(bias),
+              n_bias=N, relu=True, Cb=Cb, ldcb=N, nb=N)
+  got = Cb.cpu().double()
+  want = torch.relu(ref)
+  # fp32 accumulation of exact bf16 products, one bf16 rounding at the end: 2^-8 relative + tiny abs.
+  np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2**-7, atol=1e-2)
+  # fp32 output window + partial bf16 window + bias bound + mask
+  Cf = torch.zeros((M, 3), dtype=torch.float32).cuda()
+  Cb2 = torch.full((M, N), 9.0, dtype=torch.bfloat16).cuda()
+  mask = _bf((torch.rand((M, N), generator=gen) > 0.5).float())
+  ops.gemm_nt(dev(A1), dev(Bt), M=M, N=N, K1=K1, A2=None if A2 is None else dev(A2), K2=K2, bias=dev(bias),
+              n_bias=70, relu=False, mask=dev(mask), ldmask=N, Cb=Cb2, ldcb=N, nb=66, Cf=Cf, ldcf=3, f0=65, nf=3)
+  b2 = bias.double().clone()
+  b2[70:] = 0
+  want2 = (A.double() @ Bt.double().T + b2) * mask.double()
+  np.testing.assert_allclose(Cf.cpu().double().numpy(), want2[:, 65:68].numpy(), rtol=1e-4, atol=2e-4)
+  got2 = Cb2.cpu().double()
+  np.testing.assert_allclose(got2[:, :66].numpy(), want2[:, :66].numpy(), rtol=2**-7, atol=1e-2)
+  assert (got2[:, 66:] == 9.0).all()
+
+
+def test_gemm_nt_rejects_bad_shapes(ops):
+  a = torch.zeros((128, 64), dtype=torch.bfloat16).cuda()
+  with pytest.raises(ValueError, match='multiple of 128'):
+    ops.gemm_nt(a, a, M=100, N=128, K1=64, Cb=a, ldcb=64, nb=64)
+  with pytest.raises(ValueError, match='multiples of 64'):
+    ops.gemm_nt(a, a, M=128, N=128, K1=48, Cb=a, ldcb=64, nb=64)
+
+
+@pytest.mark.parametrize('M,K,N', [(64, 128, 128), (4096, 256, 128), (8192, 512, 256), (2048 + 64, 128, 384)])
+def test_gemm_tn(ops, M, K, N):
+  gen = torch.Generator().manual_seed(7)
+  A = _bf(torch.randn((M, K), generator=gen))
+  Bm = _bf(torch.randn((M, N), generator=gen))
+  ref = A.double().T @ Bm.double()
+  Cout = torch.ones((K, N), dtype=torch.float32).cuda()
+  ops.gemm_tn(dev(A), dev(Bm), Cout, M=M, K=K, N=N)
+  np.testing.assert_allclose(Cout.cpu().double().numpy(), (ref + 1).numpy(), rtol=1e-4, atol=1e-3 * math.sqrt(M))
+  # bounds: only a [k_valid, n_valid] window is touched, with a wider ldc
+  C2 = torch.zeros((K, N + 8), dtype=torch.float32).cuda()
+  ops.gemm_tn(dev(A), dev(Bm), C2, M=M, K=K, N=N, k_valid=K - 5, n_valid=N - 3)
+  got = C2.cpu().double()
+  np.testing.assert_allclose(got[:K - 5, :N - 3].numpy(), ref[:K - 5, :N - 3].numpy(), rtol=1e-4, atol=1e-3 * math.sqrt(M))
+  assert (got[K - 5:] == 0).all() and (got[:, N - 3:] == 0).all()
+
+
+def test_colsum_pack_scatter_cast_smallhead(ops):
+  gen = torch.Generator().manual_seed(8)
+  M, N = 3000, 320
+  X = _bf(torch.randn((M, N), generator=gen))
+  out = torch.zeros(N).cuda()
+  ops.colsum(dev(X), M, 257, out)
+  ref = X.double().sum(0)
+  np.testing.assert_allclose(out.cpu().double()[:257].numpy(), ref[:257].numpy(), rtol=1e-5, atol=1e-3)
+  assert (out.cpu()[257:] == 0).all()
+
+  # pack: a [in=5,out=7] kernel, plain at (1,2) of a [8,16] matrix and transposed at (0,3) of a [16,8] one.
+  import ctypes as C
+  from multinerf_amd import _lib as L
+  params = torch.randn(100, generator=gen)
+  descs = (L.PackDesc * 2)(L.PackDesc(10, 5, 7, 0, 16, 1, 2, 0), L.PackDesc(10, 5, 7, 128, 8, 0, 3, 1))
+  dbytes = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).cuda()
+  dst = torch.zeros(128 + 128, dtype=torch.bfloat16).cuda()
+  ops.pack_weights(dev(params), dbytes, 2, 35, dst)
+  W = params[10:45].reshape(5, 7)
+  d = dst.cpu().float()
+  a = d[:128].reshape(8, 16)
+  b = d[128:].reshape(16, 8)
+  wb = W.to(torch.bfloat16).float()
+  assert torch.equal(a[1:6, 2:9], wb) and a.abs().sum() == wb.abs().sum()
+  assert torch.equal(b[0:7, 3:8], wb.T) and b.abs().sum() == wb.abs().sum()
+
+  src = torch.randn((6, 10), generator=gen)
+  dstf = torch.ones((3, 4)).cuda()
+  ops.scatter_add(dev(src), 10, 2, 5, 3, 4, dstf, 4)
+  np.testing.assert_allclose(dstf.cpu().numpy(), (1 + src[2:5, 5:9]).numpy(), rtol=1e-6)
+
+  g = torch.randn((M, 3), generator=gen)
+  cb = torch.zeros((M, 8), dtype=torch.bfloat16).cuda()
+  ops.cast_f32_to_bf16(dev(g), 3, M, 3, cb, 8, 2)
+  assert torch.equal(cb.cpu()[:, 2:5], g.to(torch.bfloat16)) and (cb.cpu()[:, 5:] == 0).all()
+
+  K = 128
+  H = _bf(torch.relu(torch.randn((M, K), generator=gen)))
+  Wk = torch.randn((K, 3), generator=gen)
+  dX = torch.zeros((M, K), dtype=torch.bfloat16).cuda()
+  dW = torch.zeros((K, 3)).cuda()
+  db = torch.zeros(3).cuda()
+  ops.small_head_bwd(dev(H), K, dev(g), dev(Wk), M=M, K=K, Cn=3, dX=dX, lddx=K, relu_mask=True, dW=dW, db=db)
+  ref_dx = (g.double() @ Wk.double().T) * (H.double() > 0)
+  np.testing.assert_allclose(dX.cpu().double().numpy(), ref_dx.numpy(), rtol=2**-7, atol=1e-3)
+  np.testing.assert_allclose(dW.cpu().double().numpy(), (H.double().T @ g.double()).numpy(), rtol=1e-4, atol=1e-2)
+  np.testing.assert_allclose(db.cpu().double().numpy(), g.double().sum(0).numpy(), rtol=1e-5, atol=1e-3)
+
+
+# ----------------------------------------------------------------------------- compositing
+
+
+@pytest.mark.parametrize('n,opaque,has_rgb,rgb_act,pad,noise', [(32, True, True, 'sigmoid', 0.001, False),
+                                                                (64, True, False, 'sigmoid', 0.001, False),
+                                                                (128, False, True, 'safe_exp', 0.0, True)])
+def test_composite_fwd_bwd(ops, n, opaque, has_rgb, rgb_act, pad, noise):
+  gen = torch.Generator().manual_seed(9)
+  B = 150
+  raw_d = torch.randn((B, n), generator=gen) * 2
+  raw_rgb = torch.randn((B, n, 3), generator=gen)
+  tdist = torch.cumsum(torch.rand((B, n + 1), generator=gen) * 0.1 + 1e-3, -1) + 0.2
+  dirs = torch.randn((B, 3), generator=gen)
+  bg = torch.rand((B, 3), generator=gen)
+  expo = (0.5 + torch.rand((B, 3), generator=gen)) if rgb_act == 'safe_exp' else None
+  dnoise = torch.randn((B, n), generator=gen) if noise else None
+  premult, rgb_bias, dbias = 1.0, (-5.0 if rgb_act == 'safe_exp' else 0.0), -1.0
+  g_out = torch.randn((B, 3), generator=gen)
+  g_w = torch.randn((B, n), generator=gen) * 0.1
+
+  rd = raw_d.clone().requires_grad_(True)
+  rr = raw_rgb.clone().requires_grad_(True)
+  raw = rd + (dnoise if noise else 0.0)
+  density = torch.nn.functional.softplus(raw + dbias)
+  w_ref, _, _ = orender.compute_alpha_weights(density, tdist, dirs, opaque_background=opaque)
+  if has_rgb:
+    act = omodels._ACT[rgb_act]
+    rgb = act(premult * rr + rgb_bias) * (1 + 2 * pad) - pad
+    if expo is not None:
+      rgb = rgb * expo[:, None, :]
+  else:
+    rgb = torch.zeros((B, n, 3))
+  rend = orender.volumetric_rendering(rgb, w_ref, tdist, bg, tdist[:, -1:], False)
+  obj = (rend['rgb'] * g_out).sum() + (w_ref * g_w).sum()
+  obj.backward()
+
+  cfg = ops.composite_cfg(n, opaque_background=opaque, density_act='softplus', density_bias=dbias,
+                          density_noise_std=1.0 if noise else 0.0, has_rgb=has_rgb, rgb_act=rgb_act,
+                          rgb_premultiplier=premult, rgb_bias=rgb_bias, rgb_padding=pad, bg_mode=1, bg_value=0.0)
+  kw = dict(raw_rgb=dev(raw_rgb) if has_rgb else None, density_noise=dev(dnoise) if noise else None, bg=dev(bg),
+            exposure_scale=dev(expo) if expo is not None else None)
+  den, rgb_s, w, rgb_out, acc = ops.composite_fwd(cfg, dev(raw_d), dev(tdist), dev(dirs), **kw)
+  np.testing.assert_allclose(den.cpu().numpy(), density.detach().numpy(), rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(w.cpu().numpy(), w_ref.detach().numpy(), rtol=2e-5, atol=1e-6)
+  np.testing.assert_allclose(rgb_out.cpu().numpy(), rend['rgb'].detach().numpy(), rtol=2e-5, atol=2e-6)
+  np.testing.assert_allclose(acc.cpu().numpy(), w_ref.detach().sum(-1).numpy(), rtol=2e-5, atol=1e-6)
+  if has_rgb:
+    np.testing.assert_allclose(rgb_s.cpu().numpy(), rgb.detach().numpy(), rtol=2e-5, atol=1e-6)
+  gbf = torch.zeros((B * n, 8), dtype=torch.bfloat16).cuda()
+  g_rd, g_rr = ops.composite_bwd(cfg, dev(raw_d), dev(tdist), dev(dirs), w, g_rgb_out=dev(g_out), g_weights=dev(g_w),
+                                 g_den_bf16=gbf[:, 3:], ld_bf16=8, **kw)
+  sc = rd.grad.abs().max().item()
+  np.testing.assert_allclose(g_rd.cpu().numpy(), rd.grad.numpy(), rtol=2e-4, atol=2e-5 * sc)
+  assert torch.equal(gbf.cpu()[:, 3].reshape(B, n), g_rd.cpu().to(torch.bfloat16))
+  if has_rgb:
+    np.testing.assert_allclose(g_rr.cpu().numpy(), rr.grad.numpy(), rtol=2e-4, atol=2e-5 * rr.grad.abs().max().item())
+
+
+def test_render_extras(ops):
+  gen = torch.Generator().manual_seed(10)
+  B, n = 77, 32
+  density = torch.exp(torch.randn((B, n), generator=gen))
+  density[5] = 0
+  tdist = torch.cumsum(torch.rand((B, n + 1), generator=gen) * 0.1 + 1e-3, -1) + 0.2
+  dirs = torch.randn((B, 3), generator=gen)
+  w, _, _ = orender.compute_alpha_weights(density, tdist, dirs, opaque_background=False)
+  far = torch.full((B, 1), 1e6)
+  ref = orender.volumetric_rendering(torch.zeros((B, n, 3)), w, tdist, 0.5, far, True)
+  out = ops.render_extras(dev(w), dev(tdist), dev(far.reshape(-1))).cpu()
+  for i, k in enumerate(['distance_mean', 'distance_percentile_5', 'distance_median', 'distance_percentile_95']):
+    np.testing.assert_allclose(out[:, i].numpy(), ref[k].numpy(), rtol=2e-4, atol=1e-5, err_msg=k)
+
+
+# ----------------------------------------------------------------------------- losses / optimiser
+
+
+def test_losses(ops):
+  gen = torch.Generator().manual_seed(11)
+  B, Bv, n, ne = 300, 290, 32, 64
+  t, w = rand_stepfun(gen, B, n)
+  te, we = rand_stepfun(gen, B, ne)
+  w, we = w * 0.9, we * 0.95
+  np.testing.assert_allclose(ops.lossfun_outer(dev(t), dev(w), dev(te), dev(we)).cpu().numpy(),
+                             ostepfun.lossfun_outer(t, w, te, we).numpy(), rtol=1e-3, atol=1e-7)
+  np.testing.assert_allclose(ops.lossfun_distortion(dev(t), dev(w)).cpu().numpy(),
+                             ostepfun.lossfun_distortion(t, w).numpy(), rtol=1e-5, atol=1e-8)
+  # interlevel + distortion with gradients, B_valid < B (padded rays contribute nothing)
+  wv = w[:Bv].clone().requires_grad_(True)
+  wev = we[:Bv].clone().requires_grad_(True)
+  li = 1.0 * torch.mean(ostepfun.lossfun_outer(t[:Bv], wv.detach(), te[:Bv], wev))
+  ld = 0.01 * torch.mean(ostepfun.lossfun_distortion(t[:Bv], wv))
+  (li + ld).backward()
+  stats = torch.zeros(2).cuda()
+  g_we = torch.zeros((B, ne)).cuda()
+  g_w = torch.zeros((B, n)).cuda()
+  ops.interlevel_loss(1.0, dev(t), dev(w), dev(te), dev(we), stats[0:1], g_we, B_valid=Bv)
+  ops.distortion_loss(0.01, dev(t), dev(w), stats[1:2], g_w, B_valid=Bv)
+  np.testing.assert_allclose(stats.cpu().numpy(), [li.item(), ld.item()], rtol=1e-4)
+  np.testing.assert_allclose(g_we.cpu()[:Bv].numpy(), wev.grad.numpy(), rtol=1e-3, atol=1e-9)
+  np.testing.assert_allclose(g_w.cpu()[:Bv].numpy(), wv.grad.numpy(), rtol=1e-4, atol=1e-10)
+  assert (g_we.cpu()[Bv:] == 0).all() and (g_w.cpu()[Bv:] == 0).all()
+
+  class Cfg:
+    disable_multiscale_loss = False
+    charb_padding = 0.001
+    data_coarse_loss_mult = 0.0
+    data_loss_mult = 1.0
+    compute_disp_metrics = False
+    compute_normal_metrics = False
+
+  class Obj:
+    pass
+
+  for loss_type, lm_c in [('charb', 1), ('mse', 1), ('rawnerf', 3)]:
+    Cfg.data_loss_type = loss_type
+    rgb = (torch.rand((B, 3), generator=gen) * 1.3).requires_grad_(True)
+    gt = torch.rand((B, 3), generator=gen)
+    lm = torch.rand((B, lm_c), generator=gen)
+    batch, rays = Obj(), Obj()
+    batch.rgb, rays.lossmult = gt[:Bv], lm[:Bv]
+    loss, st = otrain.compute_data_loss(batch, [{'rgb': rgb[:Bv]}], rays, Cfg)
+    loss.backward()
+    denom = torch.zeros(1).cuda()
+    ops.lossmult_sum(dev(lm), Bv, denom)
+    stats = torch.zeros(2).cuda()
+    g = ops.data_loss(loss_type, 0.001, 1.0, dev(rgb.detach()), dev(gt), dev(lm), denom, stats, B_valid=Bv)
+    np.testing.assert_allclose(stats.cpu().numpy(), [st['mses'][0].item(), loss.item()], rtol=1e-4)
+    np.testing.assert_allclose(g.cpu().numpy(), rgb.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+def test_clip_adam(ops):
+  gen = torch.Generator().manual_seed(12)
+  P = 100003
+  seg = [(0, 60000), (60000, P)]
+  params = torch.randn(P, generator=gen)
+  grad = torch.randn(P, generator=gen) * 1e-2
+  grad[7] = float('nan')
+  mu = torch.randn(P, generator=gen) * 1e-3
+  nu = torch.rand(P, generator=gen) * 1e-5
+
+  class Cfg:
+    adam_beta1, adam_beta2, adam_eps = 0.9, 0.999, 1e-6
+    lr_init, lr_final, max_steps, lr_delay_steps, lr_delay_mult = 2e-3, 2e-5, 250000, 512, 0.01
+    grad_max_norm, grad_max_val = 1e-3, 0.05
+
+  tree_p = {'a': {'k': params[:60000].clone()}, 'b': {'k': params[60000:].clone()}}
+  tree_g = {'a': {'k': grad[:60000].clone()}, 'b': {'k': grad[60000:].clone()}}
+  g = otrain.clip_gradients(tree_g, Cfg)
+  g = otrain.tree_map(torch.nan_to_num, g)
+  state = {'count': 41, 'mu': {'a': {'k': mu[:60000].clone()}, 'b': {'k': mu[60000:].clone()}},
+           'nu': {'a': {'k': nu[:60000].clone()}, 'b': {'k': nu[60000:].clone()}}}
+  new_p, new_s = otrain.adam_update(tree_p, g, state, Cfg)
+  dp, dg, dmu, dnu = dev(params), dev(grad), dev(mu), dev(nu)
+  lr = float(otrain.lr_fn(Cfg, 41))
+  for (b, e) in seg:
+    sq = torch.zeros(1).cuda()
+    ops.grad_sqnorm(dg, b, e, Cfg.grad_max_val, sq)
+    ops.clip_adam(dg, dp, dmu, dnu, b, e, sq, lr=lr, b1=0.9, b2=0.999, eps=1e-6, step=42,
+                  grad_max_val=Cfg.grad_max_val, grad_max_norm=Cfg.grad_max_norm)
+  ref_p = torch.cat([new_p['a']['k'], new_p['b']['k']])
+  # NaN gradient: the reference's norm is NaN for that module (mult = NaN -> nan_to_num(0)); the kernel
+  # reproduces this because the NaN enters the sum of squares the same way.
+  np.testing.assert_allclose(dp.cpu().numpy(), ref_p.numpy(), rtol=1e-5, atol=1e-7)
+  np.testing.assert_allclose(dmu.cpu().numpy(), torch.cat([new_s['mu']['a']['k'], new_s['mu']['b']['k']]).numpy(), rtol=1e-5, atol=1e-9)
+  np.testing.assert_allclose(dnu.cpu().numpy(), torch.cat([new_s['nu']['a']['k'], new_s['nu']['b']['k']]).numpy(), rtol=1e-5, atol=1e-12)

@@ -1,0 +1,164 @@
+"""Composed parity on the GPU: Model forward, train_step gradients and one Adam update
+through the C ABI vs the CPU oracle on identical rays, weights and jitter.  -m gpu.
+
+Tolerance model.  The Dense stack runs bf16 x bf16 -> fp32 on the MFMA units.  The
+oracle is evaluated twice: (a) emulating that rounding (dense_dtype=bfloat16): the
+kernels must agree with it up to accumulation-order noise + rare 1-ulp bf16 flips;
+(b) plain fp32: the distance (a)-(b) is the bf16 precision cost and is REPORTED,
+with the kernel held to 3x that distance.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multinerf_amd import configs, models, train_utils
+from oracle import models as omodels
+from oracle import train_utils as otrain
+from tests import helpers
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _gpu():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+
+
+def _setup(name, extra, B, seed=3):
+  cfg = configs.load_preset(name, list(extra))
+  model = models.Model(config=cfg)
+  model.build('cuda')
+  om, on, op = helpers.oracle_hparams(model)
+  params = omodels.init_params(om, on, op, seed=seed)
+  # non-zero biases so that bias paths are exercised
+  g = torch.Generator().manual_seed(seed + 1)
+  for mod in params.values():
+    for d in mod.values():
+      d['bias'] = 0.05 * torch.randn(d['bias'].shape, generator=g)
+  flat = model.flat_from_tree(params)
+  near, far = cfg.near, cfg.far
+  batch = helpers.synthetic_rays(B, near=near, far=far)
+  return cfg, model, (om, on, op), params, flat, batch
+
+
+CASES = [
+    ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128'], 40),
+    ('blender_256', [], 24),
+]
+
+
+@pytest.mark.parametrize('name,extra,B', CASES)
+@pytest.mark.parametrize('randomized', [False, True])
+def test_forward_parity(name, extra, B, randomized):
+  cfg, model, (om, on, op), params, flat, batch = _setup(name, extra, B)
+  noise = helpers.make_noise(model, B) if randomized else None
+  tf = 0.5
+  r_bf, h_bf = omodels.model_apply(om, on, op, params, batch.rays, tf, True, noise=noise,
+                                   dense_dtype=torch.bfloat16)
+  r_32, h_32 = omodels.model_apply(om, on, op, params, batch.rays, tf, True, noise=noise)
+  rays_d = batch.rays.map(lambda t: t.cuda())
+  rend, hist = model.apply({'flat': flat}, None, rays_d, tf, True, noise=noise)
+  torch.cuda.synchronize()
+  for lv in range(model.num_levels):
+    s_k, s_o = hist[lv]['sdist'].cpu(), h_bf[lv]['sdist']
+    # level 0 depends on no MLP output: fp32-exact up to transcendental ulps.
+    tol_s = 2e-6 if lv == 0 else 2e-3
+    err_s = (s_k - s_o).abs().max().item()
+    cost_s = (h_bf[lv]['sdist'] - h_32[lv]['sdist']).abs().max().item()
+    print(f'{name} rand={randomized} level {lv}: |sdist - oracle_bf16| = {err_s:.2e} (bf16 cost {cost_s:.2e})')
+    assert err_s <= max(tol_s, 3 * cost_s)
+    w_k, w_o = hist[lv]['weights'].cpu(), h_bf[lv]['weights']
+    err_w = (w_k - w_o).abs().max().item()
+    cost_w = (h_bf[lv]['weights'] - h_32[lv]['weights']).abs().max().item()
+    print(f'    weights err {err_w:.2e} (bf16 cost {cost_w:.2e})')
+    assert err_w <= max(5e-3, 3 * cost_w)
+  rgb_k, rgb_o, rgb_32 = rend[-1]['rgb'].cpu(), r_bf[-1]['rgb'], r_32[-1]['rgb']
+  err = (rgb_k - rgb_o).abs().max().item()
+  cost = (rgb_o - rgb_32).abs().max().item()
+  print(f'{name} rand={randomized}: rgb |kernel - oracle_bf16| = {err:.2e}; bf16 cost |oracle_bf16 - oracle_fp32| = {cost:.2e}; '
+        f'|kernel - oracle_fp32| = {(rgb_k - rgb_32).abs().max().item():.2e}')
+  assert err <= max(5e-3, 3 * cost)
+  for k in ('acc', 'distance_mean', 'distance_median', 'distance_percentile_5', 'distance_percentile_95'):
+    a, b = rend[-1][k].cpu(), r_bf[-1][k]
+    rel = ((a - b).abs() / b.abs().clamp_min(1e-3)).max().item()
+    assert rel < 0.05, (k, rel)
+  assert rend[0]['ray_sdist'].shape == r_bf[0]['ray_sdist'].shape
+  assert rend[0]['ray_rgbs'].shape == r_bf[0]['ray_rgbs'].shape
+
+
+def _flat_grads(model, grads_tree):
+  return model.flat_from_tree(grads_tree, device='cpu')
+
+
+@pytest.mark.parametrize('name,extra,B', CASES)
+def test_train_step_parity(name, extra, B):
+  cfg, model, (om, on, op), params, flat, batch = _setup(name, extra, B)
+  noise = helpers.make_noise(model, B)
+  tf = 0.3
+  st = otrain.init_opt_state(params)
+  new_p, new_s, stats_o, grads_o = otrain.train_step(params, st, om, on, op, cfg, batch, tf, noise=noise,
+                                                     dense_dtype=torch.bfloat16)
+  _, _, stats_32, grads_32 = otrain.train_step(params, st, om, on, op, cfg, batch, tf, noise=noise)
+  g_ref = _flat_grads(model, grads_o)
+  g_32 = _flat_grads(model, grads_32)
+
+  variables = {'flat': flat.clone(), 'params': None}
+  state, lr_fn = train_utils.create_optimizer(cfg, variables)
+  step = train_utils.create_train_step(model, cfg)
+  batch_d = batch.map(lambda t: t.cuda())
+  state2, stats, _ = step(0, state, batch_d, None, tf, 0.0, noise=noise, return_grads=True)
+  torch.cuda.synchronize()
+  g = stats['_grads'].cpu()
+  s = stats.materialize()
+  print(f'{name}: loss kernel {s["loss"]:.6f} oracle_bf16 {float(stats_o["loss"]):.6f} oracle_fp32 {float(stats_32["loss"]):.6f}')
+  assert abs(s['loss'] - float(stats_o['loss'])) <= 0.02 * abs(float(stats_o['loss'])) + 1e-5
+  np.testing.assert_allclose(s['mses'], stats_o['mses'].detach().numpy(), rtol=0.03, atol=1e-5)
+  for mod, b, e in model.modules:
+    a, r, r32 = g[b:e].double(), g_ref[b:e].double(), g_32[b:e].double()
+    cos = (a @ r / (a.norm() * r.norm() + 1e-30)).item()
+    rel = ((a - r).norm() / (r.norm() + 1e-30)).item()
+    cost = ((r - r32).norm() / (r32.norm() + 1e-30)).item()
+    print(f'{name} {mod}: grad cos {cos:.6f} rel err {rel:.3e} (bf16 cost {cost:.3e}) |g| {r.norm().item():.3e}')
+    assert cos > 0.995 and rel < max(0.05, 3 * cost)
+  # per-Dense check (catches a layer whose gradient lands at the wrong offset)
+  for p in model._plans:
+    for d in p.dense:
+      for (o, nelem, what) in ((d.kernel_off, d.fan_in * d.fan_out, 'kernel'), (d.bias_off, d.fan_out, 'bias')):
+        a, r = g[o:o + nelem].double(), g_ref[o:o + nelem].double()
+        if r.norm() < 1e-12:
+          assert a.norm() < 1e-6, (p.module_name, d.name, what)
+          continue
+        rel = ((a - r).norm() / r.norm()).item()
+        assert rel < 0.12, (p.module_name, d.name, what, rel)
+  # one Adam step
+  ref_flat = model.flat_from_tree(new_p, device='cpu')
+  got = state2.params['flat'].cpu()
+  upd_ref = ref_flat - flat.cpu()
+  upd = got - flat.cpu()
+  # first Adam step is lr * sign-like; compare where the reference gradient is not ~0.
+  big = g_ref.abs() > 1e-3 * g_ref.abs().max()
+  agree = (torch.sign(upd[big]) == torch.sign(upd_ref[big])).float().mean().item()
+  print(f'{name}: Adam update sign agreement on significant grads {agree:.4f}')
+  assert agree > 0.97
+  assert state2.step == 1
+
+
+def test_unsupported_features_fail_loudly():
+  cfg = configs.load_preset('blender_refnerf')
+  with pytest.raises(NotImplementedError, match='HIP path'):
+    models.Model(config=cfg).build('cuda')
+
+
+def test_render_image_chunks():
+  cfg, model, _, params, flat, _ = _setup('blender_256', ['Config.render_chunk_size = 96'], 8)
+  H, W = 10, 14
+  b = helpers.synthetic_rays(H * W, near=cfg.near, far=cfg.far)
+  rays = b.rays.map(lambda t: t.reshape(H, W, -1).cuda())
+  fn = train_utils.create_render_fn(model)
+  out = models.render_image(lambda rng, r: fn({'flat': flat}, 1.0, None, r), rays, None, cfg, verbose=False)
+  assert out['rgb'].shape == (H, W, 3) and out['acc'].shape == (H, W)
+  full, _ = model.apply({'flat': flat}, None, b.rays.map(lambda t: t.cuda()), 1.0, True)
+  np.testing.assert_allclose(out['rgb'].reshape(-1, 3).cpu().numpy(), full[-1]['rgb'].cpu().numpy(), atol=1e-6)
+  assert len(out['ray_sdist']) == model.num_levels
