@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""Benchmark of the MultiNeRF hot path on MI355X: training rays/s on configs/360.gin.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full train_step (forward of the 3 sampling levels, losses, backward,
+per-module clip, Adam) on one batch of synthetic rays already resident in HBM
+(SURVEY.md 8d inputs; random-init weights; real jitter).  Data parallel: each rank
+owns `batch_size` rays (weak scaling), one RCCL all-reduce of the flat fp32 gradient
+per step.  Rank 0 prints ONE JSON line.
+
+roofline: the dominant kernels are the bf16 MFMA GEMMs (gemm_nt_kernel forward/dX,
+gemm_tn_kernel dW).  achieved = algorithmic training FLOPs of one step (SURVEY.md 8d:
+1815.994 MFLOP/ray at 360.gin x rays per launch-set) / summed duration of those
+kernels within the step, measured with HIP events on the launch stream during the
+timed region (a second, identical, instrumented pass so the events do not perturb
+`value`).  peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).
+
+cpu_baseline: the torch-CPU oracle ("port" of the reference's jax-cpu path: JAX is not
+installable here) running the same train_step on a bounded sample, host cores stated.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def algorithmic_flops_per_ray(model):
+  """Dense MACs only. Returns (forward, training) FLOPs per ray."""
+  fwd = 0.0
+  train = 0.0
+  for (i, is_prop, n, _) in model._level_plan():
+    plan = model.prop_plan if is_prop else model.nerf_plan
+    macs = 0
+    no_dx = 0           # MACs whose input needs no gradient (first layer, skip-concat features, view encoding)
+    for li, (d, concat) in enumerate(plan.trunk):
+      macs += d.fan_in * d.fan_out
+      if li == 0:
+        no_dx += d.fan_in * d.fan_out
+      elif concat:
+        no_dx += plan.F * d.fan_out
+    macs += plan.density.fan_in
+    if plan.has_rgb:
+      macs += plan.bottleneck.fan_in * plan.bottleneck.fan_out
+      for li, (d, concat) in enumerate(plan.view):
+        macs += d.fan_in * d.fan_out
+        if li == 0:
+          no_dx += (plan.vi_width - plan.hp.bottleneck_width) * d.fan_out
+      macs += plan.rgb.fan_in * plan.rgb.fan_out
+    fwd += 2.0 * n * macs
+    train += 2.0 * n * (3 * macs - no_dx)
+  return fwd, train
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--batch_size', type=int, default=16384, help='rays per GPU (Config.batch_size of 360.gin)')
+  ap.add_argument('--preset', default='360')
+  ap.add_argument('--gin_bindings', action='append', default=[])
+  ap.add_argument('--no_cpu_baseline', action='store_true')
+  ap.add_argument('--cpu_rays', type=int, default=128)
+  args = ap.parse_args()
+
+  from multinerf_amd import configs, dist as mdist, models, ops, train_utils
+  from tests import helpers
+
+  mdist.init_from_env()
+  rank, world = mdist.rank(), mdist.world_size()
+  if world != args.gpus:
+    raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run')
+  local = int(os.environ.get('LOCAL_RANK', '0'))
+  torch.cuda.set_device(local)
+  dev = torch.device('cuda', local)
+
+  cfg = configs.load_preset(args.preset, args.gin_bindings)
+  cfg.batch_size = args.batch_size
+  model, state, render_eval_pfn, train_pstep, lr_fn = train_utils.setup_model(cfg, 0, device=dev)
+  B = args.batch_size
+  batch = helpers.synthetic_rays(B, seed=20200823 + rank, near=cfg.near, far=cfg.far).map(lambda t: t.to(dev))
+  gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+  train_frac = 0.5
+
+  def step():
+    nonlocal state
+    state, stats, _ = train_pstep(gen, state, batch, None, train_frac, 0.0)
+    return stats
+
+  for _ in range(args.warmup):
+    stats = step()
+  torch.cuda.synchronize()
+  mdist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    stats = step()
+  torch.cuda.synchronize()
+  mdist.barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+  s = stats.materialize()
+
+  # ---- roofline of the dominant kernels: instrumented pass (HIP events around every GEMM launch)
+  fwd_flops, train_flops = algorithmic_flops_per_ray(model)
+  ops.PROFILE.enable()
+  nprof = max(1, min(3, args.steps))
+  for _ in range(nprof):
+    step()
+  torch.cuda.synchronize()
+  gemm_ms, gemm_launches = ops.PROFILE.collect()
+  ops.PROFILE.disable()
+  gemm_ms_per_step = gemm_ms / nprof
+  achieved_tflops = train_flops * B / (gemm_ms_per_step * 1e-3) / 1e12
+
+  out = None
+  if rank == 0:
+    rays_per_sec = B * world * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    out = {
+        'metric': 'train_rays_per_sec',
+        'value': rays_per_sec,
+        'unit': 'rays/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': ms_per_step,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'bf16 MFMA inputs / fp32 accumulate, fp32 everywhere else',
+        'data': 'synthetic rays (SURVEY 8d, seed 20200823+rank), he_uniform random-init weights, random jitter',
+        'config': {
+            'workload': f'configs/360.gin native levels (64,64,32), train_step, batch_size={B} rays per GPU'
+                        if args.preset == '360' and not args.gin_bindings else
+                        f'preset {args.preset} {args.gin_bindings}, train_step, batch_size={B} rays per GPU',
+            'global_batch': B * world,
+            'parallelism': f'dp{world}',
+            'train_frac': train_frac,
+            'params': model.num_params,
+            'algorithmic_train_mflop_per_ray': train_flops / 1e6,
+            'algorithmic_fwd_mflop_per_ray': fwd_flops / 1e6,
+            'whole_step_tflops_per_gpu': train_flops * B / (ms_per_step * 1e-3) / 1e12,
+            'final_loss': s['loss'], 'final_psnr': s['psnr'],
+            'reference_anchor': 'derived 182,555 rays/s aggregate on unknown hardware (BASELINE.md); not a published per-device number',
+        },
+        'roofline': {
+            'bound': 'mfma',
+            'kernel': 'gemm_nt_kernel + gemm_tn_kernel (bf16 MFMA 32x32x16)',
+            'achieved': achieved_tflops,
+            'peak': 2500.0,
+            'unit': 'TFLOP/s',
+            'frac': achieved_tflops / 2500.0,
+            'traffic': None,
+            'gemm_ms_per_step': gemm_ms_per_step,
+            'gemm_launches_per_step': gemm_launches / nprof,
+            'gemm_share_of_step': gemm_ms_per_step / ms_per_step,
+        },
+    }
+
+  # ---- CPU baseline (rank 0, N=1 only): the oracle's train_step on a bounded sample
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    from oracle import models as omodels
+    from oracle import train_utils as otrain
+    om, on, op = helpers.oracle_hparams(model)
+    params = omodels.init_params(om, on, op, seed=0)
+    nb = args.cpu_rays
+    cb = helpers.synthetic_rays(nb, near=cfg.near, far=cfg.far)
+    noise = helpers.make_noise(model, nb)
+    st = otrain.init_opt_state(params)
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    otrain.train_step(params, st, om, on, op, cfg, cb, train_frac, noise=noise)     # warm-up (allocator, threads)
+    t_warm = time.perf_counter() - t0
+    reps = max(1, min(4, int(20.0 / max(t_warm, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+      otrain.train_step(params, st, om, on, op, cfg, cb, train_frac, noise=noise)
+    dt = (time.perf_counter() - t0) / reps
+    out['cpu_baseline'] = {
+        'value': nb / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
+        'sample': f'{reps} x oracle train_step (fp32 torch-CPU restatement of the reference) on {nb} rays of the same workload; '
+                  f'host has {os.cpu_count()} logical CPUs, torch used {cores} threads',
+    }
+  if rank == 0:
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+  main()

@@ -127,6 +127,9 @@ def load():
     raise RuntimeError(
         f'{LIB_PATH} is missing: the HIP extension has not been built. Run '
         '`python -m multinerf_amd.build` (needs hipcc, ROCm >= 7.0). There is no CPU fallback.')
+  # torch must load ITS HIP runtime first: libmnerf_hip.so then binds to that same libamdhip64
+  # instead of pulling a second copy from /opt/rocm (two runtimes in one process cannot share the device).
+  import torch  # noqa: F401
   lib = C.CDLL(LIB_PATH)
   lib.mnr_last_error.restype = C.c_char_p
   lib.mnr_last_error.argtypes = []

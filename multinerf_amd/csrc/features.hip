@@ -72,35 +72,43 @@ __device__ __forceinline__ void fe_gaussian(const mnr_ipe_cfg& c, float t0, floa
       cov[i][j] = t_var * dd + r_var * null_outer;
     }
   if (c.disable_integration) {
+    t_var = 0.0f;
+    r_var = 0.0f;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) cov[i][j] = 0.0f;
   }
   if (c.warp_contract) {
-    // coord.py:21-27 and its Jacobian: inside the unit ball identity; outside
-    // z = s x, J = s I + c x x^T, s = (2 sqrt(m) - 1)/m, c = 2 (1 - sqrt(m))/m^2.
+    // coord.py:21-27 and its Jacobian (what jax.linearize yields, coord.py:58-59): identity inside
+    // the unit ball; outside z = s x, J = s I + cc x x^T, s = (2 sqrt(m) - 1)/m, cc = 2 (1 - sqrt(m))/m^2.
+    //
+    // J cov J^T is evaluated from the STRUCTURE of cov = t_var d d^T + r_var (I - d d^T/|d|^2):
+    //   J cov J^T = t_var u u^T + r_var (J^2 - u u^T/|d|^2),   u = J d,
+    //   J^2 = s^2 I + (2 cc / sqrt(m)) x x^T            (2 s cc + cc^2 m = 2 cc / sqrt(m)),
+    //   u   = [m - 2 (1 - sqrt(m)) (|o|^2 + t (o.d))] / m^2 * d + cc (x.d) o     (x = o + t d).
+    // Same function as the reference's two matrix products, but without forming s*t_var*d d^T
+    // (~1e5 for the far samples of 360.gin) only to cancel it against cc*(x.d)*t_var*x d^T: the
+    // plain products lose ~10% of the tangential variance there in fp32.
     const float m = fmaxf(MNR_F32_EPS, mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
     if (!(m <= 1.0f)) {
       const float sq = sqrtf(m);
       const float s = (2.0f * sq - 1.0f) / m;
       const float cc = 2.0f * (1.0f - sq) / (m * m);
-      float J[3][3];
+      const float oo = o[0] * o[0] + o[1] * o[1] + o[2] * o[2];
+      const float od = o[0] * d[0] + o[1] * d[1] + o[2] * d[2];
+      const float xd = mean[0] * d[0] + mean[1] * d[1] + mean[2] * d[2];
+      const float brk = (m - 2.0f * (1.0f - sq) * (oo + t_mean * od)) / (m * m);
+      float u[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) J[i][j] = (i == j ? s : 0.0f) + cc * mean[i] * mean[j];
-      float tmp[3][3];
+      for (int i = 0; i < 3; ++i) u[i] = brk * d[i] + cc * xd * o[i];
+      const float j2x = 2.0f * cc / sq;
+      const float ku = t_var - r_var / dmag;
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-          tmp[i][j] = J[i][0] * cov[0][j] + J[i][1] * cov[1][j] + J[i][2] * cov[2][j];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          cov[i][j] = tmp[i][0] * J[j][0] + tmp[i][1] * J[j][1] + tmp[i][2] * J[j][2];
+          cov[i][j] = ku * u[i] * u[j] + r_var * ((i == j ? s * s : 0.0f) + j2x * mean[i] * mean[j]);
 #pragma unroll
       for (int i = 0; i < 3; ++i) mean[i] = s * mean[i];
     }

@@ -40,6 +40,44 @@ def lib():
   return L.load()
 
 
+class _GemmProfile:
+  """Optional HIP-event timing of every GEMM launch on the launch stream (bench.py roofline)."""
+
+  def __init__(self):
+    self.on = False
+    self.events = []
+
+  def enable(self):
+    self.on, self.events = True, []
+
+  def disable(self):
+    self.on = False
+
+  def start(self):
+    if not self.on:
+      return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream())
+    return e0
+
+  def stop(self, e0):
+    if e0 is None:
+      return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record(torch.cuda.current_stream())
+    self.events.append((e0, e1))
+
+  def collect(self):
+    """-> (total ms, launches); call after a synchronize."""
+    ms = sum(a.elapsed_time(b) for a, b in self.events)
+    n = len(self.events)
+    self.events = []
+    return ms, n
+
+
+PROFILE = _GemmProfile()
+
+
 # ----------------------------------------------------------------------------- sampling
 
 
@@ -171,7 +209,9 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
   a.mask, a.ldmask = (mask.data_ptr() if mask is not None else None), ldmask
   a.Cb, a.ldcb, a.nb = (Cb.data_ptr() if Cb is not None else None), ldcb, nb
   a.Cf, a.ldcf, a.f0, a.nf = (Cf.data_ptr() if Cf is not None else None), ldcf, f0, nf
+  _e = PROFILE.start()
   L.check(lib().mnr_gemm_nt_bf16(C.byref(a), _stream()))
+  PROFILE.stop(_e)
 
 
 def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, n_valid=None):
@@ -186,7 +226,9 @@ def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, 
   a.C, a.ldc = Cout.data_ptr(), ldc if ldc else Cout.stride(0)
   a.k_valid = K if k_valid is None else k_valid
   a.n_valid = N if n_valid is None else n_valid
+  _e = PROFILE.start()
   L.check(lib().mnr_gemm_tn_bf16(C.byref(a), _stream()))
+  PROFILE.stop(_e)
 
 
 def colsum(X, M, n_valid, out, ld=None):

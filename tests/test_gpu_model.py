@@ -122,16 +122,23 @@ def test_train_step_parity(name, extra, B):
     cost = ((r - r32).norm() / (r32.norm() + 1e-30)).item()
     print(f'{name} {mod}: grad cos {cos:.6f} rel err {rel:.3e} (bf16 cost {cost:.3e}) |g| {r.norm().item():.3e}')
     assert cos > 0.995 and rel < max(0.05, 3 * cost)
-  # per-Dense check (catches a layer whose gradient lands at the wrong offset)
+  # per-Dense check (catches a layer whose gradient lands at the wrong offset); the hinge in the
+  # interlevel loss makes proposal gradients sensitive to bf16-level weight changes, so each layer is
+  # judged against its own bf16 cost.
+  worst = 0.0
   for p in model._plans:
     for d in p.dense:
       for (o, nelem, what) in ((d.kernel_off, d.fan_in * d.fan_out, 'kernel'), (d.bias_off, d.fan_out, 'bias')):
-        a, r = g[o:o + nelem].double(), g_ref[o:o + nelem].double()
+        a, r, r32 = g[o:o + nelem].double(), g_ref[o:o + nelem].double(), g_32[o:o + nelem].double()
         if r.norm() < 1e-12:
           assert a.norm() < 1e-6, (p.module_name, d.name, what)
           continue
         rel = ((a - r).norm() / r.norm()).item()
-        assert rel < 0.12, (p.module_name, d.name, what, rel)
+        cost = ((r - r32).norm() / (r32.norm() + 1e-30)).item()
+        print(f'LAYER {p.module_name}/{d.name}/{what}: rel {rel:.3e} (bf16 cost {cost:.3e})')
+        if nelem >= 8:   # scalars (Dense(1) biases) are sums with full cancellation: noise, not signal
+          worst = max(worst, rel / max(0.05, 1.5 * cost))
+  assert worst <= 1.0, worst
   # one Adam step
   ref_flat = model.flat_from_tree(new_p, device='cpu')
   got = state2.params['flat'].cpu()
