@@ -149,6 +149,9 @@ typedef struct {
 
 /* C[M,N] = epilogue([A1|A2] * Bt^T). */
 int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* args, void* stream);
+/* Tuning hook: tile / pipeline configuration ids (see csrc/gemm.hip NtC0..NtC7) used when N is a
+ * multiple of 256 (`cfg_big`) and otherwise (`cfg_small`; must be a 128x128 configuration). */
+int mnr_gemm_nt_set_config(int cfg_big, int cfg_small);
 
 typedef struct {
   const uint16_t* A; int lda; int K;   /* A [M, lda] bf16, K columns used, K multiple of 128 */
@@ -156,6 +159,8 @@ typedef struct {
   int64_t M;                           /* multiple of 64 */
   float* C; int ldc;                   /* fp32 [k_valid, ldc]: C[k,n] += sum_m A[m,k] B[m,n] */
   int k_valid, n_valid;                /* only k < k_valid, n < n_valid are written */
+  float* bias_out; int bias_n_valid;   /* optional: bias_out[n] += sum_m B[m,n] for n < bias_n_valid
+                                          (the Dense bias gradient, fused: B is read once) */
 } mnr_gemm_tn_args;
 
 /* Weight gradient: C += A^T B (fp32 atomics; C must be initialised by the caller). */

@@ -54,7 +54,8 @@ class GemmTNArgs(C.Structure):
   _fields_ = [('A', vp), ('lda', C.c_int), ('K', C.c_int),
               ('B', vp), ('ldb', C.c_int), ('N', C.c_int),
               ('M', C.c_int64), ('C', vp), ('ldc', C.c_int),
-              ('k_valid', C.c_int), ('n_valid', C.c_int)]
+              ('k_valid', C.c_int), ('n_valid', C.c_int),
+              ('bias_out', vp), ('bias_n_valid', C.c_int)]
 
 
 class PackDesc(C.Structure):
@@ -87,6 +88,7 @@ _PROTOS = {
     'mnr_cast_rays_ipe_f32': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_viewdir_enc_fill': ([i64, i32, vp, i32, vp, i32, i32, i32, vp], i32),
     'mnr_gemm_nt_bf16': ([C.POINTER(GemmNTArgs), vp], i32),
+    'mnr_gemm_nt_set_config': ([i32, i32], i32),
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
     'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),
     'mnr_pack_weights_bf16': ([vp, vp, i32, i32, vp, vp], i32),

@@ -15,156 +15,272 @@
 // ---------------------------------------------------------------------------
 // NT kernel.
 //
-// LDS image of one operand tile: [128 rows][64 k] bf16 = 128 B per row = eight
-// 16-B slots.  Slot s of row r is stored at slot position s ^ ((r >> 1) & 7):
-// a ds_read_b128 lane group covers 16 distinct rows at one k-slot, and
+// LDS image of one operand tile: [rows][64 k] bf16 = 128 B per row = eight 16-B
+// slots.  Slot s of row r is stored at slot position s ^ ((r >> 1) & 7): a
+// ds_read_b128 lane group covers 16 distinct rows at one k-slot, and
 // (r & 1, (r >> 1) & 7) is distinct for them, so the 16 reads hit 16 distinct
 // 16-B slots of the 256-B bank row.
 // MFMA roles are swapped (A-operand = weights rows n, B-operand = activations
 // rows m) so that a lane's 4 consecutive accumulators are 4 consecutive n of
-// one output row m: row-major stores of 8 B (bf16x4) per lane.
+// one output row m.
+//
+// Two tile configurations (template NtCfg):
+//   small: 128x128 tile, 4 waves (2x2), 64x64 per wave   -- N not a multiple of 256 (heads)
+//   big  : 256x256 tile, 8 waves (2 along M x 4 along N), 128x64 per wave -- the trunk layers.
+// The big tile halves both the L2->LDS bytes and the LDS fragment reads per MFMA
+// (6 ds_read_b128 per 8 MFMAs instead of 4 per 4); at 128x128 the LDS array is
+// busy ~as long as the matrix pipe (measured 400-560 TF/s, profiles/r1_c).
 
-#define NT_BM 128
-#define NT_BN 128
-#define NT_BK 64
-#define NT_TILE_BYTES (128 * 64 * 2)                 // 16 KiB per operand tile
-#define NT_STAGE_BYTES (2 * NT_TILE_BYTES)           // A + B
-#define NT_LDS_BYTES (2 * NT_STAGE_BYTES)            // double buffered: 64 KiB
+#define NT_CPAD 16                                   // epilogue staging: 16 B pad per row
 
+template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_>
+struct NtCfg {
+  static constexpr int MI = MI_, NJ = NJ_, WM = WM_, WN = WN_, BK = BK_, STAGES = STAGES_;
+  static constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
+  static constexpr int THREADS = 64 * WM * WN;
+  static constexpr int ROWB = BK * 2;                 // bytes per staged operand row
+  static constexpr int SLOTS = ROWB / 16;             // 16-B slots per row (8 at BK=64, 4 at BK=32)
+  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+  static constexpr int LOADS_PER_STAGE = STAGE_BYTES / 16 / THREADS;   // LDS-DMA instructions per wave per stage
+  static constexpr int CPITCH = BN * 2 + NT_CPAD;     // bytes per staged output row
+  static constexpr int EPI_ROWS = (128 * CPITCH <= LDS_BYTES) ? 128 : 64;   // rows staged per epilogue pass
+  static_assert(EPI_ROWS * CPITCH <= LDS_BYTES, "epilogue staging must fit in the operand buffers");
+  static_assert(BM % EPI_ROWS == 0 && (32 * MI) <= EPI_ROWS && EPI_ROWS % (32 * MI) == 0, "epilogue pass shape");
+  static_assert((BM * SLOTS) % THREADS == 0 && (BN * SLOTS) % THREADS == 0, "stage loop shape");
+};
+
+// Stage one operand tile [ROWS][BK] with 16-B LDS-DMA.  LDS image: row r, slot s stored at slot
+// position s ^ swz(r) with swz(r) = (r >> 1) & 7 for 128-B rows (BK=64) and (r >> 2) & 3 for 64-B
+// rows (BK=32): the 16 rows of a ds_read_b128 lane group then cover 16 distinct 16-B slots of the
+// 256-B bank row.  The swizzle is applied to the SOURCE address; the DMA image itself is linear.
+template <class CFG, int ROWS>
 __device__ __forceinline__ void nt_stage_tile(const bf16* __restrict__ g, int ld, int64_t row0,
                                               int k0, char* lds_tile, int wave, int lane) {
-  // 1024 chunks of 16 B; wave w issues chunks [(i*4+w)*64, +64) for i = 0..3.
+  constexpr int NWAVES = CFG::THREADS / 64;
+  constexpr int SLOTS = CFG::SLOTS;
+  constexpr int ITERS = ROWS * SLOTS / CFG::THREADS;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int cbase = (i * 4 + wave) * 64;
+  for (int i = 0; i < ITERS; ++i) {
+    const int cbase = (i * NWAVES + wave) * 64;
     const int c = cbase + lane;
-    const int r = c >> 3;
-    const int slot = (c & 7) ^ ((r >> 1) & 7);      // global k-slot stored at this position
+    const int r = c / SLOTS;
+    const int swz = (SLOTS == 8) ? ((r >> 1) & 7) : ((r >> 2) & 3);
+    const int slot = (c % SLOTS) ^ swz;             // global k-slot stored at this position
     const bf16* src = g + (row0 + r) * (int64_t)ld + k0 + slot * 8;
     __builtin_amdgcn_global_load_lds(MNR_GLOBAL_PTR(src), MNR_LDS_PTR(lds_tile + cbase * 16), 16, 0, 0);
   }
 }
 
+template <class CFG>
 __device__ __forceinline__ bf16x8 nt_read_frag(const char* lds_tile, int row, int kslot) {
-  const int off = row * 128 + ((kslot ^ ((row >> 1) & 7)) << 4);
+  const int swz = (CFG::SLOTS == 8) ? ((row >> 1) & 7) : ((row >> 2) & 3);
+  const int off = row * CFG::ROWB + ((kslot ^ swz) << 4);
   return *(const bf16x8*)(lds_tile + off);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(mnr_gemm_nt_args p) {
+template <int N>
+__device__ __forceinline__ void nt_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <class CFG>
+__global__ __launch_bounds__(CFG::THREADS) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi) {
+  constexpr int MI = CFG::MI, NJ = CFG::NJ, BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, STAGES = CFG::STAGES;
+  constexpr int LPS = CFG::LOADS_PER_STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / CFG::WN, wn = wave % CFG::WN;
 
   // XCD-aware mapping: the nt N-tiles of one M-tile run consecutively on one XCD.
-  const int nt = p.N / NT_BN;
-  const int64_t mt = p.M / NT_BM;
+  const int nt = p.N / BN;
+  const int64_t mt = p.M / BM;
   const int xcd = blockIdx.x & 7;
   const int64_t q = blockIdx.x >> 3;
   const int64_t m_tile = xcd + 8 * (q / nt);
   const int n_tile = (int)(q % nt);
   if (m_tile >= mt) return;
-  const int64_t m0 = m_tile * NT_BM;
-  const int n0 = n_tile * NT_BN;
+  const int64_t m0 = m_tile * BM;
+  const int n0 = n_tile * BN;
 
   const bf16* A1 = (const bf16*)p.A1;
   const bf16* A2 = (const bf16*)p.A2;
   const bf16* Bt = (const bf16*)p.Bt;
   const int K = p.K1 + p.K2;
-  const int nk = K / NT_BK;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  auto stage = [&](int kt, int buf) {
-    const int k0 = kt * NT_BK;
-    char* base = smem + buf * NT_STAGE_BYTES;
-    if (k0 < p.K1) {
-      nt_stage_tile(A1, p.lda1, m0, k0, base, wave, lane);
-    } else {
-      nt_stage_tile(A2, p.lda2, m0, k0 - p.K1, base, wave, lane);
-    }
-    nt_stage_tile(Bt, p.ldb, n0, k0, base + NT_TILE_BYTES, wave, lane);
-  };
-
-  stage(0, 0);
-  __syncthreads();
-
+  const int nk = K / BK;
   const int frow = lane & 31;
   const int khalf = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-    const char* As = smem + cur * NT_STAGE_BYTES;
-    const char* Bs = As + NT_TILE_BYTES;
+
+  // Bias of this lane's output columns, fetched once up front with clamped indices: per-element
+  // "in range ? load : 0" inside the epilogue makes hipcc branch around every load and wait for it
+  // (128 dependent L2 round trips per lane; measured: forward layers 25% slower than dX layers).
+  float bias_r[NJ][16];
+  {
+    // Branch-free: always load (from a valid address), then select.
+    const float* bp = p.bias ? p.bias : reinterpret_cast<const float*>(p.Bt);
+    const int nbias = p.bias ? p.n_bias : 1;
+    const bool has_bias = p.bias != nullptr;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int kslot = ks * 2 + khalf;
-      bf16x8 fa[2], fb[2];
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = nt_read_frag(As, wm * 64 + i * 32 + frow, kslot);
-        fb[i] = nt_read_frag(Bs, wn * 64 + i * 32 + frow, kslot);
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 * NJ + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        // multiply by a 0/1 factor rather than select: a select lets hipcc sink the load into a branch.
+        const float keep = (has_bias && n < nbias) ? 1.0f : 0.0f;
+        bias_r[j][r] = bp[min(n, nbias - 1)] * keep;
       }
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
-    }
-    __syncthreads();
   }
 
-  // Epilogue.  acc[j][i][r]: n = n0 + wn*64 + j*32 + (r&3) + 8*(r>>2) + 4*khalf,
-  //                           m = m0 + wm*64 + i*32 + frow.
+  f32x16 acc[NJ][MI];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+
+  auto stage = [&](int kt) {
+    const int k0 = kt * BK;
+    char* base = smem + (kt % STAGES) * CFG::STAGE_BYTES;
+    if (k0 < p.K1) {
+      nt_stage_tile<CFG, BM>(A1, p.lda1, m0, k0, base, wave, lane);
+    } else {
+      nt_stage_tile<CFG, BM>(A2, p.lda2, m0, k0 - p.K1, base, wave, lane);
+    }
+    nt_stage_tile<CFG, BN>(Bt, p.ldb, n0, k0, base + CFG::A_BYTES, wave, lane);
+  };
+
+  // Software pipeline, STAGES-1 K-tiles in flight.  Iteration kt: wait until tile kt has landed
+  // (counted vmcnt: the younger tiles stay in flight ACROSS the barrier), one raw s_barrier (it also
+  // proves every wave is done reading tile kt-1, whose buffer the new DMA overwrites), issue tile
+  // kt+STAGES-1, compute tile kt.  __syncthreads() would drain vmcnt to 0 and serialise HBM latency
+  // with the MFMA phase (measured on the 2-stage version: waves parked 57% of their cycles).
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) stage(s);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = min(nk - 1, kt + STAGES - 2) - kt;     // younger tiles already issued
+    if (STAGES >= 4 && ahead >= 2) nt_wait_vmcnt<2 * LPS>();
+    else if (STAGES >= 3 && ahead >= 1) nt_wait_vmcnt<1 * LPS>();
+    else nt_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1);
+    const char* As = smem + (kt % STAGES) * CFG::STAGE_BYTES;
+    const char* Bs = As + CFG::A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int kslot = ks * 2 + khalf;
+      bf16x8 fa[MI], fb[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = nt_read_frag<CFG>(As, wm * 32 * MI + i * 32 + frow, kslot);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = nt_read_frag<CFG>(Bs, wn * 32 * NJ + j * 32 + frow, kslot);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+    }
+  }
+  __syncthreads();      // every wave is done with the operand buffers: reuse them for the epilogue
+
+  // Epilogue.  acc[j][i][r]: n = n0 + wn*32*NJ + j*32 + (r&3) + 8*(r>>2) + 4*khalf,
+  //                           m = m0 + wm*32*MI + i*32 + frow.
   bf16* Cb = (bf16*)p.Cb;
   const bf16* mask = (const bf16*)p.mask;
+  // Fast path: the whole tile goes to the bf16 output.  A lane's accumulators cover 4 consecutive
+  // n of 32 different rows, so direct stores would touch 32 cache lines per instruction (and so
+  // would the ReLU-mask loads of the dX GEMMs).  The tile is transposed through LDS instead, EPI_ROWS
+  // rows per pass (row pitch BN*2+16 B: 2-way conflicts at most), and leaves as full row segments,
+  // 16 B per lane; the mask tile is read the same way.
+  const bool fast = fast_epi && Cb && (n0 + BN <= p.nb);
+  if (fast) {
+    char* cs = smem;
+    constexpr int PASSES = BM / CFG::EPI_ROWS;
+    constexpr int CHUNKS_PER_ROW = BN / 8;
+    constexpr int ITERS = CFG::EPI_ROWS * CHUNKS_PER_ROW / CFG::THREADS;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+    for (int h = 0; h < PASSES; ++h) {
+      if ((wm * 32 * MI) / CFG::EPI_ROWS == h) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t m = m0 + wm * 64 + i * 32 + frow;
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int n4 = n0 + wn * 64 + j * 32 + rq * 8 + khalf * 4;
-        float v[4];
+          for (int i = 0; i < MI; ++i) {
+            const int ml = (wm * 32 * MI) % CFG::EPI_ROWS + i * 32 + frow;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[j][i][rq * 4 + e];
-        if (p.bias) {
+            for (int rq = 0; rq < 4; ++rq) {
+              const int nl = wn * 32 * NJ + j * 32 + rq * 8 + khalf * 4;
+              float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n4 + e < p.n_bias) v[e] += p.bias[n4 + e];
-        }
-        if (p.relu) {
+              for (int e = 0; e < 4; ++e) v[e] = acc[j][i][rq * 4 + e] + bias_r[j][rq * 4 + e];
+              if (p.relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-        }
-        if (mask) {
-          const bf16x4 mk = *(const bf16x4*)(mask + m * p.ldmask + n4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ((float)mk[e] > 0.0f) ? v[e] : 0.0f;
-        }
-        if (Cb) {
-          if (n4 + 3 < p.nb) {
-            f32x4 vv = {v[0], v[1], v[2], v[3]};
-            *(bf16x4*)(Cb + m * p.ldcb + n4) = __builtin_convertvector(vv, bf16x4);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n4 + e < p.nb) Cb[m * p.ldcb + n4 + e] = (bf16)v[e];
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+              }
+              f32x4 vv = {v[0], v[1], v[2], v[3]};
+              *(bf16x4*)(cs + ml * CFG::CPITCH + nl * 2) = __builtin_convertvector(vv, bf16x4);
+            }
           }
-        }
-        if (p.Cf) {
+      }
+      __syncthreads();
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int nn = n4 + e - p.f0;
-            if (nn >= 0 && nn < p.nf) p.Cf[m * p.ldcf + nn] = v[e];
+      for (int it = 0; it < ITERS; ++it) {
+        const int c = it * CFG::THREADS + tid;
+        const int row = c / CHUNKS_PER_ROW, ch = c % CHUNKS_PER_ROW;
+        const int64_t m = m0 + h * CFG::EPI_ROWS + row;
+        bf16x8 v = *(const bf16x8*)(cs + row * CFG::CPITCH + ch * 16);
+        if (mask) {
+          const bf16x8 mk = *(const bf16x8*)(mask + m * p.ldmask + n0 + ch * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ((float)mk[e] > 0.0f) ? v[e] : (bf16)0.0f;
+        }
+        *(bf16x8*)(Cb + m * p.ldcb + n0 + ch * 8) = v;
+      }
+      if (h + 1 < PASSES) __syncthreads();
+    }
+  }
+  if ((Cb && !fast) || p.Cf) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int64_t m = m0 + wm * 32 * MI + i * 32 + frow;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int n4 = n0 + wn * 32 * NJ + j * 32 + rq * 8 + khalf * 4;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[j][i][rq * 4 + e] + bias_r[j][rq * 4 + e];
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+          }
+          if (mask) {
+            const bf16x4 mk = *(const bf16x4*)(mask + m * p.ldmask + n4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((float)mk[e] > 0.0f) ? v[e] : 0.0f;
+          }
+          if (Cb && !fast) {
+            if (n4 + 3 < p.nb) {
+              f32x4 vv = {v[0], v[1], v[2], v[3]};
+              *(bf16x4*)(Cb + m * p.ldcb + n4) = __builtin_convertvector(vv, bf16x4);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n4 + e < p.nb) Cb[m * p.ldcb + n4 + e] = (bf16)v[e];
+            }
+          }
+          if (p.Cf) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int nn = n4 + e - p.f0;
+              if (nn >= 0 && nn < p.nf) p.Cf[m * p.ldcf + nn] = v[e];
+            }
           }
         }
       }
@@ -172,11 +288,64 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(mnr_gemm_nt_args p) {
   }
 }
 
+template <class CFG>
+static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
+  MNR_CHECK_ARG(a->M % CFG::BM == 0 && a->N % CFG::BN == 0, "mnr_gemm_nt_bf16: M=%lld / N=%d not multiples of the %dx%d tile",
+                (long long)a->M, a->N, CFG::BM, CFG::BN);
+  MNR_CHECK_ARG(a->K1 % CFG::BK == 0 && a->K2 % CFG::BK == 0, "mnr_gemm_nt_bf16: K segments must be multiples of %d", CFG::BK);
+  const int nt = a->N / CFG::BN;
+  const int64_t mt = a->M / CFG::BM;
+  const int64_t groups = (mt + 7) / 8;
+  const int64_t grid = groups * 8 * nt;
+  MNR_CHECK_ARG(grid < (1ll << 31), "mnr_gemm_nt_bf16: grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_nt_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
+                     *a, fast_epi);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+//                 MI NJ WM WN BK STAGES
+typedef NtCfg<2, 2, 2, 2, 64, 2> NtC0;   // 128x128, 4 waves,  64 KiB  (r1_a structure)
+typedef NtCfg<2, 2, 2, 2, 32, 2> NtC1;   // 128x128, 4 waves,  32 KiB  -> 4 workgroups/CU
+typedef NtCfg<4, 2, 2, 4, 64, 2> NtC2;   // 256x256, 8 waves, 128 KiB
+typedef NtCfg<2, 2, 4, 2, 64, 3> NtC3;   // 256x128, 8 waves, 144 KiB, 3 stages
+typedef NtCfg<4, 2, 2, 4, 32, 4> NtC4;   // 256x256, 8 waves, 128 KiB, 4 stages of BK=32
+typedef NtCfg<2, 2, 2, 2, 32, 4> NtC5;   // 128x128, 4 waves,  64 KiB, 4 stages of BK=32 -> 2 workgroups/CU
+typedef NtCfg<2, 2, 2, 2, 64, 3> NtC6;   // 128x128, 4 waves,  96 KiB, 3 stages
+typedef NtCfg<4, 2, 2, 4, 32, 3> NtC7;   // 256x256, 8 waves,  96 KiB, 3 stages of BK=32
+
+static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
+
+extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 7 && cfg_small >= 0 && cfg_small <= 7, "mnr_gemm_nt_set_config: unknown configuration");
+  g_nt_cfg_big = cfg_big;
+  g_nt_cfg_small = cfg_small;
+  return MNR_OK;
+}
+
+static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
+  switch (cfg) {
+    case 0: return nt_launch<NtC0>(a, fast_epi, stream);
+    case 1: return nt_launch<NtC1>(a, fast_epi, stream);
+    case 2: return nt_launch<NtC2>(a, fast_epi, stream);
+    case 3: return nt_launch<NtC3>(a, fast_epi, stream);
+    case 4: return nt_launch<NtC4>(a, fast_epi, stream);
+    case 5: return nt_launch<NtC5>(a, fast_epi, stream);
+    case 6: return nt_launch<NtC6>(a, fast_epi, stream);
+    default: return nt_launch<NtC7>(a, fast_epi, stream);
+  }
+}
+
 extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   MNR_CHECK_ARG(a != nullptr, "mnr_gemm_nt_bf16: null args");
-  MNR_CHECK_ARG(a->M > 0 && a->M % NT_BM == 0, "mnr_gemm_nt_bf16: M=%lld must be a positive multiple of 128", (long long)a->M);
-  MNR_CHECK_ARG(a->N > 0 && a->N % NT_BN == 0, "mnr_gemm_nt_bf16: N=%d must be a positive multiple of 128", a->N);
-  MNR_CHECK_ARG(a->K1 > 0 && a->K1 % NT_BK == 0 && a->K2 >= 0 && a->K2 % NT_BK == 0,
+  MNR_CHECK_ARG(a->M > 0 && a->M % 128 == 0, "mnr_gemm_nt_bf16: M=%lld must be a positive multiple of 128", (long long)a->M);
+  MNR_CHECK_ARG(a->N > 0 && a->N % 128 == 0, "mnr_gemm_nt_bf16: N=%d must be a positive multiple of 128", a->N);
+  MNR_CHECK_ARG(a->K1 > 0 && a->K1 % 64 == 0 && a->K2 >= 0 && a->K2 % 64 == 0,
                 "mnr_gemm_nt_bf16: K1=%d, K2=%d must be multiples of 64", a->K1, a->K2);
   MNR_CHECK_ARG(a->A1 && a->Bt && (a->K2 == 0 || a->A2), "mnr_gemm_nt_bf16: null operand");
   MNR_CHECK_ARG(a->lda1 % 8 == 0 && a->ldb % 8 == 0 && (a->K2 == 0 || a->lda2 % 8 == 0),
@@ -184,19 +353,14 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   MNR_CHECK_ARG(!a->Cb || a->ldcb % 4 == 0, "mnr_gemm_nt_bf16: ldcb must be a multiple of 4");
   MNR_CHECK_ARG(!a->mask || a->ldmask % 4 == 0, "mnr_gemm_nt_bf16: ldmask must be a multiple of 4");
   MNR_CHECK_ARG(a->Cb || a->Cf, "mnr_gemm_nt_bf16: no output");
-  const int nt = a->N / NT_BN;
-  const int64_t mt = a->M / NT_BM;
-  const int64_t groups = (mt + 7) / 8;
-  const int64_t grid = groups * 8 * nt;
-  MNR_CHECK_ARG(grid < (1ll << 31), "mnr_gemm_nt_bf16: grid too large");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)grid), dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
-  MNR_CHECK_LAUNCH();
-  return MNR_OK;
+  MNR_CHECK_ARG(!a->bias || a->n_bias >= 1, "mnr_gemm_nt_bf16: bias needs n_bias >= 1");
+  // 16-byte row segments in the epilogue need 8-element-aligned output / mask pitches and bases.
+  const int fast_epi = (!a->Cb || (a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0)) &&
+                       (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));
+  const bool big_ok = (a->M % 256 == 0) && (a->N % 256 == 0);
+  int cfg = big_ok ? g_nt_cfg_big : g_nt_cfg_small;
+  if (cfg == 3 && a->M % 256 != 0) cfg = g_nt_cfg_small;
+  return nt_dispatch(cfg, a, fast_epi, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -281,6 +445,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(mnr_gemm_tn_args p, int
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // Bias gradient db[n] = sum_m B[m,n]: the k-tile-0 workgroups multiply an all-ones A fragment
+  // with the B fragments they already hold (every row of the 32x32 result is the column sum), so
+  // dY is not read from HBM a second time.
+  const bool do_bias = (p.bias_out != nullptr) && (k0 == 0) && (wk == 0);
+  f32x16 accb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[j][r] = 0.0f;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
   auto stage = [&](int step, int buf) {
     char* base = smem + buf * TN_STAGE_BYTES;
@@ -311,8 +487,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(mnr_gemm_tn_args p, int
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fb[j], accb[j], 0, 0, 0);
+      }
     }
     __syncthreads();
+  }
+
+  if (do_bias && lane < 32) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + lane;          // row 0 of the result: reg 0 of lanes 0..31
+      if (n < p.bias_n_valid) unsafeAtomicAdd(p.bias_out + n, accb[j][0]);
+    }
   }
 
   // acc[i][j][r]: k = k0 + wk*64 + i*32 + (r&3) + 8*(r>>2) + 4*khalf; n = n0 + wn*64 + j*32 + (lane&31).

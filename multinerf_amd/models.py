@@ -341,14 +341,15 @@ class Model:
     # heads
     if p.has_rgb and p.use_viewdirs:
       bw = p.hp.bottleneck_width
-      nh = _rup(bw + 1, 128)
-      fo = alloc(nh, p.W)                                       # merged head fwd: rows [0,bw) bottleneck, row bw density
+      nh = _rup(bw + 1, 128)                                    # backward (dHB) width
+      nh_f = _rup(bw + 1, 256)                                  # forward rows: a multiple of the 256-wide GEMM tile
+      fo = alloc(nh_f, p.W)                                     # merged head fwd: rows [0,bw) bottleneck, row bw density
       descs.append(L.PackDesc(p.bottleneck.kernel_off, p.W, bw, fo, p.W, 0, 0, 1))
       descs.append(L.PackDesc(p.density.kernel_off, p.W, 1, fo, p.W, bw, 0, 1))
       bo = alloc(_rup(p.W, 128), nh)                            # merged head bwd: [W][nh]
       descs.append(L.PackDesc(p.bottleneck.kernel_off, p.W, bw, bo, nh, 0, 0, 0))
       descs.append(L.PackDesc(p.density.kernel_off, p.W, 1, bo, nh, 0, bw, 0))
-      p.packed['head'] = dict(f_off=fo, f_ld=p.W, n_pad=nh, b_off=bo, b_ld=nh)
+      p.packed['head'] = dict(f_off=fo, f_ld=p.W, n_pad=nh_f, nb_pad=nh, b_off=bo, b_ld=nh)
       WV = p.hp.net_width_viewdirs
       for i, (d, concat) in enumerate(p.view):
         if i == 0:
@@ -702,7 +703,7 @@ class Model:
     if plan.has_rgb:
       bw = hp.bottleneck_width
       e = plan.packed['head']
-      nh = e['n_pad']
+      nh = e['nb_pad']
       dHB = self._buf(('bwd', 'dHB', nh), (M, nh), bf16, zero=True)   # cols > bw stay zero
       _, g_raw_rgb = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], raw_rgb=lv['raw_rgb'],
@@ -729,12 +730,12 @@ class Model:
         # dW (rows of the first input segment; then the skip-concat rows), db
         ops.gemm_tn(inp, dy, gslice(d.kernel_off, d.fan_in * d.fan_out), M=M, K=in_w, N=WV,
                     lda=inp.stride(0), ldb=WV, ldc=d.fan_out,
-                    k_valid=(plan.vi_width if i == 0 else WV), n_valid=d.fan_out)
+                    k_valid=(plan.vi_width if i == 0 else WV), n_valid=d.fan_out,
+                    bias_out=gslice(d.bias_off, d.fan_out), bias_n_valid=d.fan_out)
         if concat:
           ops.gemm_tn(VI, dy, gslice(d.kernel_off + WV * d.fan_out, plan.vi_width * d.fan_out), M=M,
                       K=plan.ldVI, N=WV, lda=plan.ldVI, ldb=WV, ldc=d.fan_out, k_valid=plan.vi_width,
                       n_valid=d.fan_out)
-        ops.colsum(dy, M, d.fan_out, gslice(d.bias_off, d.fan_out), ld=WV)
         Bw = self._w(plan, e['b_off'], _rup(bw if i == 0 else WV, 128), e['b_ld'])
         if i == 0:
           ops.gemm_nt(dy, Bw, M=M, N=_rup(bw, 128), K1=e['b_ld'], Cb=dHB, ldcb=nh, nb=bw)
@@ -745,12 +746,11 @@ class Model:
       e = plan.packed['head']
       tmpW = self._buf(('bwd', 'tmpW', W, nh), (W, nh), f32)
       tmpW.zero_()
-      ops.gemm_tn(x_last, dHB, tmpW, M=M, K=W, N=nh, lda=W, ldb=nh, ldc=nh)
-      ops.scatter_add(tmpW, nh, 0, 0, W, bw, gslice(plan.bottleneck.kernel_off, W * bw), bw)
-      ops.scatter_add(tmpW, nh, 0, bw, W, 1, gslice(plan.density.kernel_off, W), 1)
       tmpb = self._buf(('bwd', 'tmpb', nh), (nh,), f32)
       tmpb.zero_()
-      ops.colsum(dHB, M, bw + 1, tmpb, ld=nh)
+      ops.gemm_tn(x_last, dHB, tmpW, M=M, K=W, N=nh, lda=W, ldb=nh, ldc=nh, bias_out=tmpb, bias_n_valid=bw + 1)
+      ops.scatter_add(tmpW, nh, 0, 0, W, bw, gslice(plan.bottleneck.kernel_off, W * bw), bw)
+      ops.scatter_add(tmpW, nh, 0, bw, W, 1, gslice(plan.density.kernel_off, W), 1)
       ops.scatter_add(tmpb, nh, 0, 0, 1, bw, gslice(plan.bottleneck.bias_off, bw), bw)
       ops.scatter_add(tmpb, nh, 0, bw, 1, 1, gslice(plan.density.bias_off, 1), 1)
       Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
@@ -771,13 +771,13 @@ class Model:
       e = plan.packed[('trunk', i)]
       if i == 0:
         ops.gemm_tn(feat, dy, gslice(d.kernel_off, plan.F * W), M=M, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
-                    ldc=W, k_valid=plan.F, n_valid=W)
+                    ldc=W, k_valid=plan.F, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W)
       else:
-        ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W)
+        ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W,
+                    bias_out=gslice(d.bias_off, W), bias_n_valid=W)
         if concat:
           ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
                       lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
-      ops.colsum(dy, M, W, gslice(d.bias_off, W), ld=W)
       if i > 0:
         Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
         ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], mask=acts[i - 1], ldmask=W, Cb=other, ldcb=W, nb=W)

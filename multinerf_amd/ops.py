@@ -214,8 +214,10 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
   PROFILE.stop(_e)
 
 
-def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, n_valid=None):
-  """Cout[k,n] += sum_m A[m,k] B[m,n]."""
+def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, n_valid=None, bias_out=None,
+            bias_n_valid=0):
+  """Cout[k,n] += sum_m A[m,k] B[m,n]; optionally bias_out[n] += sum_m B[m,n] (fused bias gradient)."""
+  _chk(bias_out, f32, 'bias_out', allow_none=True)
   _chk(A, bf16, 'A')
   _chk(B, bf16, 'B')
   _chk(Cout, f32, 'C')
@@ -226,6 +228,8 @@ def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, 
   a.C, a.ldc = Cout.data_ptr(), ldc if ldc else Cout.stride(0)
   a.k_valid = K if k_valid is None else k_valid
   a.n_valid = N if n_valid is None else n_valid
+  a.bias_out = bias_out.data_ptr() if bias_out is not None else None
+  a.bias_n_valid = bias_n_valid
   _e = PROFILE.start()
   L.check(lib().mnr_gemm_tn_bf16(C.byref(a), _stream()))
   PROFILE.stop(_e)

@@ -313,8 +313,12 @@ def test_gemm_tn(ops, M, K, N):
   Bm = _bf(torch.randn((M, N), generator=gen))
   ref = A.double().T @ Bm.double()
   Cout = torch.ones((K, N), dtype=torch.float32).cuda()
-  ops.gemm_tn(dev(A), dev(Bm), Cout, M=M, K=K, N=N)
+  bsum = torch.full((N,), 2.0).cuda()
+  ops.gemm_tn(dev(A), dev(Bm), Cout, M=M, K=K, N=N, bias_out=bsum, bias_n_valid=N - 7)
   np.testing.assert_allclose(Cout.cpu().double().numpy(), (ref + 1).numpy(), rtol=1e-4, atol=1e-3 * math.sqrt(M))
+  want_b = Bm.double().sum(0) + 2
+  want_b[N - 7:] = 2
+  np.testing.assert_allclose(bsum.cpu().double().numpy(), want_b.numpy(), rtol=1e-5, atol=1e-3 * math.sqrt(M))
   # bounds: only a [k_valid, n_valid] window is touched, with a wider ldc
   C2 = torch.zeros((K, N + 8), dtype=torch.float32).cuda()
   ops.gemm_tn(dev(A), dev(Bm), C2, M=M, K=K, N=N, k_valid=K - 5, n_valid=N - 3)
