@@ -376,36 +376,51 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
 // position b ^ (r & 3), so the 4 rows of one transpose read (r & 3 = 0..3) use
 // four different 64-B bank ranges.
 
-#define TN_BK 128      // output rows (columns of A)
-#define TN_BN 128      // output cols (columns of B)
 #define TN_BM 64       // reduction rows per step
-#define TN_TILE_BYTES (64 * 128 * 2)
-#define TN_STAGE_BYTES (2 * TN_TILE_BYTES)
-#define TN_LDS_BYTES (2 * TN_STAGE_BYTES)
 
+template <int KI_, int NJ_, int WK_, int WN_>
+struct TnCfg {
+  static constexpr int KI = KI_, NJ = NJ_, WK = WK_, WN = WN_;
+  static constexpr int BKO = 32 * KI * WK;            // output rows (columns of A)
+  static constexpr int BNO = 32 * NJ * WN;            // output cols (columns of B)
+  static constexpr int THREADS = 64 * WK * WN;
+  static constexpr int A_BYTES = TN_BM * BKO * 2, B_BYTES = TN_BM * BNO * 2;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+};
+typedef TnCfg<2, 2, 2, 2> TnSmall;   // 128x128 output tile, 4 waves,  64 KiB
+typedef TnCfg<4, 2, 2, 4> TnBig;     // 256x256 output tile, 8 waves, 128 KiB
+
+// Stage a [64 m][COLS] tile; 64-B block b of row r is stored at block position b ^ (r & 3).
+template <int COLS, int THREADS>
 __device__ __forceinline__ void tn_stage_tile(const bf16* __restrict__ g, int ld, int64_t row0,
                                               int col0, char* lds_tile, int wave, int lane) {
+  constexpr int CPR = COLS / 8;                      // 16-B chunks per row
+  constexpr int NWAVES = THREADS / 64;
+  constexpr int ITERS = TN_BM * CPR / THREADS;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int cbase = (i * 4 + wave) * 64;
+  for (int i = 0; i < ITERS; ++i) {
+    const int cbase = (i * NWAVES + wave) * 64;
     const int c = cbase + lane;
-    const int r = c >> 4;              // 16 chunks (256 B) per row
-    const int pos = c & 15;
+    const int r = c / CPR;
+    const int pos = c % CPR;
     const int blk = (pos >> 2) ^ (r & 3);
     const bf16* src = g + (row0 + r) * (int64_t)ld + col0 + blk * 32 + (pos & 3) * 8;
     __builtin_amdgcn_global_load_lds(MNR_GLOBAL_PTR(src), MNR_LDS_PTR(lds_tile + cbase * 16), 16, 0, 0);
   }
 }
 
-// Fragment of 8 reduction elements for column (colbase + 16*g16 + c) of the tile.
+// Fragment of 8 reduction elements for column (colbase + 16*g16 + c) of a [64][COLS] tile.
+template <int COLS>
 __device__ __forceinline__ bf16x8 tn_read_frag(const char* lds_tile, int mbase, int colbase, int lane) {
+  constexpr int ROWB = COLS * 2;
   const int p = lane & 15;
   const int g16 = (lane >> 4) & 1;
   const int col = colbase + g16 * 16 + (p & 3) * 4;
   const int r0 = mbase + (p >> 2);
   const int r1 = r0 + 4;
-  const int off0 = r0 * 256 + ((((col >> 5) ^ (r0 & 3))) << 6) + (col & 31) * 2;
-  const int off1 = r1 * 256 + ((((col >> 5) ^ (r1 & 3))) << 6) + (col & 31) * 2;
+  const int off0 = r0 * ROWB + ((((col >> 5) ^ (r0 & 3))) << 6) + (col & 31) * 2;
+  const int off1 = r1 * ROWB + ((((col >> 5) ^ (r1 & 3))) << 6) + (col & 31) * 2;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_tile + off0));
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_tile + off1));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -413,14 +428,16 @@ __device__ __forceinline__ bf16x8 tn_read_frag(const char* lds_tile, int mbase, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
+template <class CFG>
+__global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
+  constexpr int KI = CFG::KI, NJ = CFG::NJ, BKO = CFG::BKO, BNO = CFG::BNO;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wk = wave >> 1, wn = wave & 1;
+  const int wk = wave / CFG::WN, wn = wave % CFG::WN;
 
-  const int ktiles = p.K / TN_BK, ntiles = p.N / TN_BN;
+  const int ktiles = p.K / BKO, ntiles = p.N / BNO;
   const int tiles = ktiles * ntiles;
   // All tiles of one M-split run consecutively on one XCD (operand rows shared through its L2).
   const int xcd = blockIdx.x & 7;
@@ -428,8 +445,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(mnr_gemm_tn_args p, int
   const int split = xcd + 8 * (q / tiles);
   const int tile = q % tiles;
   if (split >= splits) return;
-  const int k0 = (tile / ntiles) * TN_BK;
-  const int n0 = (tile % ntiles) * TN_BN;
+  const int k0 = (tile / ntiles) * BKO;
+  const int n0 = (tile % ntiles) * BNO;
   const int total_steps = (int)(p.M / TN_BM);
   const int s_begin = split * steps_per_split;
   const int s_end = min(total_steps, s_begin + steps_per_split);
@@ -438,20 +455,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(mnr_gemm_tn_args p, int
   const bf16* A = (const bf16*)p.A;
   const bf16* B = (const bf16*)p.B;
 
-  f32x16 acc[2][2];
+  f32x16 acc[KI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < KI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   // Bias gradient db[n] = sum_m B[m,n]: the k-tile-0 workgroups multiply an all-ones A fragment
   // with the B fragments they already hold (every row of the 32x32 result is the column sum), so
   // dY is not read from HBM a second time.
   const bool do_bias = (p.bias_out != nullptr) && (k0 == 0) && (wk == 0);
-  f32x16 accb[2];
+  f32x16 accb[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[j][r] = 0.0f;
   bf16x8 ones;
@@ -459,10 +476,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(mnr_gemm_tn_args p, int
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
   auto stage = [&](int step, int buf) {
-    char* base = smem + buf * TN_STAGE_BYTES;
+    char* base = smem + buf * CFG::STAGE_BYTES;
     const int64_t row0 = (int64_t)step * TN_BM;
-    tn_stage_tile(A, p.lda, row0, k0, base, wave, lane);
-    tn_stage_tile(B, p.ldb, row0, n0, base + TN_TILE_BYTES, wave, lane);
+    tn_stage_tile<BKO, CFG::THREADS>(A, p.lda, row0, k0, base, wave, lane);
+    tn_stage_tile<BNO, CFG::THREADS>(B, p.ldb, row0, n0, base + CFG::A_BYTES, wave, lane);
   };
 
   stage(s_begin, 0);
@@ -471,25 +488,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(mnr_gemm_tn_args p, int
   for (int s = s_begin; s < s_end; ++s) {
     const int cur = (s - s_begin) & 1;
     if (s + 1 < s_end) stage(s + 1, cur ^ 1);
-    const char* As = smem + cur * TN_STAGE_BYTES;
-    const char* Bs = As + TN_TILE_BYTES;
+    const char* As = smem + cur * CFG::STAGE_BYTES;
+    const char* Bs = As + CFG::A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int mbase = ks * 16 + khalf * 8;
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[KI], fb[NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = tn_read_frag(As, mbase, wk * 64 + i * 32, lane);
-        fb[i] = tn_read_frag(Bs, mbase, wn * 64 + i * 32, lane);
-      }
+      for (int i = 0; i < KI; ++i) fa[i] = tn_read_frag<BKO>(As, mbase, wk * 32 * KI + i * 32, lane);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < NJ; ++j) fb[j] = tn_read_frag<BNO>(Bs, mbase, wn * 32 * NJ + j * 32, lane);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < KI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       if (do_bias) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fb[j], accb[j], 0, 0, 0);
       }
     }
@@ -498,50 +514,66 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(mnr_gemm_tn_args p, int
 
   if (do_bias && lane < 32) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + lane;          // row 0 of the result: reg 0 of lanes 0..31
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * 32 * NJ + j * 32 + lane;     // row 0 of the result: reg 0 of lanes 0..31
       if (n < p.bias_n_valid) unsafeAtomicAdd(p.bias_out + n, accb[j][0]);
     }
   }
 
-  // acc[i][j][r]: k = k0 + wk*64 + i*32 + (r&3) + 8*(r>>2) + 4*khalf; n = n0 + wn*64 + j*32 + (lane&31).
+  // acc[i][j][r]: k = k0 + wk*32*KI + i*32 + (r&3) + 8*(r>>2) + 4*khalf; n = n0 + wn*32*NJ + j*32 + (lane&31).
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < KI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * 32 * NJ + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const int k = k0 + wk * 32 * KI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         if (k < p.k_valid && n < p.n_valid) unsafeAtomicAdd(p.C + (int64_t)k * p.ldc + n, acc[i][j][r]);
       }
     }
 }
 
-extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
-  MNR_CHECK_ARG(a != nullptr, "mnr_gemm_tn_bf16: null args");
-  MNR_CHECK_ARG(a->M > 0 && a->M % TN_BM == 0, "mnr_gemm_tn_bf16: M=%lld must be a positive multiple of 64", (long long)a->M);
-  MNR_CHECK_ARG(a->K > 0 && a->K % TN_BK == 0 && a->N > 0 && a->N % TN_BN == 0,
-                "mnr_gemm_tn_bf16: K=%d, N=%d must be multiples of 128", a->K, a->N);
-  MNR_CHECK_ARG(a->A && a->B && a->C, "mnr_gemm_tn_bf16: null operand");
-  MNR_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0, "mnr_gemm_tn_bf16: lda/ldb must be multiples of 8");
-  const int tiles = (a->K / TN_BK) * (a->N / TN_BN);
+template <class CFG>
+static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
+  const int tiles = (a->K / CFG::BKO) * (a->N / CFG::BNO);
   const int total_steps = (int)(a->M / TN_BM);
-  // Enough M-splits for >= ~768 workgroups, in multiples of 8 (one group of tiles per XCD).
-  int splits = ((768 + tiles - 1) / tiles + 7) / 8 * 8;
+  // Enough M-splits for >= target_wgs workgroups, in multiples of 8 (one group of tiles per XCD).
+  int splits = ((target_wgs + tiles - 1) / tiles + 7) / 8 * 8;
   if (splits < 8) splits = 8;
   while (splits > 8 && (total_steps + splits - 1) / splits < 4) splits -= 8;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   const int64_t grid = (int64_t)splits * tiles;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(256), TN_LDS_BYTES, (hipStream_t)stream, *a,
-                     splits, steps_per_split);
+  hipLaunchKernelGGL(gemm_tn_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
+                     *a, splits, steps_per_split);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
+}
+
+static int g_tn_big_min_tiles = 1;
+
+extern "C" int mnr_gemm_tn_set_config(int big_min_tiles) {
+  g_tn_big_min_tiles = big_min_tiles;
+  return MNR_OK;
+}
+
+extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
+  MNR_CHECK_ARG(a != nullptr, "mnr_gemm_tn_bf16: null args");
+  MNR_CHECK_ARG(a->M > 0 && a->M % TN_BM == 0, "mnr_gemm_tn_bf16: M=%lld must be a positive multiple of 64", (long long)a->M);
+  MNR_CHECK_ARG(a->K > 0 && a->K % 128 == 0 && a->N > 0 && a->N % 128 == 0,
+                "mnr_gemm_tn_bf16: K=%d, N=%d must be multiples of 128", a->K, a->N);
+  MNR_CHECK_ARG(a->A && a->B && a->C, "mnr_gemm_tn_bf16: null operand");
+  MNR_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0, "mnr_gemm_tn_bf16: lda/ldb must be multiples of 8");
+  // The 256x256 tile halves operand traffic per MFMA but issues 4x the atomics per workgroup: use it
+  // when the output has enough tiles (the 1024-wide trunk); the narrow proposal layers keep 128x128.
+  const bool big = (a->K % 256 == 0) && (a->N % 256 == 0) && ((a->K / 256) * (a->N / 256) >= g_tn_big_min_tiles);
+  if (big) return tn_launch<TnBig>(a, 512, stream);
+  return tn_launch<TnSmall>(a, 768, stream);
 }
 
 // ---------------------------------------------------------------------------

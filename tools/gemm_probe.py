@@ -66,6 +66,21 @@ def main():
     C = torch.empty((M, N), dtype=bf, device=dev)
     mask = rnd(M, N)
     time_it(f'nt  dX   M={M} N={N} K={K} +mask', lambda: ops.gemm_nt(A, Bt, M=M, N=N, K1=K, mask=mask, ldmask=N, Cb=C, ldcb=N, nb=N), 2.0 * M * N * K)
+  if 'tncfg' in which:
+    Bm = rnd(M, N)
+    Cw = torch.zeros((K, N), device=dev)
+    bb = torch.zeros(N, device=dev)
+    A2 = rnd(2 * M, 256)
+    Bm2 = rnd(2 * M, 256)
+    Cw2 = torch.zeros((256, 256), device=dev)
+    A3 = rnd(2 * M, 512)
+    Cw3 = torch.zeros((512, 256), device=dev)
+    for mt in (4, 1, 1 << 30):
+      ops.L.check(ops.lib().mnr_gemm_tn_set_config(mt))
+      time_it(f'tn big_min_tiles={mt} dW 1024x1024', lambda: ops.gemm_tn(A, Bm, Cw, M=M, K=K, N=N, bias_out=bb, bias_n_valid=N), 2.0 * M * N * K)
+      time_it(f'tn big_min_tiles={mt} dW prop 256x256', lambda: ops.gemm_tn(A2, Bm2, Cw2, M=2 * M, K=256, N=256), 2.0 * 2 * M * 256 * 256)
+      time_it(f'tn big_min_tiles={mt} dW prop 512x256', lambda: ops.gemm_tn(A3, Bm2, Cw3, M=2 * M, K=512, N=256), 2.0 * 2 * M * 512 * 256)
+    ops.L.check(ops.lib().mnr_gemm_tn_set_config(1))
   if 'tn' in which:
     Bm = rnd(M, N)
     Cw = torch.zeros((K, N), device=dev)
