@@ -145,6 +145,10 @@ typedef struct {
   const uint16_t* mask; int ldmask;   /* optional: out *= (mask[m,n] > 0)  (ReLU VJP) */
   uint16_t* Cb; int ldcb; int nb;     /* bf16 output for columns n < nb (may be NULL) */
   float* Cf; int ldcf; int f0; int nf;/* fp32 output for f0 <= n < f0+nf at column n-f0 */
+  /* 1-bit ReLU masks, bit (n & 7) of byte [m*ld + n/8]: the forward layer writes (out > 0), the dX
+   * GEMM of the next layer reads it instead of re-reading the bf16 activation (16x less traffic). */
+  uint8_t* mask_bits_out; int ld_bits_out;
+  const uint8_t* mask_bits_in; int ld_bits_in;
 } mnr_gemm_nt_args;
 
 /* C[M,N] = epilogue([A1|A2] * Bt^T). */

@@ -47,7 +47,9 @@ class GemmNTArgs(C.Structure):
               ('bias', vp), ('n_bias', C.c_int), ('relu', C.c_int),
               ('mask', vp), ('ldmask', C.c_int),
               ('Cb', vp), ('ldcb', C.c_int), ('nb', C.c_int),
-              ('Cf', vp), ('ldcf', C.c_int), ('f0', C.c_int), ('nf', C.c_int)]
+              ('Cf', vp), ('ldcf', C.c_int), ('f0', C.c_int), ('nf', C.c_int),
+              ('mask_bits_out', vp), ('ld_bits_out', C.c_int),
+              ('mask_bits_in', vp), ('ld_bits_in', C.c_int)]
 
 
 class GemmTNArgs(C.Structure):

@@ -33,9 +33,10 @@
 
 #define NT_CPAD 16                                   // epilogue staging: 16 B pad per row
 
-template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_>
+template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_, int MINW_ = 1>
 struct NtCfg {
   static constexpr int MI = MI_, NJ = NJ_, WM = WM_, WN = WN_, BK = BK_, STAGES = STAGES_;
+  static constexpr int MINW = MINW_;                  // __launch_bounds__ min waves per SIMD (register cap)
   static constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   static constexpr int THREADS = 64 * WM * WN;
   static constexpr int ROWB = BK * 2;                 // bytes per staged operand row
@@ -85,8 +86,8 @@ __device__ __forceinline__ void nt_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class CFG>
-__global__ __launch_bounds__(CFG::THREADS) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi) {
+template <class CFG, bool BITS_IN>
+__global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi) {
   constexpr int MI = CFG::MI, NJ = CFG::NJ, BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, STAGES = CFG::STAGES;
   constexpr int LPS = CFG::LOADS_PER_STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -131,6 +132,25 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_nt_kernel(mnr_gemm_nt_args 
         // multiply by a 0/1 factor rather than select: a select lets hipcc sink the load into a branch.
         const float keep = (has_bias && n < nbias) ? 1.0f : 0.0f;
         bias_r[j][r] = bp[min(n, nbias - 1)] * keep;
+      }
+  }
+
+  // ReLU-mask bits of the output chunks this thread will write in the epilogue, fetched now: loading
+  // them inside the store loop serialises 16 L2/HBM round trips per tile behind the MFMA phase
+  // (measured: dX layers 20% slower than forward layers with identical operands).
+  constexpr int EPI_PASSES = BM / CFG::EPI_ROWS;
+  constexpr int EPI_CPR = BN / 8;
+  constexpr int EPI_ITERS = CFG::EPI_ROWS * EPI_CPR / CFG::THREADS;
+  unsigned mbits[BITS_IN ? EPI_PASSES : 1][BITS_IN ? EPI_ITERS : 1];
+  if (BITS_IN) {
+#pragma unroll
+    for (int h = 0; h < EPI_PASSES; ++h)
+#pragma unroll
+      for (int it = 0; it < EPI_ITERS; ++it) {
+        const int c = it * CFG::THREADS + tid;
+        const int row = c / EPI_CPR, ch = c % EPI_CPR;
+        const int64_t idx = (m0 + h * CFG::EPI_ROWS + row) * (int64_t)p.ld_bits_in + ((n0 + ch * 8) >> 3);
+        mbits[h][it] = p.mask_bits_in[idx];
       }
   }
 
@@ -234,10 +254,26 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_nt_kernel(mnr_gemm_nt_args 
         const int row = c / CHUNKS_PER_ROW, ch = c % CHUNKS_PER_ROW;
         const int64_t m = m0 + h * CFG::EPI_ROWS + row;
         bf16x8 v = *(const bf16x8*)(cs + row * CFG::CPITCH + ch * 16);
-        if (mask) {
+        if (BITS_IN) {
+          // 1 bit per element, written by the forward epilogue of the layer whose ReLU this undoes.
+          const unsigned mb = mbits[BITS_IN ? h : 0][BITS_IN ? it : 0];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : (bf16)0.0f;
+        } else if (mask) {
           const bf16x8 mk = *(const bf16x8*)(mask + m * p.ldmask + n0 + ch * 8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = ((float)mk[e] > 0.0f) ? v[e] : (bf16)0.0f;
+        }
+        if (p.mask_bits_out) {
+          // 8 bits per lane; 4 neighbouring lanes (same row, consecutive chunks) combine theirs into
+          // one aligned 32-bit store (byte stores cost ~an order of magnitude more per byte).
+          unsigned mb = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mb |= ((float)v[e] > 0.0f ? 1u : 0u) << e;
+          mb |= __shfl_down(mb, 1, 64) << 8;
+          mb |= __shfl_down(mb, 2, 64) << 16;
+          if ((ch & 3) == 0)
+            *(unsigned*)(p.mask_bits_out + m * p.ld_bits_out + ((n0 + ch * 8) >> 3)) = mb;
         }
         *(bf16x8*)(Cb + m * p.ldcb + n0 + ch * 8) = v;
       }
@@ -260,7 +296,11 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_nt_kernel(mnr_gemm_nt_args 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
           }
-          if (mask) {
+          if (BITS_IN) {
+            const unsigned mb = p.mask_bits_in[m * p.ld_bits_in + (n4 >> 3)] >> (n4 & 7);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.0f;
+          } else if (mask) {
             const bf16x4 mk = *(const bf16x4*)(mask + m * p.ldmask + n4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ((float)mk[e] > 0.0f) ? v[e] : 0.0f;
@@ -300,11 +340,17 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   MNR_CHECK_ARG(grid < (1ll << 31), "mnr_gemm_nt_bf16: grid too large");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_nt_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
-                     *a, fast_epi);
+  if (a->mask_bits_in) {
+    hipLaunchKernelGGL((gemm_nt_kernel<CFG, true>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
+                       (hipStream_t)stream, *a, fast_epi);
+  } else {
+    hipLaunchKernelGGL((gemm_nt_kernel<CFG, false>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
+                       (hipStream_t)stream, *a, fast_epi);
+  }
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
@@ -318,11 +364,15 @@ typedef NtCfg<4, 2, 2, 4, 32, 4> NtC4;   // 256x256, 8 waves, 128 KiB, 4 stages 
 typedef NtCfg<2, 2, 2, 2, 32, 4> NtC5;   // 128x128, 4 waves,  64 KiB, 4 stages of BK=32 -> 2 workgroups/CU
 typedef NtCfg<2, 2, 2, 2, 64, 3> NtC6;   // 128x128, 4 waves,  96 KiB, 3 stages
 typedef NtCfg<4, 2, 2, 4, 32, 3> NtC7;   // 256x256, 8 waves,  96 KiB, 3 stages of BK=32
+typedef NtCfg<4, 2, 2, 2, 32, 2, 2> NtC8;   // 256x128, 4 waves (128x64 each), 48 KiB -> 2 workgroups/CU
+typedef NtCfg<4, 2, 2, 2, 32, 3, 2> NtC9;   // 256x128, 4 waves, 72 KiB, 3 stages -> 2 workgroups/CU
+typedef NtCfg<4, 2, 2, 2, 64, 2, 2> NtC10;  // 256x128, 4 waves, 96 KiB
+typedef NtCfg<2, 4, 2, 2, 32, 3, 2> NtC11;  // 128x256, 4 waves (64x128 each), 72 KiB, 3 stages
 
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 7 && cfg_small >= 0 && cfg_small <= 7, "mnr_gemm_nt_set_config: unknown configuration");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 11 && cfg_small >= 0 && cfg_small <= 11, "mnr_gemm_nt_set_config: unknown configuration");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -337,7 +387,11 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 4: return nt_launch<NtC4>(a, fast_epi, stream);
     case 5: return nt_launch<NtC5>(a, fast_epi, stream);
     case 6: return nt_launch<NtC6>(a, fast_epi, stream);
-    default: return nt_launch<NtC7>(a, fast_epi, stream);
+    case 7: return nt_launch<NtC7>(a, fast_epi, stream);
+    case 8: return nt_launch<NtC8>(a, fast_epi, stream);
+    case 9: return nt_launch<NtC9>(a, fast_epi, stream);
+    case 10: return nt_launch<NtC10>(a, fast_epi, stream);
+    default: return nt_launch<NtC11>(a, fast_epi, stream);
   }
 }
 
@@ -354,6 +408,9 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   MNR_CHECK_ARG(!a->mask || a->ldmask % 4 == 0, "mnr_gemm_nt_bf16: ldmask must be a multiple of 4");
   MNR_CHECK_ARG(a->Cb || a->Cf, "mnr_gemm_nt_bf16: no output");
   MNR_CHECK_ARG(!a->bias || a->n_bias >= 1, "mnr_gemm_nt_bf16: bias needs n_bias >= 1");
+  MNR_CHECK_ARG(!a->mask_bits_out || (a->Cb && a->nb == a->N && a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0 &&
+                                      a->ld_bits_out % 4 == 0 && ((uintptr_t)a->mask_bits_out % 4) == 0),
+                "mnr_gemm_nt_bf16: mask_bits_out needs a full-width, 16-byte-aligned bf16 output and a 4-byte-aligned bit matrix");
   // 16-byte row segments in the epilogue need 8-element-aligned output / mask pitches and bases.
   const int fast_epi = (!a->Cb || (a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0)) &&
                        (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));

@@ -36,6 +36,10 @@ def _rup(x, m):
   return (x + m - 1) // m * m
 
 
+import os as _os
+_USE_BITS = _os.environ.get('MNR_RELU_BITS', '1') != '0'   # A/B switch: 1-bit ReLU masks vs re-reading activations
+
+
 # =============================================================================
 # Hyper-parameters (gin surface).
 
@@ -622,25 +626,28 @@ class Model:
 
   def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep):
     hp = plan.hp
-    acts = []
+    acts, bits = [], []
     x = None
     for i, (d, concat) in enumerate(plan.trunk):
       e = plan.packed[('trunk', i)]
       out = self._buf((tag, 'act', i if keep else i % 2), (M, plan.W), bf16)
+      # 1-bit ReLU mask for the backward pass (training only)
+      bo = self._buf((tag, 'bits', i), (M, plan.W // 8), torch.uint8) if (keep and _USE_BITS) else None
+      bits.append(bo)
       Bt = self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])
       bias = flat[d.bias_off:d.bias_off + d.fan_out]
       if i == 0:
         ops.gemm_nt(feat, Bt, M=M, N=e['n_pad'], K1=plan.ldF, bias=bias, n_bias=d.fan_out, relu=True,
-                    Cb=out, ldcb=plan.W, nb=plan.W)
+                    Cb=out, ldcb=plan.W, nb=plan.W, bits_out=bo)
       elif concat:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, A2=feat, K2=plan.ldF, bias=bias, n_bias=d.fan_out,
-                    relu=True, Cb=out, ldcb=plan.W, nb=plan.W)
+                    relu=True, Cb=out, ldcb=plan.W, nb=plan.W, bits_out=bo)
       else:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=bias, n_bias=d.fan_out, relu=True,
-                    Cb=out, ldcb=plan.W, nb=plan.W)
+                    Cb=out, ldcb=plan.W, nb=plan.W, bits_out=bo)
       acts.append(out)
       x = out
-    res = dict(acts=acts)
+    res = dict(acts=acts, bits=bits)
     raw_density = self._buf((tag, 'raw_density'), (M,), f32)
     if plan.has_rgb:
       bw = hp.bottleneck_width
@@ -754,7 +761,8 @@ class Model:
       ops.scatter_add(tmpb, nh, 0, 0, 1, bw, gslice(plan.bottleneck.bias_off, bw), bw)
       ops.scatter_add(tmpb, nh, 0, bw, 1, 1, gslice(plan.density.bias_off, 1), 1)
       Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
-      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=nh, mask=x_last, ldmask=W, Cb=dA, ldcb=W, nb=W)
+      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=nh, bits_in=mlp['bits'][-1],
+                  mask=None if _USE_BITS else x_last, ldmask=W, Cb=dA, ldcb=W, nb=W)
     else:
       g_raw_density, _ = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], density_noise=lv['dnoise'],
@@ -780,7 +788,8 @@ class Model:
                       lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
       if i > 0:
         Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
-        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], mask=acts[i - 1], ldmask=W, Cb=other, ldcb=W, nb=W)
+        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], bits_in=mlp['bits'][i - 1],
+                    mask=None if _USE_BITS else acts[i - 1], ldmask=W, Cb=other, ldcb=W, nb=W)
         dy, other = other, dy
 
 

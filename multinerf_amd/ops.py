@@ -191,7 +191,8 @@ def viewdir_enc_fill(viewdirs, n, deg_view, dst, col0, col_end):
 
 
 def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, bias=None, n_bias=0,
-            relu=False, mask=None, ldmask=0, Cb=None, ldcb=0, nb=0, Cf=None, ldcf=0, f0=0, nf=0):
+            relu=False, mask=None, ldmask=0, Cb=None, ldcb=0, nb=0, Cf=None, ldcf=0, f0=0, nf=0,
+            bits_out=None, bits_in=None):
   """C[M,N] = epilogue([A1|A2] @ Bt^T).  Pointers may be views with explicit leading dimensions."""
   _chk(A1, bf16, 'A1')
   _chk(Bt, bf16, 'Bt')
@@ -209,6 +210,10 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
   a.mask, a.ldmask = (mask.data_ptr() if mask is not None else None), ldmask
   a.Cb, a.ldcb, a.nb = (Cb.data_ptr() if Cb is not None else None), ldcb, nb
   a.Cf, a.ldcf, a.f0, a.nf = (Cf.data_ptr() if Cf is not None else None), ldcf, f0, nf
+  for t_, nm_ in ((bits_out, 'bits_out'), (bits_in, 'bits_in')):
+    _chk(t_, torch.uint8, nm_, allow_none=True)
+  a.mask_bits_out, a.ld_bits_out = (bits_out.data_ptr(), bits_out.stride(0)) if bits_out is not None else (None, 0)
+  a.mask_bits_in, a.ld_bits_in = (bits_in.data_ptr(), bits_in.stride(0)) if bits_in is not None else (None, 0)
   _e = PROFILE.start()
   L.check(lib().mnr_gemm_nt_bf16(C.byref(a), _stream()))
   PROFILE.stop(_e)

@@ -298,6 +298,33 @@ def test_gemm_nt(ops, M, N, K1, K2):
   assert (got2[:, 66:] == 9.0).all()
 
 
+def test_gemm_nt_bit_masks(ops):
+  """Forward epilogue writes (out > 0) bits; the dX epilogue consuming them == the bf16-mask path."""
+  gen = torch.Generator().manual_seed(66)
+  M, N, K = 512, 256, 128
+  A = _bf(torch.randn((M, K), generator=gen))
+  Bt = _bf(torch.randn((N, K), generator=gen) / math.sqrt(K))
+  act = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
+  bits = torch.zeros((M, N // 8), dtype=torch.uint8).cuda()
+  ops.gemm_nt(dev(A), dev(Bt), M=M, N=N, K1=K, relu=True, Cb=act, ldcb=N, nb=N, bits_out=bits)
+  want = (act.cpu().float() > 0).reshape(M, N // 8, 8)
+  got = ((bits.cpu().int()[..., None] >> torch.arange(8)) & 1).bool()
+  assert torch.equal(got, want)
+  G = _bf(torch.randn((M, N), generator=gen))
+  W2 = _bf(torch.randn((N, N), generator=gen) / math.sqrt(N))
+  d1 = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
+  d2 = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
+  ops.gemm_nt(dev(G), dev(W2), M=M, N=N, K1=N, mask=act, ldmask=N, Cb=d1, ldcb=N, nb=N)
+  ops.gemm_nt(dev(G), dev(W2), M=M, N=N, K1=N, bits_in=bits, Cb=d2, ldcb=N, nb=N)
+  assert torch.equal(d1.cpu(), d2.cpu())
+  # 128-wide (small-tile) configuration
+  act3 = torch.zeros((M, 128), dtype=torch.bfloat16).cuda()
+  bits3 = torch.zeros((M, 16), dtype=torch.uint8).cuda()
+  ops.gemm_nt(dev(A), dev(Bt[:128].contiguous()), M=M, N=128, K1=K, relu=True, Cb=act3, ldcb=128, nb=128, bits_out=bits3)
+  got3 = ((bits3.cpu().int()[..., None] >> torch.arange(8)) & 1).bool()
+  assert torch.equal(got3, (act3.cpu().float() > 0).reshape(M, 16, 8))
+
+
 def test_gemm_nt_rejects_bad_shapes(ops):
   a = torch.zeros((128, 64), dtype=torch.bfloat16).cuda()
   with pytest.raises(ValueError, match='multiple of 128'):
