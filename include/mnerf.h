@@ -247,7 +247,16 @@ int mnr_composite_bwd(const mnr_composite_cfg* cfg, int64_t B, const float* raw_
                       const float* dirs, const float* bg, const float* exposure_scale,
                       const float* weights, const float* g_rgb_out, const float* g_weights,
                       float* g_raw_density, uint16_t* g_raw_density_bf16, int ld_bf16,
-                      float* g_raw_rgb, void* stream);
+                      float* g_raw_rgb, float* g_exposure_scale /* [B,3] +=, may be NULL */, void* stream);
+
+/* RawNeRF exposure (replaces models.py:257-267).  out[b,c] = exposure_values[b] *
+ * (1 + [idx[b] > 0] * offsets[idx[b], c]); offsets = the 'exposure_scaling_offsets' embedding
+ * [num_embeddings,3] or NULL when Model.learned_exposure_scaling is off.  The backward scatters
+ * g_offsets[idx[b], c] += exposure_values[b] * g_scale[b, c] for idx[b] > 0. */
+int mnr_exposure_scale(int64_t B, const float* exposure_values, const int32_t* exposure_idx,
+                       const float* offsets, float* out, void* stream);
+int mnr_exposure_scale_bwd(int64_t B_valid, const float* exposure_values, const int32_t* exposure_idx,
+                           const float* g_scale, float* g_offsets, void* stream);
 
 /* The compute_extras outputs of render.volumetric_rendering (render.py:184-211):
  * distance_mean, distance_percentile_5 / median / percentile_95 -> out [B,4]. */

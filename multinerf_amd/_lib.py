@@ -100,7 +100,9 @@ _PROTOS = {
     'mnr_small_head_bwd': ([i64, i32, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp], i32),
     'mnr_composite_fwd': ([C.POINTER(CompositeCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_composite_bwd': ([C.POINTER(CompositeCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32,
-                           vp, vp], i32),
+                           vp, vp, vp], i32),
+    'mnr_exposure_scale': ([i64, vp, vp, vp, vp, vp], i32),
+    'mnr_exposure_scale_bwd': ([i64, vp, vp, vp, vp, vp], i32),
     'mnr_render_extras': ([i64, i32, vp, vp, vp, vp, vp], i32),
     'mnr_lossmult_sum': ([i64, vp, i32, vp, vp], i32),
     'mnr_data_loss': ([i32, f32, f32, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp], i32),

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
     const float* __restrict__ raw_rgb, const float* __restrict__ tdist, const float* __restrict__ dirs,
     const float* __restrict__ bg, const float* __restrict__ expo, const float* __restrict__ weights,
     const float* __restrict__ g_rgb_out, const float* __restrict__ g_weights, float* __restrict__ g_raw_density,
-    bf16* __restrict__ g_den_bf16, int ld_bf16, float* __restrict__ g_raw_rgb) {
+    bf16* __restrict__ g_den_bf16, int ld_bf16, float* __restrict__ g_raw_rgb, float* __restrict__ g_expo) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n = c.n;
   float* l_den = lds;                       // n   raw density in, g_raw_density out
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
       run += sigma * (l_t[(i + 1) * S + r] - l_t[i * S + r]) * dnorm;
     }
     float suffix = 0.0f;                    // sum_{k>i} g^_k w_k
+    float ges[3] = {0.0f, 0.0f, 0.0f};      // d L / d exposure_scale[ray]
     for (int i = n - 1; i >= 0; --i) {
       const float w = l_w[i * S + r];
       const float raw = l_den[i * S + r] + c.density_bias;
@@ -220,8 +221,10 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
         for (int ch = 0; ch < 3; ++ch) {
           const float z = c.rgb_premultiplier * l_rgb[(3 * i + ch) * S + r] + c.rgb_bias;
           const float y = cp_act(c.rgb_act, z);
-          const float col = (y * (1.0f + 2.0f * c.rgb_padding) - c.rgb_padding) * ex[ch];
+          const float col_pre = y * (1.0f + 2.0f * c.rgb_padding) - c.rgb_padding;
+          const float col = col_pre * ex[ch];
           ghat += go[ch] * col;
+          ges[ch] += w * go[ch] * col_pre;
           // d col / d raw = ex * (1+2pad) * act'(z) * premult
           gc[ch] = w * go[ch] * ex[ch] * (1.0f + 2.0f * c.rgb_padding) * cp_act_grad(c.rgb_act, z, y) *
                    c.rgb_premultiplier;
@@ -237,6 +240,10 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
         const float sp = cp_act(c.density_act, l_den[(i - 1) * S + r] + c.density_bias);
         run -= sp * (l_t[i * S + r] - l_t[(i - 1) * S + r]) * dnorm;
       }
+    }
+    if (g_expo) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) g_expo[ray * 3 + ch] += ges[ch];
     }
   }
   __syncthreads();
@@ -255,7 +262,7 @@ extern "C" int mnr_composite_bwd(const mnr_composite_cfg* cfg, int64_t B, const 
                                  const float* dirs, const float* bg, const float* exposure_scale,
                                  const float* weights, const float* g_rgb_out, const float* g_weights,
                                  float* g_raw_density, uint16_t* g_raw_density_bf16, int ld_bf16,
-                                 float* g_raw_rgb, void* stream) {
+                                 float* g_raw_rgb, float* g_exposure_scale, void* stream) {
   MNR_CHECK_ARG(cfg && B > 0 && raw_density && tdist && dirs && weights, "mnr_composite_bwd: null argument");
   MNR_CHECK_ARG(g_raw_density || g_raw_density_bf16, "mnr_composite_bwd: no density-gradient output");
   MNR_CHECK_ARG(!cfg->has_rgb || raw_rgb, "mnr_composite_bwd: has_rgb needs raw_rgb");
@@ -270,7 +277,8 @@ extern "C" int mnr_composite_bwd(const mnr_composite_cfg* cfg, int64_t B, const 
   }
   hipLaunchKernelGGL(composite_bwd_kernel, dim3(mnr_cdiv(B, S)), dim3(CP_THREADS), lds, (hipStream_t)stream,
                      *cfg, B, S, raw_density, density_noise, raw_rgb, tdist, dirs, bg, exposure_scale, weights,
-                     g_rgb_out, g_weights, g_raw_density, (bf16*)g_raw_density_bf16, ld_bf16, g_raw_rgb);
+                     g_rgb_out, g_weights, g_raw_density, (bf16*)g_raw_density_bf16, ld_bf16, g_raw_rgb,
+                     g_exposure_scale);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
@@ -330,6 +338,50 @@ extern "C" int mnr_render_extras(int64_t B, int n, const float* weights, const f
   MNR_CHECK_ARG(B > 0 && n > 0 && weights && tdist && t_far && out, "mnr_render_extras: bad arguments");
   hipLaunchKernelGGL(render_extras_kernel, dim3(mnr_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, B, n, weights,
                      tdist, t_far, out);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// RawNeRF exposure scaling (models.py:257-267): rgb *= exposure_values; rgb *= 1 + [idx > 0] * offsets[idx].
+// Both factors are per ray, so they are folded into one [B,3] scale consumed by the compositing kernels.
+
+__global__ void exposure_scale_kernel(int64_t B, const float* __restrict__ ev, const int32_t* __restrict__ idx,
+                                      const float* __restrict__ offsets, float* __restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int i = idx[b];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float sc = (offsets && i > 0) ? 1.0f + offsets[(int64_t)i * 3 + c] : 1.0f;
+    out[b * 3 + c] = ev[b] * sc;
+  }
+}
+
+extern "C" int mnr_exposure_scale(int64_t B, const float* exposure_values, const int32_t* exposure_idx,
+                                  const float* offsets, float* out, void* stream) {
+  MNR_CHECK_ARG(B > 0 && exposure_values && exposure_idx && out, "mnr_exposure_scale: bad arguments");
+  hipLaunchKernelGGL(exposure_scale_kernel, dim3(mnr_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, B,
+                     exposure_values, exposure_idx, offsets, out);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+__global__ void exposure_scale_bwd_kernel(int64_t B, const float* __restrict__ ev, const int32_t* __restrict__ idx,
+                                          const float* __restrict__ g_scale, float* g_offsets) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int i = idx[b];
+  if (i <= 0) return;                        // the reference pins exposure 0 as the brightness reference
+#pragma unroll
+  for (int c = 0; c < 3; ++c) unsafeAtomicAdd(g_offsets + (int64_t)i * 3 + c, ev[b] * g_scale[b * 3 + c]);
+}
+
+extern "C" int mnr_exposure_scale_bwd(int64_t B_valid, const float* exposure_values, const int32_t* exposure_idx,
+                                      const float* g_scale, float* g_offsets, void* stream) {
+  MNR_CHECK_ARG(B_valid > 0 && exposure_values && exposure_idx && g_scale && g_offsets, "mnr_exposure_scale_bwd: bad arguments");
+  hipLaunchKernelGGL(exposure_scale_bwd_kernel, dim3(mnr_cdiv(B_valid, 256)), dim3(256), 0, (hipStream_t)stream,
+                     B_valid, exposure_values, exposure_idx, g_scale, g_offsets);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }

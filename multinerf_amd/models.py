@@ -260,8 +260,6 @@ class Model:
       bad.append('stop_level_grad=False')
     if self.num_glo_features > 0:
       bad.append('GLO vectors (num_glo_features > 0)')
-    if self.learned_exposure_scaling:
-      bad.append('learned_exposure_scaling (RawNeRF)')
     if self.ray_shape not in ('cone', 'cylinder'):
       raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')
     if self.raydist_fn not in L.RAYDIST:
@@ -283,10 +281,16 @@ class Model:
     else:
       self.prop_plan = MLPPlan(self.prop_hp, 'PropMLP_0', self.use_viewdirs, 0, self.nerf_plan.param_end)
       end = self.prop_plan.param_end
-    self.num_params = end
     self.modules = [(self.nerf_plan.module_name, self.nerf_plan.param_begin, self.nerf_plan.param_end)]
     if not self.single_mlp:
       self.modules.append((self.prop_plan.module_name, self.prop_plan.param_begin, self.prop_plan.param_end))
+    self.expo_off = None
+    if self.learned_exposure_scaling:
+      # nn.Embed(num_glo_embeddings, 3, zeros init, name='exposure_scaling_offsets') (models.py:112-121)
+      self.expo_off = end
+      end += self.num_glo_embeddings * 3
+      self.modules.append(('exposure_scaling_offsets', self.expo_off, end))
+    self.num_params = end
     self._plans = [self.nerf_plan] + ([] if self.single_mlp else [self.prop_plan])
     for p in self._plans:
       p.basis_dev = torch.as_tensor(p.basis, dtype=f32, device=self.device).contiguous()
@@ -422,6 +426,9 @@ class Model:
             'bias': flat[d.bias_off:d.bias_off + d.fan_out],
         }
       tree[p.module_name] = m
+    if self.expo_off is not None:
+      n = self.num_glo_embeddings * 3
+      tree['exposure_scaling_offsets'] = {'embedding': flat[self.expo_off:self.expo_off + n].view(-1, 3)}
     return tree
 
   def flat_from_tree(self, tree, device=None):
@@ -431,6 +438,9 @@ class Model:
       for d in p.dense:
         flat[d.kernel_off:d.kernel_off + d.fan_in * d.fan_out] = tree[p.module_name][d.name]['kernel'].detach().reshape(-1).float().cpu()
         flat[d.bias_off:d.bias_off + d.fan_out] = tree[p.module_name][d.name]['bias'].detach().float().cpu()
+    if self.expo_off is not None:
+      n = self.num_glo_embeddings * 3
+      flat[self.expo_off:self.expo_off + n] = tree['exposure_scaling_offsets']['embedding'].detach().reshape(-1).float().cpu()
     return flat.to(device or self.device)
 
   # Workspace -------------------------------------------------------------------------
@@ -486,8 +496,15 @@ class Model:
       pad = Bp - B0
       flat_rays = flat_rays.map(lambda r: torch.cat([r, r[-1:].expand(pad, r.shape[-1])], 0).contiguous())
     R = flat_rays
-    if R.exposure_idx is not None or self.learned_exposure_scaling:
-      raise NotImplementedError('RawNeRF exposure scaling is not yet on the HIP path')
+    expo = None
+    if R.exposure_idx is not None:
+      # models.py:257-267: rgb *= exposure_values; rgb *= 1 + [idx > 0] * exposure_scaling_offsets[idx]
+      ev = R.exposure_values.reshape(-1).contiguous().float()
+      eidx = R.exposure_idx.reshape(-1).to(torch.int32).contiguous()
+      offs = None
+      if self.learned_exposure_scaling:
+        offs = flat[self.expo_off:self.expo_off + self.num_glo_embeddings * 3]
+      expo = ops.exposure_scale(ev, eidx, offs)
     near = R.near.reshape(-1).contiguous()
     far = R.far.reshape(-1).contiguous()
     radii = R.radii.reshape(-1).contiguous()
@@ -582,7 +599,8 @@ class Model:
       raw_density = mlp_out['raw_density'].view(Bp, n)
       raw_rgb = mlp_out['raw_rgb'].view(Bp, n, 3) if plan.has_rgb else None
       density, rgb, weights, rgb_out, acc = ops.composite_fwd(
-          ccfg, raw_density, tdist, R.directions, raw_rgb=raw_rgb, density_noise=dnoise, bg=bg)
+          ccfg, raw_density, tdist, R.directions, raw_rgb=raw_rgb, density_noise=dnoise, bg=bg,
+          exposure_scale=expo if plan.has_rgb else None)
 
       rendering = {'rgb': rgb_out[:B0].reshape(lead + (3,))}
       if compute_extras:
@@ -606,7 +624,7 @@ class Model:
       if keep_for_backward:
         saved.append(dict(level=i_level, is_prop=is_prop, n=n, plan=plan, M=M, tag=tag, feat=feat, mlp=mlp_out,
                           ccfg=ccfg, raw_density=raw_density, raw_rgb=raw_rgb, dnoise=dnoise, bg=bg,
-                          tdist=tdist, sdist=sdist, weights=weights, rgb_out=rgb_out))
+                          tdist=tdist, sdist=sdist, weights=weights, rgb_out=rgb_out, expo=expo))
 
     if compute_extras:
       # models.py:299-310: proposal levels show the final level's average colour.
@@ -690,7 +708,7 @@ class Model:
     res['raw_density'] = raw_density
     return res
 
-  def backward_level(self, lv, flat, grads, g_rgb_out, g_weights):
+  def backward_level(self, lv, flat, grads, g_rgb_out, g_weights, g_expo=None):
     """VJP of one level w.r.t. the parameters: compositing -> heads -> trunk.
     grads: flat fp32 gradient vector (accumulated into)."""
     plan: MLPPlan = lv['plan']
@@ -715,7 +733,8 @@ class Model:
       _, g_raw_rgb = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], raw_rgb=lv['raw_rgb'],
           density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights,
-          g_den_bf16=dHB.view(-1)[bw:], ld_bf16=nh, want_f32=False)
+          g_den_bf16=dHB.view(-1)[bw:], ld_bf16=nh, want_f32=False, exposure_scale=lv['expo'],
+          g_exposure_scale=g_expo if lv['expo'] is not None else None)
       g_raw_rgb = g_raw_rgb.view(M, 3)
       # rgb Dense(3): dH, dW, db
       WV = hp.net_width_viewdirs

@@ -305,7 +305,7 @@ def composite_fwd(cfg, raw_density, tdist, dirs, *, raw_rgb=None, density_noise=
 
 def composite_bwd(cfg, raw_density, tdist, dirs, weights, *, raw_rgb=None, density_noise=None, bg=None,
                   exposure_scale=None, g_rgb_out=None, g_weights=None, g_den_bf16=None, ld_bf16=0,
-                  want_f32=True):
+                  want_f32=True, g_exposure_scale=None):
   B, n = raw_density.shape
   dev = raw_density.device
   for x, nm in ((raw_density, 'raw_density'), (tdist, 'tdist'), (dirs, 'dirs'), (weights, 'weights')):
@@ -318,8 +318,25 @@ def composite_bwd(cfg, raw_density, tdist, dirs, weights, *, raw_rgb=None, densi
   L.check(lib().mnr_composite_bwd(C.byref(cfg), B, _ptr(raw_density), _ptr(density_noise), _ptr(raw_rgb),
                                   _ptr(tdist), _ptr(dirs), _ptr(bg), _ptr(exposure_scale), _ptr(weights),
                                   _ptr(g_rgb_out), _ptr(g_weights), _ptr(g_raw_density), _ptr(g_den_bf16),
-                                  ld_bf16, _ptr(g_raw_rgb), _stream()))
+                                  ld_bf16, _ptr(g_raw_rgb), _ptr(g_exposure_scale), _stream()))
   return g_raw_density, g_raw_rgb
+
+
+def exposure_scale(exposure_values, exposure_idx, offsets):
+  _chk(exposure_values, f32, 'exposure_values')
+  _chk(exposure_idx, torch.int32, 'exposure_idx')
+  _chk(offsets, f32, 'offsets', allow_none=True)
+  B = exposure_values.numel()
+  out = torch.empty((B, 3), dtype=f32, device=exposure_values.device)
+  L.check(lib().mnr_exposure_scale(B, _ptr(exposure_values), _ptr(exposure_idx), _ptr(offsets), _ptr(out), _stream()))
+  return out
+
+
+def exposure_scale_bwd(exposure_values, exposure_idx, g_scale, g_offsets, B_valid):
+  _chk(g_scale, f32, 'g_scale')
+  _chk(g_offsets, f32, 'g_offsets')
+  L.check(lib().mnr_exposure_scale_bwd(B_valid, _ptr(exposure_values), _ptr(exposure_idx), _ptr(g_scale),
+                                       _ptr(g_offsets), _stream()))
 
 
 def render_extras(weights, tdist, t_far):

@@ -123,10 +123,19 @@ def create_train_step(model: models.Model, config, dataset=None):
       ops.distortion_loss(config.distortion_loss_mult, last['sdist'], last['weights'],
                           stats[2 * nlev + 1:2 * nlev + 2], g_w[-1], B_valid=B0)
 
+    g_expo = None
+    if model.expo_off is not None and R.exposure_idx is not None:
+      g_expo = model._buf(('train', 'g_expo'), (Bp, 3), f32)
+      g_expo.zero_()
     for li, lv in enumerate(levels):
       if g_rgb[li] is None and g_w[li] is None:
         continue                                                       # this level receives no gradient
-      model.backward_level(lv, flat, grads, g_rgb[li], g_w[li])
+      model.backward_level(lv, flat, grads, g_rgb[li], g_w[li], g_expo)
+    if g_expo is not None:
+      n_off = model.num_glo_embeddings * 3
+      ops.exposure_scale_bwd(R.exposure_values.reshape(-1).contiguous().float(),
+                             R.exposure_idx.reshape(-1).to(torch.int32).contiguous(), g_expo,
+                             grads[model.expo_off:model.expo_off + n_off], B0)
 
     # pmean over the 'batch' axis (train_utils.py:319-321): RCCL all-reduce of the flat buffers.
     mdist.all_reduce_mean_(grads)

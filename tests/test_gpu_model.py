@@ -34,18 +34,27 @@ def _setup(name, extra, B, seed=3):
   params = omodels.init_params(om, on, op, seed=seed)
   # non-zero biases so that bias paths are exercised
   g = torch.Generator().manual_seed(seed + 1)
-  for mod in params.values():
+  for mname, mod in params.items():
+    if mname == 'exposure_scaling_offsets':
+      continue
     for d in mod.values():
       d['bias'] = 0.05 * torch.randn(d['bias'].shape, generator=g)
-  flat = model.flat_from_tree(params)
   near, far = cfg.near, cfg.far
   batch = helpers.synthetic_rays(B, near=near, far=far)
+  if name == 'llff_raw':
+    batch.rays.exposure_idx = torch.randint(0, 5, (B, 1), generator=g).to(torch.int32)
+    batch.rays.exposure_values = 0.5 + torch.rand((B, 1), generator=g)
+    batch.rays.lossmult = (torch.rand((B, 3), generator=g) > 0.4).float()
+    batch.rgb = batch.rgb * 0.3
+    params['exposure_scaling_offsets']['embedding'] = 0.1 * torch.randn((1000, 3), generator=g)
+  flat = model.flat_from_tree(params)
   return cfg, model, (om, on, op), params, flat, batch
 
 
 CASES = [
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128'], 40),
     ('blender_256', [], 24),
+    ('llff_raw', [], 16),          # RawNeRF: cylinder rays, single MLP, safe_exp rgb, exposure scaling, Bayer lossmult
 ]
 
 
