@@ -33,8 +33,9 @@
 
 #define NT_CPAD 16                                   // epilogue staging: 16 B pad per row
 
-template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_, int MINW_ = 1>
+template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_, int MINW_ = 1, int FRAGPIPE_ = 0>
 struct NtCfg {
+  static constexpr int FRAGPIPE = FRAGPIPE_;          // 1: explicit register double-buffering of LDS fragments
   static constexpr int MI = MI_, NJ = NJ_, WM = WM_, WN = WN_, BK = BK_, STAGES = STAGES_;
   static constexpr int MINW = MINW_;                  // __launch_bounds__ min waves per SIMD (register cap)
   static constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
@@ -192,19 +193,52 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
     if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1);
     const char* As = smem + (kt % STAGES) * CFG::STAGE_BYTES;
     const char* Bs = As + CFG::A_BYTES;
+    if constexpr (CFG::FRAGPIPE) {
+      // Fragment registers are double-buffered across the k-sub-steps: the ds_reads of sub-step ks+1
+      // are issued BEFORE the MFMAs of sub-step ks, so LDS latency hides under a full MFMA batch.
+      constexpr int NKS = BK / 16;
+      bf16x8 fa[2][MI], fb[2][NJ];
+  #pragma unroll
+      for (int i = 0; i < MI; ++i) fa[0][i] = nt_read_frag<CFG>(As, wm * 32 * MI + i * 32 + frow, khalf);
+  #pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[0][j] = nt_read_frag<CFG>(Bs, wn * 32 * NJ + j * 32 + frow, khalf);
+      __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
+  #pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int cb = ks & 1, nb2 = cb ^ 1;
+        if (ks + 1 < NKS) {
+          const int kslot = (ks + 1) * 2 + khalf;
+  #pragma unroll
+          for (int i = 0; i < MI; ++i) fa[nb2][i] = nt_read_frag<CFG>(As, wm * 32 * MI + i * 32 + frow, kslot);
+  #pragma unroll
+          for (int j = 0; j < NJ; ++j) fb[nb2][j] = nt_read_frag<CFG>(Bs, wn * 32 * NJ + j * 32 + frow, kslot);
+        }
+  #pragma unroll
+        for (int j = 0; j < NJ; ++j)
+  #pragma unroll
+          for (int i = 0; i < MI; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][j], fa[cb][i], acc[j][i], 0, 0, 0);
+        // Pin the issue order: this sub-step's (next-fragment) ds_reads first, then its MFMAs.  Left to
+        // itself hipcc interleaves them 1:1 and drains lgkmcnt to 0 in front of every MFMA group, i.e.
+        // it waits for reads it has just issued.
+        if (ks + 1 < NKS) __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);
+      }
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int kslot = ks * 2 + khalf;
-      bf16x8 fa[MI], fb[NJ];
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        const int kslot = ks * 2 + khalf;
+        bf16x8 fa[MI], fb[NJ];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = nt_read_frag<CFG>(As, wm * 32 * MI + i * 32 + frow, kslot);
+        for (int i = 0; i < MI; ++i) fa[i] = nt_read_frag<CFG>(As, wm * 32 * MI + i * 32 + frow, kslot);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = nt_read_frag<CFG>(Bs, wn * 32 * NJ + j * 32 + frow, kslot);
+        for (int j = 0; j < NJ; ++j) fb[j] = nt_read_frag<CFG>(Bs, wn * 32 * NJ + j * 32 + frow, kslot);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+          for (int i = 0; i < MI; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+      }
     }
   }
   __syncthreads();      // every wave is done with the operand buffers: reuse them for the epilogue
@@ -368,11 +402,13 @@ typedef NtCfg<4, 2, 2, 2, 32, 2, 2> NtC8;   // 256x128, 4 waves (128x64 each), 4
 typedef NtCfg<4, 2, 2, 2, 32, 3, 2> NtC9;   // 256x128, 4 waves, 72 KiB, 3 stages -> 2 workgroups/CU
 typedef NtCfg<4, 2, 2, 2, 64, 2, 2> NtC10;  // 256x128, 4 waves, 96 KiB
 typedef NtCfg<2, 4, 2, 2, 32, 3, 2> NtC11;  // 128x256, 4 waves (64x128 each), 72 KiB, 3 stages
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 1> NtC12; // = NtC2 with register double-buffered fragments
+typedef NtCfg<4, 2, 2, 4, 32, 4, 1, 1> NtC13; // = NtC4 with register double-buffered fragments
 
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 11 && cfg_small >= 0 && cfg_small <= 11, "mnr_gemm_nt_set_config: unknown configuration");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 13 && cfg_small >= 0 && cfg_small <= 13, "mnr_gemm_nt_set_config: unknown configuration");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -391,7 +427,9 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 8: return nt_launch<NtC8>(a, fast_epi, stream);
     case 9: return nt_launch<NtC9>(a, fast_epi, stream);
     case 10: return nt_launch<NtC10>(a, fast_epi, stream);
-    default: return nt_launch<NtC11>(a, fast_epi, stream);
+    case 11: return nt_launch<NtC11>(a, fast_epi, stream);
+    case 12: return nt_launch<NtC12>(a, fast_epi, stream);
+    default: return nt_launch<NtC13>(a, fast_epi, stream);
   }
 }
 
@@ -764,36 +802,66 @@ __global__ __launch_bounds__(256) void small_head_bwd_kernel(int64_t M, int K, i
                                                               const float* __restrict__ W, bf16* __restrict__ dX,
                                                               int lddx, int relu_mask, float* dW, float* db,
                                                               int rows_per_block) {
-  // Thread t owns columns k = t, t+256, ... ; loops over the block's rows.
+  // Thread (rl, cg): column group cg of 8 consecutive k (16-byte accesses), row lane rl; the block's
+  // rows are strided over the row lanes.  dW partials are reduced across row lanes through LDS.
+  __shared__ float red[256 * 8];
+  const int groups = K / 8;                       // host guarantees K % 8 == 0 and groups <= 256
+  const int row_lanes = 256 / groups;
+  const int cg = threadIdx.x % groups;
+  const int rl = threadIdx.x / groups;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(M, r0 + rows_per_block);
-  for (int k = threadIdx.x; k < K; k += 256) {
-    float w[4], aw[4];
+  float w[8][4], aw[8][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      w[c] = (c < C) ? W[(int64_t)k * C + c] : 0.0f;
-      aw[c] = 0.0f;
+      w[e][c] = (c < C) ? W[(int64_t)(cg * 8 + e) * C + c] : 0.0f;
+      aw[e][c] = 0.0f;
     }
-    for (int64_t r = r0; r < r1; ++r) {
-      const float h = (float)H[r * ldh + k];
-      float gx = 0.0f;
+  float sb[4] = {0.0f, 0.0f, 0.0f, 0.0f};       // bias gradient partial (row lanes of column group 0)
+  if (rl < row_lanes) {
+    for (int64_t r = r0 + rl; r < r1; r += row_lanes) {
+      const bf16x8 h = *(const bf16x8*)(H + r * ldh + cg * 8);
+      float gc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (c < C) {
-          const float gc = g[r * C + c];
-          gx += gc * w[c];
-          aw[c] += h * gc;
+      for (int c = 0; c < 4; ++c)
+        if (c < C) gc[c] = g[r * C + c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sb[c] += gc[c];
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float hv = (float)h[e];
+        float gx = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          gx += gc[c] * w[e][c];
+          aw[e][c] += hv * gc[c];
+        }
+        o[e] = (bf16)((relu_mask && !(hv > 0.0f)) ? 0.0f : gx);
+      }
+      if (dX) *(bf16x8*)(dX + r * lddx + cg * 8) = o;
+    }
+  }
+  if (dW) {
+    for (int c = 0; c < C; ++c) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = aw[e][c];
+      __syncthreads();
+      if (rl == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float sum = 0.0f;
+          for (int k2 = 0; k2 < row_lanes; ++k2) sum += red[(k2 * groups + cg) * 8 + e];
+          unsafeAtomicAdd(dW + (int64_t)(cg * 8 + e) * C + c, sum);
         }
       }
-      if (dX) dX[r * lddx + k] = (bf16)((relu_mask && !(h > 0.0f)) ? 0.0f : gx);
     }
-    if (dW)
-      for (int c = 0; c < C; ++c) unsafeAtomicAdd(dW + (int64_t)k * C + c, aw[c]);
   }
-  if (db && threadIdx.x < C) {
-    float s = 0.0f;
-    for (int64_t r = r0; r < r1; ++r) s += g[r * C + threadIdx.x];
-    unsafeAtomicAdd(db + threadIdx.x, s);
+  if (db && cg == 0 && rl < row_lanes) {
+    for (int c = 0; c < C; ++c) unsafeAtomicAdd(db + c, sb[c]);
   }
 }
 
@@ -801,7 +869,9 @@ extern "C" int mnr_small_head_bwd(int64_t M, int K, int C, const uint16_t* H, in
                                   const float* W, uint16_t* dX, int lddx, int apply_relu_mask, float* dW,
                                   float* db, void* stream) {
   MNR_CHECK_ARG(M > 0 && K > 0 && C >= 1 && C <= 4 && H && g && W, "mnr_small_head_bwd: bad arguments (1 <= C <= 4)");
-  const int rows_per_block = 128;
+  MNR_CHECK_ARG(K % 8 == 0 && K / 8 <= 256 && ldh % 8 == 0 && (!dX || lddx % 8 == 0),
+                "mnr_small_head_bwd: K must be a multiple of 8 (<= 2048) and the pitches multiples of 8");
+  const int rows_per_block = 512;
   const int grid = mnr_cdiv(M, rows_per_block);
   hipLaunchKernelGGL(small_head_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, C,
                      (const bf16*)H, ldh, g, W, (bf16*)dX, lddx, apply_relu_mask, dW, db, rows_per_block);
