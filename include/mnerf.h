@@ -120,6 +120,13 @@ int mnr_cast_rays_ipe_f32(const mnr_ipe_cfg* cfg, int64_t B, int n, const float*
                           const float* origins, const float* directions, const float* radii,
                           const float* basis, float* feat_out, void* stream);
 
+/* Tangent features for the density-gradient normals (models.py:478-492 via forward mode):
+ * row c*B*n + s of feat_out (bf16 [3*B*n, ld_feat]) = d(IPE features of sample s)/d(mean_c), c = x,y,z.
+ * Only valid without a warp (the covariance then does not depend on the mean). */
+int mnr_cast_rays_ipe_tangent(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist,
+                              const float* origins, const float* directions, const float* radii,
+                              const float* basis, uint16_t* feat_out, int ld_feat, void* stream);
+
 /* coord.pos_enc(viewdirs, 0, deg_view, append_identity=True) per ray, written
  * (bf16) into columns [col0, col0+3+6*deg_view) of every one of the ray's n
  * rows of `dst` [B*n, ld]; columns up to col_end are zero-filled
@@ -149,6 +156,8 @@ typedef struct {
    * GEMM of the next layer reads it instead of re-reading the bf16 activation (16x less traffic). */
   uint8_t* mask_bits_out; int ld_bits_out;
   const uint8_t* mask_bits_in; int ld_bits_in;
+  int64_t bits_row_mod;               /* > 0: row m reads the bits of row m % bits_row_mod (tangent rows
+                                         c*M + s share the primal mask of sample s) */
 } mnr_gemm_nt_args;
 
 /* C[M,N] = epilogue([A1|A2] * Bt^T). */
@@ -262,6 +271,47 @@ int mnr_exposure_scale_bwd(int64_t B_valid, const float* exposure_values, const 
  * distance_mean, distance_percentile_5 / median / percentile_95 -> out [B,4]. */
 int mnr_render_extras(int64_t B, int n, const float* weights, const float* tdist, const float* t_far,
                       float* out, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Ref-NeRF branch  (replaces models.py:478-503,512-523,540-563,588-602, ref_utils.py:22-42,99-159,
+ * image.py:48-56, train_utils.py:162-197).  Merged head column layout, bw = bottleneck width:
+ *   [0,bw) bottleneck | bw density | bw+1..3 grad_pred | bw+4..6 raw diffuse | bw+7..9 raw tint | bw+10 raw roughness
+ * `small` [M,11] fp32 = columns bw..bw+10 of the head GEMM; `raw_grad` [3,M] fp32 = d raw_density/d mean.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  int T; int lmax;            /* number of (m,l) terms; largest degree (<= 16) */
+  const int32_t* m; const int32_t* l;   /* [T] device arrays (ref_utils.get_ml_array) */
+  const float* sigma;         /* [T] 0.5 l (l+1) */
+  const float* mat;           /* [lmax+1, T] z-polynomial coefficients (ref_utils.py:119-125) */
+} mnr_ide_tables;
+
+/* normals = -l2norm(raw_grad), normals_pred = -l2norm(grad_pred), roughness = softplus(raw + bias),
+ * refdirs = reflect(-viewdirs, normals_pred), IDE(refdirs, roughness) and n.v written (bf16) into
+ * columns [col0, col0 + 2T + 1) of every row of `vi` [M, ldvi]; columns up to col_end zero-filled. */
+int mnr_ref_head_fwd(int64_t M, int n, const float* small, const float* raw_grad, const float* viewdirs,
+                     const mnr_ide_tables* tabs, float roughness_bias, uint16_t* vi, int ldvi, int col0,
+                     int col_end, float* normals_out, float* normals_pred_out, float* roughness_out, void* stream);
+/* VJP: dvi_a (+ dvi_b, may be NULL) bf16 [M, lddvi] = gradient w.r.t. the view-MLP input; g_npred / g_n
+ * [M,3] fp32 from mnr_ref_losses (may be NULL).  Writes bf16 columns col_gp..+2 and col_rough of dhb
+ * [M, lddhb] and g_raw_grad [3,M] fp32. */
+int mnr_ref_head_bwd(int64_t M, int n, const float* small, const float* raw_grad, const float* viewdirs,
+                     const mnr_ide_tables* tabs, float roughness_bias, const uint16_t* dvi_a,
+                     const uint16_t* dvi_b, int lddvi, int col0, const float* g_npred, const float* g_n,
+                     uint16_t* dhb, int lddhb, int col_gp, int col_rough, float* g_raw_grad, void* stream);
+/* rgb = clip(linear_to_srgb(tint * sigmoid(premult raw_rgb + bias) + sigmoid(raw_diffuse - log 3)), 0, 1)
+ * * (1 + 2 pad) - pad; VJP writes g_raw_rgb [M,3] fp32 and the diffuse / tint columns of dhb (bf16). */
+int mnr_ref_color_fwd(int64_t M, const float* raw_rgb, const float* small, float rgb_premultiplier, float rgb_bias,
+                      float rgb_padding, int use_tint, float* rgb_out, void* stream);
+int mnr_ref_color_bwd(int64_t M, const float* raw_rgb, const float* small, float rgb_premultiplier, float rgb_bias,
+                      float rgb_padding, int use_tint, const float* g_rgb, float* g_raw_rgb, uint16_t* dhb,
+                      int lddhb, int col_diffuse, int col_tint, void* stream);
+/* One level of orientation_loss + predicted_normal_loss: stats[0] += mult_o * mean_rays sum_i w min(0, n.(-v))^2,
+ * stats[1] += mult_p * mean_rays sum_i w (1 - n.n_pred); g_weights [B,n] +=, g_normals / g_normals_pred [M,3] =. */
+int mnr_ref_losses(int64_t B_valid, int n, float mult_orientation, float mult_pred_normal, int target_is_pred,
+                   const float* weights, const float* normals, const float* normals_pred, const float* viewdirs,
+                   float* stats, float* g_weights, float* g_normals, float* g_normals_pred, void* stream);
+/* out[b,c] = sum_i weights[b,i] values[b,i,c]  (render.py:187-190 extras). */
+int mnr_weighted_sum(int64_t B, int n, int C, const float* weights, const float* values, float* out, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Losses  (replaces train_utils.compute_data_loss train_utils.py:72-136,

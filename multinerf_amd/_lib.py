@@ -49,7 +49,8 @@ class GemmNTArgs(C.Structure):
               ('Cb', vp), ('ldcb', C.c_int), ('nb', C.c_int),
               ('Cf', vp), ('ldcf', C.c_int), ('f0', C.c_int), ('nf', C.c_int),
               ('mask_bits_out', vp), ('ld_bits_out', C.c_int),
-              ('mask_bits_in', vp), ('ld_bits_in', C.c_int)]
+              ('mask_bits_in', vp), ('ld_bits_in', C.c_int),
+              ('bits_row_mod', C.c_int64)]
 
 
 class GemmTNArgs(C.Structure):
@@ -73,6 +74,10 @@ class CompositeCfg(C.Structure):
               ('rgb_padding', C.c_float), ('bg_mode', C.c_int), ('bg_value', C.c_float)]
 
 
+class IdeTables(C.Structure):
+  _fields_ = [('T', C.c_int), ('lmax', C.c_int), ('m', vp), ('l', vp), ('sigma', vp), ('mat', vp)]
+
+
 class AdamCfg(C.Structure):
   _fields_ = [('lr', C.c_float), ('b1', C.c_float), ('b2', C.c_float), ('eps', C.c_float),
               ('bias_corr1', C.c_float), ('bias_corr2', C.c_float), ('grad_max_val', C.c_float),
@@ -88,6 +93,7 @@ _PROTOS = {
     'mnr_max_dilate_weights': ([i64, i32, vp, vp, f32, f32, f32, vp, vp, vp, vp], i32),
     'mnr_cast_rays_ipe': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp], i32),
     'mnr_cast_rays_ipe_f32': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp], i32),
+    'mnr_cast_rays_ipe_tangent': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, i32, vp], i32),
     'mnr_viewdir_enc_fill': ([i64, i32, vp, i32, vp, i32, i32, i32, vp], i32),
     'mnr_gemm_nt_bf16': ([C.POINTER(GemmNTArgs), vp], i32),
     'mnr_gemm_nt_set_config': ([i32, i32], i32),
@@ -104,6 +110,12 @@ _PROTOS = {
     'mnr_exposure_scale': ([i64, vp, vp, vp, vp, vp], i32),
     'mnr_exposure_scale_bwd': ([i64, vp, vp, vp, vp, vp], i32),
     'mnr_render_extras': ([i64, i32, vp, vp, vp, vp, vp], i32),
+    'mnr_ref_head_fwd': ([i64, i32, vp, vp, vp, C.POINTER(IdeTables), f32, vp, i32, i32, i32, vp, vp, vp, vp], i32),
+    'mnr_ref_head_bwd': ([i64, i32, vp, vp, vp, C.POINTER(IdeTables), f32, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp], i32),
+    'mnr_ref_color_fwd': ([i64, vp, vp, f32, f32, f32, i32, vp, vp], i32),
+    'mnr_ref_color_bwd': ([i64, vp, vp, f32, f32, f32, i32, vp, vp, vp, i32, i32, i32, vp], i32),
+    'mnr_ref_losses': ([i64, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
+    'mnr_weighted_sum': ([i64, i32, i32, vp, vp, vp, vp], i32),
     'mnr_lossmult_sum': ([i64, vp, i32, vp, vp], i32),
     'mnr_data_loss': ([i32, f32, f32, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp], i32),
     'mnr_interlevel_loss': ([f32, i64, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp], i32),

@@ -296,3 +296,8 @@ def load_preset(name, gin_bindings=None):
   for b in (gin_bindings or []):
     gin.parse_config(b, skip_unknown=False)
   return Config()
+
+
+# Importing this module must register every configurable the .gin files bind (gin drops bindings of
+# unknown configurables when skip_unknown=True, internal/configs.py:185-186): pull in Model/NerfMLP/PropMLP.
+from multinerf_amd import models as _models  # noqa: E402,F401

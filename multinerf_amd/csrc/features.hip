@@ -124,7 +124,7 @@ __device__ __forceinline__ void fe_gaussian(const mnr_ipe_cfg& c, float t0, floa
   g.cov[5] = cov[2][2];
 }
 
-template <bool OUT_F32>
+template <bool OUT_F32, bool TANGENT>
 __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
     mnr_ipe_cfg c, int64_t total, int n, int spb, const float* __restrict__ tdist,
     const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ radii,
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
   __syncthreads();
 
   const int row_elems = OUT_F32 ? nfeat : ld_feat;
+  // TANGENT: three rows per sample (d/d mean_x, d/d mean_y, d/d mean_z), staged as [c][sample][ld].
   for (int pair = threadIdx.x; pair < ns * K; pair += FE_THREADS) {
     const int si = pair / K, k = pair % K;
     const FeSample g = gs[si];
@@ -203,7 +204,17 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
       const float fs = att * sn;
       const float fc = att * cs;
       const int col = l * K + k;
-      if (OUT_F32) {
+      if (TANGENT) {
+        // d/d mean_c of att sin(lm 2^l) = att 2^l cos(.) p_k[c];  of att cos(.) = -att 2^l sin(.) p_k[c]
+        // (no warp: the variance does not depend on the mean).
+        const float pc[3] = {px, py, pz};
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          bf16* rowp = (bf16*)rows + ((size_t)cc * spb + si) * row_elems;
+          rowp[col] = (bf16)(fc * sc * pc[cc]);
+          rowp[K * L + col] = (bf16)(-fs * sc * pc[cc]);
+        }
+      } else if (OUT_F32) {
         float* rowp = (float*)rows + (size_t)si * row_elems;
         rowp[col] = fs;
         rowp[K * L + col] = fc;
@@ -220,12 +231,24 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
   if (!OUT_F32) {
     // zero the padding columns [nfeat, ld)
     const int pad = ld_feat - nfeat;
-    for (int e = threadIdx.x; e < ns * pad; e += FE_THREADS) {
+    const int nrows = TANGENT ? 3 * spb : ns;
+    for (int e = threadIdx.x; e < nrows * pad; e += FE_THREADS) {
       const int si = e / pad, cidx = nfeat + e % pad;
       ((bf16*)rows)[(size_t)si * ld_feat + cidx] = (bf16)0.0f;
     }
   }
   __syncthreads();
+  if (TANGENT) {
+    const size_t row_bytes_t = (size_t)ld_feat * 2;
+    for (int cc = 0; cc < 3; ++cc) {
+      const size_t nbytes_t = (size_t)ns * row_bytes_t;
+      char* dst_t = (char*)feat_out + ((size_t)cc * total + s0) * row_bytes_t;
+      const char* src_t = rows + (size_t)cc * spb * row_bytes_t;
+      for (size_t off = (size_t)threadIdx.x * 16; off < nbytes_t; off += (size_t)FE_THREADS * 16)
+        *(uint4*)(dst_t + off) = *(const uint4*)(src_t + off);
+    }
+    return;
+  }
   // Coalesced write-out: the block's rows are contiguous in HBM (16 B per lane).
   const size_t row_bytes = (size_t)row_elems * (OUT_F32 ? 4 : 2);
   const size_t nbytes = (size_t)ns * row_bytes;
@@ -234,7 +257,7 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
     *(uint4*)(dst + off) = *(const uint4*)(rows + off);
 }
 
-static int fe_launch(bool f32, const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist, const float* origins,
+static int fe_launch(int mode /*0 bf16, 1 f32, 2 tangent*/, const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist, const float* origins,
                      const float* directions, const float* radii, const float* basis, void* feat_out, int ld_feat,
                      float* means_out, float* covs_out, void* stream) {
   MNR_CHECK_ARG(cfg && B > 0 && n > 0 && tdist && origins && directions && radii && basis && feat_out,
@@ -242,23 +265,29 @@ static int fe_launch(bool f32, const mnr_ipe_cfg* cfg, int64_t B, int n, const f
   MNR_CHECK_ARG(cfg->ray_shape == 0 || cfg->ray_shape == 1, "ray_shape must be 'cone' or 'cylinder'");  // render.py:124
   const int K = cfg->basis_k, L = cfg->max_deg - cfg->min_deg;
   MNR_CHECK_ARG(K >= 1 && K <= 128 && L >= 1 && L <= 32, "mnr_cast_rays_ipe: basis_k=%d / degrees=%d out of range", K, L);
+  const bool f32 = mode == 1;
+  const bool tangent = mode == 2;
+  MNR_CHECK_ARG(!tangent || !cfg->warp_contract, "mnr_cast_rays_ipe_tangent: not valid with a warp");
   const int nfeat = 2 * K * L;
   const int row_elems = f32 ? nfeat : ld_feat;
   MNR_CHECK_ARG(f32 || (ld_feat >= nfeat && ld_feat % 8 == 0), "mnr_cast_rays_ipe: ld_feat=%d must be >= %d and a multiple of 8", ld_feat, nfeat);
   MNR_CHECK_ARG(!f32 || nfeat % 4 == 0, "mnr_cast_rays_ipe_f32: feature count must be a multiple of 4");
   const size_t row_bytes = (size_t)row_elems * (f32 ? 4 : 2);
-  int spb = (int)((32 * 1024) / row_bytes);
+  int spb = (int)((32 * 1024) / (row_bytes * (tangent ? 3 : 1)));
   if (spb > FE_THREADS) spb = FE_THREADS;
   spb &= ~3;                       // keeps the row buffer 16-byte aligned behind the FeSample array
   MNR_CHECK_ARG(spb >= 4, "mnr_cast_rays_ipe: feature row too long");
-  const size_t lds = (size_t)spb * sizeof(FeSample) + (size_t)((K * 3 + 3) & ~3) * 4 + (size_t)spb * row_bytes;
+  const size_t lds = (size_t)spb * sizeof(FeSample) + (size_t)((K * 3 + 3) & ~3) * 4 + (size_t)spb * row_bytes * (tangent ? 3 : 1);
   const int64_t total = B * n;
   const int grid = mnr_cdiv(total, spb);
-  if (f32) {
-    hipLaunchKernelGGL(cast_rays_ipe_kernel<true>, dim3(grid), dim3(FE_THREADS), lds, (hipStream_t)stream, *cfg,
+  if (tangent) {
+    hipLaunchKernelGGL((cast_rays_ipe_kernel<false, true>), dim3(grid), dim3(FE_THREADS), lds, (hipStream_t)stream, *cfg,
+                       total, n, spb, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out, covs_out);
+  } else if (f32) {
+    hipLaunchKernelGGL((cast_rays_ipe_kernel<true, false>), dim3(grid), dim3(FE_THREADS), lds, (hipStream_t)stream, *cfg,
                        total, n, spb, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out, covs_out);
   } else {
-    hipLaunchKernelGGL(cast_rays_ipe_kernel<false>, dim3(grid), dim3(FE_THREADS), lds, (hipStream_t)stream, *cfg,
+    hipLaunchKernelGGL((cast_rays_ipe_kernel<false, false>), dim3(grid), dim3(FE_THREADS), lds, (hipStream_t)stream, *cfg,
                        total, n, spb, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out, covs_out);
   }
   MNR_CHECK_LAUNCH();
@@ -269,14 +298,20 @@ extern "C" int mnr_cast_rays_ipe(const mnr_ipe_cfg* cfg, int64_t B, int n, const
                                  const float* origins, const float* directions, const float* radii,
                                  const float* basis, uint16_t* feat_out, int ld_feat, float* means_out,
                                  float* covs_out, void* stream) {
-  return fe_launch(false, cfg, B, n, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out,
+  return fe_launch(0, cfg, B, n, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out,
                    covs_out, stream);
 }
 
 extern "C" int mnr_cast_rays_ipe_f32(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist,
                                      const float* origins, const float* directions, const float* radii,
                                      const float* basis, float* feat_out, void* stream) {
-  return fe_launch(true, cfg, B, n, tdist, origins, directions, radii, basis, feat_out, 0, nullptr, nullptr, stream);
+  return fe_launch(1, cfg, B, n, tdist, origins, directions, radii, basis, feat_out, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int mnr_cast_rays_ipe_tangent(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist,
+                                         const float* origins, const float* directions, const float* radii,
+                                         const float* basis, uint16_t* feat_out, int ld_feat, void* stream) {
+  return fe_launch(2, cfg, B, n, tdist, origins, directions, radii, basis, feat_out, ld_feat, nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -33,8 +33,9 @@
 
 #define NT_CPAD 16                                   // epilogue staging: 16 B pad per row
 
-template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_, int MINW_ = 1, int FRAGPIPE_ = 0>
+template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_, int MINW_ = 1, int FRAGPIPE_ = 0, int ABLATE_ = 0>
 struct NtCfg {
+  static constexpr int ABLATE = ABLATE_;              // probe only: 1 no MFMA, 2 no in-loop DMA, 4 no ds_reads
   static constexpr int FRAGPIPE = FRAGPIPE_;          // 1: explicit register double-buffering of LDS fragments
   static constexpr int MI = MI_, NJ = NJ_, WM = WM_, WN = WN_, BK = BK_, STAGES = STAGES_;
   static constexpr int MINW = MINW_;                  // __launch_bounds__ min waves per SIMD (register cap)
@@ -150,7 +151,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
       for (int it = 0; it < EPI_ITERS; ++it) {
         const int c = it * CFG::THREADS + tid;
         const int row = c / EPI_CPR, ch = c % EPI_CPR;
-        const int64_t idx = (m0 + h * CFG::EPI_ROWS + row) * (int64_t)p.ld_bits_in + ((n0 + ch * 8) >> 3);
+        int64_t mrow = m0 + h * CFG::EPI_ROWS + row;
+        if (p.bits_row_mod > 0) mrow %= p.bits_row_mod;
+        const int64_t idx = mrow * (int64_t)p.ld_bits_in + ((n0 + ch * 8) >> 3);
         mbits[h][it] = p.mask_bits_in[idx];
       }
   }
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
     else nt_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1);
+    if ((CFG::ABLATE & 2) == 0 && kt + STAGES - 1 < nk) stage(kt + STAGES - 1);
     const char* As = smem + (kt % STAGES) * CFG::STAGE_BYTES;
     const char* Bs = As + CFG::A_BYTES;
     if constexpr (CFG::FRAGPIPE) {
@@ -229,15 +232,33 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
       for (int ks = 0; ks < BK / 16; ++ks) {
         const int kslot = ks * 2 + khalf;
         bf16x8 fa[MI], fb[NJ];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i] = nt_read_frag<CFG>(As, wm * 32 * MI + i * 32 + frow, kslot);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) fb[j] = nt_read_frag<CFG>(Bs, wn * 32 * NJ + j * 32 + frow, kslot);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        if constexpr (CFG::ABLATE & 4) {
 #pragma unroll
           for (int i = 0; i < MI; ++i)
-            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fa[i][e] = (bf16)(float)(kslot + i);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fb[j][e] = (bf16)(float)(kslot - j);
+        } else {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) fa[i] = nt_read_frag<CFG>(As, wm * 32 * MI + i * 32 + frow, kslot);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) fb[j] = nt_read_frag<CFG>(Bs, wn * 32 * NJ + j * 32 + frow, kslot);
+        }
+        if constexpr (CFG::ABLATE & 1) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(fb[j]));
+        } else {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+              acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+        }
       }
     }
   }
@@ -331,7 +352,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
           }
           if (BITS_IN) {
-            const unsigned mb = p.mask_bits_in[m * p.ld_bits_in + (n4 >> 3)] >> (n4 & 7);
+            const int64_t mrow = p.bits_row_mod > 0 ? m % p.bits_row_mod : m;
+            const unsigned mb = p.mask_bits_in[mrow * p.ld_bits_in + (n4 >> 3)] >> (n4 & 7);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.0f;
           } else if (mask) {
@@ -404,11 +426,15 @@ typedef NtCfg<4, 2, 2, 2, 64, 2, 2> NtC10;  // 256x128, 4 waves, 96 KiB
 typedef NtCfg<2, 4, 2, 2, 32, 3, 2> NtC11;  // 128x256, 4 waves (64x128 each), 72 KiB, 3 stages
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 1> NtC12; // = NtC2 with register double-buffered fragments
 typedef NtCfg<4, 2, 2, 4, 32, 4, 1, 1> NtC13; // = NtC4 with register double-buffered fragments
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 1> NtC14; // probe: NtC2 without MFMAs
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 2> NtC15; // probe: NtC2 without in-loop DMA
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 6> NtC16; // probe: NtC2 MFMAs only (no DMA, no ds_reads)
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 5> NtC17; // probe: NtC2 DMA only (no ds_reads, no MFMAs)
 
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 13 && cfg_small >= 0 && cfg_small <= 13, "mnr_gemm_nt_set_config: unknown configuration");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 17 && cfg_small >= 0 && cfg_small <= 17, "mnr_gemm_nt_set_config: unknown configuration");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -429,7 +455,11 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 10: return nt_launch<NtC10>(a, fast_epi, stream);
     case 11: return nt_launch<NtC11>(a, fast_epi, stream);
     case 12: return nt_launch<NtC12>(a, fast_epi, stream);
-    default: return nt_launch<NtC13>(a, fast_epi, stream);
+    case 13: return nt_launch<NtC13>(a, fast_epi, stream);
+    case 14: return nt_launch<NtC14>(a, fast_epi, stream);
+    case 15: return nt_launch<NtC15>(a, fast_epi, stream);
+    case 16: return nt_launch<NtC16>(a, fast_epi, stream);
+    default: return nt_launch<NtC17>(a, fast_epi, stream);
   }
 }
 

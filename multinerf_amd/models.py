@@ -21,7 +21,6 @@ import numpy as np
 import torch
 
 from multinerf_amd import _lib as L
-from multinerf_amd import configs
 from multinerf_amd import geopoly
 from multinerf_amd import gin
 from multinerf_amd import ops

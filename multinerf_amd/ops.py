@@ -178,6 +178,23 @@ def cast_rays_ipe_f32(tdist, origins, directions, radii, basis, *, ray_shape, wa
   return out
 
 
+def cast_rays_ipe_tangent(tdist, origins, directions, radii, basis, *, ray_shape, min_deg, max_deg, ld_feat,
+                          out=None):
+  """-> bf16 [3*B*n, ld_feat]: rows c*B*n + s = d(features of sample s)/d(mean_c) (no warp)."""
+  for x, nm in ((tdist, 'tdist'), (origins, 'origins'), (directions, 'directions'), (radii, 'radii'),
+                (basis, 'basis')):
+    _chk(x, f32, nm)
+  B, n1 = tdist.shape
+  n = n1 - 1
+  cfg = _ipe_cfg(ray_shape, False, False, basis, min_deg, max_deg)
+  if out is None:
+    out = torch.empty((3 * B * n, ld_feat), dtype=bf16, device=tdist.device)
+  _chk(out, bf16, 'out')
+  L.check(lib().mnr_cast_rays_ipe_tangent(C.byref(cfg), B, n, _ptr(tdist), _ptr(origins), _ptr(directions),
+                                          _ptr(radii), _ptr(basis), _ptr(out), ld_feat, _stream()))
+  return out
+
+
 def viewdir_enc_fill(viewdirs, n, deg_view, dst, col0, col_end):
   _chk(viewdirs, f32, 'viewdirs')
   _chk(dst, bf16, 'dst')
@@ -192,7 +209,7 @@ def viewdir_enc_fill(viewdirs, n, deg_view, dst, col0, col_end):
 
 def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, bias=None, n_bias=0,
             relu=False, mask=None, ldmask=0, Cb=None, ldcb=0, nb=0, Cf=None, ldcf=0, f0=0, nf=0,
-            bits_out=None, bits_in=None):
+            bits_out=None, bits_in=None, bits_row_mod=0):
   """C[M,N] = epilogue([A1|A2] @ Bt^T).  Pointers may be views with explicit leading dimensions."""
   _chk(A1, bf16, 'A1')
   _chk(Bt, bf16, 'Bt')
@@ -214,6 +231,7 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
     _chk(t_, torch.uint8, nm_, allow_none=True)
   a.mask_bits_out, a.ld_bits_out = (bits_out.data_ptr(), bits_out.stride(0)) if bits_out is not None else (None, 0)
   a.mask_bits_in, a.ld_bits_in = (bits_in.data_ptr(), bits_in.stride(0)) if bits_in is not None else (None, 0)
+  a.bits_row_mod = bits_row_mod
   _e = PROFILE.start()
   L.check(lib().mnr_gemm_nt_bf16(C.byref(a), _stream()))
   PROFILE.stop(_e)
@@ -345,6 +363,96 @@ def render_extras(weights, tdist, t_far):
   B, n = weights.shape
   out = torch.empty((B, 4), dtype=f32, device=weights.device)
   L.check(lib().mnr_render_extras(B, n, _ptr(weights), _ptr(tdist), _ptr(t_far), _ptr(out), _stream()))
+  return out
+
+
+# ----------------------------------------------------------------------------- Ref-NeRF
+
+
+class IdeTablesDev:
+  """Device copies of ref_utils.ide_tables(deg_view) + the C struct that points at them."""
+
+  def __init__(self, deg_view, device):
+    from multinerf_amd import ref_utils
+    m, l, mat, sigma = ref_utils.ide_tables(deg_view)
+    self.T = len(m)
+    self.m = torch.as_tensor(m, dtype=torch.int32, device=device)
+    self.l = torch.as_tensor(l, dtype=torch.int32, device=device)
+    self.mat = torch.as_tensor(mat, dtype=f32, device=device).contiguous()
+    self.sigma = torch.as_tensor(sigma, dtype=f32, device=device)
+    self.c = L.IdeTables(self.T, mat.shape[0] - 1, self.m.data_ptr(), self.l.data_ptr(), self.sigma.data_ptr(),
+                         self.mat.data_ptr())
+
+
+def ref_head_fwd(small, raw_grad, viewdirs, n, tabs, roughness_bias, vi, col0, col_end):
+  for x, nm in ((small, 'small'), (raw_grad, 'raw_grad'), (viewdirs, 'viewdirs')):
+    _chk(x, f32, nm)
+  _chk(vi, bf16, 'vi')
+  M = small.shape[0]
+  dev = small.device
+  normals = torch.empty((M, 3), dtype=f32, device=dev)
+  npred = torch.empty((M, 3), dtype=f32, device=dev)
+  rough = torch.empty((M,), dtype=f32, device=dev)
+  L.check(lib().mnr_ref_head_fwd(M, n, _ptr(small), _ptr(raw_grad), _ptr(viewdirs), C.byref(tabs.c),
+                                 float(roughness_bias), _ptr(vi), vi.stride(0), col0, col_end, _ptr(normals),
+                                 _ptr(npred), _ptr(rough), _stream()))
+  return normals, npred, rough
+
+
+def ref_head_bwd(small, raw_grad, viewdirs, n, tabs, roughness_bias, dvi_a, dvi_b, col0, g_npred, g_n, dhb, col_gp,
+                 col_rough):
+  M = small.shape[0]
+  _chk(dvi_a, bf16, 'dvi_a')
+  _chk(dvi_b, bf16, 'dvi_b', allow_none=True)
+  _chk(dhb, bf16, 'dhb')
+  g_raw_grad = torch.empty((3, M), dtype=f32, device=small.device)
+  L.check(lib().mnr_ref_head_bwd(M, n, _ptr(small), _ptr(raw_grad), _ptr(viewdirs), C.byref(tabs.c),
+                                 float(roughness_bias), _ptr(dvi_a), _ptr(dvi_b), dvi_a.stride(0), col0,
+                                 _ptr(g_npred), _ptr(g_n), _ptr(dhb), dhb.stride(0), col_gp, col_rough,
+                                 _ptr(g_raw_grad), _stream()))
+  return g_raw_grad
+
+
+def ref_color_fwd(raw_rgb, small, premult, rgb_bias, pad, use_tint):
+  _chk(raw_rgb, f32, 'raw_rgb')
+  _chk(small, f32, 'small')
+  M = small.shape[0]
+  out = torch.empty((M, 3), dtype=f32, device=small.device)
+  L.check(lib().mnr_ref_color_fwd(M, _ptr(raw_rgb), _ptr(small), float(premult), float(rgb_bias), float(pad),
+                                  int(use_tint), _ptr(out), _stream()))
+  return out
+
+
+def ref_color_bwd(raw_rgb, small, premult, rgb_bias, pad, use_tint, g_rgb, dhb, col_diffuse, col_tint):
+  _chk(g_rgb, f32, 'g_rgb')
+  _chk(dhb, bf16, 'dhb')
+  M = small.shape[0]
+  g_raw_rgb = torch.empty((M, 3), dtype=f32, device=small.device)
+  L.check(lib().mnr_ref_color_bwd(M, _ptr(raw_rgb), _ptr(small), float(premult), float(rgb_bias), float(pad),
+                                  int(use_tint), _ptr(g_rgb), _ptr(g_raw_rgb), _ptr(dhb), dhb.stride(0), col_diffuse,
+                                  col_tint, _stream()))
+  return g_raw_rgb
+
+
+def ref_losses(mult_o, mult_p, target_is_pred, weights, normals, npred, viewdirs, stats, g_w, want_grad, *, B_valid):
+  for x, nm in ((weights, 'weights'), (normals, 'normals'), (npred, 'npred'), (viewdirs, 'viewdirs'), (stats, 'stats')):
+    _chk(x, f32, nm)
+  B, n = weights.shape
+  g_n = torch.zeros_like(normals) if want_grad else None
+  g_np = torch.zeros_like(npred) if want_grad else None
+  L.check(lib().mnr_ref_losses(B_valid, n, float(mult_o), float(mult_p), int(target_is_pred), _ptr(weights),
+                               _ptr(normals), _ptr(npred), _ptr(viewdirs), _ptr(stats), _ptr(g_w), _ptr(g_n),
+                               _ptr(g_np), _stream()))
+  return g_n, g_np
+
+
+def weighted_sum(weights, values):
+  _chk(weights, f32, 'weights')
+  _chk(values, f32, 'values')
+  B, n = weights.shape
+  Cn = values.numel() // (B * n)
+  out = torch.empty((B, Cn), dtype=f32, device=weights.device)
+  L.check(lib().mnr_weighted_sum(B, n, Cn, _ptr(weights), _ptr(values), _ptr(out), _stream()))
   return out
 
 

@@ -1,0 +1,192 @@
+"""Ref-NeRF kernels (refnerf.hip, tangent features) vs the oracle and its autograd.  -m gpu."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import coord as ocoord
+from oracle import image as oimage
+from oracle import ref_utils as oref
+from oracle import render as orender
+from oracle import train_utils as otrain
+
+
+@pytest.fixture(scope='module')
+def ops():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  from multinerf_amd import ops as _ops
+  _ops.lib()
+  return _ops
+
+
+def dev(x):
+  return x.contiguous().cuda()
+
+
+def _head_ref(small, raw_grad, viewdirs_s, rb):
+  """Oracle composition of models.py:492-563 for already-flattened samples (viewdirs per sample)."""
+  gp = small[:, 1:4]
+  npred = -oref.l2_normalize(gp)
+  nrm = -oref.l2_normalize(raw_grad.T)
+  rough = torch.nn.functional.softplus(small[:, 10] + rb)
+  refdirs = oref.reflect(-viewdirs_s, npred)
+  ide = oref.generate_ide_fn(5)(refdirs, rough[:, None])
+  ndv = (npred * viewdirs_s).sum(-1, keepdim=True)
+  return nrm, npred, rough, torch.cat([ide, ndv], -1)
+
+
+def test_ref_head_fwd_bwd(ops):
+  gen = torch.Generator().manual_seed(21)
+  B, n = 23, 16
+  M = B * n
+  small = torch.randn((M, 11), generator=gen)
+  small[5, 1:4] = 0.0                      # zero predicted gradient: the eps clamp of l2_normalize
+  raw_grad = torch.randn((3, M), generator=gen) * 3
+  v = torch.randn((B, 3), generator=gen)
+  v = v / v.norm(dim=-1, keepdim=True)
+  vs = v[:, None, :].expand(B, n, 3).reshape(M, 3)
+  rb = -1.0
+  tabs = ops.IdeTablesDev(5, 'cuda')
+  vi = torch.full((M, 256), 3.0, dtype=torch.bfloat16).cuda()
+  nrm, npred, rough = ops.ref_head_fwd(dev(small), dev(raw_grad), dev(v), n, tabs, rb, vi, 128, 256)
+
+  s64, rg64, vs64 = small.double().requires_grad_(True), raw_grad.double().requires_grad_(True), vs.double()
+  nrm_r, npred_r, rough_r, enc_r = _head_ref(s64, rg64, vs64, rb)
+  np.testing.assert_allclose(nrm.cpu().numpy(), nrm_r.detach().numpy(), rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(npred.cpu().numpy(), npred_r.detach().numpy(), rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(rough.cpu().numpy(), rough_r.detach().numpy(), rtol=1e-5, atol=1e-6)
+  enc = vi.cpu().float()[:, 128:128 + 73]
+  # bf16 storage (2^-8 relative) on top of the fp32 evaluation of the degree-16 polynomials.
+  np.testing.assert_allclose(enc.numpy(), enc_r.detach().numpy(), rtol=2**-7, atol=2e-3)
+  assert (vi.cpu().float()[:, :128] == 3.0).all() and (vi.cpu().float()[:, 201:] == 0.0).all()
+
+  # VJP vs autograd (fp64 oracle)
+  g_enc = torch.randn((M, 73), generator=gen) * 0.1
+  g_np_l = torch.randn((M, 3), generator=gen) * 0.1
+  g_n_l = torch.randn((M, 3), generator=gen) * 0.1
+  obj = (enc_r * g_enc.double()).sum() + (npred_r * g_np_l.double()).sum() + (nrm_r * g_n_l.double()).sum()
+  obj.backward()
+  dvi_a = torch.zeros((M, 256), dtype=torch.bfloat16)
+  dvi_b = torch.zeros((M, 256), dtype=torch.bfloat16)
+  ga = (g_enc * 0.6).to(torch.bfloat16)
+  gb = (g_enc - ga.float()).to(torch.bfloat16)
+  dvi_a[:, 128:201], dvi_b[:, 128:201] = ga, gb
+  g_used = ga.float() + gb.float()
+  dhb = torch.zeros((M, 256), dtype=torch.bfloat16).cuda()
+  g_rg = ops.ref_head_bwd(dev(small), dev(raw_grad), dev(v), n, tabs, rb, dev(dvi_a), dev(dvi_b), 128,
+                          dev(g_np_l), dev(g_n_l), dhb, 129, 138)
+  # autograd with the bf16-rounded upstream actually fed to the kernel
+  s2, rg2 = small.double().requires_grad_(True), raw_grad.double().requires_grad_(True)
+  nrm2, npred2, rough2, enc2 = _head_ref(s2, rg2, vs64, rb)
+  ((enc2 * g_used.double()).sum() + (npred2 * g_np_l.double()).sum() + (nrm2 * g_n_l.double()).sum()).backward()
+  np.testing.assert_allclose(g_rg.cpu().numpy(), rg2.grad.numpy(), rtol=1e-4, atol=1e-6)
+  got = dhb.cpu().float()
+  ref_gp, ref_r = s2.grad[:, 1:4], s2.grad[:, 10]
+  sc = ref_gp.abs().max().item()
+  np.testing.assert_allclose(got[:, 129:132].numpy(), ref_gp.numpy(), rtol=2e-2, atol=2e-3 * sc)
+  np.testing.assert_allclose(got[:, 138].numpy(), ref_r.numpy(), rtol=2e-2, atol=2e-3 * ref_r.abs().max().item())
+  assert (got[:, :129] == 0).all() and (got[:, 132:138] == 0).all()
+
+
+def test_ref_color_fwd_bwd(ops):
+  gen = torch.Generator().manual_seed(22)
+  M = 999
+  raw_rgb = torch.randn((M, 3), generator=gen) * 2
+  small = torch.randn((M, 11), generator=gen) * 2
+  small[:7, 4:7] = -12.0                   # tiny diffuse: exercises the linear branch of linear_to_srgb
+  raw_rgb[:7] = -12.0
+  pad = 0.001
+  rr, sm = raw_rgb.double().requires_grad_(True), small.double().requires_grad_(True)
+  spec = torch.sigmoid(rr)
+  lin = torch.sigmoid(sm[:, 7:10]) * spec + torch.sigmoid(sm[:, 4:7] - math.log(3.0))
+  ref = torch.clamp(oimage.linear_to_srgb(lin), 0.0, 1.0) * (1 + 2 * pad) - pad
+  out = ops.ref_color_fwd(dev(raw_rgb), dev(small), 1.0, 0.0, pad, True)
+  np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-6)
+  g = torch.randn((M, 3), generator=gen)
+  (ref * g.double()).sum().backward()
+  dhb = torch.zeros((M, 256), dtype=torch.bfloat16).cuda()
+  g_rr = ops.ref_color_bwd(dev(raw_rgb), dev(small), 1.0, 0.0, pad, True, dev(g), dhb, 132, 135)
+  np.testing.assert_allclose(g_rr.cpu().numpy(), rr.grad.numpy(), rtol=2e-4, atol=1e-6)
+  got = dhb.cpu().float()
+  np.testing.assert_allclose(got[:, 132:135].numpy(), sm.grad[:, 4:7].numpy(), rtol=2**-7, atol=1e-4)
+  np.testing.assert_allclose(got[:, 135:138].numpy(), sm.grad[:, 7:10].numpy(), rtol=2**-7, atol=1e-4)
+
+
+def test_ref_losses_and_weighted_sum(ops):
+  gen = torch.Generator().manual_seed(23)
+  B, Bv, n = 50, 47, 24
+  w = torch.rand((B, n), generator=gen) * 0.05
+  nrm = torch.randn((B, n, 3), generator=gen)
+  nrm = nrm / nrm.norm(dim=-1, keepdim=True)
+  npred = torch.randn((B, n, 3), generator=gen)
+  npred = npred / npred.norm(dim=-1, keepdim=True)
+  v = torch.randn((B, 3), generator=gen)
+  v = v / v.norm(dim=-1, keepdim=True)
+
+  class Cfg:
+    orientation_loss_target = 'normals_pred'
+    orientation_coarse_loss_mult, orientation_loss_mult = 0.01, 0.1
+    predicted_normal_coarse_loss_mult, predicted_normal_loss_mult = 3e-5, 3e-4
+
+  class Obj:
+    pass
+
+  rays, model = Obj(), Obj()
+  rays.viewdirs, model.num_levels = v[:Bv], 2
+  wv, nv, pv = (w[:Bv].clone().requires_grad_(True), nrm[:Bv].clone().requires_grad_(True),
+                npred[:Bv].clone().requires_grad_(True))
+  hist = [{'weights': wv, 'normals': nv, 'normals_pred': pv}]      # one level = the fine level when num_levels == 1
+  model.num_levels = 1
+  lo = otrain.orientation_loss(rays, model, hist, Cfg)
+  lp = otrain.predicted_normal_loss(model, hist, Cfg)
+  (lo + lp).backward()
+  stats = torch.zeros(2).cuda()
+  g_w = torch.zeros((B, n)).cuda()
+  g_n, g_np = ops.ref_losses(0.1, 3e-4, True, dev(w), dev(nrm.reshape(-1, 3)), dev(npred.reshape(-1, 3)), dev(v), stats,
+                             g_w, True, B_valid=Bv)
+  np.testing.assert_allclose(stats.cpu().numpy(), [lo.item(), lp.item()], rtol=1e-4)
+  np.testing.assert_allclose(g_w.cpu()[:Bv].numpy(), wv.grad.numpy(), rtol=1e-4, atol=1e-9)
+  np.testing.assert_allclose(g_n.cpu().reshape(B, n, 3)[:Bv].numpy(), nv.grad.numpy(), rtol=1e-4, atol=1e-10)
+  np.testing.assert_allclose(g_np.cpu().reshape(B, n, 3)[:Bv].numpy(), pv.grad.numpy(), rtol=1e-4, atol=1e-10)
+  assert (g_w.cpu()[Bv:] == 0).all()
+  ws = ops.weighted_sum(dev(w), dev(nrm))
+  np.testing.assert_allclose(ws.cpu().numpy(), (w[..., None] * nrm).sum(1).numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_tangent_features(ops):
+  """d(features)/d(mean_c) (forward mode) vs autograd of the oracle's IPE w.r.t. the means."""
+  from multinerf_amd import geopoly
+  gen = torch.Generator().manual_seed(24)
+  B, n, maxdeg = 20, 16, 16
+  o = torch.rand((B, 3), generator=gen) * 2 - 1
+  d = torch.randn((B, 3), generator=gen)
+  d = d / d.norm(dim=-1, keepdim=True)
+  radii = torch.full((B, 1), 5e-4)
+  tdist = 2.0 + 4.0 * torch.sort(torch.rand((B, n + 1), generator=gen), -1).values
+  basis = torch.as_tensor(geopoly.generate_basis('octahedron', 1), dtype=torch.float32)
+  means, covs = orender.cast_rays(tdist.double(), o.double(), d.double(), radii.double(), 'cone', diag=False)
+  bT = basis.T.contiguous().double()
+
+  def feats(mu):
+    lm, lv = ocoord.lift_and_diagonalize(mu, covs, bT)
+    return ocoord.integrated_pos_enc(lm, lv, 0, maxdeg)
+
+  F = 2 * 3 * maxdeg
+  tang = ops.cast_rays_ipe_tangent(dev(tdist), dev(o), dev(d), dev(radii.reshape(-1)), dev(basis), ray_shape='cone',
+                                   min_deg=0, max_deg=maxdeg, ld_feat=128).cpu().float()
+  M = B * n
+  assert tang.shape == (3 * M, 128) and (tang[:, F:] == 0).all()
+  for c in range(3):
+    e = torch.zeros_like(means)
+    e[..., c] = 1
+    _, jvp = torch.func.jvp(feats, (means,), (e,))
+    ref = jvp.reshape(M, F)
+    got = tang[c * M:(c + 1) * M, :F].double()
+    scale = ref.abs().max(0, keepdim=True).values.clamp_min(1e-3)
+    # bf16 storage + the 4-degree sincos recurrence; columns compared relative to their own scale.
+    assert ((got - ref).abs() / scale).max().item() < 2e-2
