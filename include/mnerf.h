@@ -212,7 +212,9 @@ int mnr_cast_f32_to_bf16(const float* src, int ld_src, int64_t M, int n, uint16_
  * H bf16 [M, ldh] (K columns), g fp32 [M, C], W fp32 [K, C] (flax kernel). */
 int mnr_small_head_bwd(int64_t M, int K, int C, const uint16_t* H, int ldh, const float* g,
                        const float* W, uint16_t* dX, int lddx, int apply_relu_mask,
-                       float* dW, float* db, void* stream);
+                       float* dW, float* db,
+                       const uint8_t* mask_bits /* optional 1-bit mask [*, ld_bits], row m %% bits_row_mod */,
+                       int ld_bits, int64_t bits_row_mod, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Compositing  (replaces the density/rgb activations models.py:506,584-602,
@@ -292,8 +294,8 @@ int mnr_ref_head_fwd(int64_t M, int n, const float* small, const float* raw_grad
                      const mnr_ide_tables* tabs, float roughness_bias, uint16_t* vi, int ldvi, int col0,
                      int col_end, float* normals_out, float* normals_pred_out, float* roughness_out, void* stream);
 /* VJP: dvi_a (+ dvi_b, may be NULL) bf16 [M, lddvi] = gradient w.r.t. the view-MLP input; g_npred / g_n
- * [M,3] fp32 from mnr_ref_losses (may be NULL).  Writes bf16 columns col_gp..+2 and col_rough of dhb
- * [M, lddhb] and g_raw_grad [3,M] fp32. */
+ * [M,3] fp32 from mnr_ref_losses (may be NULL).  Writes bf16 columns [0,col0) (bottleneck = dvi_a + dvi_b),
+ * col_gp..+2 and col_rough of dhb [M, lddhb] and g_raw_grad [3,M] fp32. */
 int mnr_ref_head_bwd(int64_t M, int n, const float* small, const float* raw_grad, const float* viewdirs,
                      const mnr_ide_tables* tabs, float roughness_bias, const uint16_t* dvi_a,
                      const uint16_t* dvi_b, int lddvi, int col0, const float* g_npred, const float* g_n,
@@ -323,6 +325,13 @@ typedef enum { MNR_LOSS_MSE = 0, MNR_LOSS_CHARB = 1, MNR_LOSS_RAWNERF = 2 } mnr_
 
 /* out[0] += sum(lossmult broadcast to [B,3]) over the first B_valid rays. lossmult [B,lm_c], lm_c in {1,3}. */
 int mnr_lossmult_sum(int64_t B_valid, const float* lossmult, int lm_c, float* out, void* stream);
+
+/* compute_data_loss's gradient-free metrics (train_utils.py:113-128), either may be NULL:
+ * *out_disp = mean (1/(1+distance_mean) - disps)^2;  *out_normal = weighted mean angular error in degrees
+ * (ref_utils.compute_weighted_mae ref_utils.py:45-50) with weights acc * alphas. */
+int mnr_render_metrics(int64_t B_valid, const float* distance_mean, const float* disps, const float* acc,
+                       const float* alphas, const float* normals, const float* normals_gt, float* out_disp,
+                       float* out_normal, void* stream);
 
 /* One level of compute_data_loss.  rgb [B,3] rendered, gt [B,3], denom = device
  * scalar from mnr_lossmult_sum.  stats[0] += mse numerator/denom, stats[1] +=

@@ -18,7 +18,7 @@ MNR_ERR_INVALID_ARGUMENT = -1
 # enums of mnerf.h
 RAYDIST = {None: 0, 'identity': 0, 'reciprocal': 1, 'piecewise': 2, 'log': 3, 'exp': 4, 'sqrt': 5,
            'square': 6}
-ACT = {'sigmoid': 0, 'safe_exp': 1, 'softplus': 2, 'exp': 3, 'relu': 4}
+ACT = {'sigmoid': 0, 'safe_exp': 1, 'softplus': 2, 'exp': 3, 'relu': 4, 'identity': 5}
 DATA_LOSS = {'mse': 0, 'charb': 1, 'rawnerf': 2}
 
 c_f32p = C.POINTER(C.c_float)
@@ -103,7 +103,7 @@ _PROTOS = {
     'mnr_pack_weights_bf16': ([vp, vp, i32, i32, vp, vp], i32),
     'mnr_scatter_add_f32': ([vp, i32, i32, i32, i32, i32, vp, i32, vp], i32),
     'mnr_cast_f32_to_bf16': ([vp, i32, i64, i32, vp, i32, i32, vp], i32),
-    'mnr_small_head_bwd': ([i64, i32, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp], i32),
+    'mnr_small_head_bwd': ([i64, i32, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i64, vp], i32),
     'mnr_composite_fwd': ([C.POINTER(CompositeCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_composite_bwd': ([C.POINTER(CompositeCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32,
                            vp, vp, vp], i32),
@@ -117,6 +117,7 @@ _PROTOS = {
     'mnr_ref_losses': ([i64, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_weighted_sum': ([i64, i32, i32, vp, vp, vp, vp], i32),
     'mnr_lossmult_sum': ([i64, vp, i32, vp, vp], i32),
+    'mnr_render_metrics': ([i64, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_data_loss': ([i32, f32, f32, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp], i32),
     'mnr_interlevel_loss': ([f32, i64, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp], i32),
     'mnr_distortion_loss': ([f32, i64, i64, i32, vp, vp, vp, vp, vp], i32),

@@ -831,7 +831,8 @@ __global__ __launch_bounds__(256) void small_head_bwd_kernel(int64_t M, int K, i
                                                               int ldh, const float* __restrict__ g,
                                                               const float* __restrict__ W, bf16* __restrict__ dX,
                                                               int lddx, int relu_mask, float* dW, float* db,
-                                                              int rows_per_block) {
+                                                              int rows_per_block, const uint8_t* __restrict__ mbits,
+                                                              int ld_bits, int64_t bits_row_mod) {
   // Thread (rl, cg): column group cg of 8 consecutive k (16-byte accesses), row lane rl; the block's
   // rows are strided over the row lanes.  dW partials are reduced across row lanes through LDS.
   __shared__ float red[256 * 8];
@@ -859,6 +860,8 @@ __global__ __launch_bounds__(256) void small_head_bwd_kernel(int64_t M, int K, i
         if (c < C) gc[c] = g[r * C + c];
 #pragma unroll
       for (int c = 0; c < 4; ++c) sb[c] += gc[c];
+      unsigned mb = 0xffu;
+      if (mbits) mb = mbits[(bits_row_mod > 0 ? r % bits_row_mod : r) * ld_bits + cg];
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(256) void small_head_bwd_kernel(int64_t M, int K, i
           gx += gc[c] * w[e][c];
           aw[e][c] += hv * gc[c];
         }
-        o[e] = (bf16)((relu_mask && !(hv > 0.0f)) ? 0.0f : gx);
+        o[e] = (bf16)(((relu_mask && !(hv > 0.0f)) || !((mb >> e) & 1u)) ? 0.0f : gx);
       }
       if (dX) *(bf16x8*)(dX + r * lddx + cg * 8) = o;
     }
@@ -897,14 +900,16 @@ __global__ __launch_bounds__(256) void small_head_bwd_kernel(int64_t M, int K, i
 
 extern "C" int mnr_small_head_bwd(int64_t M, int K, int C, const uint16_t* H, int ldh, const float* g,
                                   const float* W, uint16_t* dX, int lddx, int apply_relu_mask, float* dW,
-                                  float* db, void* stream) {
+                                  float* db, const uint8_t* mask_bits, int ld_bits, int64_t bits_row_mod,
+                                  void* stream) {
   MNR_CHECK_ARG(M > 0 && K > 0 && C >= 1 && C <= 4 && H && g && W, "mnr_small_head_bwd: bad arguments (1 <= C <= 4)");
   MNR_CHECK_ARG(K % 8 == 0 && K / 8 <= 256 && ldh % 8 == 0 && (!dX || lddx % 8 == 0),
                 "mnr_small_head_bwd: K must be a multiple of 8 (<= 2048) and the pitches multiples of 8");
   const int rows_per_block = 512;
   const int grid = mnr_cdiv(M, rows_per_block);
   hipLaunchKernelGGL(small_head_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, C,
-                     (const bf16*)H, ldh, g, W, (bf16*)dX, lddx, apply_relu_mask, dW, db, rows_per_block);
+                     (const bf16*)H, ldh, g, W, (bf16*)dX, lddx, apply_relu_mask, dW, db, rows_per_block, mask_bits,
+                     ld_bits, bits_row_mod);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }

@@ -37,6 +37,79 @@ extern "C" int mnr_lossmult_sum(int64_t B_valid, const float* lossmult, int lm_c
   return MNR_OK;
 }
 
+// Training-time metrics of compute_data_loss (train_utils.py:113-128): no gradient, one block.
+//   out_disp   = mean_b (1 / (1 + distance_mean_b) - disps_b)^2
+//   out_normal = sum_b w_b acos(clip(n_b . ngt_b)) / sum_b w_b * 180/pi,  w = acc * alphas, n / ngt l2-normalised
+__global__ __launch_bounds__(1024) void render_metrics_kernel(int64_t B_valid, const float* __restrict__ distance_mean,
+                                                              const float* __restrict__ disps,
+                                                              const float* __restrict__ acc,
+                                                              const float* __restrict__ alphas,
+                                                              const float* __restrict__ normals,
+                                                              const float* __restrict__ normals_gt,
+                                                              float* out_disp, float* out_normal) {
+  __shared__ float red[3][16];
+  float sd = 0.0f, sn = 0.0f, sw = 0.0f;
+  for (int64_t b = threadIdx.x; b < B_valid; b += blockDim.x) {
+    if (out_disp) {
+      const float d = 1.0f / (1.0f + distance_mean[b]) - disps[b];
+      sd += d * d;
+    }
+    if (out_normal) {
+      const float w = acc[b] * alphas[b];
+      float n[3], g[3], nn = 0.0f, gg = 0.0f, dot = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        n[c] = normals[b * 3 + c];
+        g[c] = normals_gt[b * 3 + c];
+        nn += n[c] * n[c];
+        gg += g[c] * g[c];
+      }
+      const float rn = 1.0f / sqrtf(fmaxf(nn, MNR_F32_EPS)), rg = 1.0f / sqrtf(fmaxf(gg, MNR_F32_EPS));   // ref_utils.py:40-42
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dot += (n[c] * rn) * (g[c] * rg);
+      const float one_eps = 1.0f - MNR_F32_EPS;
+      sn += w * acosf(fminf(fmaxf(dot, -one_eps), one_eps));                                              // :45-50
+      sw += w;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sd += __shfl_down(sd, off, 64);
+    sn += __shfl_down(sn, off, 64);
+    sw += __shfl_down(sw, off, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][wave] = sd;
+    red[1][wave] = sn;
+    red[2][wave] = sw;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, b = 0.0f, c = 0.0f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+      a += red[0][i];
+      b += red[1][i];
+      c += red[2][i];
+    }
+    if (out_disp) *out_disp = a / (float)B_valid;
+    if (out_normal) *out_normal = b / c * (180.0f / 3.14159265358979323846f);
+  }
+}
+
+extern "C" int mnr_render_metrics(int64_t B_valid, const float* distance_mean, const float* disps, const float* acc,
+                                  const float* alphas, const float* normals, const float* normals_gt, float* out_disp,
+                                  float* out_normal, void* stream) {
+  MNR_CHECK_ARG(B_valid > 0 && (out_disp || out_normal), "mnr_render_metrics: nothing to compute");
+  MNR_CHECK_ARG(!out_disp || (distance_mean && disps), "mnr_render_metrics: disparity metric needs distance_mean and disps");
+  MNR_CHECK_ARG(!out_normal || (acc && alphas && normals && normals_gt),
+                "mnr_render_metrics: normal metric needs acc, alphas, normals and normals_gt");
+  hipLaunchKernelGGL(render_metrics_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B_valid, distance_mean, disps,
+                     acc, alphas, normals, normals_gt, out_disp, out_normal);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
 __global__ void data_loss_kernel(int loss_type, float charb_padding, float loss_mult, int64_t B, int64_t B_valid,
                                  const float* __restrict__ rgb, const float* __restrict__ gt,
                                  const float* __restrict__ lm, int lm_c, const float* __restrict__ denom_p,

@@ -87,15 +87,27 @@ class MLP:
     if self.use_reflections and not (self.enable_pred_normals or not self.disable_density_normals):
       raise ValueError('Normals must be computed for reflection directions.')
 
+  def is_ref(self):
+    """The complete Ref-NeRF head of configs/blender_refnerf.gin."""
+    return (self.enable_pred_normals and self.use_reflections and self.use_directional_enc and
+            self.enable_pred_roughness and self.use_diffuse_color and self.use_specular_tint and
+            self.use_n_dot_v and not self.disable_density_normals and not self.disable_rgb)
+
   def hip_supported(self):
     """Which reference features the HIP path implements in this round (scope)."""
     bad = []
+    ref_flags = ('enable_pred_normals', 'use_reflections', 'use_directional_enc', 'enable_pred_roughness',
+                 'use_diffuse_color', 'use_specular_tint', 'use_n_dot_v')
+    on = [f for f in ref_flags if getattr(self, f)]
     if not self.disable_density_normals:
-      bad.append('density-gradient normals (disable_density_normals=False)')
-    for f in ('enable_pred_normals', 'use_reflections', 'use_directional_enc', 'enable_pred_roughness',
-              'use_diffuse_color', 'use_specular_tint', 'use_n_dot_v'):
-      if getattr(self, f):
-        bad.append(f)
+      on.append('density normals')
+    if on and not self.is_ref():
+      # The Ref-NeRF branch is implemented as one unit (blender_refnerf.gin); partial mixes are not.
+      bad.append('partial Ref-NeRF feature set ' + str(on) + ' (all of them, or none)')
+    if self.is_ref() and self.warp_fn is not None:
+      bad.append('density-gradient normals with a warp_fn')
+    if self.is_ref() and self.roughness_activation != 'softplus':
+      bad.append('roughness_activation != softplus')
     if self.bottleneck_noise > 0:
       bad.append('bottleneck_noise')
     if self.net_activation != 'relu':
@@ -175,14 +187,29 @@ class MLPPlan:
     self.x_concat = concat                     # trunk output carries the features too (depth ending on a skip)
     self.x_width = self.W + (self.F if concat else 0)
     self.density = add(self.x_width, 1)        # models.py:460
+    self.ref = hp.is_ref()
     self.view: List[Tuple[DenseSpec, bool]] = []
     self.bottleneck = None
     self.rgb = None
+    self.gradpred = self.diffuse = self.tint = self.rough = None
+    if hp.enable_pred_normals:
+      self.gradpred = add(self.x_width, 3)                           # models.py:495
     if self.has_rgb:
       if self.use_viewdirs:
+        if hp.use_diffuse_color:
+          self.diffuse = add(self.x_width, hp.num_rgb_channels)      # models.py:515
+        if hp.use_specular_tint:
+          self.tint = add(self.x_width, 3)                           # models.py:518
+        if hp.enable_pred_roughness:
+          self.rough = add(self.x_width, 1)                          # models.py:521
         self.bottleneck = add(self.x_width, hp.bottleneck_width)     # models.py:527
-        self.dir_enc_dim = 3 + 2 * 3 * hp.deg_view                   # coord.pos_enc, append_identity
-        self.vi_width = hp.bottleneck_width + self.dir_enc_dim + num_glo_features
+        if hp.use_directional_enc:
+          from multinerf_amd import ref_utils
+          self.dir_enc_dim = 2 * len(ref_utils.ide_tables(hp.deg_view)[0])   # IDE: real + imaginary parts
+        else:
+          self.dir_enc_dim = 3 + 2 * 3 * hp.deg_view                 # coord.pos_enc, append_identity
+        self.vi_width = (hp.bottleneck_width + self.dir_enc_dim + (1 if hp.use_n_dot_v else 0) +
+                         num_glo_features)
         self.ldVI = _rup(self.vi_width, 128)
         WV = hp.net_width_viewdirs
         concat, first = False, True
@@ -198,6 +225,12 @@ class MLPPlan:
       else:
         rgb_in = self.x_width
       self.rgb = add(rgb_in, hp.num_rgb_channels)                    # models.py:585
+      # merged head: (Dense, first column) -- bottleneck first, then the scalar / 3-vector heads
+      bw = hp.bottleneck_width
+      self.head_segs = [(self.bottleneck, 0), (self.density, bw)]
+      if self.ref:
+        self.head_segs += [(self.gradpred, bw + 1), (self.diffuse, bw + 4), (self.tint, bw + 7), (self.rough, bw + 10)]
+      self.head_cols = bw + (11 if self.ref else 1)
     # flat parameter offsets: kernel then bias, Dense_k in creation order
     off = param_base
     for d in self.dense:
@@ -348,15 +381,16 @@ class Model:
     # heads
     if p.has_rgb and p.use_viewdirs:
       bw = p.hp.bottleneck_width
-      nh = _rup(bw + 1, 128)                                    # backward (dHB) width
-      nh_f = _rup(bw + 1, 256)                                  # forward rows: a multiple of the 256-wide GEMM tile
-      fo = alloc(nh_f, p.W)                                     # merged head fwd: rows [0,bw) bottleneck, row bw density
-      descs.append(L.PackDesc(p.bottleneck.kernel_off, p.W, bw, fo, p.W, 0, 0, 1))
-      descs.append(L.PackDesc(p.density.kernel_off, p.W, 1, fo, p.W, bw, 0, 1))
+      nh = _rup(p.head_cols, 128)                               # backward (dHB) width
+      nh_f = _rup(p.head_cols, 256)                             # forward rows: a multiple of the 256-wide GEMM tile
+      fo = alloc(nh_f, p.W)                                     # merged head fwd: row c0.. of each Dense
       bo = alloc(_rup(p.W, 128), nh)                            # merged head bwd: [W][nh]
-      descs.append(L.PackDesc(p.bottleneck.kernel_off, p.W, bw, bo, nh, 0, 0, 0))
-      descs.append(L.PackDesc(p.density.kernel_off, p.W, 1, bo, nh, 0, bw, 0))
+      for (d, c0) in p.head_segs:
+        descs.append(L.PackDesc(d.kernel_off, p.W, d.fan_out, fo, p.W, c0, 0, 1))
+        descs.append(L.PackDesc(d.kernel_off, p.W, d.fan_out, bo, nh, 0, c0, 0))
       p.packed['head'] = dict(f_off=fo, f_ld=p.W, n_pad=nh_f, nb_pad=nh, b_off=bo, b_ld=nh)
+      if p.ref:
+        pack_layer('density', p.density, [(0, p.W, 0, p.W)], 128)   # tangent rows only need the density column
       WV = p.hp.net_width_viewdirs
       for i, (d, concat) in enumerate(p.view):
         if i == 0:
@@ -366,10 +400,17 @@ class Model:
         else:
           segs = [(0, WV, 0, WV)]
         e = pack_layer(('view', i), d, segs, _rup(d.fan_out, 128))
-        rows = bw if i == 0 else WV                             # dX target: bottleneck cols / previous hidden
+        # dX target: the bottleneck columns (all view-input columns for Ref-NeRF, whose IDE / n.v
+        # columns carry gradient) for layer 0, the previous hidden layer otherwise.
+        rows = (p.vi_width if p.ref else bw) if i == 0 else WV
         bo = alloc(_rup(rows, 128), _rup(d.fan_out, 64))
         descs.append(L.PackDesc(d.kernel_off, rows, d.fan_out, bo, _rup(d.fan_out, 64), 0, 0, 0))
-        e.update(b_off=bo, b_ld=_rup(d.fan_out, 64))
+        e.update(b_off=bo, b_ld=_rup(d.fan_out, 64), b_rows=_rup(rows, 128))
+        if concat and p.ref:
+          # second backward image: the skip-concat rows [WV, WV+vi_width) -> gradient w.r.t. the view input
+          b2 = alloc(p.ldVI, _rup(d.fan_out, 64))
+          descs.append(L.PackDesc(d.kernel_off + WV * d.fan_out, p.vi_width, d.fan_out, b2, _rup(d.fan_out, 64), 0, 0, 0))
+          e.update(b2_off=b2)
       assert not getattr(p, 'v_concat', False), 'view MLP ending on a skip layer is not supported on the HIP path'
       pack_layer('rgb', p.rgb, [(0, p.rgb.fan_in, 0, _rup(p.rgb.fan_in, 64))], 128)
     elif p.has_rgb:
@@ -383,16 +424,17 @@ class Model:
     p.pack_max_elems = max(d.rows_in * d.cols_out for d in descs)
     p.wbf = torch.zeros(off, dtype=bf16, device=self.device)     # padding stays zero forever
     if p.has_rgb and p.use_viewdirs:
-      p.head_bias = torch.zeros(_rup(p.hp.bottleneck_width + 1, 128), dtype=f32, device=self.device)
+      p.head_bias = torch.zeros(_rup(p.head_cols, 128), dtype=f32, device=self.device)
+    if p.ref:
+      p.ide = ops.IdeTablesDev(p.hp.deg_view, self.device) if self.device.type == 'cuda' else None
 
   def pack_weights(self, flat_params):
     """fp32 master parameters -> bf16 GEMM operands (one launch per MLP)."""
     for p in self._plans:
       ops.pack_weights(flat_params, p.pack_descs_dev, len(p.pack_descs), p.pack_max_elems, p.wbf)
       if p.has_rgb and p.use_viewdirs:
-        bw = p.hp.bottleneck_width
-        p.head_bias[:bw].copy_(flat_params[p.bottleneck.bias_off:p.bottleneck.bias_off + bw])
-        p.head_bias[bw:bw + 1].copy_(flat_params[p.density.bias_off:p.density.bias_off + 1])
+        for (d, c0) in p.head_segs:
+          p.head_bias[c0:c0 + d.fan_out].copy_(flat_params[d.bias_off:d.bias_off + d.fan_out])
 
   # Parameters ------------------------------------------------------------------------
 
@@ -563,7 +605,7 @@ class Model:
                         warp_contract=(hp.warp_fn == 'contract'), min_deg=hp.min_deg_point,
                         max_deg=hp.max_deg_point, ld_feat=plan.ldF, disable_integration=self.disable_integration,
                         out=feat)
-      mlp_out = self._mlp_forward(plan, flat, feat, M, n, R, tag, keep_for_backward)
+      mlp_out = self._mlp_forward(plan, flat, feat, M, n, R, tag, keep_for_backward, tdist=tdist)
 
       # --- density noise (models.py:462-464), background colour (:241-254)
       dnoise = None
@@ -592,9 +634,10 @@ class Model:
         bg = (lo + (hi - lo) * u).contiguous()
       ccfg = ops.composite_cfg(n, opaque_background=self.opaque_background, density_act=hp.density_activation,
                                density_bias=hp.density_bias, density_noise_std=hp.density_noise if dnoise is not None else 0.0,
-                               has_rgb=plan.has_rgb, rgb_act=hp.rgb_activation,
-                               rgb_premultiplier=hp.rgb_premultiplier, rgb_bias=hp.rgb_bias,
-                               rgb_padding=hp.rgb_padding, bg_mode=bg_mode, bg_value=bg_value)
+                               has_rgb=plan.has_rgb, rgb_act='identity' if plan.ref else hp.rgb_activation,
+                               rgb_premultiplier=1.0 if plan.ref else hp.rgb_premultiplier,
+                               rgb_bias=0.0 if plan.ref else hp.rgb_bias,
+                               rgb_padding=0.0 if plan.ref else hp.rgb_padding, bg_mode=bg_mode, bg_value=bg_value)
       raw_density = mlp_out['raw_density'].view(Bp, n)
       raw_rgb = mlp_out['raw_rgb'].view(Bp, n, 3) if plan.has_rgb else None
       density, rgb, weights, rgb_out, acc = ops.composite_fwd(
@@ -613,11 +656,20 @@ class Model:
         rendering['ray_weights'] = weights[:B0][:nvis]
         rendering['ray_rgbs'] = (rgb[:B0][:nvis] if rgb is not None
                                  else torch.zeros((min(nvis, B0), n, 3), dtype=f32, device=dev))
+        if plan.ref:
+          # render.py:187-190: extras composited with the same weights
+          rendering['normals'] = ops.weighted_sum(weights, mlp_out['normals'])[:B0].reshape(lead + (3,))
+          rendering['normals_pred'] = ops.weighted_sum(weights, mlp_out['npred'])[:B0].reshape(lead + (3,))
+          rendering['roughness'] = ops.weighted_sum(weights, mlp_out['rough'])[:B0].reshape(lead + (1,))
       renderings.append(rendering)
       rgb_hist = rgb[:B0] if rgb is not None else torch.zeros((B0, n, 3), dtype=f32, device=dev)
       ray_history.append(dict(
           density=density[:B0].reshape(lead + (n,)), rgb=rgb_hist.reshape(lead + (n, 3)),
-          raw_grad_density=None, grad_pred=None, normals=None, normals_pred=None, roughness=None,
+          raw_grad_density=(mlp_out['raw_grad'].t().reshape(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.ref else None),
+          grad_pred=(mlp_out['small'][:, 1:4].reshape(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.ref else None),
+          normals=(mlp_out['normals'].view(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.ref else None),
+          normals_pred=(mlp_out['npred'].view(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.ref else None),
+          roughness=(mlp_out['rough'].view(Bp, n, 1)[:B0].reshape(lead + (n, 1)) if plan.ref else None),
           sdist=sdist[:B0].reshape(lead + (n + 1,)), weights=weights[:B0].reshape(lead + (n,)),
           tdist=tdist[:B0].reshape(lead + (n + 1,))))
       if keep_for_backward:
@@ -632,7 +684,7 @@ class Model:
         r['ray_rgbs'] = final_rgb[:, None, :].expand(r['ray_rgbs'].shape)
 
     if keep_for_backward:
-      self._saved = dict(levels=saved, rays=R, B0=B0, Bp=Bp)
+      self._saved = dict(levels=saved, rays=R, B0=B0, Bp=Bp, renderings=renderings)
     return renderings, ray_history
 
   # ------------------------------------------------------------------ MLP forward / backward
@@ -641,15 +693,17 @@ class Model:
     """A [rows, ld] view into the packed bf16 operand buffer."""
     return plan.wbf[off:off + rows * ld].view(rows, ld)
 
-  def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep):
+  def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep, tdist=None):
+    """MLP.__call__ (models.py:402-612) for the M = B*n samples of one level."""
     hp = plan.hp
+    need_bits = (keep and _USE_BITS) or plan.ref
     acts, bits = [], []
     x = None
     for i, (d, concat) in enumerate(plan.trunk):
       e = plan.packed[('trunk', i)]
       out = self._buf((tag, 'act', i if keep else i % 2), (M, plan.W), bf16)
-      # 1-bit ReLU mask for the backward pass (training only)
-      bo = self._buf((tag, 'bits', i), (M, plan.W // 8), torch.uint8) if (keep and _USE_BITS) else None
+      # 1-bit ReLU mask: backward pass (training) and the tangent pass of the density-gradient normals
+      bo = self._buf((tag, 'bits', i if (keep or plan.ref) else i % 2), (M, plan.W // 8), torch.uint8) if need_bits else None
       bits.append(bo)
       Bt = self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])
       bias = flat[d.bias_off:d.bias_off + d.fan_out]
@@ -671,11 +725,47 @@ class Model:
       e = plan.packed['head']
       VI = self._buf((tag, 'VI'), (M, plan.ldVI), bf16)
       Bt = self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])
-      ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=bw + 1, relu=False,
-                  Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=raw_density, ldcf=1, f0=bw, nf=1)
-      ops.viewdir_enc_fill(R.viewdirs, n, hp.deg_view, VI, bw, plan.ldVI)
+      if plan.ref:
+        small = self._buf((tag, 'small'), (M, 11), f32)
+        ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=plan.head_cols, relu=False,
+                    Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=small, ldcf=11, f0=bw, nf=11)
+        raw_density.copy_(small[:, 0])
+        # density-gradient normals by forward mode: tangent features -> tangent trunk (primal ReLU bits)
+        T_feat = self._buf((tag, 'T_feat'), (3 * M, plan.ldF), bf16)
+        ops.cast_rays_ipe_tangent(tdist, R.origins, R.directions, R.radii.reshape(-1).contiguous(), plan.basis_dev,
+                                  ray_shape=self.ray_shape, min_deg=hp.min_deg_point, max_deg=hp.max_deg_point,
+                                  ld_feat=plan.ldF, out=T_feat)
+        T_acts = []
+        t = None
+        for i, (d, concat) in enumerate(plan.trunk):
+          e2 = plan.packed[('trunk', i)]
+          tout = self._buf((tag, 'T_act', i if keep else i % 2), (3 * M, plan.W), bf16)
+          Bt2 = self._w(plan, e2['f_off'], e2['n_pad'], e2['f_ld'])
+          if i == 0:
+            ops.gemm_nt(T_feat, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.ldF, bits_in=bits[i], bits_row_mod=M,
+                        Cb=tout, ldcb=plan.W, nb=plan.W)
+          elif concat:
+            ops.gemm_nt(t, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.W, A2=T_feat, K2=plan.ldF, bits_in=bits[i],
+                        bits_row_mod=M, Cb=tout, ldcb=plan.W, nb=plan.W)
+          else:
+            ops.gemm_nt(t, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.W, bits_in=bits[i], bits_row_mod=M,
+                        Cb=tout, ldcb=plan.W, nb=plan.W)
+          T_acts.append(tout)
+          t = tout
+        raw_grad = self._buf((tag, 'raw_grad'), (3, M), f32)
+        ed = plan.packed['density']
+        ops.gemm_nt(t, self._w(plan, ed['f_off'], ed['n_pad'], ed['f_ld']), M=3 * M, N=ed['n_pad'], K1=plan.W,
+                    Cf=raw_grad, ldcf=1, f0=0, nf=1)
+        normals, npred, rough = ops.ref_head_fwd(small, raw_grad, R.viewdirs, n, plan.ide, hp.roughness_bias, VI,
+                                                 bw, plan.ldVI)
+        res.update(small=small, T_feat=T_feat, T_acts=T_acts, raw_grad=raw_grad, normals=normals, npred=npred,
+                   rough=rough)
+      else:
+        ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=bw + 1, relu=False,
+                    Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=raw_density, ldcf=1, f0=bw, nf=1)
+        ops.viewdir_enc_fill(R.viewdirs, n, hp.deg_view, VI, bw, plan.ldVI)
       h = VI
-      vacts = []
+      vacts, vbits = [], []
       WV = hp.net_width_viewdirs
       for i, (d, concat) in enumerate(plan.view):
         e = plan.packed[('view', i)]
@@ -699,6 +789,11 @@ class Model:
       ops.gemm_nt(h, self._w(plan, e['f_off'], e['n_pad'], e['f_ld']), M=M, N=e['n_pad'], K1=e['kpad'],
                   bias=flat[d.bias_off:d.bias_off + 3], n_bias=3, relu=False, Cf=raw_rgb, ldcf=3, f0=0, nf=3)
       res.update(VI=VI, vacts=vacts, raw_rgb=raw_rgb)
+      if plan.ref:
+        # models.py:584-602: tinted specular + diffuse, tone-mapped; compositing then sees final colours
+        res['raw_rgb_pre'] = raw_rgb
+        res['raw_rgb'] = ops.ref_color_fwd(raw_rgb, res['small'], hp.rgb_premultiplier, hp.rgb_bias, hp.rgb_padding,
+                                           True)
     else:
       e = plan.packed['density']
       d = plan.density
@@ -707,9 +802,10 @@ class Model:
     res['raw_density'] = raw_density
     return res
 
-  def backward_level(self, lv, flat, grads, g_rgb_out, g_weights, g_expo=None):
+  def backward_level(self, lv, flat, grads, g_rgb_out, g_weights, g_expo=None, g_normals=None, g_npred=None):
     """VJP of one level w.r.t. the parameters: compositing -> heads -> trunk.
-    grads: flat fp32 gradient vector (accumulated into)."""
+    grads: flat fp32 gradient vector (accumulated into).  g_normals / g_npred [M,3]: from the Ref-NeRF
+    normal losses (train_utils.py:162-197)."""
     plan: MLPPlan = lv['plan']
     hp = plan.hp
     M, n, tag = lv['M'], lv['n'], lv['tag']
@@ -724,17 +820,28 @@ class Model:
     def gslice(off, size):
       return grads[off:off + size]
 
+    def mask_kw(i):
+      """ReLU VJP of trunk layer i's output: 1-bit mask if available, else the saved activation."""
+      if mlp['bits'][i] is not None:
+        return dict(bits_in=mlp['bits'][i])
+      return dict(mask=acts[i], ldmask=W)
+
+    g_raw_grad = None
     if plan.has_rgb:
       bw = hp.bottleneck_width
       e = plan.packed['head']
       nh = e['nb_pad']
-      dHB = self._buf(('bwd', 'dHB', nh), (M, nh), bf16, zero=True)   # cols > bw stay zero
-      _, g_raw_rgb = ops.composite_bwd(
+      dHB = self._buf(('bwd', 'dHB', nh), (M, nh), bf16, zero=True)   # columns beyond head_cols stay zero
+      _, g_rgb = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], raw_rgb=lv['raw_rgb'],
           density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights,
           g_den_bf16=dHB.view(-1)[bw:], ld_bf16=nh, want_f32=False, exposure_scale=lv['expo'],
           g_exposure_scale=g_expo if lv['expo'] is not None else None)
-      g_raw_rgb = g_raw_rgb.view(M, 3)
+      g_raw_rgb = g_rgb.view(M, 3)
+      if plan.ref:
+        # colour combine VJP: -> d raw specular rgb, and the diffuse / tint columns of the head gradient
+        g_raw_rgb = ops.ref_color_bwd(mlp['raw_rgb_pre'], mlp['small'], hp.rgb_premultiplier, hp.rgb_bias,
+                                      hp.rgb_padding, True, g_raw_rgb.contiguous(), dHB, bw + 4, bw + 7)
       # rgb Dense(3): dH, dW, db
       WV = hp.net_width_viewdirs
       vacts = mlp['vacts']
@@ -747,6 +854,7 @@ class Model:
                          dW=gslice(d.kernel_off, d.fan_in * 3), db=gslice(d.bias_off, 3))
       dy, other = dV0, dV1
       VI = mlp['VI']
+      dVIa = dVIb = None
       for i in reversed(range(len(plan.view))):
         d, concat = plan.view[i]
         e = plan.packed[('view', i)]
@@ -761,26 +869,39 @@ class Model:
           ops.gemm_tn(VI, dy, gslice(d.kernel_off + WV * d.fan_out, plan.vi_width * d.fan_out), M=M,
                       K=plan.ldVI, N=WV, lda=plan.ldVI, ldb=WV, ldc=d.fan_out, k_valid=plan.vi_width,
                       n_valid=d.fan_out)
-        Bw = self._w(plan, e['b_off'], _rup(bw if i == 0 else WV, 128), e['b_ld'])
+          if plan.ref:
+            # the view input also receives gradient through the skip concat (its IDE / n.v columns matter)
+            dVIb = self._buf(('bwd', 'dVIb'), (M, plan.ldVI), bf16)
+            B2 = self._w(plan, e['b2_off'], plan.ldVI, e['b_ld'])
+            ops.gemm_nt(dy, B2, M=M, N=plan.ldVI, K1=e['b_ld'], Cb=dVIb, ldcb=plan.ldVI, nb=plan.ldVI)
+        Bw = self._w(plan, e['b_off'], e['b_rows'], e['b_ld'])
         if i == 0:
-          ops.gemm_nt(dy, Bw, M=M, N=_rup(bw, 128), K1=e['b_ld'], Cb=dHB, ldcb=nh, nb=bw)
+          if plan.ref:
+            dVIa = self._buf(('bwd', 'dVIa'), (M, plan.ldVI), bf16)
+            ops.gemm_nt(dy, Bw, M=M, N=e['b_rows'], K1=e['b_ld'], Cb=dVIa, ldcb=plan.ldVI, nb=plan.ldVI)
+          else:
+            ops.gemm_nt(dy, Bw, M=M, N=e['b_rows'], K1=e['b_ld'], Cb=dHB, ldcb=nh, nb=bw)
         else:
           ops.gemm_nt(dy, Bw, M=M, N=WV, K1=e['b_ld'], mask=vacts[i - 1], ldmask=WV, Cb=other, ldcb=WV, nb=WV)
           dy, other = other, dy
-      # merged head (bottleneck + density): dW, db, dX_last
+      if plan.ref:
+        # IDE / reflection / normalisation VJP: fills the bottleneck (dVIa + dVIb), grad_pred and roughness
+        # columns of dHB and returns the gradient w.r.t. d raw_density / d mean for the tangent network.
+        g_raw_grad = ops.ref_head_bwd(mlp['small'], mlp['raw_grad'], R.viewdirs, n, plan.ide, hp.roughness_bias,
+                                      dVIa, dVIb, bw, g_npred, g_normals, dHB, bw + 1, bw + 10)
+      # merged head: dW, db, dX_last
       e = plan.packed['head']
       tmpW = self._buf(('bwd', 'tmpW', W, nh), (W, nh), f32)
       tmpW.zero_()
       tmpb = self._buf(('bwd', 'tmpb', nh), (nh,), f32)
       tmpb.zero_()
-      ops.gemm_tn(x_last, dHB, tmpW, M=M, K=W, N=nh, lda=W, ldb=nh, ldc=nh, bias_out=tmpb, bias_n_valid=bw + 1)
-      ops.scatter_add(tmpW, nh, 0, 0, W, bw, gslice(plan.bottleneck.kernel_off, W * bw), bw)
-      ops.scatter_add(tmpW, nh, 0, bw, W, 1, gslice(plan.density.kernel_off, W), 1)
-      ops.scatter_add(tmpb, nh, 0, 0, 1, bw, gslice(plan.bottleneck.bias_off, bw), bw)
-      ops.scatter_add(tmpb, nh, 0, bw, 1, 1, gslice(plan.density.bias_off, 1), 1)
+      ops.gemm_tn(x_last, dHB, tmpW, M=M, K=W, N=nh, lda=W, ldb=nh, ldc=nh, bias_out=tmpb,
+                  bias_n_valid=plan.head_cols)
+      for (d, c0) in plan.head_segs:
+        ops.scatter_add(tmpW, nh, 0, c0, W, d.fan_out, gslice(d.kernel_off, W * d.fan_out), d.fan_out)
+        ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
       Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
-      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=nh, bits_in=mlp['bits'][-1],
-                  mask=None if _USE_BITS else x_last, ldmask=W, Cb=dA, ldcb=W, nb=W)
+      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=nh, Cb=dA, ldcb=W, nb=W, **mask_kw(len(acts) - 1))
     else:
       g_raw_density, _ = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], density_noise=lv['dnoise'],
@@ -789,9 +910,11 @@ class Model:
       ops.small_head_bwd(x_last, W, g_raw_density.view(M, 1), flat[d.kernel_off:d.kernel_off + W].view(W, 1),
                          M=M, K=W, Cn=1, dX=dA, lddx=W, relu_mask=True,
                          dW=gslice(d.kernel_off, W), db=gslice(d.bias_off, 1))
+    feat = lv['feat']
+    if g_raw_grad is not None:
+      self._tangent_backward(plan, flat, grads, mlp, feat, M, g_raw_grad)
     # trunk
     dy, other = dA, dB
-    feat = lv['feat']
     for i in reversed(range(len(plan.trunk))):
       d, concat = plan.trunk[i]
       e = plan.packed[('trunk', i)]
@@ -806,9 +929,43 @@ class Model:
                       lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
       if i > 0:
         Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
-        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], bits_in=mlp['bits'][i - 1],
-                    mask=None if _USE_BITS else acts[i - 1], ldmask=W, Cb=other, ldcb=W, nb=W)
+        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, **mask_kw(i - 1))
         dy, other = other, dy
+
+  def _tangent_backward(self, plan, flat, grads, mlp, feat, M, g_raw_grad):
+    """Backward pass through the tangent network T_l = bits_l * (T_{l-1} W_l), raw_grad = T_last w_density
+    (the "double backward" of the density-gradient normals): the network is linear in each W_l with
+    fixed masks, so dW_l += T_{l-1}^T G_l and G_{l-1} = bits_{l-1} * (G_l W_l^T) on 3*M rows."""
+    W = plan.W
+    M3 = 3 * M
+    T_acts, T_feat, bits = mlp['T_acts'], mlp['T_feat'], mlp['bits']
+
+    def gslice(off, size):
+      return grads[off:off + size]
+
+    gA = self._buf(('bwd', 'gTA', W), (M3, W), bf16)
+    gB = self._buf(('bwd', 'gTB', W), (M3, W), bf16)
+    d = plan.density
+    # G_last = bits_last * (g_raw_grad[:, None] w_density^T);  dW_density += T_last^T g_raw_grad
+    ops.small_head_bwd(T_acts[-1], W, g_raw_grad.view(M3, 1), flat[d.kernel_off:d.kernel_off + W].view(W, 1),
+                       M=M3, K=W, Cn=1, dX=gA, lddx=W, relu_mask=False, dW=gslice(d.kernel_off, W), db=None,
+                       bits=bits[-1], bits_row_mod=M)
+    gy, other = gA, gB
+    for i in reversed(range(len(plan.trunk))):
+      d, concat = plan.trunk[i]
+      e = plan.packed[('trunk', i)]
+      if i == 0:
+        ops.gemm_tn(T_feat, gy, gslice(d.kernel_off, plan.F * W), M=M3, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
+                    ldc=W, k_valid=plan.F, n_valid=W)
+      else:
+        ops.gemm_tn(T_acts[i - 1], gy, gslice(d.kernel_off, W * W), M=M3, K=W, N=W, lda=W, ldb=W, ldc=W)
+        if concat:
+          ops.gemm_tn(T_feat, gy, gslice(d.kernel_off + W * W, plan.F * W), M=M3, K=plan.ldF, N=W,
+                      lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
+        Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
+        ops.gemm_nt(gy, Bw, M=M3, N=_rup(W, 128), K1=e['b_ld'], bits_in=bits[i - 1], bits_row_mod=M,
+                    Cb=other, ldcb=W, nb=W)
+        gy, other = other, gy
 
 
 # =============================================================================

@@ -282,12 +282,15 @@ def cast_f32_to_bf16(src, ld_src, M, n, dst, ld_dst, col0):
   L.check(lib().mnr_cast_f32_to_bf16(_ptr(src), ld_src, M, n, _ptr(dst), ld_dst, col0, _stream()))
 
 
-def small_head_bwd(H, ldh, g, W, *, M, K, Cn, dX=None, lddx=0, relu_mask=True, dW=None, db=None):
+def small_head_bwd(H, ldh, g, W, *, M, K, Cn, dX=None, lddx=0, relu_mask=True, dW=None, db=None, bits=None,
+                   bits_row_mod=0):
+  _chk(bits, torch.uint8, 'bits', allow_none=True)
   _chk(H, bf16, 'H')
   _chk(g, f32, 'g')
   _chk(W, f32, 'W')
   L.check(lib().mnr_small_head_bwd(M, K, Cn, _ptr(H), ldh, _ptr(g), _ptr(W), _ptr(dX), lddx, int(relu_mask),
-                                   _ptr(dW), _ptr(db), _stream()))
+                                   _ptr(dW), _ptr(db), _ptr(bits), bits.stride(0) if bits is not None else 0,
+                                   bits_row_mod, _stream()))
 
 
 # ----------------------------------------------------------------------------- compositing
@@ -463,6 +466,15 @@ def lossmult_sum(lossmult, B_valid, out):
   _chk(lossmult, f32, 'lossmult')
   _chk(out, f32, 'out')
   L.check(lib().mnr_lossmult_sum(B_valid, _ptr(lossmult), lossmult.shape[-1], _ptr(out), _stream()))
+
+
+def render_metrics(B_valid, *, distance_mean=None, disps=None, acc=None, alphas=None, normals=None, normals_gt=None,
+                   out_disp=None, out_normal=None):
+  for x, nm in ((distance_mean, 'distance_mean'), (disps, 'disps'), (acc, 'acc'), (alphas, 'alphas'),
+                (normals, 'normals'), (normals_gt, 'normals_gt'), (out_disp, 'out_disp'), (out_normal, 'out_normal')):
+    _chk(x, f32, nm, allow_none=True)
+  L.check(lib().mnr_render_metrics(B_valid, _ptr(distance_mean), _ptr(disps), _ptr(acc), _ptr(alphas), _ptr(normals),
+                                   _ptr(normals_gt), _ptr(out_disp), _ptr(out_normal), _stream()))
 
 
 def data_loss(loss_type, charb_padding, loss_mult, rgb, gt, lossmult, denom, stats, *, B_valid, want_grad=True):

@@ -68,9 +68,10 @@ def create_train_step(model: models.Model, config, dataset=None):
     raise NotImplementedError(f'data_loss_type {config.data_loss_type!r} is out of scope')
   if config.weight_decay_mults:
     raise NotImplementedError('weight_decay_mults is not yet on the HIP path')
-  if (config.orientation_loss_mult > 0 or config.orientation_coarse_loss_mult > 0 or
-      config.predicted_normal_loss_mult > 0 or config.predicted_normal_coarse_loss_mult > 0):
-    raise NotImplementedError('Ref-NeRF normal losses are not yet on the HIP path')
+  use_orient = config.orientation_loss_mult > 0 or config.orientation_coarse_loss_mult > 0
+  use_prednorm = config.predicted_normal_loss_mult > 0 or config.predicted_normal_coarse_loss_mult > 0
+  if config.orientation_loss_target not in ('normals', 'normals_pred'):
+    raise ValueError(f'orientation_loss_target {config.orientation_loss_target!r} is not a ray_history field')
   lr_fn = lambda step: learning_rate_decay(step, config.lr_init, config.lr_final, config.max_steps,
                                            config.lr_delay_steps, config.lr_delay_mult)
 
@@ -89,8 +90,9 @@ def create_train_step(model: models.Model, config, dataset=None):
     R = saved['rays']
 
     nlev = len(levels)
-    # stats layout: [mse_l, data_l]*nlev | interlevel | distortion | denom
-    stats = model._buf(('train', 'stats'), (2 * nlev + 3,), f32)
+    # stats layout: [mse_l, data_l]*nlev | interlevel | distortion | denom | orientation | predicted_normals
+    #               | disparity_mse_l * nlev | normal_mae_l * nlev
+    stats = model._buf(('train', 'stats'), (4 * nlev + 5,), f32)
     stats.zero_()
     denom = stats[2 * nlev + 2:2 * nlev + 3]
     lossmult = R.lossmult
@@ -110,6 +112,24 @@ def create_train_step(model: models.Model, config, dataset=None):
       g = ops.data_loss(config.data_loss_type, config.charb_padding, mult, lv['rgb_out'], gt, lossmult, denom,
                         stats[2 * li:2 * li + 2], B_valid=B0, want_grad=mult > 0)
       g_rgb[li] = g if mult > 0 else None
+      rd = saved['renderings'][li]
+      k0 = 2 * nlev + 5
+      if config.compute_disp_metrics:                                  # train_utils.py:113-115
+        if batch.disps is None:
+          raise ValueError('compute_disp_metrics needs batch.disps')
+        ops.render_metrics(B0, distance_mean=rd['distance_mean'].reshape(-1).contiguous(),
+                           disps=batch.disps.reshape(-1).contiguous().float(), out_disp=stats[k0 + li:k0 + li + 1])
+      if config.compute_normal_metrics:                                # train_utils.py:117-128
+        if 'normals' in rd:
+          if batch.alphas is None or batch.normals is None:
+            raise ValueError('compute_normal_metrics needs batch.alphas and batch.normals')
+          ops.render_metrics(B0, acc=rd['acc'].reshape(-1).contiguous(),
+                             alphas=batch.alphas.reshape(-1).contiguous().float(),
+                             normals=rd['normals'].reshape(-1, 3).contiguous(),
+                             normals_gt=batch.normals.reshape(-1, 3).contiguous().float(),
+                             out_normal=stats[k0 + nlev + li:k0 + nlev + li + 1])
+        else:
+          stats[k0 + nlev + li] = float('nan')
     last = levels[-1]
     if config.interlevel_loss_mult > 0:                                # train_utils.py:139-150
       for li, lv in enumerate(levels[:-1]):
@@ -123,6 +143,22 @@ def create_train_step(model: models.Model, config, dataset=None):
       ops.distortion_loss(config.distortion_loss_mult, last['sdist'], last['weights'],
                           stats[2 * nlev + 1:2 * nlev + 2], g_w[-1], B_valid=B0)
 
+    g_nrm, g_npr = [None] * nlev, [None] * nlev
+    if use_orient or use_prednorm:                                     # train_utils.py:162-197
+      for li, lv in enumerate(levels):
+        if lv['mlp'].get('normals') is None:
+          raise ValueError('Normals cannot be None if orientation loss is on.' if use_orient else
+                           'Predicted normals and gradient normals cannot be None if predicted normal loss is on.')
+        fine = li == nlev - 1
+        mo = config.orientation_loss_mult if fine else config.orientation_coarse_loss_mult
+        mp = config.predicted_normal_loss_mult if fine else config.predicted_normal_coarse_loss_mult
+        if g_w[li] is None:
+          g_w[li] = model._buf(('train', 'g_w', li), (Bp, lv['n']), f32)
+          g_w[li].zero_()
+        g_nrm[li], g_npr[li] = ops.ref_losses(mo, mp, config.orientation_loss_target == 'normals_pred',
+                                              lv['weights'], lv['mlp']['normals'], lv['mlp']['npred'], R.viewdirs,
+                                              stats[2 * nlev + 3:2 * nlev + 5], g_w[li], True, B_valid=B0)
+
     g_expo = None
     if model.expo_off is not None and R.exposure_idx is not None:
       g_expo = model._buf(('train', 'g_expo'), (Bp, 3), f32)
@@ -130,7 +166,7 @@ def create_train_step(model: models.Model, config, dataset=None):
     for li, lv in enumerate(levels):
       if g_rgb[li] is None and g_w[li] is None:
         continue                                                       # this level receives no gradient
-      model.backward_level(lv, flat, grads, g_rgb[li], g_w[li], g_expo)
+      model.backward_level(lv, flat, grads, g_rgb[li], g_w[li], g_expo, g_nrm[li], g_npr[li])
     if g_expo is not None:
       n_off = model.num_glo_embeddings * 3
       ops.exposure_scale_bwd(R.exposure_values.reshape(-1).contiguous().float(),
@@ -154,7 +190,8 @@ def create_train_step(model: models.Model, config, dataset=None):
                     grad_max_val=config.grad_max_val, grad_max_norm=config.grad_max_norm)
     new_state = TrainState(step=step_count + 1, params=state.params, mu=state.mu, nu=state.nu)
 
-    out_stats = {'_raw': stats, '_nlev': nlev, 'grad_sqnorms': sq}
+    out_stats = {'_raw': stats, '_nlev': nlev, 'grad_sqnorms': sq, '_disp': config.compute_disp_metrics,
+                 '_normal': config.compute_normal_metrics}
     if return_grads:
       out_stats['_grads'] = raw_grads
     return new_state, TrainStats(out_stats), rng
@@ -175,6 +212,13 @@ class TrainStats(dict):
         'psnrs': -10. / math.log(10.) * np.log(mses),
         'losses': {'data': float(data.sum()), 'interlevel': float(raw[2 * n]), 'distortion': float(raw[2 * n + 1])},
     }
+    if raw[2 * n + 3] != 0 or raw[2 * n + 4] != 0:
+      out['losses']['orientation'] = float(raw[2 * n + 3])
+      out['losses']['predicted_normals'] = float(raw[2 * n + 4])
+    if self.get('_disp'):
+      out['disparity_mses'] = raw[2 * n + 5:3 * n + 5]
+    if self.get('_normal'):
+      out['normal_maes'] = raw[3 * n + 5:4 * n + 5]
     out['loss'] = sum(out['losses'].values())
     out['psnr'] = float(out['psnrs'][-1])
     out['grad_norms'] = np.sqrt(self['grad_sqnorms'].detach().cpu().numpy())

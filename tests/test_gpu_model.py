@@ -47,6 +47,9 @@ def _setup(name, extra, B, seed=3):
     batch.rays.lossmult = (torch.rand((B, 3), generator=g) > 0.4).float()
     batch.rgb = batch.rgb * 0.3
     params['exposure_scaling_offsets']['embedding'] = 0.1 * torch.randn((1000, 3), generator=g)
+  if cfg.compute_normal_metrics:
+    batch.alphas = torch.rand((B,), generator=g)
+    batch.normals = torch.randn((B, 3), generator=g)
   flat = model.flat_from_tree(params)
   return cfg, model, (om, on, op), params, flat, batch
 
@@ -55,6 +58,9 @@ CASES = [
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128'], 40),
     ('blender_256', [], 24),
     ('llff_raw', [], 16),          # RawNeRF: cylinder rays, single MLP, safe_exp rgb, exposure scaling, Bayer lossmult
+    # Ref-NeRF: single MLP at both levels, density-gradient + predicted normals, IDE of the reflected direction,
+    # diffuse / tint / roughness heads, orientation + predicted-normal losses
+    ('blender_refnerf', [], 12),
 ]
 
 
@@ -124,6 +130,11 @@ def test_train_step_parity(name, extra, B):
   print(f'{name}: loss kernel {s["loss"]:.6f} oracle_bf16 {float(stats_o["loss"]):.6f} oracle_fp32 {float(stats_32["loss"]):.6f}')
   assert abs(s['loss'] - float(stats_o['loss'])) <= 0.02 * abs(float(stats_o['loss'])) + 1e-5
   np.testing.assert_allclose(s['mses'], stats_o['mses'].detach().numpy(), rtol=0.03, atol=1e-5)
+  if cfg.compute_normal_metrics:
+    print(f'{name}: normal_maes kernel {s["normal_maes"]} oracle {stats_o["normal_maes"].detach().numpy()}')
+    np.testing.assert_allclose(s['normal_maes'], stats_o['normal_maes'].detach().numpy(), rtol=0.02)
+    for k in ('orientation', 'predicted_normals'):
+      assert abs(s['losses'][k] - float(stats_o['losses'][k])) <= 0.03 * abs(float(stats_o['losses'][k])) + 1e-7, k
   for mod, b, e in model.modules:
     a, r, r32 = g[b:e].double(), g_ref[b:e].double(), g_32[b:e].double()
     cos = (a @ r / (a.norm() * r.norm() + 1e-30)).item()
@@ -162,8 +173,13 @@ def test_train_step_parity(name, extra, B):
 
 
 def test_unsupported_features_fail_loudly():
-  cfg = configs.load_preset('blender_refnerf')
+  # a partial Ref-NeRF mix (reflections without the rest) has no HIP path: it must raise, not fall back
+  cfg = configs.load_preset('blender_256', ['NerfMLP.enable_pred_normals = True', 'NerfMLP.use_reflections = True',
+                                            'NerfMLP.disable_density_normals = False'])
   with pytest.raises(NotImplementedError, match='HIP path'):
+    models.Model(config=cfg).build('cuda')
+  cfg = configs.load_preset('360', ['Model.num_glo_features = 4'])
+  with pytest.raises(NotImplementedError, match='GLO'):
     models.Model(config=cfg).build('cuda')
 
 
