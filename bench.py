@@ -58,8 +58,19 @@ def algorithmic_flops_per_ray(model):
         if li == 0:
           no_dx += (plan.vi_width - plan.hp.bottleneck_width) * d.fan_out
       macs += plan.rgb.fan_in * plan.rgb.fan_out
-    fwd += 2.0 * n * macs
-    train += 2.0 * n * (3 * macs - no_dx)
+    extra_fwd = extra_train = 0
+    if plan.ref:
+      # Ref-NeRF: small heads, the view MLP's skip input needs dX, and the forward-mode tangent network for
+      # the density-gradient normals (3 tangent rows per sample through the trunk; its backward = dW + dX).
+      for d in (plan.gradpred, plan.diffuse, plan.tint, plan.rough):
+        macs += d.fan_in * d.fan_out
+      no_dx -= (plan.vi_width - plan.hp.bottleneck_width) * plan.view[0][0].fan_out   # IDE / n.v columns do need dX
+      tmacs = sum(d.fan_in * d.fan_out for d, _ in plan.trunk) + plan.density.fan_in
+      t_no_dx = plan.trunk[0][0].fan_in * plan.trunk[0][0].fan_out + sum(plan.F * d.fan_out for d, c in plan.trunk if c)
+      extra_fwd = 3 * tmacs
+      extra_train = 3 * (3 * tmacs - t_no_dx)
+    fwd += 2.0 * n * (macs + extra_fwd)
+    train += 2.0 * n * (3 * macs - no_dx + extra_train)
   return fwd, train
 
 
@@ -92,6 +103,15 @@ def main():
   B = args.batch_size
   batch = helpers.synthetic_rays(B, seed=20200823 + rank, near=cfg.near, far=cfg.far).map(lambda t: t.to(dev))
   gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+  if cfg.compute_normal_metrics:      # blender ground-truth normals / alphas (synthetic)
+    batch.alphas = torch.rand((B,), generator=gen, device=dev)
+    batch.normals = torch.randn((B, 3), generator=gen, device=dev)
+  if cfg.compute_disp_metrics:
+    batch.disps = torch.rand((B,), generator=gen, device=dev)
+  if cfg.rawnerf_mode:                # RawNeRF: per-ray exposure index / value, Bayer-mask lossmult
+    batch.rays.exposure_idx = torch.randint(0, 5, (B, 1), generator=gen, device=dev).to(torch.int32)
+    batch.rays.exposure_values = 0.5 + torch.rand((B, 1), generator=gen, device=dev)
+    batch.rays.lossmult = (torch.rand((B, 3), generator=gen, device=dev) > 0.4).float()
   train_frac = 0.5
 
   def step():

@@ -134,6 +134,14 @@ int mnr_cast_rays_ipe_tangent(const mnr_ipe_cfg* cfg, int64_t B, int n, const fl
 int mnr_viewdir_enc_fill(int64_t B, int n, const float* viewdirs, int deg_view,
                          uint16_t* dst, int ld, int col0, int col_end, void* stream);
 
+/* GLO vectors (models.py:101-110,565-568): dst[b*n+i, col0+g] = table[cam_idx[b], g] (bf16), or 0 when
+ * cam_idx is NULL (zero_glo=True).  table [num_embeddings, G] fp32 = params['Embed_0']['embedding']. */
+int mnr_glo_fill(int64_t B, int n, int G, const float* table, const int32_t* cam_idx, int num_embeddings,
+                 uint16_t* dst, int ld, int col0, void* stream);
+/* VJP: grad_table[cam_idx[b], g] += sum_i (g_a[b*n+i, g] + g_b[b*n+i, g]); g_a / g_b fp32 [B*n, G] (g_b may be NULL). */
+int mnr_glo_bwd(int64_t B, int n, int G, const float* g_a, const float* g_b, const int32_t* cam_idx,
+                int num_embeddings, float* grad_table, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Dense layers  (replaces flax.linen.Dense at models.py:436-437,456,460,495,
  * 515,518,521,527,577,585: y = x @ kernel[in,out] + bias, and their VJPs)
@@ -300,6 +308,9 @@ int mnr_ref_head_bwd(int64_t M, int n, const float* small, const float* raw_grad
                      const mnr_ide_tables* tabs, float roughness_bias, const uint16_t* dvi_a,
                      const uint16_t* dvi_b, int lddvi, int col0, const float* g_npred, const float* g_n,
                      uint16_t* dhb, int lddhb, int col_gp, int col_rough, float* g_raw_grad, void* stream);
+/* dst[:, :cols] = a[:, :cols] + b[:, :cols] (bf16, b may be NULL; dst may alias a): gradient joins of skip concats. */
+int mnr_add_cols_bf16(int64_t M, int cols, const uint16_t* a, int lda, const uint16_t* b, int ldb, uint16_t* dst,
+                      int lddst, void* stream);
 /* rgb = clip(linear_to_srgb(tint * sigmoid(premult raw_rgb + bias) + sigmoid(raw_diffuse - log 3)), 0, 1)
  * * (1 + 2 pad) - pad; VJP writes g_raw_rgb [M,3] fp32 and the diffuse / tint columns of dhb (bf16). */
 int mnr_ref_color_fwd(int64_t M, const float* raw_rgb, const float* small, float rgb_premultiplier, float rgb_bias,

@@ -95,6 +95,8 @@ _PROTOS = {
     'mnr_cast_rays_ipe_f32': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_cast_rays_ipe_tangent': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, i32, vp], i32),
     'mnr_viewdir_enc_fill': ([i64, i32, vp, i32, vp, i32, i32, i32, vp], i32),
+    'mnr_glo_fill': ([i64, i32, i32, vp, vp, i32, vp, i32, i32, vp], i32),
+    'mnr_glo_bwd': ([i64, i32, i32, vp, vp, vp, i32, vp, vp], i32),
     'mnr_gemm_nt_bf16': ([C.POINTER(GemmNTArgs), vp], i32),
     'mnr_gemm_nt_set_config': ([i32, i32], i32),
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
@@ -112,6 +114,7 @@ _PROTOS = {
     'mnr_render_extras': ([i64, i32, vp, vp, vp, vp, vp], i32),
     'mnr_ref_head_fwd': ([i64, i32, vp, vp, vp, C.POINTER(IdeTables), f32, vp, i32, i32, i32, vp, vp, vp, vp], i32),
     'mnr_ref_head_bwd': ([i64, i32, vp, vp, vp, C.POINTER(IdeTables), f32, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp], i32),
+    'mnr_add_cols_bf16': ([i64, i32, vp, i32, vp, i32, vp, i32, vp], i32),
     'mnr_ref_color_fwd': ([i64, vp, vp, f32, f32, f32, i32, vp, vp], i32),
     'mnr_ref_color_bwd': ([i64, vp, vp, f32, f32, f32, i32, vp, vp, vp, i32, i32, i32, vp], i32),
     'mnr_ref_losses': ([i64, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),

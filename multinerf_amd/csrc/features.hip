@@ -345,3 +345,59 @@ extern "C" int mnr_viewdir_enc_fill(int64_t B, int n, const float* viewdirs, int
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// GLO vectors (models.py:101-110 nn.Embed lookup by cam_idx; :565-568 broadcast + concat into the view input).
+
+__global__ void glo_fill_kernel(int64_t total, int n, int G, const float* __restrict__ table,
+                                const int32_t* __restrict__ cam_idx, int num_embeddings, bf16* __restrict__ dst,
+                                int ld, int col0) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int64_t row = e / G;
+  const int g = (int)(e % G);
+  float v = 0.0f;                                             // zero_glo (models.py:109-110)
+  if (cam_idx) {
+    int idx = cam_idx[row / n];
+    idx = idx < 0 ? 0 : (idx >= num_embeddings ? num_embeddings - 1 : idx);   // jnp gather clamps
+    v = table[(int64_t)idx * G + g];
+  }
+  dst[row * ld + col0 + g] = (bf16)v;
+}
+
+extern "C" int mnr_glo_fill(int64_t B, int n, int G, const float* table, const int32_t* cam_idx, int num_embeddings,
+                            uint16_t* dst, int ld, int col0, void* stream) {
+  MNR_CHECK_ARG(B > 0 && n > 0 && G > 0 && dst && (cam_idx == nullptr || table), "mnr_glo_fill: bad arguments");
+  MNR_CHECK_ARG(col0 >= 0 && col0 + G <= ld && num_embeddings > 0, "mnr_glo_fill: columns out of range");
+  const int64_t total = B * n * G;
+  hipLaunchKernelGGL(glo_fill_kernel, dim3(mnr_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, total, n, G, table,
+                     cam_idx, num_embeddings, (bf16*)dst, ld, col0);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// VJP: grad_table[cam_idx[b], g] += sum_i (g_a[b*n+i, g] + g_b[b*n+i, g]).
+__global__ void glo_bwd_kernel(int64_t B, int n, int G, const float* __restrict__ g_a, const float* __restrict__ g_b,
+                               const int32_t* __restrict__ cam_idx, int num_embeddings, float* grad_table) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * G) return;
+  const int64_t b = e / G;
+  const int g = (int)(e % G);
+  float acc = 0.0f;
+  for (int i = 0; i < n; ++i) {
+    acc += g_a[(b * n + i) * G + g];
+    if (g_b) acc += g_b[(b * n + i) * G + g];
+  }
+  int idx = cam_idx[b];
+  idx = idx < 0 ? 0 : (idx >= num_embeddings ? num_embeddings - 1 : idx);
+  unsafeAtomicAdd(grad_table + (int64_t)idx * G + g, acc);
+}
+
+extern "C" int mnr_glo_bwd(int64_t B, int n, int G, const float* g_a, const float* g_b, const int32_t* cam_idx,
+                           int num_embeddings, float* grad_table, void* stream) {
+  MNR_CHECK_ARG(B > 0 && n > 0 && G > 0 && g_a && cam_idx && grad_table && num_embeddings > 0, "mnr_glo_bwd: bad arguments");
+  hipLaunchKernelGGL(glo_bwd_kernel, dim3(mnr_cdiv(B * G, 256)), dim3(256), 0, (hipStream_t)stream, B, n, G, g_a, g_b,
+                     cam_idx, num_embeddings, grad_table);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}

@@ -229,19 +229,31 @@ __global__ __launch_bounds__(RF_THREADS) void ref_head_bwd_kernel(
 
 // dhb[:, :cols] = dvi_a[:, :cols] (+ dvi_b[:, :cols]): the bottleneck part of the view-input gradient.
 __global__ void ref_bottleneck_grad_kernel(int64_t M, int cols8, const bf16* __restrict__ dvi_a,
-                                           const bf16* __restrict__ dvi_b, int lddvi, bf16* __restrict__ dhb,
-                                           int lddhb) {
+                                           const bf16* __restrict__ dvi_b, int lddvi, int lddvi_b,
+                                           bf16* __restrict__ dhb, int lddhb) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= M * cols8) return;
   const int64_t r = t / cols8;
   const int c = (int)(t % cols8) * 8;
   bf16x8 a = *reinterpret_cast<const bf16x8*>(dvi_a + r * lddvi + c);
   if (dvi_b) {
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(dvi_b + r * lddvi + c);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(dvi_b + r * lddvi_b + c);
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] = (bf16)((float)a[e] + (float)b[e]);
   }
   *reinterpret_cast<bf16x8*>(dhb + r * lddhb + c) = a;
+}
+
+extern "C" int mnr_add_cols_bf16(int64_t M, int cols, const uint16_t* a, int lda, const uint16_t* b, int ldb,
+                                 uint16_t* dst, int lddst, void* stream) {
+  MNR_CHECK_ARG(M > 0 && cols > 0 && a && dst, "mnr_add_cols_bf16: null argument");
+  MNR_CHECK_ARG(cols % 8 == 0 && lda % 8 == 0 && lddst % 8 == 0 && (!b || ldb % 8 == 0),
+                "mnr_add_cols_bf16: widths / strides must be multiples of 8");
+  const int cols8 = cols / 8;
+  hipLaunchKernelGGL(ref_bottleneck_grad_kernel, dim3(mnr_cdiv(M * cols8, 256)), dim3(256), 0, (hipStream_t)stream, M,
+                     cols8, (const bf16*)a, (const bf16*)b, lda, ldb, (bf16*)dst, lddst);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
 }
 
 extern "C" int mnr_ref_head_bwd(int64_t M, int n, const float* small, const float* raw_grad, const float* viewdirs,
@@ -259,7 +271,7 @@ extern "C" int mnr_ref_head_bwd(int64_t M, int n, const float* small, const floa
     MNR_CHECK_ARG(col0 % 8 == 0 && lddvi % 8 == 0 && lddhb % 8 == 0, "mnr_ref_head_bwd: bottleneck width / strides must be multiples of 8");
     const int cols8 = col0 / 8;
     hipLaunchKernelGGL(ref_bottleneck_grad_kernel, dim3(mnr_cdiv(M * cols8, 256)), dim3(256), 0, (hipStream_t)stream,
-                       M, cols8, (const bf16*)dvi_a, (const bf16*)dvi_b, lddvi, (bf16*)dhb, lddhb);
+                       M, cols8, (const bf16*)dvi_a, (const bf16*)dvi_b, lddvi, lddvi, (bf16*)dhb, lddhb);
     MNR_CHECK_LAUNCH();
   }
   return MNR_OK;

@@ -192,6 +192,7 @@ class MLPPlan:
     self.bottleneck = None
     self.rgb = None
     self.gradpred = self.diffuse = self.tint = self.rough = None
+    self.glo = 0
     if hp.enable_pred_normals:
       self.gradpred = add(self.x_width, 3)                           # models.py:495
     if self.has_rgb:
@@ -208,8 +209,9 @@ class MLPPlan:
           self.dir_enc_dim = 2 * len(ref_utils.ide_tables(hp.deg_view)[0])   # IDE: real + imaginary parts
         else:
           self.dir_enc_dim = 3 + 2 * 3 * hp.deg_view                 # coord.pos_enc, append_identity
-        self.vi_width = (hp.bottleneck_width + self.dir_enc_dim + (1 if hp.use_n_dot_v else 0) +
-                         num_glo_features)
+        self.glo = num_glo_features
+        self.glo_col = hp.bottleneck_width + self.dir_enc_dim + (1 if hp.use_n_dot_v else 0)   # models.py:565-568
+        self.vi_width = self.glo_col + num_glo_features
         self.ldVI = _rup(self.vi_width, 128)
         WV = hp.net_width_viewdirs
         concat, first = False, True
@@ -290,10 +292,11 @@ class Model:
       bad += [f'{name}: {b}' for b in hp.hip_supported()]
     if not self.stop_level_grad:
       bad.append('stop_level_grad=False')
-    if self.num_glo_features > 0:
-      bad.append('GLO vectors (num_glo_features > 0)')
     if self.ray_shape not in ('cone', 'cylinder'):
       raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')
+    if self.num_glo_features > 0 and self.single_mlp:
+      # the reference feeds glo_vec to the last level only (models.py:228): one shared MLP cannot take both widths
+      raise ValueError('num_glo_features > 0 is incompatible with single_mlp')
     if self.raydist_fn not in L.RAYDIST:
       bad.append(f'raydist_fn={self.raydist_fn}')
     if self.num_prop_samples % 32 or self.num_nerf_samples % 32:
@@ -316,6 +319,12 @@ class Model:
     self.modules = [(self.nerf_plan.module_name, self.nerf_plan.param_begin, self.nerf_plan.param_end)]
     if not self.single_mlp:
       self.modules.append((self.prop_plan.module_name, self.prop_plan.param_begin, self.prop_plan.param_end))
+    self.glo_off = None
+    if self.num_glo_features > 0:
+      # nn.Embed(num_glo_embeddings, num_glo_features) auto-named Embed_0 (models.py:101-106)
+      self.glo_off = end
+      end += self.num_glo_embeddings * self.num_glo_features
+      self.modules.append(('Embed_0', self.glo_off, end))
     self.expo_off = None
     if self.learned_exposure_scaling:
       # nn.Embed(num_glo_embeddings, 3, zeros init, name='exposure_scaling_offsets') (models.py:112-121)
@@ -402,11 +411,12 @@ class Model:
         e = pack_layer(('view', i), d, segs, _rup(d.fan_out, 128))
         # dX target: the bottleneck columns (all view-input columns for Ref-NeRF, whose IDE / n.v
         # columns carry gradient) for layer 0, the previous hidden layer otherwise.
-        rows = (p.vi_width if p.ref else bw) if i == 0 else WV
+        full = p.ref or p.glo > 0               # gradient also needed w.r.t. the non-bottleneck view-input columns
+        rows = (p.vi_width if full else bw) if i == 0 else WV
         bo = alloc(_rup(rows, 128), _rup(d.fan_out, 64))
         descs.append(L.PackDesc(d.kernel_off, rows, d.fan_out, bo, _rup(d.fan_out, 64), 0, 0, 0))
         e.update(b_off=bo, b_ld=_rup(d.fan_out, 64), b_rows=_rup(rows, 128))
-        if concat and p.ref:
+        if concat:
           # second backward image: the skip-concat rows [WV, WV+vi_width) -> gradient w.r.t. the view input
           b2 = alloc(p.ldVI, _rup(d.fan_out, 64))
           descs.append(L.PackDesc(d.kernel_off + WV * d.fan_out, p.vi_width, d.fan_out, b2, _rup(d.fan_out, 64), 0, 0, 0))
@@ -454,6 +464,11 @@ class Model:
           raise NotImplementedError(f'weight_init {kind}')
         w = (torch.rand((d.fan_in, d.fan_out), generator=gen, dtype=torch.float64) * 2 - 1) * lim
         flat[d.kernel_off:d.kernel_off + d.fan_in * d.fan_out] = w.reshape(-1).float()
+    if self.glo_off is not None:
+      # flax nn.Embed default init: variance_scaling(1.0, 'fan_in', 'normal', out_axis=0) -> std 1/sqrt(features)
+      G = self.num_glo_features
+      e = torch.randn((self.num_glo_embeddings, G), generator=gen, dtype=torch.float64) / math.sqrt(G)
+      flat[self.glo_off:self.glo_off + e.numel()] = e.reshape(-1).float()
     return flat.to(self.device)
 
   def params_tree(self, flat):
@@ -467,6 +482,9 @@ class Model:
             'bias': flat[d.bias_off:d.bias_off + d.fan_out],
         }
       tree[p.module_name] = m
+    if self.glo_off is not None:
+      n = self.num_glo_embeddings * self.num_glo_features
+      tree['Embed_0'] = {'embedding': flat[self.glo_off:self.glo_off + n].view(-1, self.num_glo_features)}
     if self.expo_off is not None:
       n = self.num_glo_embeddings * 3
       tree['exposure_scaling_offsets'] = {'embedding': flat[self.expo_off:self.expo_off + n].view(-1, 3)}
@@ -479,6 +497,9 @@ class Model:
       for d in p.dense:
         flat[d.kernel_off:d.kernel_off + d.fan_in * d.fan_out] = tree[p.module_name][d.name]['kernel'].detach().reshape(-1).float().cpu()
         flat[d.bias_off:d.bias_off + d.fan_out] = tree[p.module_name][d.name]['bias'].detach().float().cpu()
+    if self.glo_off is not None:
+      n = self.num_glo_embeddings * self.num_glo_features
+      flat[self.glo_off:self.glo_off + n] = tree['Embed_0']['embedding'].detach().reshape(-1).float().cpu()
     if self.expo_off is not None:
       n = self.num_glo_embeddings * 3
       flat[self.expo_off:self.expo_off + n] = tree['exposure_scaling_offsets']['embedding'].detach().reshape(-1).float().cpu()
@@ -549,6 +570,10 @@ class Model:
     near = R.near.reshape(-1).contiguous()
     far = R.far.reshape(-1).contiguous()
     radii = R.radii.reshape(-1).contiguous()
+    # GLO (models.py:101-110): the NeRF level looks Embed_0 up by cam_idx; zero_glo feeds zeros instead.
+    self._glo_cam = None
+    if self.num_glo_features > 0 and not zero_glo:
+      self._glo_cam = R.cam_idx.reshape(-1).to(torch.int32).contiguous()
 
     init_s_near = 0. if self.near_anneal_rate is None else float(
         np.clip(1 - train_frac / self.near_anneal_rate, 0, self.near_anneal_init))
@@ -764,6 +789,8 @@ class Model:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=bw + 1, relu=False,
                     Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=raw_density, ldcf=1, f0=bw, nf=1)
         ops.viewdir_enc_fill(R.viewdirs, n, hp.deg_view, VI, bw, plan.ldVI)
+      if plan.glo > 0:
+        ops.glo_fill(self._glo_table(flat), self._glo_cam, M // n, n, VI, plan.glo_col)
       h = VI
       vacts, vbits = [], []
       WV = hp.net_width_viewdirs
@@ -801,6 +828,10 @@ class Model:
                   bias=flat[d.bias_off:d.bias_off + 1], n_bias=1, relu=False, Cf=raw_density, ldcf=1, f0=0, nf=1)
     res['raw_density'] = raw_density
     return res
+
+  def _glo_table(self, flat):
+    G = self.num_glo_features
+    return flat[self.glo_off:self.glo_off + self.num_glo_embeddings * G].view(self.num_glo_embeddings, G)
 
   def backward_level(self, lv, flat, grads, g_rgb_out, g_weights, g_expo=None, g_normals=None, g_npred=None):
     """VJP of one level w.r.t. the parameters: compositing -> heads -> trunk.
@@ -855,6 +886,10 @@ class Model:
       dy, other = dV0, dV1
       VI = mlp['VI']
       dVIa = dVIb = None
+      want_glo = plan.glo > 0 and self._glo_cam is not None
+      gGa = self._buf(('bwd', 'gGa'), (M, plan.glo), f32) if want_glo else None
+      gGb = None
+      glo_kw = lambda t: dict(Cf=t, ldcf=plan.glo, f0=plan.glo_col, nf=plan.glo) if want_glo else {}
       for i in reversed(range(len(plan.view))):
         d, concat = plan.view[i]
         e = plan.packed[('view', i)]
@@ -869,21 +904,35 @@ class Model:
           ops.gemm_tn(VI, dy, gslice(d.kernel_off + WV * d.fan_out, plan.vi_width * d.fan_out), M=M,
                       K=plan.ldVI, N=WV, lda=plan.ldVI, ldb=WV, ldc=d.fan_out, k_valid=plan.vi_width,
                       n_valid=d.fan_out)
-          if plan.ref:
-            # the view input also receives gradient through the skip concat (its IDE / n.v columns matter)
-            dVIb = self._buf(('bwd', 'dVIb'), (M, plan.ldVI), bf16)
-            B2 = self._w(plan, e['b2_off'], plan.ldVI, e['b_ld'])
-            ops.gemm_nt(dy, B2, M=M, N=plan.ldVI, K1=e['b_ld'], Cb=dVIb, ldcb=plan.ldVI, nb=plan.ldVI)
+          # the view input also receives gradient through the skip concat (bottleneck, IDE / n.v / GLO columns)
+          first_skip = dVIb is None
+          tVI = self._buf(('bwd', 'dVIb', 0 if first_skip else 1), (M, plan.ldVI), bf16)
+          tG = self._buf(('bwd', 'gGb', 0 if first_skip else 1), (M, plan.glo), f32) if want_glo else None
+          B2 = self._w(plan, e['b2_off'], plan.ldVI, e['b_ld'])
+          ops.gemm_nt(dy, B2, M=M, N=plan.ldVI, K1=e['b_ld'], Cb=tVI, ldcb=plan.ldVI, nb=plan.ldVI, **glo_kw(tG))
+          if first_skip:
+            dVIb, gGb = tVI, tG
+          else:                                    # more than one skip layer: sum the contributions
+            ops.add_cols_bf16(dVIb, tVI, dVIb, plan.ldVI)
+            if want_glo:
+              gGb.add_(tG)
         Bw = self._w(plan, e['b_off'], e['b_rows'], e['b_ld'])
         if i == 0:
           if plan.ref:
             dVIa = self._buf(('bwd', 'dVIa'), (M, plan.ldVI), bf16)
-            ops.gemm_nt(dy, Bw, M=M, N=e['b_rows'], K1=e['b_ld'], Cb=dVIa, ldcb=plan.ldVI, nb=plan.ldVI)
+            ops.gemm_nt(dy, Bw, M=M, N=e['b_rows'], K1=e['b_ld'], Cb=dVIa, ldcb=plan.ldVI, nb=plan.ldVI, **glo_kw(gGa))
           else:
-            ops.gemm_nt(dy, Bw, M=M, N=e['b_rows'], K1=e['b_ld'], Cb=dHB, ldcb=nh, nb=bw)
+            ops.gemm_nt(dy, Bw, M=M, N=e['b_rows'], K1=e['b_ld'], Cb=dHB, ldcb=nh, nb=bw, **glo_kw(gGa))
         else:
           ops.gemm_nt(dy, Bw, M=M, N=WV, K1=e['b_ld'], mask=vacts[i - 1], ldmask=WV, Cb=other, ldcb=WV, nb=WV)
           dy, other = other, dy
+      if want_glo:
+        G = plan.glo
+        ops.glo_bwd(gGa, gGb, self._glo_cam, M // n, n, grads[self.glo_off:self.glo_off + self.num_glo_embeddings * G],
+                    self.num_glo_embeddings, G)
+      if dVIb is not None and not plan.ref:
+        # bottleneck gradient through the skip concat (a view MLP deeper than skip_layer_dir)
+        ops.add_cols_bf16(dHB, dVIb, dHB, bw)
       if plan.ref:
         # IDE / reflection / normalisation VJP: fills the bottleneck (dVIa + dVIb), grad_pred and roughness
         # columns of dHB and returns the gradient w.r.t. d raw_density / d mean for the tangent network.

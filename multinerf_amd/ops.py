@@ -207,6 +207,23 @@ def viewdir_enc_fill(viewdirs, n, deg_view, dst, col0, col_end):
 # ----------------------------------------------------------------------------- dense
 
 
+def glo_fill(table, cam_idx, B, n, dst, col0):
+  """cam_idx None == zero_glo."""
+  _chk(table, f32, 'table')
+  _chk(cam_idx, torch.int32, 'cam_idx', allow_none=True)
+  _chk(dst, bf16, 'dst')
+  E, G = table.shape
+  L.check(lib().mnr_glo_fill(B, n, G, _ptr(table), _ptr(cam_idx), E, _ptr(dst), dst.stride(0), col0, _stream()))
+
+
+def glo_bwd(g_a, g_b, cam_idx, B, n, grad_table, num_embeddings, G):
+  _chk(g_a, f32, 'g_a')
+  _chk(g_b, f32, 'g_b', allow_none=True)
+  _chk(cam_idx, torch.int32, 'cam_idx')
+  _chk(grad_table, f32, 'grad_table')
+  L.check(lib().mnr_glo_bwd(B, n, G, _ptr(g_a), _ptr(g_b), _ptr(cam_idx), num_embeddings, _ptr(grad_table), _stream()))
+
+
 def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, bias=None, n_bias=0,
             relu=False, mask=None, ldmask=0, Cb=None, ldcb=0, nb=0, Cf=None, ldcf=0, f0=0, nf=0,
             bits_out=None, bits_in=None, bits_row_mod=0):
@@ -414,6 +431,16 @@ def ref_head_bwd(small, raw_grad, viewdirs, n, tabs, roughness_bias, dvi_a, dvi_
                                  _ptr(g_npred), _ptr(g_n), _ptr(dhb), dhb.stride(0), col_gp, col_rough,
                                  _ptr(g_raw_grad), _stream()))
   return g_raw_grad
+
+
+def add_cols_bf16(a, b, dst, cols):
+  """dst[:, :cols] = a[:, :cols] + b[:, :cols] (row strides taken from the tensors)."""
+  for x, nm in ((a, 'a'), (dst, 'dst')):
+    if x.dtype != bf16 or not x.is_cuda:
+      raise ValueError(f'{nm} must be a bf16 device tensor')
+  M = a.shape[0]
+  L.check(lib().mnr_add_cols_bf16(M, cols, _ptr(a), a.stride(0), _ptr(b), b.stride(0) if b is not None else 0,
+                                  _ptr(dst), dst.stride(0), _stream()))
 
 
 def ref_color_fwd(raw_rgb, small, premult, rgb_bias, pad, use_tint):

@@ -35,7 +35,7 @@ def _setup(name, extra, B, seed=3):
   # non-zero biases so that bias paths are exercised
   g = torch.Generator().manual_seed(seed + 1)
   for mname, mod in params.items():
-    if mname == 'exposure_scaling_offsets':
+    if mname in ('exposure_scaling_offsets', 'Embed_0'):
       continue
     for d in mod.values():
       d['bias'] = 0.05 * torch.randn(d['bias'].shape, generator=g)
@@ -61,6 +61,10 @@ CASES = [
     # Ref-NeRF: single MLP at both levels, density-gradient + predicted normals, IDE of the reflected direction,
     # diffuse / tint / roughness heads, orientation + predicted-normal losses
     ('blender_refnerf', [], 12),
+    # 360_glo4.gin: per-camera GLO vectors appended to the view-MLP input (Embed_0 gets gradient)
+    ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_glo_features = 4'], 24),
+    # a view MLP deep enough to hit its own skip connection (models.py:579): bottleneck gradient joins two paths
+    ('blender_256', ['NerfMLP.net_depth_viewdirs = 6', 'NerfMLP.skip_layer_dir = 2'], 16),
 ]
 
 
@@ -178,8 +182,8 @@ def test_unsupported_features_fail_loudly():
                                             'NerfMLP.disable_density_normals = False'])
   with pytest.raises(NotImplementedError, match='HIP path'):
     models.Model(config=cfg).build('cuda')
-  cfg = configs.load_preset('360', ['Model.num_glo_features = 4'])
-  with pytest.raises(NotImplementedError, match='GLO'):
+  cfg = configs.load_preset('360', ['NerfMLP.net_activation = "softplus"'])
+  with pytest.raises(NotImplementedError, match='net_activation'):
     models.Model(config=cfg).build('cuda')
 
 

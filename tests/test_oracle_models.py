@@ -27,21 +27,29 @@ def test_param_counts_match_published(name):
   params = omodels.init_params(om, on, op)
   assert omodels.param_count(params) == PUBLISHED[name]
   assert list(params)[0] == 'NerfMLP_0'                       # construction order, models.py:98-99
-  if name in ('360', 'blender_256'):
+  if True:
     m.build('cpu')
     assert m.num_params == PUBLISHED[name]                    # product layout agrees
     tree = m.params_tree(torch.zeros(m.num_params))
     for mod in params:
       assert list(tree[mod]) == list(params[mod])
       for dn in params[mod]:
-        assert tree[mod][dn]['kernel'].shape == params[mod][dn]['kernel'].shape
+        if dn == 'embedding':
+          assert tree[mod][dn].shape == params[mod][dn].shape
+        else:
+          assert tree[mod][dn]['kernel'].shape == params[mod][dn]['kernel'].shape
 
 
 def test_360_glo4_param_count():
   cfg = configs.load_preset('360', ['Model.num_glo_features = 4'])
   m = models.Model(config=cfg)
   om, on, op = helpers.oracle_hparams(m)
-  assert omodels.param_count(omodels.init_params(om, on, op)) == 9012005   # ipynb:155/164
+  params = omodels.init_params(om, on, op)
+  assert omodels.param_count(params) == 9012005   # ipynb:155/164
+  m.build('cpu')
+  assert m.num_params == 9012005
+  tree = m.params_tree(torch.zeros(m.num_params))
+  assert tree['Embed_0']['embedding'].shape == params['Embed_0']['embedding'].shape == (1000, 4)
 
 
 def _tiny(name, extra=()):
