@@ -371,6 +371,12 @@ int mnr_lossfun_distortion(int64_t B, int n, const float* t, const float* w, flo
  * Optimiser  (replaces train_utils.clip_gradients train_utils.py:200-218,
  * jnp.nan_to_num :328 and optax.adam state.apply_gradients :330,372)
  * ------------------------------------------------------------------------- */
+/* Weight regulariser of one top-level module (train_utils.py:300-305, Config.weight_decay_mults):
+ * *loss_out += mult * sum(params[begin:end]^2); grad[begin:end] += 2 mult params; *sqnorm_out += sum p^2
+ * (stats['weight_l2s']).  grad / loss_out / sqnorm_out may be NULL. */
+int mnr_weight_decay(const float* params, int64_t begin, int64_t end, float mult, float* grad, float* loss_out,
+                     float* sqnorm_out, void* stream);
+
 /* out[0] += sum of squares of grad[begin:end] (each element first clipped to
  * +-max_val when max_val > 0): one call per top-level module. */
 int mnr_grad_sqnorm(const float* grad, int64_t begin, int64_t end, float max_val, float* out, void* stream);

@@ -126,6 +126,7 @@ _PROTOS = {
     'mnr_distortion_loss': ([f32, i64, i64, i32, vp, vp, vp, vp, vp], i32),
     'mnr_lossfun_outer': ([i64, i32, vp, vp, i32, vp, vp, vp, vp], i32),
     'mnr_lossfun_distortion': ([i64, i32, vp, vp, vp, vp], i32),
+    'mnr_weight_decay': ([vp, i64, i64, f32, vp, vp, vp, vp], i32),
     'mnr_grad_sqnorm': ([vp, i64, i64, f32, vp, vp], i32),
     'mnr_clip_adam': ([C.POINTER(AdamCfg), i64, i64, vp, vp, vp, vp, vp, vp], i32),
 }

@@ -33,6 +33,39 @@ extern "C" int mnr_grad_sqnorm(const float* grad, int64_t begin, int64_t end, fl
   return MNR_OK;
 }
 
+// losses['weight'] term of one top-level module (train_utils.py:302-305): loss += mult * sum p^2, grad += 2 mult p.
+__global__ void weight_decay_kernel(const float* __restrict__ p, int64_t begin, int64_t end, float mult,
+                                    float* __restrict__ grad, float* loss_out, float* sqnorm_out) {
+  float s = 0.0f;
+  for (int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = p[i];
+    s += v * v;
+    if (grad && mult != 0.0f) grad[i] += 2.0f * mult * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = part[0] + part[1] + part[2] + part[3];
+    if (loss_out) unsafeAtomicAdd(loss_out, mult * t);
+    if (sqnorm_out) unsafeAtomicAdd(sqnorm_out, t);
+  }
+}
+
+extern "C" int mnr_weight_decay(const float* params, int64_t begin, int64_t end, float mult, float* grad,
+                                float* loss_out, float* sqnorm_out, void* stream) {
+  MNR_CHECK_ARG(params && end > begin, "mnr_weight_decay: bad arguments");
+  int grid = mnr_cdiv(end - begin, 256 * 8);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(weight_decay_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, begin, end, mult, grad,
+                     loss_out, sqnorm_out);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
 __device__ __forceinline__ float op_nan_to_num(float x) {
   if (x != x) return 0.0f;
   if (x > MNR_F32_MAX) return MNR_F32_MAX;

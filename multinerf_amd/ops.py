@@ -556,6 +556,12 @@ def lossfun_distortion(t, w):
 # ----------------------------------------------------------------------------- optimiser
 
 
+def weight_decay(params, begin, end, mult, grad, loss_out, sqnorm_out=None):
+  _chk(params, f32, 'params')
+  L.check(lib().mnr_weight_decay(_ptr(params), begin, end, float(mult), _ptr(grad), _ptr(loss_out), _ptr(sqnorm_out),
+                                 _stream()))
+
+
 def grad_sqnorm(grad, begin, end, max_val, out):
   _chk(grad, f32, 'grad')
   _chk(out, f32, 'out')

@@ -66,8 +66,6 @@ def create_train_step(model: models.Model, config, dataset=None):
     raise NotImplementedError('cast_rays_in_train_step (camera_utils on device) is a "next" row (SURVEY 8f N2)')
   if config.data_loss_type not in ('mse', 'charb', 'rawnerf'):
     raise NotImplementedError(f'data_loss_type {config.data_loss_type!r} is out of scope')
-  if config.weight_decay_mults:
-    raise NotImplementedError('weight_decay_mults is not yet on the HIP path')
   use_orient = config.orientation_loss_mult > 0 or config.orientation_coarse_loss_mult > 0
   use_prednorm = config.predicted_normal_loss_mult > 0 or config.predicted_normal_coarse_loss_mult > 0
   if config.orientation_loss_target not in ('normals', 'normals_pred'):
@@ -91,8 +89,8 @@ def create_train_step(model: models.Model, config, dataset=None):
 
     nlev = len(levels)
     # stats layout: [mse_l, data_l]*nlev | interlevel | distortion | denom | orientation | predicted_normals
-    #               | disparity_mse_l * nlev | normal_mae_l * nlev
-    stats = model._buf(('train', 'stats'), (4 * nlev + 5,), f32)
+    #               | disparity_mse_l * nlev | normal_mae_l * nlev | weight loss
+    stats = model._buf(('train', 'stats'), (4 * nlev + 6,), f32)
     stats.zero_()
     denom = stats[2 * nlev + 2:2 * nlev + 3]
     lossmult = R.lossmult
@@ -173,6 +171,13 @@ def create_train_step(model: models.Model, config, dataset=None):
                              R.exposure_idx.reshape(-1).to(torch.int32).contiguous(), g_expo,
                              grads[model.expo_off:model.expo_off + n_off], B0)
 
+    if config.weight_decay_mults:                                      # train_utils.py:300-305
+      mods = {name: (b, e) for name, b, e in model.modules}
+      for name, mult in config.weight_decay_mults.items():
+        if name not in mods:
+          raise KeyError(name)
+        ops.weight_decay(flat, mods[name][0], mods[name][1], mult, grads, stats[4 * nlev + 5:4 * nlev + 6])
+
     # pmean over the 'batch' axis (train_utils.py:319-321): RCCL all-reduce of the flat buffers.
     mdist.all_reduce_mean_(grads)
     mdist.all_reduce_mean_(stats)
@@ -215,6 +220,8 @@ class TrainStats(dict):
     if raw[2 * n + 3] != 0 or raw[2 * n + 4] != 0:
       out['losses']['orientation'] = float(raw[2 * n + 3])
       out['losses']['predicted_normals'] = float(raw[2 * n + 4])
+    if raw[4 * n + 5] != 0:
+      out['losses']['weight'] = float(raw[4 * n + 5])
     if self.get('_disp'):
       out['disparity_mses'] = raw[2 * n + 5:3 * n + 5]
     if self.get('_normal'):

@@ -65,6 +65,8 @@ CASES = [
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_glo_features = 4'], 24),
     # a view MLP deep enough to hit its own skip connection (models.py:579): bottleneck gradient joins two paths
     ('blender_256', ['NerfMLP.net_depth_viewdirs = 6', 'NerfMLP.skip_layer_dir = 2'], 16),
+    # weight regulariser per top-level module (train_utils.py:300-305)
+    ('blender_256', ["Config.weight_decay_mults = {'NerfMLP_0': 3e-5, 'PropMLP_0': 1e-5}"], 16),
 ]
 
 
