@@ -84,6 +84,7 @@ def main():
   ap.add_argument('--gin_bindings', action='append', default=[])
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--cpu_rays', type=int, default=128)
+  ap.add_argument('--no_aux', action='store_true', help='skip the secondary measurements (4096x192 north-star shape, render)')
   args = ap.parse_args()
 
   from multinerf_amd import configs, dist as mdist, models, ops, train_utils
@@ -149,6 +150,46 @@ def main():
   gemm_ms_per_step = gemm_ms / nprof
   achieved_tflops = train_flops * B / (gemm_ms_per_step * 1e-3) / 1e12
 
+  # ---- secondary measurements (reported under "aux", never as `value`)
+  aux = {}
+  if not args.no_aux and args.preset == '360' and not args.gin_bindings:
+    def timed(fn, warm, reps):
+      for _ in range(warm):
+        fn()
+      torch.cuda.synchronize()
+      mdist.barrier()
+      t0 = time.perf_counter()
+      for _ in range(reps):
+        fn()
+      torch.cuda.synchronize()
+      mdist.barrier()
+      dt = time.perf_counter() - t0
+      if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+      return dt / reps
+    # (i) render: deterministic forward with extras on one 16384-ray chunk per GPU (train_utils.py:377-396)
+    rays_only = batch.rays
+    dt = timed(lambda: render_eval_pfn(state.params, 1.0, None, rays_only), 2, 5)
+    aux['render_rays_per_sec'] = {'value': B * world / dt, 'ms_per_chunk': 1e3 * dt, 'chunk_rays_per_gpu': B,
+                                  'algorithmic_tflops_per_gpu': fwd_flops * B / dt / 1e12}
+    # (ii) the north-star's synthetic shape: 4096 rays x 192 samples (360.gin with num_nerf_samples = 64)
+    cfg_b = configs.load_preset('360', ['Model.num_nerf_samples = 64'])
+    Bb = 4096
+    cfg_b.batch_size = Bb
+    model_b, state_b, _, step_b, _ = train_utils.setup_model(cfg_b, 0, device=dev)
+    batch_b = helpers.synthetic_rays(Bb, seed=20200823 + rank, near=cfg_b.near, far=cfg_b.far).map(lambda t: t.to(dev))
+    def run_b():
+      nonlocal state_b
+      state_b, _, _ = step_b(gen, state_b, batch_b, None, train_frac, 0.0)
+    dt = timed(run_b, 3, 10)
+    fwd_b, train_b = algorithmic_flops_per_ray(model_b)
+    aux['train_4096x192'] = {'value': Bb * world / dt, 'unit': 'rays/s', 'ms_per_step': 1e3 * dt,
+                             'algorithmic_train_mflop_per_ray': train_b / 1e6,
+                             'whole_step_frac_of_mfma_peak': train_b * Bb / dt / 2.5e15}
+    del model_b, state_b, step_b, batch_b
+
   out = None
   if rank == 0:
     rays_per_sec = B * world * args.steps / elapsed
@@ -193,6 +234,8 @@ def main():
             'gemm_share_of_step': gemm_ms_per_step / ms_per_step,
         },
     }
+    if aux:
+      out['aux'] = aux
 
   # ---- CPU baseline (rank 0, N=1 only): the oracle's train_step on a bounded sample
   if rank == 0 and world == 1 and not args.no_cpu_baseline:

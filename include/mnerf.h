@@ -166,12 +166,21 @@ typedef struct {
   const uint8_t* mask_bits_in; int ld_bits_in;
   int64_t bits_row_mod;               /* > 0: row m reads the bits of row m % bits_row_mod (tangent rows
                                          c*M + s share the primal mask of sample s) */
+  const uint16_t* Bp;                 /* optional: the same Bt in MFMA-fragment-major order (mnr_pack_desc.transpose
+                                         |= 2): element (n, k) at ((n/32 * K/16 + k/16) * 64 + (k%16/8) * 32 + n%32) * 8
+                                         + k%8, K = K1 + K2.  When given and M, N are multiples of 256 the weight
+                                         fragments go global -> registers (1 KiB per load) and only the activation
+                                         tiles are staged through LDS. */
 } mnr_gemm_nt_args;
 
 /* C[M,N] = epilogue([A1|A2] * Bt^T). */
 int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* args, void* stream);
 /* Tuning hook: tile / pipeline configuration ids (see csrc/gemm.hip NtC0..NtC7) used when N is a
  * multiple of 256 (`cfg_big`) and otherwise (`cfg_small`; must be a 128x128 configuration). */
+/* Profiling hook: device buffer of 8 uint64 per workgroup (s_memtime at entry, K-loop start, K-loop end, exit;
+ * s_memrealtime at entry, exit; XCC_ID<<32|HW_ID; unused) written by
+ * every following mnr_gemm_nt_bf16 launch; NULL switches it off. */
+int mnr_debug_gemm_timeline(unsigned long long* device_buffer);
 int mnr_gemm_nt_set_config(int cfg_big, int cfg_small);
 
 typedef struct {

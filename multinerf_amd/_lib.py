@@ -50,7 +50,8 @@ class GemmNTArgs(C.Structure):
               ('Cf', vp), ('ldcf', C.c_int), ('f0', C.c_int), ('nf', C.c_int),
               ('mask_bits_out', vp), ('ld_bits_out', C.c_int),
               ('mask_bits_in', vp), ('ld_bits_in', C.c_int),
-              ('bits_row_mod', C.c_int64)]
+              ('bits_row_mod', C.c_int64),
+              ('Bp', vp)]
 
 
 class GemmTNArgs(C.Structure):
@@ -98,6 +99,7 @@ _PROTOS = {
     'mnr_glo_fill': ([i64, i32, i32, vp, vp, i32, vp, i32, i32, vp], i32),
     'mnr_glo_bwd': ([i64, i32, i32, vp, vp, vp, i32, vp, vp], i32),
     'mnr_gemm_nt_bf16': ([C.POINTER(GemmNTArgs), vp], i32),
+    'mnr_debug_gemm_timeline': ([vp], i32),
     'mnr_gemm_nt_set_config': ([i32, i32], i32),
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
     'mnr_gemm_tn_set_config': ([i32], i32),

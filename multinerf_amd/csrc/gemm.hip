@@ -10,6 +10,8 @@
 // address so the linear DMA image is conflict-free for the fragment reads.
 // Workgroup ids are remapped so that the tiles sharing an operand panel run
 // back to back on one XCD (block b lands on XCD b%8; each XCD has a private L2).
+#include <type_traits>
+
 #include "common.h"
 
 // ---------------------------------------------------------------------------
@@ -45,7 +47,14 @@ struct NtCfg {
   static constexpr int SLOTS = ROWB / 16;             // 16-B slots per row (8 at BK=64, 4 at BK=32)
   static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+  // phase-interleaved loop (FRAGPIPE >= 2): PH_S half-tile slots of 16 KiB, staged PH_L phases ahead
+  static constexpr int PH_S = FRAGPIPE_ == 3 ? 10 : 8;
+  static constexpr int PH_L = FRAGPIPE_ == 2 ? 6 : FRAGPIPE_ == 3 ? 8 : FRAGPIPE_ == 5 ? 4 : 0;
+  // FRAGPIPE >= 6: weights straight from global memory in fragment-major order, LDS ring holds activation
+  // half-tiles only: 3 + PH_D slots for the first halves, 2 + PH_D for the second halves.
+  static constexpr int PH_D = FRAGPIPE_ >= 6 ? FRAGPIPE_ - 6 : 0;
+  static constexpr int LDS_BYTES = FRAGPIPE_ >= 6 ? ((5 + 2 * PH_D) * 16384 < 128 * (BN * 2 + NT_CPAD) ? 128 * (BN * 2 + NT_CPAD) : (5 + 2 * PH_D) * 16384)
+                                   : FRAGPIPE_ >= 2 ? PH_S * 16384 : STAGES * STAGE_BYTES;
   static constexpr int LOADS_PER_STAGE = STAGE_BYTES / 16 / THREADS;   // LDS-DMA instructions per wave per stage
   static constexpr int CPITCH = BN * 2 + NT_CPAD;     // bytes per staged output row
   static constexpr int EPI_ROWS = (128 * CPITCH <= LDS_BYTES) ? 128 : 64;   // rows staged per epilogue pass
@@ -88,6 +97,78 @@ __device__ __forceinline__ void nt_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+
+// ---------------------------------------------------------------------------
+// Phase-interleaved K loop for the 256x256 tile (NtCfg FRAGPIPE_ = 2).
+//
+// The 2-stage loop above tops out near 0.9 PFLOP/s: every wave drains lgkmcnt to 0 in front of each
+// MFMA group and all waves stage, read and multiply in lock step.  Here the two M-halves of the
+// workgroup (waves 0-3 / 4-7, i.e. one wave of each half per SIMD) run half a phase apart: while one
+// half issues its MFMAs the other issues its ds_reads and LDS-DMA, so the matrix pipe of every SIMD
+// always has a wave to run.  A K tile (BK = 64) is four phases, one 64x32 output quadrant each:
+//     phase 0: read Bf, Af   mfma q(0,0)         Af/As = rows {0..63}/{64..127} of each wave's A strip
+//     phase 1: read Bs       mfma q(0,1)         Bf/Bs = cols {0..31}/{32..63}  of each wave's B strip
+//     phase 2: read As       mfma q(1,1)
+//     phase 3: -             mfma q(1,0)         (Bf stays in registers)
+// LDS is a ring of PH_S (8 or 10) half-tile slots of 16 KiB; half-tile H = 4t + {0:Af, 1:Bf, 2:Bs, 3:As} of
+// K tile t lives in slot H mod PH_S.  Half-tiles are staged in
+// consumption order, one half-tile per phase, PH_L phases ahead of its first read.  After its
+// issue each wave waits vmcnt(2*(PH_L-2)): everything up to the half-tile needed in the NEXT
+// phase has landed (2 DMA instructions per wave and half-tile), younger ones stay in flight across
+// the barrier; the read happens one phase (two barriers) after the wait, which also covers the other
+// half's waves.  A slot is restaged two or more phases after its last read retired.
+#define NT_HT_BYTES 16384
+
+template <int C>
+__device__ __forceinline__ void nt_stage_half(const mnr_gemm_nt_args& p, const bf16* __restrict__ A1,
+                                              const bf16* __restrict__ A2, const bf16* __restrict__ Bt, int64_t m0,
+                                              int n0, int t, char* dst, int wave, int lane) {
+  const int k0 = t * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int cbase = (i * 8 + wave) * 64;
+    const int c = cbase + lane;
+    const int lr = c >> 3;                                 // local row 0..127 of the half-tile
+    const int slot = (c & 7) ^ ((lr >> 1) & 7);           // source-side swizzle (see nt_stage_tile)
+    const bf16* src;
+    if (C == 0 || C == 3) {
+      const int64_t grow = m0 + (lr >> 6) * 128 + (C == 3 ? 64 : 0) + (lr & 63);
+      if (k0 < p.K1) src = A1 + grow * (int64_t)p.lda1 + k0 + slot * 8;
+      else src = A2 + grow * (int64_t)p.lda2 + (k0 - p.K1) + slot * 8;
+    } else {
+      const int grow = n0 + (lr >> 5) * 64 + (C == 2 ? 32 : 0) + (lr & 31);
+      src = Bt + grow * (int64_t)p.ldb + k0 + slot * 8;
+    }
+    __builtin_amdgcn_global_load_lds(MNR_GLOBAL_PTR(src), MNR_LDS_PTR(dst + cbase * 16), 16, 0, 0);
+  }
+}
+
+template <bool REAL = true>
+__device__ __forceinline__ bf16x8 nt_read_half(const char* ht, int lrow, int kslot) {
+  if constexpr (!REAL) {                                   // ablation probe: no LDS traffic
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)(float)(kslot + e);
+    return v;
+  } else {
+    return *(const bf16x8*)(ht + lrow * 128 + ((kslot ^ ((lrow >> 1) & 7)) << 4));
+  }
+}
+
+// Profiling hook (tools/gemm_probe.py --timeline): when set, wave 0 of every workgroup records s_memtime at
+// kernel entry, K-loop start, K-loop end and kernel exit into g_nt_timeline[8 * blockIdx.x + 0..3], s_memrealtime
+// (100 MHz) at entry / exit into [4], [5] and XCC_ID << 32 | HW_ID into [6].
+__device__ unsigned long long* g_nt_timeline = nullptr;
+
+extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_nt_timeline), &device_buffer, sizeof(device_buffer));
+  if (e != hipSuccess) {
+    mnr_set_error("mnr_debug_gemm_timeline: %s", hipGetErrorString(e));
+    return MNR_ERR_HIP;
+  }
+  return MNR_OK;
+}
+
 template <class CFG, bool BITS_IN>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi) {
   constexpr int MI = CFG::MI, NJ = CFG::NJ, BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, STAGES = CFG::STAGES;
@@ -97,6 +178,12 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / CFG::WN, wn = wave % CFG::WN;
+  unsigned long long* const tl = g_nt_timeline;
+  if (tl && tid == 0) {
+    tl[8 * (int64_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    tl[8 * (int64_t)blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();
+    tl[8 * (int64_t)blockIdx.x + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+  }
 
   // XCD-aware mapping: the nt N-tiles of one M-tile run consecutively on one XCD.
   const int nt = p.N / BN;
@@ -166,6 +253,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
 
+  if (tl && tid == 0) tl[8 * (int64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
   auto stage = [&](int kt) {
     const int k0 = kt * BK;
     char* base = smem + (kt % STAGES) * CFG::STAGE_BYTES;
@@ -182,6 +270,248 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
   // proves every wave is done reading tile kt-1, whose buffer the new DMA overwrites), issue tile
   // kt+STAGES-1, compute tile kt.  __syncthreads() would drain vmcnt to 0 and serialise HBM latency
   // with the MFMA phase (measured on the 2-stage version: waves parked 57% of their cycles).
+  if constexpr (CFG::FRAGPIPE >= 6) {
+    // Direct-B phased loop.  The LDS-DMA path sustains ~23-30 B/clk per CU (tools/gemm_probe.py --timeline,
+    // DMA-only probe), less than the 64 KiB per K tile the MFMA rate of a 256x256 tile asks for, so the
+    // weights bypass it: each wave loads its own 64 n x 64 k of weights per K tile as eight fully coalesced
+    // 1-KiB vector loads from the fragment-major image (p.Bp), two K-tile-halves ahead of their use, and
+    // only the activation rows go through LDS.  Quadrant order per K tile t (two wave groups half a phase
+    // apart as above):
+    //   p0: ds_read A0(t)   issue B1(t)     wait B0(t)   mfma q(0,0)
+    //   p1: ds_read A1(t)   issue DMA A1(t+1+D)          mfma q(1,0)
+    //   p2:                 issue B0(t+1)   wait B1(t)   mfma q(1,1)
+    //   p3: ds_read A0(t)   issue DMA A0(t+2+D)          mfma q(0,1)
+    // vmcnt retires in order, so waiting for a weight fragment also proves every activation half-tile
+    // issued before it has landed; each is read at least one phase (two barriers) after such a wait.
+    static_assert(MI == 4 && NJ == 2 && CFG::WM == 2 && CFG::WN == 4 && BK == 64, "phased loop is built for the 256x256 tile");
+    constexpr int D = CFG::PH_D, S0 = 3 + D, S1 = 2 + D;
+    const bf16* Bp = (const bf16*)p.Bp;
+    const int kfr = K / 16;
+    const bf16* bfrag = Bp + ((int64_t)((n0 >> 5) + wn * 2) * kfr) * 512 + lane * 8;
+    bf16x8 fa[2][4], fb[2][4];
+    auto load_B = [&](auto bhc, int t) {
+      constexpr int BH = decltype(bhc)::value;
+      // Issued from inline asm: hipcc's waitcnt insertion forces vmcnt(0) in front of the consuming MFMAs when
+      // register loads and LDS-DMA are in flight together (it treats the counter as out of order), which would
+      // serialise these loads; the counted waits below are the only ordering, pinned by sched_barrier(0).
+      const bf16* src = bfrag + ((int64_t)BH * kfr + t * 4) * 512;
+      bf16x8 v0, v1, v2, v3;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v0) : "v"(src) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(v1) : "v"(src) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(v2) : "v"(src) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(v3) : "v"(src) : "memory");
+      fb[BH][0] = v0;
+      fb[BH][1] = v1;
+      fb[BH][2] = v2;
+      fb[BH][3] = v3;
+    };
+    int w0 = 0, w1 = 0, r0 = 0, r1 = 0;                      // ring positions (write / read) of the two slot groups
+    auto stage_A0 = [&](int t) {
+      nt_stage_half<0>(p, A1, A2, Bt, m0, n0, t, smem + w0 * NT_HT_BYTES, wave, lane);
+      w0 = (w0 + 1 == S0) ? 0 : w0 + 1;
+    };
+    auto stage_A1 = [&](int t) {
+      nt_stage_half<3>(p, A1, A2, Bt, m0, n0, t, smem + (S0 + w1) * NT_HT_BYTES, wave, lane);
+      w1 = (w1 + 1 == S1) ? 0 : w1 + 1;
+    };
+    auto wait_n = [&](int n) {                               // wave-uniform n in {0, 2, 4, 6}
+      if (n >= 6) nt_wait_vmcnt<6>();
+      else if (n >= 4) nt_wait_vmcnt<4>();
+      else if (n >= 2) nt_wait_vmcnt<2>();
+      else nt_wait_vmcnt<0>();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // prologue: A0(0 .. 1+D), A1(0 .. D), B0(0)
+#pragma unroll
+    for (int i = 0; i <= 1 + D; ++i)
+      if (i < nk) stage_A0(i);
+#pragma unroll
+    for (int i = 0; i <= D; ++i)
+      if (i < nk) stage_A1(i);
+    load_B(I0(), 0);
+    nt_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int arow = wm * 64 + frow;
+    auto read_A = [&](const char* slot) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) fa[ii][ks] = nt_read_half<(CFG::ABLATE & 4) == 0>(slot, arow + ii * 32, ks * 2 + khalf);
+    };
+    auto quadrant = [&](auto ahc, auto bhc) {
+      constexpr int AH = decltype(ahc)::value, BH = decltype(bhc)::value;
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          if constexpr (CFG::ABLATE & 1) {
+            asm volatile("" ::"v"(fb[BH][ks]), "v"(fa[ii][ks]));
+          } else {
+            acc[BH][AH * 2 + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[BH][ks], fa[ii][ks], acc[BH][AH * 2 + ii], 0, 0, 0);
+          }
+        }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    bool a0_prev = false;                                    // an A0 DMA was issued in the previous p3
+    auto tile = [&](auto steady, int t) {
+      // STEADY: every issue of this K tile happens (no tail conditions), so the counted waits are
+      // compile-time constants and hipcc's own waitcnt insertion sees straight-line code (with conditional
+      // issues it falls back to vmcnt(0) in front of the MFMAs, which serialises the weight loads).
+      constexpr bool STEADY = decltype(steady)::value;
+      const char* sA0 = smem + r0 * NT_HT_BYTES;
+      const char* sA1 = smem + (S0 + r1) * NT_HT_BYTES;
+      r0 = (r0 + 1 == S0) ? 0 : r0 + 1;
+      r1 = (r1 + 1 == S1) ? 0 : r1 + 1;
+      // p0
+      read_A(sA0);
+      load_B(I1(), t);
+      if (STEADY) nt_wait_vmcnt<6>();
+      else wait_n(4 + (a0_prev ? 2 : 0));
+      quadrant(I0(), I0());
+      // p1
+      read_A(sA1);
+      const bool a1_now = STEADY || (t + 1 + D < nk);
+      if (a1_now) stage_A1(t + 1 + D);
+      quadrant(I1(), I0());
+      // p2
+      const bool b0_now = STEADY || (t + 1 < nk);
+      if (b0_now) load_B(I0(), t + 1);
+      if (STEADY) nt_wait_vmcnt<6>();
+      else wait_n((b0_now ? 4 : 0) + (a1_now ? 2 : 0));
+      quadrant(I1(), I1());
+      // p3
+      read_A(sA0);
+      a0_prev = STEADY || (t + 2 + D < nk);
+      if (a0_prev) stage_A0(t + 2 + D);
+      quadrant(I0(), I1());
+    };
+    int t = 0;
+    if (nk > 0) {                                            // tile 0: no A0 DMA precedes its p0
+      tile(std::false_type(), 0);
+      t = 1;
+    }
+    for (; t + 2 + D < nk; ++t) tile(std::true_type(), t);
+    for (; t < nk; ++t) tile(std::false_type(), t);
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+  } else if constexpr (CFG::FRAGPIPE >= 2) {
+    static_assert(MI == 4 && NJ == 2 && CFG::WM == 2 && CFG::WN == 4 && BK == 64, "phased loop is built for the 256x256 tile");
+    constexpr int S = CFG::PH_S, LEAD = CFG::PH_L;
+    static_assert(LEAD >= 2 && LEAD <= S - 2, "a slot is restaged two or more phases after its last read");
+    constexpr int WAITN = 2 * (LEAD - 2);
+    const int nh = 4 * nk;                                   // half-tiles in this GEMM
+    int ws = 0;                                              // slot of the next half-tile to stage (= H mod S)
+    auto issue = [&](auto cc, int H) {                       // stage half-tile H (type cc = H & 3), then wait
+      constexpr int C = decltype(cc)::value;
+      if constexpr (CFG::ABLATE & 2) {
+        nt_wait_vmcnt<0>();
+      } else if (H < nh) {
+        nt_stage_half<C>(p, A1, A2, Bt, m0, n0, H >> 2, smem + ws * NT_HT_BYTES, wave, lane);
+        ws = (ws + 1 == S) ? 0 : ws + 1;
+        nt_wait_vmcnt<WAITN>();
+      } else {
+        nt_wait_vmcnt<0>();
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    // prologue: half-tiles 0 .. LEAD-1
+    {
+      auto pro = [&](auto cc, int H) {
+        constexpr int C = decltype(cc)::value;
+        if (H < nh) {
+          nt_stage_half<C>(p, A1, A2, Bt, m0, n0, H >> 2, smem + ws * NT_HT_BYTES, wave, lane);
+          ws = (ws + 1 == S) ? 0 : ws + 1;
+        }
+      };
+      pro(I0(), 0);
+      pro(I1(), 1);
+      pro(I2(), 2);
+      pro(I3(), 3);
+      if (LEAD > 4) pro(I0(), 4);
+      if (LEAD > 5) pro(I1(), 5);
+      if (LEAD > 6) pro(I2(), 6);
+      if (LEAD > 7) pro(I3(), 7);
+      if (nh >= LEAD) nt_wait_vmcnt<WAITN>();
+      else nt_wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // this half runs half a phase behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    bf16x8 fa[2][4], fb[2][4];
+    const int arow = wm * 64 + frow, brow = wn * 32 + frow;
+    auto quadrant = [&](auto ahc, auto bhc) {
+      constexpr int AH = decltype(ahc)::value, BH = decltype(bhc)::value;
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          if constexpr (CFG::ABLATE & 1) {
+            asm volatile("" ::"v"(fb[BH][ks]), "v"(fa[ii][ks]));
+          } else {
+            acc[BH][AH * 2 + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[BH][ks], fa[ii][ks], acc[BH][AH * 2 + ii], 0, 0, 0);
+          }
+        }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int rs = 0;                                              // slot of Af of K tile t
+    auto slot_ptr = [&](int k) {                             // slot (rs + k) mod S
+      int q = rs + k;
+      q = q >= S ? q - S : q;
+      return (const char*)smem + q * NT_HT_BYTES;
+    };
+    for (int t = 0; t < nk; ++t) {
+      const char* sAf = slot_ptr(0);
+      const char* sBf = slot_ptr(1);
+      const char* sBs = slot_ptr(2);
+      const char* sAs = slot_ptr(3);
+      rs = rs + 4 >= S ? rs + 4 - S : rs + 4;
+      // phase 0
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fb[0][ks] = nt_read_half<(CFG::ABLATE & 4) == 0>(sBf, brow, ks * 2 + khalf);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) fa[ii][ks] = nt_read_half<(CFG::ABLATE & 4) == 0>(sAf, arow + ii * 32, ks * 2 + khalf);
+      issue(std::integral_constant<int, (0 + LEAD) & 3>(), 4 * t + 0 + LEAD);
+      quadrant(I0(), I0());
+      // phase 1
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fb[1][ks] = nt_read_half<(CFG::ABLATE & 4) == 0>(sBs, brow, ks * 2 + khalf);
+      issue(std::integral_constant<int, (1 + LEAD) & 3>(), 4 * t + 1 + LEAD);
+      quadrant(I0(), I1());
+      // phase 2
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) fa[ii][ks] = nt_read_half<(CFG::ABLATE & 4) == 0>(sAs, arow + ii * 32, ks * 2 + khalf);
+      issue(std::integral_constant<int, (2 + LEAD) & 3>(), 4 * t + 2 + LEAD);
+      quadrant(I1(), I1());
+      // phase 3
+      issue(std::integral_constant<int, (3 + LEAD) & 3>(), 4 * t + 3 + LEAD);
+      quadrant(I1(), I0());
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // re-align the two halves
+  } else {
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) stage(s);
@@ -262,6 +592,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
       }
     }
   }
+  }   // !phased
+  if (tl && tid == 0) tl[8 * (int64_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
   __syncthreads();      // every wave is done with the operand buffers: reuse them for the epilogue
 
   // Epilogue.  acc[j][i][r]: n = n0 + wn*32*NJ + j*32 + (r&3) + 8*(r>>2) + 4*khalf,
@@ -382,6 +714,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
       }
     }
   }
+  if (tl && tid == 0) {
+    tl[8 * (int64_t)blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
+    tl[8 * (int64_t)blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 template <class CFG>
@@ -411,30 +747,30 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   return MNR_OK;
 }
 
-//                 MI NJ WM WN BK STAGES
-typedef NtCfg<2, 2, 2, 2, 64, 2> NtC0;   // 128x128, 4 waves,  64 KiB  (r1_a structure)
-typedef NtCfg<2, 2, 2, 2, 32, 2> NtC1;   // 128x128, 4 waves,  32 KiB  -> 4 workgroups/CU
-typedef NtCfg<4, 2, 2, 4, 64, 2> NtC2;   // 256x256, 8 waves, 128 KiB
-typedef NtCfg<2, 2, 4, 2, 64, 3> NtC3;   // 256x128, 8 waves, 144 KiB, 3 stages
-typedef NtCfg<4, 2, 2, 4, 32, 4> NtC4;   // 256x256, 8 waves, 128 KiB, 4 stages of BK=32
-typedef NtCfg<2, 2, 2, 2, 32, 4> NtC5;   // 128x128, 4 waves,  64 KiB, 4 stages of BK=32 -> 2 workgroups/CU
-typedef NtCfg<2, 2, 2, 2, 64, 3> NtC6;   // 128x128, 4 waves,  96 KiB, 3 stages
-typedef NtCfg<4, 2, 2, 4, 32, 3> NtC7;   // 256x256, 8 waves,  96 KiB, 3 stages of BK=32
-typedef NtCfg<4, 2, 2, 2, 32, 2, 2> NtC8;   // 256x128, 4 waves (128x64 each), 48 KiB -> 2 workgroups/CU
-typedef NtCfg<4, 2, 2, 2, 32, 3, 2> NtC9;   // 256x128, 4 waves, 72 KiB, 3 stages -> 2 workgroups/CU
-typedef NtCfg<4, 2, 2, 2, 64, 2, 2> NtC10;  // 256x128, 4 waves, 96 KiB
-typedef NtCfg<2, 4, 2, 2, 32, 3, 2> NtC11;  // 128x256, 4 waves (64x128 each), 72 KiB, 3 stages
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 1> NtC12; // = NtC2 with register double-buffered fragments
-typedef NtCfg<4, 2, 2, 4, 32, 4, 1, 1> NtC13; // = NtC4 with register double-buffered fragments
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 1> NtC14; // probe: NtC2 without MFMAs
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 2> NtC15; // probe: NtC2 without in-loop DMA
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 6> NtC16; // probe: NtC2 MFMAs only (no DMA, no ds_reads)
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 5> NtC17; // probe: NtC2 DMA only (no ds_reads, no MFMAs)
+//                 MI NJ WM WN BK STAGES MINW FRAGPIPE ABLATE
+typedef NtCfg<2, 2, 2, 2, 64, 2> NtC0;             // 128x128, 4 waves,  64 KiB: N not a multiple of 256 (heads, view MLP)
+typedef NtCfg<4, 2, 2, 4, 64, 2> NtC2;             // 256x256, 8 waves, 128 KiB: the trunk layers (default)
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 1> NtC12;      // = NtC2 with register double-buffered fragments
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 1> NtC14;   // probes of NtC2 (tools/gemm_probe.py): no MFMAs
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 2> NtC15;   //   no in-loop DMA
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 6> NtC16;   //   MFMAs only (no DMA, no ds_reads)
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 5> NtC17;   //   DMA only (no ds_reads, no MFMAs)
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2> NtC18;      // 256x256, phase-interleaved K loop (two wave groups half a phase apart), 8 slots, lead 6
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 3> NtC19;      //   same, 10 slots (160 KiB), lead 8
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 5> NtC21;      //   same, 8 slots, lead 4 (latency probe)
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 1> NtC22;   // probes of NtC18: no MFMA
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 2> NtC23;   //   no in-loop DMA
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 4> NtC24;   //   no ds_reads
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 6> NtC25;   //   MFMA + barriers only
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 5> NtC26;   //   DMA + barriers only
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 7> NtC27;   //   barriers only
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 6> NtC30;      // 256x256 phased, weights direct from the fragment-major image (needs args.Bp)
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 6, 1> NtC32;   //   probe: no MFMA
 
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 17 && cfg_small >= 0 && cfg_small <= 17, "mnr_gemm_nt_set_config: unknown configuration");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 32 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -443,23 +779,26 @@ extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
 static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   switch (cfg) {
     case 0: return nt_launch<NtC0>(a, fast_epi, stream);
-    case 1: return nt_launch<NtC1>(a, fast_epi, stream);
     case 2: return nt_launch<NtC2>(a, fast_epi, stream);
-    case 3: return nt_launch<NtC3>(a, fast_epi, stream);
-    case 4: return nt_launch<NtC4>(a, fast_epi, stream);
-    case 5: return nt_launch<NtC5>(a, fast_epi, stream);
-    case 6: return nt_launch<NtC6>(a, fast_epi, stream);
-    case 7: return nt_launch<NtC7>(a, fast_epi, stream);
-    case 8: return nt_launch<NtC8>(a, fast_epi, stream);
-    case 9: return nt_launch<NtC9>(a, fast_epi, stream);
-    case 10: return nt_launch<NtC10>(a, fast_epi, stream);
-    case 11: return nt_launch<NtC11>(a, fast_epi, stream);
     case 12: return nt_launch<NtC12>(a, fast_epi, stream);
-    case 13: return nt_launch<NtC13>(a, fast_epi, stream);
     case 14: return nt_launch<NtC14>(a, fast_epi, stream);
     case 15: return nt_launch<NtC15>(a, fast_epi, stream);
     case 16: return nt_launch<NtC16>(a, fast_epi, stream);
-    default: return nt_launch<NtC17>(a, fast_epi, stream);
+    case 17: return nt_launch<NtC17>(a, fast_epi, stream);
+    case 18: return nt_launch<NtC18>(a, fast_epi, stream);
+    case 19: return nt_launch<NtC19>(a, fast_epi, stream);
+    case 21: return nt_launch<NtC21>(a, fast_epi, stream);
+    case 22: return nt_launch<NtC22>(a, fast_epi, stream);
+    case 23: return nt_launch<NtC23>(a, fast_epi, stream);
+    case 24: return nt_launch<NtC24>(a, fast_epi, stream);
+    case 25: return nt_launch<NtC25>(a, fast_epi, stream);
+    case 26: return nt_launch<NtC26>(a, fast_epi, stream);
+    case 27: return nt_launch<NtC27>(a, fast_epi, stream);
+    case 30: return nt_launch<NtC30>(a, fast_epi, stream);
+    case 32: return nt_launch<NtC32>(a, fast_epi, stream);
+    default:
+      mnr_set_error("mnr_gemm_nt_bf16: configuration %d is not compiled in", cfg);
+      return MNR_ERR_INVALID_ARGUMENT;
   }
 }
 
@@ -484,7 +823,7 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
                        (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));
   const bool big_ok = (a->M % 256 == 0) && (a->N % 256 == 0);
   int cfg = big_ok ? g_nt_cfg_big : g_nt_cfg_small;
-  if (cfg == 3 && a->M % 256 != 0) cfg = g_nt_cfg_small;
+  if (cfg >= 30 && !a->Bp) cfg = 2;                      // the direct-weights loop needs the fragment-major image
   return nt_dispatch(cfg, a, fast_epi, stream);
 }
 

@@ -18,6 +18,8 @@ def main():
   ap.add_argument('--reps', type=int, default=10)
   ap.add_argument('--which', default='nt,ntmask,tn,prop')
   ap.add_argument('--M', type=int, default=524288)
+  ap.add_argument('--pad', type=int, default=0, help='extra elements in the leading dimension of A / Bt / C (channel-conflict probe)')
+  ap.add_argument('--timeline', action='store_true', help='per-workgroup s_memtime breakdown of the 1024-wide forward GEMM')
   ap.add_argument('--cfgs', default='', help='comma list of NT configuration ids to sweep (csrc/gemm.hip NtC*)')
   args = ap.parse_args()
   dev = 'cuda'
@@ -42,6 +44,51 @@ def main():
 
   which = args.which.split(',')
   K = N = 1024
+  if args.timeline:
+    import numpy as np
+    pad = args.pad
+    A = rnd(M, K + pad)
+    Bt = rnd(N, K + pad) * 0.05
+    bias = torch.zeros(N, device=dev)
+    C = torch.empty((M, N + pad), dtype=bf, device=dev)
+    nwg = (M // 256) * (N // 256)
+    buf = torch.zeros((nwg, 8), dtype=torch.int64, device=dev)
+    for c in [int(x) for x in (args.cfgs or '2,18').split(',')]:
+      ops.L.check(ops.lib().mnr_gemm_nt_set_config(c, 0))
+      fn = lambda: ops.gemm_nt(A, Bt, M=M, N=N, K1=K, bias=bias, n_bias=N, relu=True, Cb=C, ldcb=N + pad, nb=N,
+                               Bp=Bt if c >= 30 else None)   # timing only: Bt read as if it were fragment-major
+      for _ in range(5):
+        fn()
+      torch.cuda.synchronize()
+      ops.L.check(ops.lib().mnr_debug_gemm_timeline(buf.data_ptr()))
+      fn()
+      torch.cuda.synchronize()
+      ops.L.check(ops.lib().mnr_debug_gemm_timeline(None))
+      t = buf.cpu().numpy()
+      t = t[t[:, 3] != 0]
+      tm = t[:, :4].astype(np.float64)
+      rt = t[:, 4:6].astype(np.float64)
+      span_rt = rt[:, 1].max() - rt[:, 0].min()              # 100 MHz ticks
+      span_mt = tm[:, 3].max() - tm[:, 0].min()
+      pro, loop, epi = tm[:, 1] - tm[:, 0], tm[:, 2] - tm[:, 1], tm[:, 3] - tm[:, 2]
+      tot = tm[:, 3] - tm[:, 0]
+      hw = t[:, 6]
+      cu_key = ((hw >> 32) & 0xf) * 4096 + (hw & 0xffff & ~0xff)   # xcc, se/sh/cu fields of HW_ID (wave/simd/pipe masked)
+      ncu = len(np.unique(cu_key))
+      gaps = []
+      for k in np.unique(cu_key):
+        sel = tm[cu_key == k]
+        sel = sel[np.argsort(sel[:, 0])]
+        gaps += list(sel[1:, 0] - sel[:-1, 3])
+      gaps = np.array(gaps)
+      wg_rt = rt[:, 1] - rt[:, 0]
+      ghz = np.median(tot[wg_rt > 0] / wg_rt[wg_rt > 0]) * 100 / 1e3
+      q = lambda x: f'{np.median(x):.0f} [{np.percentile(x, 10):.0f} {np.percentile(x, 90):.0f}]'
+      print(f'pad {pad} cfg {c}: {len(t)} workgroups on {ncu} CUs; span {span_rt / 100:.1f} us '
+            f'-> {ghz:.3f} GHz tick rate (per-workgroup memtime / realtime)\n'
+            f'   per workgroup ticks median [p10 p90]: prologue {q(pro)}  K-loop {q(loop)}  epilogue {q(epi)}  total {q(tot)}\n'
+            f'   gap between consecutive workgroups of one CU: {q(gaps)}; busy fraction {tot.sum() / ncu / span_mt:.3f}', flush=True)
+    return
   A = rnd(M, K)
   Bt = rnd(N, K) * 0.05
   bias = torch.zeros(N, device=dev)
@@ -53,8 +100,41 @@ def main():
     B2 = rnd(K2, K2) * 0.05
     C2 = torch.empty((M2, K2), dtype=bf, device=dev)
     b2 = torch.zeros(K2, device=dev)
+    # reference outputs from the default configuration (same MFMA order per accumulator -> bitwise equal)
+    Kc = 512
+    Ac = rnd(M, Kc)
+    Btc = rnd(N, K + Kc) * 0.05
+    biasc = torch.randn(N, device=dev, generator=g) * 0.1
+    bits = torch.empty((M, N // 8), dtype=torch.uint8, device=dev)
+    def run_checks(tag):
+      outs = []
+      Cx = torch.empty((M, N), dtype=bf, device=dev)
+      ops.gemm_nt(A, Btc, M=M, N=N, K1=K, A2=Ac, K2=Kc, bias=biasc, n_bias=N, relu=True, Cb=Cx, ldcb=N, nb=N, bits_out=bits)
+      outs.append(Cx.clone()); outs.append(bits.clone())
+      Cy = torch.empty((M, N), dtype=bf, device=dev)
+      ops.gemm_nt(A, Bt, M=M, N=N, K1=K, Cb=Cy, ldcb=N, nb=N, bits_in=bits)
+      outs.append(Cy.clone())
+      Cz = torch.empty((M, N), dtype=bf, device=dev)
+      ops.gemm_nt(A, Bt, M=M, N=N, K1=64, lda1=K, ldb=K, Cb=Cz, ldcb=N, nb=N)   # single K tile
+      outs.append(Cz.clone())
+      ops.gemm_nt(A, Bt, M=M, N=N, K1=128, lda1=K, ldb=K, Cb=Cz, ldcb=N, nb=N)  # two K tiles
+      outs.append(Cz.clone())
+      torch.cuda.synchronize()
+      return outs
+    ops.L.check(ops.lib().mnr_gemm_nt_set_config(2, 0))
+    ref = run_checks('ref')
+    # spot check of the reference itself against torch on a slice
+    sl = slice(0, 2048)
+    want = torch.relu(torch.cat([A[sl], Ac[sl]], 1).float() @ Btc.float().t() + biasc)
+    print('cfg 2 vs torch max abs err', (ref[0][sl].float() - want).abs().max().item(), flush=True)
     for c in [int(x) for x in args.cfgs.split(',')]:
-      ops.L.check(ops.lib().mnr_gemm_nt_set_config(c, c if c in (0, 1, 5, 6) else 0))
+      ops.L.check(ops.lib().mnr_gemm_nt_set_config(c, 0))
+      if c >= 18:
+        for rep in range(3):
+          got = run_checks(f'cfg{c}')
+          bad = [i for i, (x, y) in enumerate(zip(got, ref)) if not torch.equal(x, y)]
+          print(f'cfg {c} check rep {rep}: ' + ('bitwise equal to cfg 2' if not bad else f'MISMATCH in outputs {bad}: '
+                + ', '.join(f'{(got[i].float() - ref[i].float()).abs().max().item():.3e}' for i in bad)), flush=True)
       time_it(f'cfg {c} nt fwd  1024', lambda: ops.gemm_nt(A, Bt, M=M, N=N, K1=K, bias=bias, n_bias=N, relu=True, Cb=C, ldcb=N, nb=N), 2.0 * M * N * K)
       time_it(f'cfg {c} nt dX   1024', lambda: ops.gemm_nt(A, Bt, M=M, N=N, K1=K, mask=mask, ldmask=N, Cb=C, ldcb=N, nb=N), 2.0 * M * N * K)
       time_it(f'cfg {c} nt prop  256', lambda: ops.gemm_nt(A2, B2, M=M2, N=K2, K1=K2, bias=b2, n_bias=K2, relu=True, Cb=C2, ldcb=K2, nb=K2), 2.0 * M2 * K2 * K2)
