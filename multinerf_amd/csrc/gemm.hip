@@ -156,8 +156,8 @@ __device__ __forceinline__ bf16x8 nt_read_half(const char* ht, int lrow, int ksl
 }
 
 // Profiling hook (tools/gemm_probe.py --timeline): when set, wave 0 of every workgroup records s_memtime at
-// kernel entry, K-loop start, K-loop end and kernel exit into g_nt_timeline[8 * blockIdx.x + 0..3], s_memrealtime
-// (100 MHz) at entry / exit into [4], [5] and XCC_ID << 32 | HW_ID into [6].
+// kernel entry, K-loop start, K-loop end and kernel exit into g_nt_timeline[16 * blockIdx.x + 0..3], s_memrealtime
+// (100 MHz) at entry / exit into [4], [5], XCC_ID << 32 | HW_ID into [6]; epilogue pass h: staged [8+2h], stored [9+2h].
 __device__ unsigned long long* g_nt_timeline = nullptr;
 
 extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
@@ -180,9 +180,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
   const int wm = wave / CFG::WN, wn = wave % CFG::WN;
   unsigned long long* const tl = g_nt_timeline;
   if (tl && tid == 0) {
-    tl[8 * (int64_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
-    tl[8 * (int64_t)blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();
-    tl[8 * (int64_t)blockIdx.x + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+    tl[16 * (int64_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    tl[16 * (int64_t)blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();
+    tl[16 * (int64_t)blockIdx.x + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
   }
 
   // XCD-aware mapping: the nt N-tiles of one M-tile run consecutively on one XCD.
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
 
-  if (tl && tid == 0) tl[8 * (int64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+  if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
   auto stage = [&](int kt) {
     const int k0 = kt * BK;
     char* base = smem + (kt % STAGES) * CFG::STAGE_BYTES;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
     }
   }
   }   // !phased
-  if (tl && tid == 0) tl[8 * (int64_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+  if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
   __syncthreads();      // every wave is done with the operand buffers: reuse them for the epilogue
 
   // Epilogue.  acc[j][i][r]: n = n0 + wn*32*NJ + j*32 + (r&3) + 8*(r>>2) + 4*khalf,
@@ -622,48 +622,82 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
               const int nl = wn * 32 * NJ + j * 32 + rq * 8 + khalf * 4;
-              float v[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = acc[j][i][rq * 4 + e] + bias_r[j][rq * 4 + e];
+              // packed fp32 adds (v_pk_add_f32), one v_cvt_pk_bf16_f32 per pair, ReLU on the bf16 bit
+              // patterns as a packed signed-16-bit max with 0 (negative floats are negative int16; rounding
+              // commutes with the clamp): 6 VALU ops per 4 outputs instead of 10.
+              const f32x2 a0 = {acc[j][i][rq * 4 + 0], acc[j][i][rq * 4 + 1]};
+              const f32x2 a1 = {acc[j][i][rq * 4 + 2], acc[j][i][rq * 4 + 3]};
+              const f32x2 b0 = {bias_r[j][rq * 4 + 0], bias_r[j][rq * 4 + 1]};
+              const f32x2 b1 = {bias_r[j][rq * 4 + 2], bias_r[j][rq * 4 + 3]};
+              const f32x2 s0 = a0 + b0, s1 = a1 + b1;
+              typedef short s16x2 __attribute__((ext_vector_type(2)));
+              s16x2 h0 = __builtin_bit_cast(s16x2, __builtin_convertvector(s0, bf16x2));
+              s16x2 h1 = __builtin_bit_cast(s16x2, __builtin_convertvector(s1, bf16x2));
               if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                const s16x2 z = {0, 0};
+                h0 = __builtin_elementwise_max(h0, z);
+                h1 = __builtin_elementwise_max(h1, z);
               }
-              f32x4 vv = {v[0], v[1], v[2], v[3]};
-              *(bf16x4*)(cs + ml * CFG::CPITCH + nl * 2) = __builtin_convertvector(vv, bf16x4);
+              typedef int i32x2 __attribute__((ext_vector_type(2)));
+              const i32x2 pk = {__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1)};
+              *(i32x2*)(cs + ml * CFG::CPITCH + nl * 2) = pk;
             }
           }
       }
       __syncthreads();
+      if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 8 + 2 * h] = __builtin_amdgcn_s_memtime();
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         const int c = it * CFG::THREADS + tid;
         const int row = c / CHUNKS_PER_ROW, ch = c % CHUNKS_PER_ROW;
         const int64_t m = m0 + h * CFG::EPI_ROWS + row;
-        bf16x8 v = *(const bf16x8*)(cs + row * CFG::CPITCH + ch * 16);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 w = *(const u32x4*)(cs + row * CFG::CPITCH + ch * 16);     // 8 bf16 as 4 dwords
         if (BITS_IN) {
-          // 1 bit per element, written by the forward epilogue of the layer whose ReLU this undoes.
-          const unsigned mb = mbits[BITS_IN ? h : 0][BITS_IN ? it : 0];
+          // 1 bit per element, written by the forward epilogue of the layer whose ReLU this undoes.  Dword d
+          // holds elements 2d (low half) and 2d+1: sign-extended 1-bit fields select the halves (v_bfe_i32, v_bfi).
+          const int mb = (int)mbits[BITS_IN ? h : 0][BITS_IN ? it : 0];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : (bf16)0.0f;
+          for (int d = 0; d < 4; ++d) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(mb, 2 * d, 1);
+            const unsigned hi = (unsigned)__builtin_amdgcn_sbfe(mb, 2 * d + 1, 1);
+            w[d] &= (lo & 0xffffu) | (hi & 0xffff0000u);
+          }
         } else if (mask) {
           const bf16x8 mk = *(const bf16x8*)(mask + m * p.ldmask + n0 + ch * 8);
+          bf16x8 v = __builtin_bit_cast(bf16x8, w);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = ((float)mk[e] > 0.0f) ? v[e] : (bf16)0.0f;
+          w = __builtin_bit_cast(u32x4, v);
         }
         if (p.mask_bits_out) {
-          // 8 bits per lane; 4 neighbouring lanes (same row, consecutive chunks) combine theirs into
-          // one aligned 32-bit store (byte stores cost ~an order of magnitude more per byte).
-          unsigned mb = 0;
+          // bit e = (element e > 0).  The outputs of a ReLU layer are >= 0, so "> 0" is "bits != 0" per 16-bit
+          // half: a packed unsigned min with 1 gives 0/1 in bit 0 and bit 16 of every dword; fold the 4 dwords
+          // into 8 bits.  4 neighbouring lanes (same row, consecutive chunks) combine theirs into one aligned
+          // 32-bit store (byte stores cost ~an order of magnitude more per byte).
+          typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+          unsigned f = 0;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) mb |= ((float)v[e] > 0.0f ? 1u : 0u) << e;
+          for (int d = 0; d < 4; ++d) {
+            const unsigned wd = w[d];     // (bit_cast straight from the vector element reads element 0: clang bug)
+            u16x2 hv = __builtin_bit_cast(u16x2, wd);
+            if (!p.relu) {                                               // general case: test the sign as well
+              typedef short s16x2b __attribute__((ext_vector_type(2)));
+              const s16x2b z = {0, 0};
+              hv = __builtin_bit_cast(u16x2, __builtin_elementwise_max(__builtin_bit_cast(s16x2b, hv), z));
+            }
+            const u16x2 one = {1, 1};
+            f |= __builtin_bit_cast(unsigned, __builtin_elementwise_min(hv, one)) << (2 * d);
+          }
+          unsigned mb = (f | (f >> 15)) & 0xffu;
           mb |= __shfl_down(mb, 1, 64) << 8;
           mb |= __shfl_down(mb, 2, 64) << 16;
           if ((ch & 3) == 0)
             *(unsigned*)(p.mask_bits_out + m * p.ld_bits_out + ((n0 + ch * 8) >> 3)) = mb;
         }
-        *(bf16x8*)(Cb + m * p.ldcb + n0 + ch * 8) = v;
+        *(u32x4*)(Cb + m * p.ldcb + n0 + ch * 8) = w;
       }
+      if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 9 + 2 * h] = __builtin_amdgcn_s_memtime();
       if (h + 1 < PASSES) __syncthreads();
     }
   }
@@ -715,8 +749,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
     }
   }
   if (tl && tid == 0) {
-    tl[8 * (int64_t)blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
-    tl[8 * (int64_t)blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+    tl[16 * (int64_t)blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
+    tl[16 * (int64_t)blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
   }
 }
 

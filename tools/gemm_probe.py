@@ -52,7 +52,7 @@ def main():
     bias = torch.zeros(N, device=dev)
     C = torch.empty((M, N + pad), dtype=bf, device=dev)
     nwg = (M // 256) * (N // 256)
-    buf = torch.zeros((nwg, 8), dtype=torch.int64, device=dev)
+    buf = torch.zeros((nwg, 16), dtype=torch.int64, device=dev)
     for c in [int(x) for x in (args.cfgs or '2,18').split(',')]:
       ops.L.check(ops.lib().mnr_gemm_nt_set_config(c, 0))
       fn = lambda: ops.gemm_nt(A, Bt, M=M, N=N, K1=K, bias=bias, n_bias=N, relu=True, Cb=C, ldcb=N + pad, nb=N,
@@ -84,6 +84,10 @@ def main():
       wg_rt = rt[:, 1] - rt[:, 0]
       ghz = np.median(tot[wg_rt > 0] / wg_rt[wg_rt > 0]) * 100 / 1e3
       q = lambda x: f'{np.median(x):.0f} [{np.percentile(x, 10):.0f} {np.percentile(x, 90):.0f}]'
+      ep = t[:, 8:12].astype(np.float64)
+      if (ep > 0).all():
+        e = [ep[:, 0] - tm[:, 2], ep[:, 1] - ep[:, 0], ep[:, 2] - ep[:, 1], ep[:, 3] - ep[:, 2], tm[:, 3] - ep[:, 3]]
+        print('   epilogue: stage0 ' + q(e[0]) + '  store0 ' + q(e[1]) + '  stage1 ' + q(e[2]) + '  store1 ' + q(e[3]) + '  tail ' + q(e[4]))
       print(f'pad {pad} cfg {c}: {len(t)} workgroups on {ncu} CUs; span {span_rt / 100:.1f} us '
             f'-> {ghz:.3f} GHz tick rate (per-workgroup memtime / realtime)\n'
             f'   per workgroup ticks median [p10 p90]: prologue {q(pro)}  K-loop {q(loop)}  epilogue {q(epi)}  total {q(tot)}\n'
