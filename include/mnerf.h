@@ -134,6 +134,22 @@ int mnr_cast_rays_ipe_tangent(const mnr_ipe_cfg* cfg, int64_t B, int n, const fl
 int mnr_viewdir_enc_fill(int64_t B, int n, const float* viewdirs, int deg_view,
                          uint16_t* dst, int ld, int col0, int col_end, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Ray generation  (replaces camera_utils.pixels_to_rays / cast_ray_batch,
+ * internal/camera_utils.py:520-688; used when Config.cast_rays_in_train_step,
+ * train_utils.py:267-268)
+ * pix_x_int / pix_y_int / cam_idx: int32 [B] (device).  pixtocams [num_cams,3,3],
+ * camtoworlds [num_cams,3,4] fp32 (device; num_cams == 1: one camera for all pixels,
+ * cam_idx may be NULL).  distortion6 = HOST pointer to {k1,k2,k3,k4,p1,p2} or NULL.
+ * pixtocam_ndc: device [3,3] or NULL (NDC rays, camera_utils.py:32-98).
+ * Outputs fp32 device: origins, directions, viewdirs [B,3], radii [B], imageplane [B,2].
+ * ------------------------------------------------------------------------- */
+typedef enum { MNR_CAM_PERSPECTIVE = 0, MNR_CAM_FISHEYE = 1 } mnr_camtype;
+int mnr_pixels_to_rays(int64_t B, const int32_t* pix_x_int, const int32_t* pix_y_int, const int32_t* cam_idx,
+                       int num_cams, const float* pixtocams, const float* camtoworlds, const float* distortion6,
+                       const float* pixtocam_ndc, int camtype, float* origins, float* directions, float* viewdirs,
+                       float* radii, float* imageplane, void* stream);
+
 /* GLO vectors (models.py:101-110,565-568): dst[b*n+i, col0+g] = table[cam_idx[b], g] (bf16), or 0 when
  * cam_idx is NULL (zero_glo=True).  table [num_embeddings, G] fp32 = params['Embed_0']['embedding']. */
 int mnr_glo_fill(int64_t B, int n, int G, const float* table, const int32_t* cam_idx, int num_embeddings,

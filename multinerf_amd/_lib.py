@@ -96,6 +96,7 @@ _PROTOS = {
     'mnr_cast_rays_ipe_f32': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_cast_rays_ipe_tangent': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, i32, vp], i32),
     'mnr_viewdir_enc_fill': ([i64, i32, vp, i32, vp, i32, i32, i32, vp], i32),
+    'mnr_pixels_to_rays': ([i64, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp], i32),
     'mnr_glo_fill': ([i64, i32, i32, vp, vp, i32, vp, i32, i32, vp], i32),
     'mnr_glo_bwd': ([i64, i32, i32, vp, vp, vp, i32, vp, vp], i32),
     'mnr_gemm_nt_bf16': ([C.POINTER(GemmNTArgs), vp], i32),

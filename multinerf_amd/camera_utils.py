@@ -1,0 +1,81 @@
+"""Ray generation on device: the reference's camera_utils.pixels_to_rays / cast_ray_batch
+(internal/camera_utils.py:514-688) behind the same names, backed by mnr_pixels_to_rays (csrc/camera.hip).
+
+Only the per-pixel leaves are here; pose utilities / camera paths stay out of scope.
+"""
+
+import ctypes as C
+import enum
+
+import torch
+
+from multinerf_amd import _lib as L
+from multinerf_amd import ops, utils
+
+
+class ProjectionType(enum.Enum):
+  """camera_utils.py:514-517."""
+  PERSPECTIVE = 'perspective'
+  FISHEYE = 'fisheye'
+
+
+_DIST_KEYS = ('k1', 'k2', 'k3', 'k4', 'p1', 'p2')
+
+
+def pixels_to_rays(pix_x_int, pix_y_int, pixtocams, camtoworlds, distortion_params=None, pixtocam_ndc=None,
+                   camtype=ProjectionType.PERSPECTIVE, cam_idx=None):
+  """camera_utils.py:520-631.  pixtocams [3,3] or [N,3,3] (+ cam_idx [...] selecting the camera per pixel; the
+  reference indexes the stacks before the call, `batch_index` camera_utils.py:665).  Device tensors in,
+  (origins, directions, viewdirs, radii, imageplane) out, shaped like the pixel arrays."""
+  shape = tuple(pix_x_int.shape)
+  dev = pix_x_int.device
+  if dev.type != 'cuda':
+    raise ValueError('pixels_to_rays: device tensors required (the HIP path has no CPU fallback)')
+  px = pix_x_int.reshape(-1).to(torch.int32).contiguous()
+  py = pix_y_int.reshape(-1).to(torch.int32).contiguous()
+  B = px.numel()
+  P = pixtocams.to(device=dev, dtype=torch.float32).reshape(-1, 3, 3).contiguous()
+  Cw = camtoworlds.to(device=dev, dtype=torch.float32)[..., :3, :4].reshape(-1, 3, 4).contiguous()
+  ncam = max(P.shape[0], Cw.shape[0])
+  if P.shape[0] != ncam:
+    P = P.expand(ncam, 3, 3).contiguous()
+  if Cw.shape[0] != ncam:
+    Cw = Cw.expand(ncam, 3, 4).contiguous()
+  ci = None
+  if ncam > 1:
+    if cam_idx is None:
+      raise ValueError('pixels_to_rays: stacked cameras need cam_idx')
+    ci = cam_idx.reshape(-1).to(torch.int32).contiguous()
+  dist = None
+  if distortion_params is not None:
+    unknown = set(distortion_params) - set(_DIST_KEYS)
+    if unknown:
+      raise TypeError(f'unexpected distortion parameters {sorted(unknown)}')      # **kwargs error of the reference
+    dist = (C.c_float * 6)(*[float(distortion_params.get(k, 0.0)) for k in _DIST_KEYS])
+  ndc = None
+  if pixtocam_ndc is not None:
+    ndc = torch.as_tensor(pixtocam_ndc).to(device=dev, dtype=torch.float32).reshape(3, 3).contiguous()
+  f32 = torch.float32
+  origins = torch.empty((B, 3), dtype=f32, device=dev)
+  directions = torch.empty((B, 3), dtype=f32, device=dev)
+  viewdirs = torch.empty((B, 3), dtype=f32, device=dev)
+  radii = torch.empty((B, 1), dtype=f32, device=dev)
+  imageplane = torch.empty((B, 2), dtype=f32, device=dev)
+  p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+  L.check(ops.lib().mnr_pixels_to_rays(
+      B, p(px), p(py), p(ci), ncam, p(P), p(Cw), C.cast(dist, C.c_void_p) if dist is not None else None, p(ndc),
+      1 if ProjectionType(camtype) == ProjectionType.FISHEYE else 0, p(origins), p(directions), p(viewdirs), p(radii),
+      p(imageplane), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+  r = lambda t, c: t.reshape(shape + (c,))
+  return r(origins, 3), r(directions, 3), r(viewdirs, 3), r(radii, 1), r(imageplane, 2)
+
+
+def cast_ray_batch(cameras, pixels, camtype=ProjectionType.PERSPECTIVE, xnp=None):
+  """camera_utils.py:634-688: utils.Pixels -> utils.Rays (`xnp` is accepted and ignored: arrays are torch)."""
+  pixtocams, camtoworlds, distortion_params, pixtocam_ndc = cameras
+  origins, directions, viewdirs, radii, imageplane = pixels_to_rays(
+      pixels.pix_x_int, pixels.pix_y_int, pixtocams, camtoworlds, distortion_params=distortion_params,
+      pixtocam_ndc=pixtocam_ndc, camtype=camtype, cam_idx=pixels.cam_idx[..., 0])
+  return utils.Rays(origins=origins, directions=directions, viewdirs=viewdirs, radii=radii, imageplane=imageplane,
+                    lossmult=pixels.lossmult, near=pixels.near, far=pixels.far, cam_idx=pixels.cam_idx,
+                    exposure_idx=pixels.exposure_idx, exposure_values=pixels.exposure_values)

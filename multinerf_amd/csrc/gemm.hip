@@ -10,6 +10,7 @@
 // address so the linear DMA image is conflict-free for the fragment reads.
 // Workgroup ids are remapped so that the tiles sharing an operand panel run
 // back to back on one XCD (block b lands on XCD b%8; each XCD has a private L2).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -1200,6 +1201,7 @@ extern "C" int mnr_cast_f32_to_bf16(const float* src, int ld_src, int64_t M, int
 // ---------------------------------------------------------------------------
 // Small-N head VJP (e.g. rgb Dense(3)): dX = relu'(H) * (g W^T), dW += H^T g, db += sum g.
 
+template <int U>
 __global__ __launch_bounds__(256) void small_head_bwd_kernel(int64_t M, int K, int C, const bf16* __restrict__ H,
                                                               int ldh, const float* __restrict__ g,
                                                               const float* __restrict__ W, bf16* __restrict__ dX,
@@ -1227,7 +1229,6 @@ __global__ __launch_bounds__(256) void small_head_bwd_kernel(int64_t M, int K, i
   if (rl < row_lanes) {
     // 4 rows per trip, all loads issued before the arithmetic: one row per trip leaves a single 16-byte load
     // in flight per thread and the kernel runs at ~1/5 of HBM bandwidth (profiles/r1_h: 475 us per call).
-    constexpr int U = 4;
     for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)row_lanes * U) {
       bf16x8 h[U];
       float gc[U][4];
@@ -1294,11 +1295,29 @@ extern "C" int mnr_small_head_bwd(int64_t M, int K, int C, const uint16_t* H, in
   MNR_CHECK_ARG(M > 0 && K > 0 && C >= 1 && C <= 4 && H && g && W, "mnr_small_head_bwd: bad arguments (1 <= C <= 4)");
   MNR_CHECK_ARG(K % 8 == 0 && K / 8 <= 256 && ldh % 8 == 0 && (!dX || lddx % 8 == 0),
                 "mnr_small_head_bwd: K must be a multiple of 8 (<= 2048) and the pitches multiples of 8");
-  const int rows_per_block = 256;
+  static int rows_env = -1, u_env = -1;                    // tuning hooks (tools/head_probe.py)
+  if (rows_env < 0) {
+    const char* e = getenv("MNR_SHB_ROWS");
+    rows_env = e ? atoi(e) : 0;
+    const char* u = getenv("MNR_SHB_UNROLL");
+    u_env = u ? atoi(u) : 0;
+  }
+  // Every workgroup ends with K*C fp32 atomics onto the same few cache lines of dW: more than ~512 workgroups
+  // and the kernel is bound by that serialisation (2048 workgroups: 508 us, 512: 291 us at M = 2^20, K = 256);
+  // fewer than ~256 and it loses memory parallelism.  tools/head_probe.py.
+  int rows_auto = (int)(((M + 511) / 512 + 63) / 64 * 64);
+  if (rows_auto < 512) rows_auto = 512;
+  const int rows_per_block = rows_env > 0 ? rows_env : rows_auto;
+  const int unroll = u_env > 0 ? u_env : 4;
   const int grid = mnr_cdiv(M, rows_per_block);
-  hipLaunchKernelGGL(small_head_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, C,
-                     (const bf16*)H, ldh, g, W, (bf16*)dX, lddx, apply_relu_mask, dW, db, rows_per_block, mask_bits,
-                     ld_bits, bits_row_mod);
+#define MNR_SHB_LAUNCH(UU)                                                                                          \
+  hipLaunchKernelGGL(small_head_bwd_kernel<UU>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, C,             \
+                     (const bf16*)H, ldh, g, W, (bf16*)dX, lddx, apply_relu_mask, dW, db, rows_per_block, mask_bits, \
+                     ld_bits, bits_row_mod)
+  if (unroll >= 4) MNR_SHB_LAUNCH(4);
+  else if (unroll >= 2) MNR_SHB_LAUNCH(2);
+  else MNR_SHB_LAUNCH(1);
+#undef MNR_SHB_LAUNCH
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }

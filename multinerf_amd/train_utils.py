@@ -15,7 +15,7 @@ from typing import Any, Callable, Dict, Optional
 import numpy as np
 import torch
 
-from multinerf_amd import dist as mdist
+from multinerf_amd import camera_utils, dist as mdist
 from multinerf_amd import models
 from multinerf_amd import ops
 from multinerf_amd import utils
@@ -62,8 +62,9 @@ def create_optimizer(config, variables):
 def create_train_step(model: models.Model, config, dataset=None):
   """train_utils.py:221-346.  Returns train_pstep(rng, state, batch, cameras, train_frac,
   loss_threshold) -> (new_state, stats, rng).  `batch.rays` holds THIS rank's shard."""
-  if config.cast_rays_in_train_step:
-    raise NotImplementedError('cast_rays_in_train_step (camera_utils on device) is a "next" row (SURVEY 8f N2)')
+  # train_utils.py:234-237: the dataset names the projection; perspective without one.
+  camtype = getattr(dataset, 'camtype', camera_utils.ProjectionType.PERSPECTIVE) if dataset is not None \
+      else camera_utils.ProjectionType.PERSPECTIVE
   if config.data_loss_type not in ('mse', 'charb', 'rawnerf'):
     raise NotImplementedError(f'data_loss_type {config.data_loss_type!r} is out of scope')
   use_orient = config.orientation_loss_mult > 0 or config.orientation_coarse_loss_mult > 0
@@ -78,6 +79,8 @@ def create_train_step(model: models.Model, config, dataset=None):
     flat = state.params['flat']
     dev = flat.device
     rays = batch.rays
+    if config.cast_rays_in_train_step:                                 # train_utils.py:267-268
+      rays = camera_utils.cast_ray_batch(cameras, rays, camtype)
     compute_extras = config.compute_disp_metrics or config.compute_normal_metrics
     use_rng = rng if config.randomized else None
     renderings, ray_history = model._forward(flat, use_rng, rays, train_frac, compute_extras, zero_glo=False,

@@ -302,6 +302,85 @@ def main():
   g['ru_l2n_in'] = x_l2
   g['ru_l2n'] = ref_utils.l2_normalize(x_l2)
 
+  # ---------------- camera_utils (ray generation leaves; executed with xnp = numpy) ----------------
+  # internal/camera_utils.py imports internal.configs / internal.utils (gin, flax): stub what it touches.
+  import dataclasses
+  cfg_stub = types.ModuleType('internal.configs')
+  utils_stub = types.ModuleType('internal.utils')
+
+  @dataclasses.dataclass
+  class Pixels:
+    pix_x_int: object
+    pix_y_int: object
+    lossmult: object
+    near: object
+    far: object
+    cam_idx: object
+    exposure_idx: object = None
+    exposure_values: object = None
+
+  @dataclasses.dataclass
+  class Rays:
+    origins: object
+    directions: object
+    viewdirs: object
+    radii: object
+    imageplane: object
+    lossmult: object
+    near: object
+    far: object
+    cam_idx: object
+    exposure_idx: object = None
+    exposure_values: object = None
+
+  utils_stub.Pixels, utils_stub.Rays = Pixels, Rays
+  cfg_stub.Config = object          # only used in a type annotation (camera_utils.py:344)
+  sys.modules['internal.configs'] = cfg_stub
+  sys.modules['internal.utils'] = utils_stub
+  from internal import camera_utils
+  rc = np.random.RandomState(424242)
+  ncam, B = 5, 48
+  W, H, focal = 64, 48, 70.0
+  pixtocam = np.linalg.inv(np.array([[focal, 0, W / 2.], [0, focal, H / 2.], [0, 0, 1.]]))
+  pixtocams = np.stack([pixtocam * (1 + 0.02 * i) for i in range(ncam)], 0)
+  c2w = []
+  for i in range(ncam):
+    q, _ = np.linalg.qr(rc.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+      q[:, 0] = -q[:, 0]
+    c2w.append(np.concatenate([q, rc.uniform(-1, 1, (3, 1))], 1))
+  c2w = np.stack(c2w, 0)
+  px = rc.randint(0, W, (B,))
+  py = rc.randint(0, H, (B,))
+  ci = rc.randint(0, ncam, (B, 1))
+  g['cam_pixtocams'], g['cam_camtoworlds'] = pixtocams, c2w
+  g['cam_pix_x'], g['cam_pix_y'], g['cam_idx'] = px.astype(np.int64), py.astype(np.int64), ci.astype(np.int64)
+  dist = dict(k1=0.05, k2=-0.02, k3=0.003, k4=0.0, p1=0.001, p2=-0.002)
+  g['cam_dist'] = np.array([dist[k] for k in ('k1', 'k2', 'k3', 'k4', 'p1', 'p2')])
+  # forward-facing variant for NDC (dz < 0 in OpenGL coordinates): small rotations about the identity pose
+  c2w_ff = np.stack([np.concatenate([np.eye(3) + 0.05 * rc.normal(size=(3, 3)), rc.uniform(-0.2, 0.2, (3, 1))], 1)
+                     for _ in range(ncam)], 0)
+  g['cam_camtoworlds_ff'] = c2w_ff
+  pixels = Pixels(pix_x_int=px, pix_y_int=py, lossmult=np.ones((B, 1)), near=np.full((B, 1), 0.2),
+                  far=np.full((B, 1), 100.), cam_idx=ci)
+  cases = {
+      'persp': ((pixtocams, c2w, None, None), camera_utils.ProjectionType.PERSPECTIVE),
+      'single': ((pixtocams[0], c2w[0], None, None), camera_utils.ProjectionType.PERSPECTIVE),
+      'dist': ((pixtocams, c2w, dist, None), camera_utils.ProjectionType.PERSPECTIVE),
+      'fisheye': ((pixtocams, c2w, dist, None), camera_utils.ProjectionType.FISHEYE),
+      'ndc': ((pixtocams, c2w_ff, None, pixtocam), camera_utils.ProjectionType.PERSPECTIVE),
+  }
+  for name, (cams, ct) in cases.items():
+    r = camera_utils.cast_ray_batch(cams, pixels, ct, xnp=np)
+    for f in ('origins', 'directions', 'viewdirs', 'radii', 'imageplane'):
+      g[f'cam_{name}_{f}'] = getattr(r, f)
+  xu, yu = camera_utils._radial_and_tangential_undistort(rc.uniform(-0.6, 0.6, 40), rc.uniform(-0.5, 0.5, 40), **dist)
+  g['cam_undistort_in'] = np.stack([xu * 0, yu * 0])  # placeholder overwritten below
+  xd_in, yd_in = rc.uniform(-0.6, 0.6, 40), rc.uniform(-0.5, 0.5, 40)
+  xu, yu = camera_utils._radial_and_tangential_undistort(xd_in, yd_in, **dist)
+  g['cam_undistort_in'] = np.stack([xd_in, yd_in])
+  g['cam_undistort_out'] = np.stack([xu, yu])
+
   g = {k: np.asarray(v) for k, v in g.items() if v is not None}
   np.savez_compressed(OUT, **g)
   print(f'wrote {OUT}: {len(g)} arrays, {os.path.getsize(OUT)} bytes')

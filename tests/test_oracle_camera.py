@@ -1,0 +1,52 @@
+"""oracle/camera_utils.py against the reference's own camera_utils (executed by tests/golden/make_golden.py)."""
+
+import numpy as np
+import pytest
+import torch
+
+from multinerf_amd import utils
+from oracle import camera_utils as ocam
+
+FIELDS = ('origins', 'directions', 'viewdirs', 'radii', 'imageplane')
+
+
+def _cases(golden, dtype):
+  t = lambda k: torch.as_tensor(golden[k]).to(dtype)
+  dist = dict(zip(('k1', 'k2', 'k3', 'k4', 'p1', 'p2'), [float(x) for x in golden['cam_dist']]))
+  pix = np.linalg.inv(np.array([[70.0, 0, 32.], [0, 70.0, 24.], [0, 0, 1.]]))
+  ndc = torch.as_tensor(pix).to(dtype)
+  P, C, Cff = t('cam_pixtocams'), t('cam_camtoworlds'), t('cam_camtoworlds_ff')
+  return {
+      'persp': ((P, C, None, None), ocam.ProjectionType.PERSPECTIVE),
+      'single': ((P[0], C[0], None, None), ocam.ProjectionType.PERSPECTIVE),
+      'dist': ((P, C, dist, None), ocam.ProjectionType.PERSPECTIVE),
+      'fisheye': ((P, C, dist, None), ocam.ProjectionType.FISHEYE),
+      'ndc': ((P, Cff, None, ndc), ocam.ProjectionType.PERSPECTIVE),
+  }
+
+
+def _pixels(golden):
+  B = golden['cam_pix_x'].shape[0]
+  return utils.Pixels(pix_x_int=torch.as_tensor(golden['cam_pix_x']), pix_y_int=torch.as_tensor(golden['cam_pix_y']),
+                      lossmult=torch.ones((B, 1)), near=torch.full((B, 1), 0.2), far=torch.full((B, 1), 100.),
+                      cam_idx=torch.as_tensor(golden['cam_idx']))
+
+
+@pytest.mark.parametrize('name', ['persp', 'single', 'dist', 'fisheye', 'ndc'])
+def test_cast_ray_batch_matches_reference(golden, name):
+  cams, ct = _cases(golden, torch.float64)[name]
+  rays = ocam.cast_ray_batch(cams, _pixels(golden), ct)
+  for f in FIELDS:
+    np.testing.assert_allclose(rays[f].numpy(), golden[f'cam_{name}_{f}'], rtol=1e-10, atol=1e-12, err_msg=f)
+  # fp32 (what the kernel is held to)
+  cams32, _ = _cases(golden, torch.float32)[name]
+  rays32 = ocam.cast_ray_batch(cams32, _pixels(golden), ct)
+  for f in FIELDS:
+    np.testing.assert_allclose(rays32[f].numpy(), golden[f'cam_{name}_{f}'], rtol=2e-4, atol=2e-5, err_msg=f)
+
+
+def test_undistort_matches_reference(golden):
+  dist = dict(zip(('k1', 'k2', 'k3', 'k4', 'p1', 'p2'), [float(x) for x in golden['cam_dist']]))
+  xd, yd = (torch.as_tensor(v) for v in golden['cam_undistort_in'])
+  x, y = ocam._radial_and_tangential_undistort(xd, yd, **dist)
+  np.testing.assert_allclose(torch.stack([x, y]).numpy(), golden['cam_undistort_out'], rtol=1e-12)
