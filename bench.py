@@ -190,6 +190,14 @@ def main():
                              'whole_step_frac_of_mfma_peak': train_b * Bb / dt / 2.5e15}
     del model_b, state_b, step_b, batch_b
 
+  # HBM bytes of the GEMM kernels per train step from the PMC passes of the last profiled build (same command,
+  # same workload); null for any other workload.  tools/profile_round.sh regenerates the inputs.
+  traffic = None
+  tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic.json')
+  if args.preset == '360' and not args.gin_bindings and B == 16384 and os.path.exists(tpath):
+    with open(tpath) as f:
+      traffic = json.load(f).get('gemm_hbm_bytes_per_step')
+
   out = None
   if rank == 0:
     rays_per_sec = B * world * args.steps / elapsed
@@ -228,7 +236,7 @@ def main():
             'peak': 2500.0,
             'unit': 'TFLOP/s',
             'frac': achieved_tflops / 2500.0,
-            'traffic': None,
+            'traffic': traffic,
             'gemm_ms_per_step': gemm_ms_per_step,
             'gemm_launches_per_step': gemm_launches / nprof,
             'gemm_share_of_step': gemm_ms_per_step / ms_per_step,
