@@ -79,3 +79,19 @@ def cast_ray_batch(cameras, pixels, camtype=ProjectionType.PERSPECTIVE, xnp=None
   return utils.Rays(origins=origins, directions=directions, viewdirs=viewdirs, radii=radii, imageplane=imageplane,
                     lossmult=pixels.lossmult, near=pixels.near, far=pixels.far, cam_idx=pixels.cam_idx,
                     exposure_idx=pixels.exposure_idx, exposure_values=pixels.exposure_values)
+
+
+def intrinsic_matrix(fx, fy, cx, cy):
+  """camera_utils.py:398-408."""
+  return torch.tensor([[fx, 0., cx], [0., fy, cy], [0., 0., 1.]], dtype=torch.float64)
+
+
+def get_pixtocam(focal, width, height):
+  """camera_utils.py:411-417 (inverted in fp64, returned fp32)."""
+  return torch.linalg.inv(intrinsic_matrix(focal, focal, width * .5, height * .5)).float()
+
+
+def pixel_coordinates(width, height, device='cpu'):
+  """camera_utils.py:420-424: (x, y) integer grids, each [height, width]."""
+  y, x = torch.meshgrid(torch.arange(height, device=device), torch.arange(width, device=device), indexing='ij')
+  return x, y
