@@ -570,3 +570,69 @@ def test_clip_adam(ops):
   np.testing.assert_allclose(dp.cpu().numpy(), ref_p.numpy(), rtol=1e-5, atol=1e-7)
   np.testing.assert_allclose(dmu.cpu().numpy(), torch.cat([new_s['mu']['a']['k'], new_s['mu']['b']['k']]).numpy(), rtol=1e-5, atol=1e-9)
   np.testing.assert_allclose(dnu.cpu().numpy(), torch.cat([new_s['nu']['a']['k'], new_s['nu']['b']['k']]).numpy(), rtol=1e-5, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------- small ABI leaves added with
+# GLO / Ref-NeRF / metrics / weight decay (each against a few lines of torch)
+
+def test_glo_fill_and_bwd(ops):
+  g = torch.Generator().manual_seed(3)
+  B, n, G, E, ld, col0 = 9, 4, 5, 17, 32, 8
+  table = torch.randn((E, G), generator=g).cuda()
+  cam = torch.randint(0, E, (B,), generator=g).to(torch.int32).cuda()
+  dst = torch.full((B * n, ld), 7.0, dtype=torch.bfloat16).cuda()
+  ops.glo_fill(table, cam, B, n, dst, col0)
+  want = table[cam.long()].repeat_interleave(n, 0).to(torch.bfloat16)
+  assert torch.equal(dst[:, col0:col0 + G], want)
+  assert (dst[:, :col0] == 7).all() and (dst[:, col0 + G:] == 7).all()          # only its own columns
+  ops.glo_fill(table, None, B, n, dst, col0)                                      # zero_glo
+  assert (dst[:, col0:col0 + G] == 0).all()
+  ga = torch.randn((B * n, G), generator=g).cuda()
+  gb = torch.randn((B * n, G), generator=g).cuda()
+  grad = torch.zeros((E, G)).cuda()
+  ops.glo_bwd(ga, gb, cam, B, n, grad.view(-1), E, G)
+  ref = torch.zeros((E, G)).cuda().index_add_(0, cam.long(), (ga + gb).view(B, n, G).sum(1))
+  np.testing.assert_allclose(grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_add_cols_bf16(ops):
+  g = torch.Generator().manual_seed(4)
+  a = torch.randn((64, 48), generator=g).to(torch.bfloat16).cuda()
+  b = torch.randn((64, 40), generator=g).to(torch.bfloat16).cuda()
+  dst = torch.zeros((64, 56), dtype=torch.bfloat16).cuda()
+  ops.add_cols_bf16(a, b, dst, 32)
+  assert torch.equal(dst[:, :32], (a[:, :32].float() + b[:, :32].float()).to(torch.bfloat16))
+  assert (dst[:, 32:] == 0).all()
+  ops.add_cols_bf16(a, None, dst, 16)
+  assert torch.equal(dst[:, :16], a[:, :16])
+
+
+def test_render_metrics(ops):
+  g = torch.Generator().manual_seed(5)
+  B = 777
+  dm, disp = torch.rand(B, generator=g) * 5, torch.rand(B, generator=g)
+  acc, al = torch.rand(B, generator=g), torch.rand(B, generator=g)
+  n, ngt = torch.randn((B, 3), generator=g), torch.randn((B, 3), generator=g)
+  out = torch.zeros(2).cuda()
+  ops.render_metrics(B, distance_mean=dm.cuda(), disps=disp.cuda(), acc=acc.cuda(), alphas=al.cuda(), normals=n.cuda(),
+                     normals_gt=ngt.cuda(), out_disp=out[0:1], out_normal=out[1:2])
+  want_d = ((1 / (1 + dm) - disp)**2).mean()
+  w = acc * al
+  nn = n / n.norm(dim=-1, keepdim=True)
+  gg = ngt / ngt.norm(dim=-1, keepdim=True)
+  want_n = (w * torch.arccos(torch.clamp((nn * gg).sum(-1), -1 + 1.2e-7, 1 - 1.2e-7))).sum() / w.sum() * 180 / math.pi
+  np.testing.assert_allclose(out.cpu().numpy(), [want_d.item(), want_n.item()], rtol=2e-5)
+
+
+def test_weight_decay(ops):
+  g = torch.Generator().manual_seed(6)
+  p = torch.randn(5000, generator=g).cuda()
+  grad = torch.randn(5000, generator=g).cuda()
+  g0 = grad.clone()
+  out = torch.zeros(2).cuda()
+  ops.weight_decay(p, 100, 4100, 0.25, grad, out[0:1], out[1:2])
+  sq = (p[100:4100].double()**2).sum().item()
+  np.testing.assert_allclose(out.cpu().numpy(), [0.25 * sq, sq], rtol=1e-5)
+  want = g0.clone()
+  want[100:4100] += 0.5 * p[100:4100]
+  np.testing.assert_allclose(grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-7)
