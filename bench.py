@@ -145,8 +145,14 @@ def main():
   for _ in range(nprof):
     step()
   torch.cuda.synchronize()
-  gemm_ms, gemm_launches = ops.PROFILE.collect()
+  by_tag = ops.PROFILE.collect_by_tag()
   ops.PROFILE.disable()
+  gemm_ms, gemm_launches = by_tag.get('gemm', {}).get('ms', 0.0), by_tag.get('gemm', {}).get('launches', 0)
+  # secondary report: the bandwidth-bound kernels against the 8 TB/s HBM peak, algorithmic bytes
+  hbm_kernels = {tag: {'ms_per_step': d['ms'] / nprof, 'launches_per_step': d['launches'] / nprof,
+                       'algorithmic_GBps': d['bytes'] / (d['ms'] * 1e-3) / 1e9 if d['ms'] > 0 else None,
+                       'frac_of_8TBps': d['bytes'] / (d['ms'] * 1e-3) / 8e12 if d['ms'] > 0 else None}
+                 for tag, d in by_tag.items() if tag != 'gemm'}
   gemm_ms_per_step = gemm_ms / nprof
   achieved_tflops = train_flops * B / (gemm_ms_per_step * 1e-3) / 1e12
 
@@ -240,6 +246,7 @@ def main():
             'gemm_ms_per_step': gemm_ms_per_step,
             'gemm_launches_per_step': gemm_launches / nprof,
             'gemm_share_of_step': gemm_ms_per_step / ms_per_step,
+            'hbm_bound_kernels': hbm_kernels,
         },
     }
     if aux:

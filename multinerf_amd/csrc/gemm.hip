@@ -859,6 +859,12 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   const bool big_ok = (a->M % 256 == 0) && (a->N % 256 == 0);
   int cfg = big_ok ? g_nt_cfg_big : g_nt_cfg_small;
   if (cfg >= 30 && !a->Bp) cfg = 2;                      // the direct-weights loop needs the fragment-major image
+  static int phased_min_k = -1;                          // tuning hook: phased loop for long-K forward GEMMs only
+  if (phased_min_k < 0) {
+    const char* e = getenv("MNR_NT_PHASED_MIN_K");
+    phased_min_k = e ? atoi(e) : 0;
+  }
+  if (cfg == 2 && phased_min_k > 0 && a->K1 + a->K2 >= phased_min_k && !a->mask_bits_in && !a->mask) cfg = 18;
   return nt_dispatch(cfg, a, fast_epi, stream);
 }
 

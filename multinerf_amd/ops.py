@@ -52,7 +52,8 @@ def lib():
 
 
 class _GemmProfile:
-  """Optional HIP-event timing of every GEMM launch on the launch stream (bench.py roofline)."""
+  """Optional HIP-event timing of kernel launches on the launch stream (bench.py roofline): GEMMs under the tag
+  'gemm', the bandwidth-bound kernels under their own tags together with their algorithmic HBM bytes."""
 
   def __init__(self):
     self.on = False
@@ -71,19 +72,29 @@ class _GemmProfile:
     e0.record(torch.cuda.current_stream())
     return e0
 
-  def stop(self, e0):
+  def stop(self, e0, tag='gemm', nbytes=0):
     if e0 is None:
       return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record(torch.cuda.current_stream())
-    self.events.append((e0, e1))
+    self.events.append((e0, e1, tag, nbytes))
 
   def collect(self):
-    """-> (total ms, launches); call after a synchronize."""
-    ms = sum(a.elapsed_time(b) for a, b in self.events)
-    n = len(self.events)
+    """-> (total GEMM ms, GEMM launches); call after a synchronize.  Other tags: collect_by_tag() first."""
+    by = self.collect_by_tag()
+    g = by.get('gemm', dict(ms=0.0, launches=0))
+    return g['ms'], g['launches']
+
+  def collect_by_tag(self):
+    """-> {tag: {'ms', 'launches', 'bytes'}}; empties the event list."""
+    out = {}
+    for a, b, tag, nbytes in self.events:
+      d = out.setdefault(tag, dict(ms=0.0, launches=0, bytes=0))
+      d['ms'] += a.elapsed_time(b)
+      d['launches'] += 1
+      d['bytes'] += nbytes
     self.events = []
-    return ms, n
+    return out
 
 
 PROFILE = _GemmProfile()
@@ -111,9 +122,11 @@ def resample_level(sdist_prev, w_prev, u_base, jitter, near, far, *, n_samples, 
   sdist = torch.empty((B, n_samples + 1), dtype=f32, device=dev)
   tdist = torch.empty((B, n_samples + 1), dtype=f32, device=dev)
   idx = torch.empty((B, n_samples), dtype=torch.int32, device=dev) if want_idx else None
+  _e = PROFILE.start()
   L.check(lib().mnr_resample_level(C.byref(cfg), B, _ptr(sdist_prev), _ptr(w_prev), _ptr(u_base),
                                    _ptr(jitter), _ptr(near), _ptr(far), _ptr(sdist), _ptr(tdist),
                                    _ptr(idx), _stream()))
+  PROFILE.stop(_e, 'resample', 4 * (sdist_prev.numel() + w_prev.numel() + 2 * sdist_prev.shape[0] * (n_samples + 1)))
   return (sdist, tdist, idx) if want_idx else (sdist, tdist)
 
 
@@ -168,9 +181,11 @@ def cast_rays_ipe(tdist, origins, directions, radii, basis, *, ray_shape, warp_c
   if want_gaussians:
     means = torch.empty((B * n, 3), dtype=f32, device=dev)
     covs = torch.empty((B * n, 9), dtype=f32, device=dev)
+  _e = PROFILE.start()
   L.check(lib().mnr_cast_rays_ipe(C.byref(cfg), B, n, _ptr(tdist), _ptr(origins), _ptr(directions),
                                   _ptr(radii), _ptr(basis), _ptr(out), ld_feat, _ptr(means), _ptr(covs),
                                   _stream()))
+  PROFILE.stop(_e, 'ipe', 4 * tdist.numel() + 2 * out.numel())
   return (out, means, covs) if want_gaussians else out
 
 
@@ -318,9 +333,11 @@ def small_head_bwd(H, ldh, g, W, *, M, K, Cn, dX=None, lddx=0, relu_mask=True, d
   _chk(H, bf16, 'H')
   _chk(g, f32, 'g')
   _chk(W, f32, 'W')
+  _e = PROFILE.start()
   L.check(lib().mnr_small_head_bwd(M, K, Cn, _ptr(H), ldh, _ptr(g), _ptr(W), _ptr(dX), lddx, int(relu_mask),
                                    _ptr(dW), _ptr(db), _ptr(bits), bits.stride(0) if bits is not None else 0,
                                    bits_row_mod, _stream()))
+  PROFILE.stop(_e, 'small_head_bwd', 2 * M * K * (2 if dX is not None else 1) + 4 * M * Cn)
 
 
 # ----------------------------------------------------------------------------- compositing
@@ -348,9 +365,11 @@ def composite_fwd(cfg, raw_density, tdist, dirs, *, raw_rgb=None, density_noise=
   rgb = torch.empty((B, n, 3), dtype=f32, device=dev) if cfg.has_rgb else None
   rgb_out = torch.empty((B, 3), dtype=f32, device=dev)
   acc = torch.empty((B,), dtype=f32, device=dev) if want_acc else None
+  _e = PROFILE.start()
   L.check(lib().mnr_composite_fwd(C.byref(cfg), B, _ptr(raw_density), _ptr(density_noise), _ptr(raw_rgb),
                                   _ptr(tdist), _ptr(dirs), _ptr(bg), _ptr(exposure_scale), _ptr(density),
                                   _ptr(rgb), _ptr(weights), _ptr(rgb_out), _ptr(acc), _stream()))
+  PROFILE.stop(_e, 'composite_fwd', 4 * (raw_density.numel() * (2 + 2 + (6 if raw_rgb is not None else 0))))
   return density, rgb, weights, rgb_out, acc
 
 
@@ -366,10 +385,12 @@ def composite_bwd(cfg, raw_density, tdist, dirs, weights, *, raw_rgb=None, densi
   _chk(g_den_bf16, bf16, 'g_den_bf16', allow_none=True)
   g_raw_density = torch.empty((B, n), dtype=f32, device=dev) if want_f32 else None
   g_raw_rgb = torch.empty((B, n, 3), dtype=f32, device=dev) if cfg.has_rgb else None
+  _e = PROFILE.start()
   L.check(lib().mnr_composite_bwd(C.byref(cfg), B, _ptr(raw_density), _ptr(density_noise), _ptr(raw_rgb),
                                   _ptr(tdist), _ptr(dirs), _ptr(bg), _ptr(exposure_scale), _ptr(weights),
                                   _ptr(g_rgb_out), _ptr(g_weights), _ptr(g_raw_density), _ptr(g_den_bf16),
                                   ld_bf16, _ptr(g_raw_rgb), _ptr(g_exposure_scale), _stream()))
+  PROFILE.stop(_e, 'composite_bwd', 4 * (raw_density.numel() * (3 + (3 if raw_rgb is not None else 0))) + (2 + (12 if raw_rgb is not None else 0)) * raw_density.numel())
   return g_raw_density, g_raw_rgb
 
 
@@ -586,5 +607,7 @@ def clip_adam(grad, params, mu, nu, begin, end, sqnorm, *, lr, b1, b2, eps, step
     _chk(x, f32, nm)
   cfg = L.AdamCfg(float(lr), float(b1), float(b2), float(eps), float(1 - b1**step), float(1 - b2**step),
                   float(grad_max_val), float(grad_max_norm))
+  _e = PROFILE.start()
   L.check(lib().mnr_clip_adam(C.byref(cfg), begin, end, _ptr(sqnorm), _ptr(grad), _ptr(params), _ptr(mu),
                               _ptr(nu), _stream()))
+  PROFILE.stop(_e, 'clip_adam', 28 * (end - begin))
