@@ -122,9 +122,11 @@ __global__ __launch_bounds__(CP_THREADS) void composite_fwd_kernel(
 }
 
 // Rays per block: 64 if the staging fits in LDS, else halved until it does.
-static int cp_rays_per_block(int n) {
+static int cp_rays_per_block(int n, int64_t B) {
   int s = CP_THREADS;
   while (s > 1 && (size_t)(6 * n + 1) * s * 4 > 150 * 1024) s >>= 1;
+  // lane per ray is latency-bound: spread small batches over >= 1024 workgroups (one wave each)
+  while (s > 8 && B / s < 1024) s >>= 1;
   return s;
 }
 static size_t cp_lds_bytes(int n, int s) { return (size_t)(6 * n + 1) * s * 4; }
@@ -138,7 +140,7 @@ extern "C" int mnr_composite_fwd(const mnr_composite_cfg* cfg, int64_t B, const 
   MNR_CHECK_ARG(cfg->n >= 1 && cfg->n <= 1024, "mnr_composite_fwd: n out of range");
   MNR_CHECK_ARG(!cfg->has_rgb || raw_rgb, "mnr_composite_fwd: has_rgb needs raw_rgb");
   MNR_CHECK_ARG(cfg->bg_mode == 0 || bg, "mnr_composite_fwd: bg_mode 1 needs bg");
-  const int S = cp_rays_per_block(cfg->n);
+  const int S = cp_rays_per_block(cfg->n, B);
   const size_t lds = cp_lds_bytes(cfg->n, S);
   MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_composite_fwd: n=%d too long for LDS staging", cfg->n);
   static bool attr_set = false;
@@ -267,7 +269,7 @@ extern "C" int mnr_composite_bwd(const mnr_composite_cfg* cfg, int64_t B, const 
   MNR_CHECK_ARG(g_raw_density || g_raw_density_bf16, "mnr_composite_bwd: no density-gradient output");
   MNR_CHECK_ARG(!cfg->has_rgb || raw_rgb, "mnr_composite_bwd: has_rgb needs raw_rgb");
   MNR_CHECK_ARG(cfg->bg_mode == 0 || bg, "mnr_composite_bwd: bg_mode 1 needs bg");
-  const int S = cp_rays_per_block(cfg->n);
+  const int S = cp_rays_per_block(cfg->n, B);
   const size_t lds = cp_lds_bytes(cfg->n, S);
   MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_composite_bwd: n=%d too long for LDS staging", cfg->n);
   static bool attr_set = false;

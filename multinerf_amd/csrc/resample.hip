@@ -253,7 +253,10 @@ extern "C" int mnr_resample_level(const mnr_resample_cfg* cfg, int64_t B, const 
   MNR_CHECK_ARG(cfg->n_prev >= 1 && cfg->n_prev <= 1024 && cfg->n_samples <= 1024,
                 "mnr_resample_level: n_prev=%d / n_samples=%d out of range", cfg->n_prev, cfg->n_samples);
   MNR_CHECK_ARG(cfg->raydist_fn >= 0 && cfg->raydist_fn <= MNR_RAYDIST_SQUARE, "mnr_resample_level: bad raydist_fn");
-  const RsLayout lay = rs_layout(cfg);
+  RsLayout lay = rs_layout(cfg);
+  // One lane per ray is latency-bound; with 64 rays per wave a 16384-ray batch is only 256 waves for 1024
+  // SIMDs.  Fewer rays per (64-thread) workgroup spreads the same serial work over more SIMDs.
+  while (lay.rpb > 8 && B / lay.rpb < 1024) lay.rpb >>= 1;
   const size_t lds_bytes = (size_t)(lay.a_len + lay.b_len) * lay.rpb * 4;
   MNR_CHECK_ARG(lds_bytes <= 160 * 1024, "mnr_resample_level: step function too long for LDS");
   static bool attr_set = false;

@@ -6,7 +6,6 @@ import numpy as np
 import torch
 
 from multinerf_amd import configs, gin, models, utils
-from oracle import models as omodels
 
 
 def synthetic_rays(B, seed=20200823, near=0.2, far=1e6, device='cpu'):
@@ -30,6 +29,7 @@ def synthetic_rays(B, seed=20200823, near=0.2, far=1e6, device='cpu'):
 
 def oracle_hparams(model: models.Model):
   """Product hyper-parameter objects -> the oracle's dataclasses (same field names)."""
+  from oracle import models as omodels        # imported here: bench.py uses the ray helpers without the oracle
   def conv(src, cls):
     names = {f.name for f in dataclasses.fields(cls)}
     kw = {f.name: getattr(src, f.name) for f in dataclasses.fields(src) if f.name in names and f.name != 'config'}
