@@ -799,13 +799,15 @@ typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 4> NtC24;   //   no ds_reads
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 6> NtC25;   //   MFMA + barriers only
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 5> NtC26;   //   DMA + barriers only
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 7> NtC27;   //   barriers only
+typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
+typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register double-buffered fragments
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 6> NtC30;      // 256x256 phased, weights direct from the fragment-major image (needs args.Bp)
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 6, 1> NtC32;   //   probe: no MFMA
 
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 32 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 34 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -830,6 +832,8 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 26: return nt_launch<NtC26>(a, fast_epi, stream);
     case 27: return nt_launch<NtC27>(a, fast_epi, stream);
     case 30: return nt_launch<NtC30>(a, fast_epi, stream);
+    case 33: return nt_launch<NtC33>(a, fast_epi, stream);
+    case 34: return nt_launch<NtC34>(a, fast_epi, stream);
     case 32: return nt_launch<NtC32>(a, fast_epi, stream);
     default:
       mnr_set_error("mnr_gemm_nt_bf16: configuration %d is not compiled in", cfg);
