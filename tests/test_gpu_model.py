@@ -200,3 +200,35 @@ def test_render_image_chunks():
   full, _ = model.apply({'flat': flat}, None, b.rays.map(lambda t: t.cuda()), 1.0, True)
   np.testing.assert_allclose(out['rgb'].reshape(-1, 3).cpu().numpy(), full[-1]['rgb'].cpu().numpy(), atol=1e-6)
   assert len(out['ray_sdist']) == model.num_levels
+
+
+@pytest.mark.parametrize('B', [1, 7])
+def test_tiny_and_ragged_batches(B):
+  """Batches that are not a multiple of the 8-ray padding unit (and a single ray): same as the oracle."""
+  cfg, model, (om, on, op), params, flat, batch = _setup('blender_256', [], B)
+  r_o, h_o = omodels.model_apply(om, on, op, params, batch.rays, 0.5, True, dense_dtype=torch.bfloat16)
+  rend, hist = model.apply({'flat': flat}, None, batch.rays.map(lambda t: t.cuda()), 0.5, True)
+  assert rend[-1]['rgb'].shape == (B, 3) and hist[-1]['weights'].shape == (B, model.num_nerf_samples)
+  np.testing.assert_allclose(rend[-1]['rgb'].cpu().numpy(), r_o[-1]['rgb'].numpy(), atol=5e-3)
+  np.testing.assert_allclose(rend[-1]['acc'].cpu().numpy(), r_o[-1]['acc'].numpy(), atol=5e-3)
+  # a train step on the ragged batch: padded rays must not contribute
+  st = otrain.init_opt_state(params)
+  noise = helpers.make_noise(model, B)
+  _, _, stats_o, _ = otrain.train_step(params, st, om, on, op, cfg, batch, 0.3, noise=noise, dense_dtype=torch.bfloat16)
+  state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+  _, stats, _ = train_utils.create_train_step(model, cfg)(0, state, batch.map(lambda t: t.cuda()), None, 0.3, 0.0, noise=noise)
+  s = stats.materialize()
+  assert abs(s['loss'] - float(stats_o['loss'])) <= 0.02 * abs(float(stats_o['loss'])) + 1e-5
+
+
+def test_leading_dims_are_preserved():
+  """Model.__call__ accepts arbitrary leading dims (models.py:75-94): [H, W, ...] rays in, [H, W, ...] out."""
+  cfg, model, _, params, flat, _ = _setup('blender_256', [], 8)
+  H, W = 3, 5
+  b = helpers.synthetic_rays(H * W, near=cfg.near, far=cfg.far)
+  rays = b.rays.map(lambda t: t.reshape(H, W, -1).cuda())
+  rend, hist = model.apply({'flat': flat}, None, rays, 1.0, True)
+  flat_rend, flat_hist = model.apply({'flat': flat}, None, b.rays.map(lambda t: t.cuda()), 1.0, True)
+  assert rend[-1]['rgb'].shape == (H, W, 3) and rend[-1]['acc'].shape == (H, W)
+  assert hist[0]['sdist'].shape == (H, W, model.num_prop_samples + 1)
+  np.testing.assert_allclose(rend[-1]['rgb'].reshape(-1, 3).cpu().numpy(), flat_rend[-1]['rgb'].cpu().numpy(), atol=1e-6)
