@@ -7,6 +7,7 @@ Only the per-pixel leaves are here; pose utilities / camera pa
 import ctypes as C
 import enum
 
+import numpy as np
 import torch
 
 from multinerf_amd import _lib as L
@@ -95,3 +96,78 @@ def pixel_coordinates(width, height, device='cpu'):
   """camera_utils.py:420-424: (x, y) integer grids, each [height, width]."""
   y, x = torch.meshgrid(torch.arange(height, device=device), torch.arange(width, device=device), indexing='ij')
   return x, y
+
+
+# ----------------------------------------------------------------------------- pose utilities (host, NumPy):
+# scene normalisation done once at dataset load time (camera_utils.py:101-156,191-227), not on the per-ray path.
+
+
+def pad_poses(p):
+  """camera_utils.py:101-104: [..., 3, 4] -> [..., 4, 4] with a [0, 0, 0, 1] bottom row."""
+  bottom = np.broadcast_to([0, 0, 0, 1.], p[..., :1, :4].shape)
+  return np.concatenate([p[..., :3, :4], bottom], axis=-2)
+
+
+def unpad_poses(p):
+  """camera_utils.py:107-109."""
+  return p[..., :3, :4]
+
+
+def normalize(x):
+  """camera_utils.py:139-141."""
+  return x / np.linalg.norm(x)
+
+
+def viewmatrix(lookdir, up, position):
+  """camera_utils.py:129-136."""
+  vec2 = normalize(lookdir)
+  vec0 = normalize(np.cross(up, vec2))
+  vec1 = normalize(np.cross(vec2, vec0))
+  return np.stack([vec0, vec1, vec2, position], axis=1)
+
+
+def average_pose(poses):
+  """camera_utils.py:120-126."""
+  position = poses[:, :3, 3].mean(0)
+  z_axis = poses[:, :3, 2].mean(0)
+  up = poses[:, :3, 1].mean(0)
+  return viewmatrix(z_axis, up, position)
+
+
+def recenter_poses(poses):
+  """camera_utils.py:112-117 -> (poses, transform)."""
+  cam2world = average_pose(poses)
+  transform = np.linalg.inv(pad_poses(cam2world))
+  poses = transform @ pad_poses(poses)
+  return unpad_poses(poses), transform
+
+
+def focus_point_fn(poses):
+  """camera_utils.py:144-156: the point nearest to all focal axes."""
+  directions, origins = poses[:, :3, 2:3], poses[:, :3, 3:4]
+  m = np.eye(3) - directions * np.transpose(directions, [0, 2, 1])
+  mt_m = np.transpose(m, [0, 2, 1]) @ m
+  return np.linalg.inv(mt_m.mean(0)) @ (mt_m @ origins).mean(0)[:, 0]
+
+
+def transform_poses_pca(poses):
+  """camera_utils.py:191-227: align the principal axes of the camera centres with XYZ, scale into the unit cube."""
+  t = poses[:, :3, 3]
+  t_mean = t.mean(axis=0)
+  t = t - t_mean
+  eigval, eigvec = np.linalg.eig(t.T @ t)
+  inds = np.argsort(eigval)[::-1]
+  eigvec = eigvec[:, inds]
+  rot = eigvec.T
+  if np.linalg.det(rot) < 0:
+    rot = np.diag(np.array([1, 1, -1])) @ rot
+  transform = np.concatenate([rot, rot @ -t_mean[:, None]], -1)
+  poses_recentered = unpad_poses(transform @ pad_poses(poses))
+  transform = np.concatenate([transform, np.eye(4)[3:]], axis=0)
+  if poses_recentered.mean(axis=0)[2, 1] < 0:
+    poses_recentered = np.diag(np.array([1, -1, -1])) @ poses_recentered
+    transform = np.diag(np.array([1, -1, -1, 1])) @ transform
+  scale_factor = 1. / np.max(np.abs(poses_recentered[:, :3, 3]))
+  poses_recentered[:, :3, 3] *= scale_factor
+  transform = np.diag(np.array([scale_factor] * 3 + [1])) @ transform
+  return poses_recentered, transform

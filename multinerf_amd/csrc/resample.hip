@@ -176,7 +176,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_level_kernel(
       const bool open = td[(k + 1) * rpb] > td[k * rpb];
       const float lg = open ? c.anneal * logf(wd[k * rpb] + c.resample_padding) : -INFINITY;
       wd[k * rpb] = lg;
-      mx = fmaxf(mx, lg);
+      mx = (lg != lg || mx != mx) ? NAN : fmaxf(mx, lg);      // jnp.max propagates NaN (0 * log 0 at train_frac 0)
     }
     float denom = 0.0f;
     for (int k = 0; k < nb; ++k) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_level_kernel(
       const float wk = wd[k * rpb] / denom;
       cw[k * rpb] = prev;
       run += wk;
-      prev = fminf(1.0f, run);
+      prev = (run != run) ? run : fminf(1.0f, run);           // jnp.minimum propagates NaN
     }
     cw[0] = 0.0f;
     cw[nb * rpb] = 1.0f;

@@ -5,8 +5,9 @@ scene (a few hundred MB) live in HBM, a train batch is pixel indices drawn on th
 gather, and rays come from `camera_utils.cast_ray_batch` (csrc/camera.hip) -- either here or, with
 `Config.cast_rays_in_train_step`, inside the train step exactly like the reference's fast path
 (datasets.py:431-433).  Loaders: 'blender' (transforms_*.json + PNG, datasets.py:507-560) and 'procedural'
-(an analytic scene for offline runs; tests/helpers.py uses the same scene).  LLFF / raw / DTU / TAT loaders
-need COLMAP or rawpy data that cannot be exercised here and are not restated.
+(an analytic scene for offline runs; tests/helpers.py uses the same scene) and 'llff' (COLMAP `sparse/0` binaries or
+NGP `transforms.json` poses; forward-facing NDC and 360 scenes, datasets.py:563-712).  RawNeRF / DTU / TAT loaders need
+rawpy or dataset-specific files that cannot be exercised here and are not restated.
 """
 
 import json
@@ -208,7 +209,165 @@ class Procedural(Dataset):
     self.pixtocams = camera_utils.get_pixtocam(focal, W, H).numpy()
 
 
-dataset_dict = {'blender': Blender, 'procedural': Procedural}
+# ----------------------------------------------------------------------------- COLMAP / NGP poses for LLFF
+
+
+_COLMAP_MODELS = {0: ('SIMPLE_PINHOLE', 3), 1: ('PINHOLE', 4), 2: ('SIMPLE_RADIAL', 4), 3: ('RADIAL', 5),
+                  4: ('OPENCV', 8), 5: ('OPENCV_FISHEYE', 8)}
+
+
+def read_colmap_binary(colmap_dir):
+  """cameras.bin + images.bin of a COLMAP sparse model (the published binary layout: little-endian, counts as
+  uint64; the reference reads it through pycolmap.SceneManager, datasets.py:55-78).  Returns
+  (cameras {id: (model_id, w, h, params)}, images [(name, qvec wxyz, tvec, camera_id)] in file order)."""
+  import struct
+  cams = {}
+  with open(os.path.join(colmap_dir, 'cameras.bin'), 'rb') as f:
+    (n,) = struct.unpack('<Q', f.read(8))
+    for _ in range(n):
+      cid, model, w, h = struct.unpack('<iiQQ', f.read(24))
+      if model not in _COLMAP_MODELS:
+        raise NotImplementedError(f'COLMAP camera model {model}')
+      npar = _COLMAP_MODELS[model][1]
+      cams[cid] = (model, w, h, struct.unpack(f'<{npar}d', f.read(8 * npar)))
+  images = []
+  with open(os.path.join(colmap_dir, 'images.bin'), 'rb') as f:
+    (n,) = struct.unpack('<Q', f.read(8))
+    for _ in range(n):
+      vals = struct.unpack('<i7di', f.read(64))
+      qvec, tvec, cid = np.array(vals[1:5]), np.array(vals[5:8]), vals[8]
+      name = b''
+      while True:
+        ch = f.read(1)
+        if ch in (b'\x00', b''):
+          break
+        name += ch
+      (npts,) = struct.unpack('<Q', f.read(8))
+      f.seek(24 * npts, 1)                           # (x, y, point3D_id) per 2-D point: not needed
+      images.append((name.decode(), qvec, tvec, cid))
+  return cams, images
+
+
+def _qvec_to_rotmat(q):
+  w, x, y, z = q
+  return np.array([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * z * x + 2 * w * y],
+                   [2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * x],
+                   [2 * z * x - 2 * w * y, 2 * y * z + 2 * w * x, 1 - 2 * x * x - 2 * y * y]])
+
+
+def load_colmap_posedata(colmap_dir):
+  """NeRFSceneManager.process (datasets.py:62-149): shared intrinsics of camera 1, world-to-camera -> camera-to-world,
+  COLMAP (right, down, fwd) -> NeRF (right, up, back), distortion parameters by camera model."""
+  cams, images = read_colmap_binary(colmap_dir)
+  model, _, _, prm = cams[1]
+  if model in (0, 2, 3):
+    fx = fy = prm[0]
+    cx, cy = prm[1], prm[2]
+    extra = prm[3:]
+  else:
+    fx, fy, cx, cy = prm[:4]
+    extra = prm[4:]
+  pixtocam = np.linalg.inv(camera_utils.intrinsic_matrix(fx, fy, cx, cy).numpy())
+  w2c = []
+  for _, q, t, _ in images:
+    m = np.eye(4)
+    m[:3, :3], m[:3, 3] = _qvec_to_rotmat(q), t
+    w2c.append(m)
+  poses = np.linalg.inv(np.stack(w2c, 0))[:, :3, :4] @ np.diag([1, -1, -1, 1])
+  names = [im[0] for im in images]
+  camtype = camera_utils.ProjectionType.PERSPECTIVE
+  if model in (0, 1):
+    params = None
+  elif model == 2:
+    params = dict(k1=extra[0], k2=0., k3=0., p1=0., p2=0.)
+  elif model == 3:
+    params = dict(k1=extra[0], k2=extra[1], k3=0., p1=0., p2=0.)
+  elif model == 4:
+    params = dict(k1=extra[0], k2=extra[1], k3=0., p1=extra[2], p2=extra[3])
+  else:
+    params = dict(k1=extra[0], k2=extra[1], k3=extra[2], k4=extra[3])
+    camtype = camera_utils.ProjectionType.FISHEYE
+  return names, poses, pixtocam, params, camtype
+
+
+def load_blender_posedata(data_dir, split=None):
+  """datasets.py:152-186: poses from `transforms[_split].json` (Blender / NGP layout)."""
+  suffix = '' if split is None else f'_{split}'
+  with open(os.path.join(data_dir, f'transforms{suffix}.json')) as fp:
+    meta = json.load(fp)
+  names, poses = [], []
+  for frame in meta['frames']:
+    if os.path.exists(os.path.join(data_dir, frame['file_path'])):
+      names.append(frame['file_path'].split('/')[-1])
+      poses.append(np.array(frame['transform_matrix'], dtype=np.float32))
+  poses = np.stack(poses, 0)
+  w, h = meta['w'], meta['h']
+  cx, cy = meta.get('cx', w / 2.), meta.get('cy', h / 2.)
+  fx = meta['fl_x'] if 'fl_x' in meta else 0.5 * w / np.tan(0.5 * float(meta['camera_angle_x']))
+  fy = meta['fl_y'] if 'fl_y' in meta else 0.5 * h / np.tan(0.5 * float(meta['camera_angle_y']))
+  pixtocam = np.linalg.inv(camera_utils.intrinsic_matrix(fx, fy, cx, cy).numpy())
+  coeffs = ['k1', 'k2', 'p1', 'p2']
+  params = None if not any(c in meta for c in coeffs) else {c: meta.get(c, 0.) for c in coeffs}
+  return names, poses, pixtocam, params, camera_utils.ProjectionType.PERSPECTIVE
+
+
+class LLFF(Dataset):
+  """datasets.py:563-712 for ordinary (non-raw) captures: COLMAP `sparse/0` or NGP `transforms.json` poses, images in
+  `images[_factor]`, forward-facing scenes in NDC (recenter + bound rescale) or 360 scenes (PCA alignment into the unit
+  cube), every `llffhold`-th image held out.  Render paths (spiral / ellipse / spline) and RawNeRF inputs are not restated."""
+
+  def _load_renderings(self, config):
+    from PIL import Image
+    if config.rawnerf_mode:
+      raise NotImplementedError('RawNeRF inputs need rawpy (raw_utils.load_raw_dataset)')
+    if config.render_path:
+      raise NotImplementedError('render paths are out of scope (DESIGN.md section 7)')
+    factor = config.factor if config.factor > 0 else 1
+    suffix = f'_{config.factor}' if config.factor > 0 else ''
+    colmap_dir = os.path.join(self.data_dir, 'sparse/0/')
+    pose_data = load_colmap_posedata(colmap_dir) if os.path.exists(colmap_dir) else load_blender_posedata(self.data_dir)
+    image_names, poses, pixtocam, distortion_params, camtype = pose_data
+    if config.load_alphabetical:
+      inds = np.argsort(image_names)
+      image_names = [image_names[i] for i in inds]
+      poses = poses[inds]
+    pixtocam = pixtocam @ np.diag([factor, factor, 1.])
+    self.pixtocams = pixtocam.astype(np.float32)
+    self.focal = 1. / self.pixtocams[0, 0]
+    self.distortion_params = distortion_params
+    self.camtype = camtype
+    colmap_image_dir = os.path.join(self.data_dir, 'images')
+    image_dir = os.path.join(self.data_dir, 'images' + suffix)
+    for d in (image_dir, colmap_image_dir):
+      if not os.path.exists(d):
+        raise ValueError(f'Image folder {d} does not exist.')
+    colmap_to_image = dict(zip(sorted(os.listdir(colmap_image_dir)), sorted(os.listdir(image_dir))))
+    images = np.stack([np.asarray(Image.open(os.path.join(image_dir, colmap_to_image[f])), dtype=np.float32)[..., :3]
+                       for f in image_names], 0) / 255.
+    posefile = os.path.join(self.data_dir, 'poses_bounds.npy')
+    bounds = np.load(posefile)[:, -2:] if os.path.exists(posefile) else np.array([0.01, 1.])
+    self.colmap_to_world_transform = np.eye(4)
+    poses = np.array(poses, dtype=np.float64)
+    if config.forward_facing:
+      self.pixtocam_ndc = torch.as_tensor(self.pixtocams.reshape(-1, 3, 3)[0])
+      scale = 1. / (bounds.min() * .75)
+      poses[:, :3, 3] *= scale
+      self.colmap_to_world_transform = np.diag([scale] * 3 + [1])
+      poses, transform = camera_utils.recenter_poses(poses)
+      self.colmap_to_world_transform = transform @ self.colmap_to_world_transform
+    else:
+      poses, transform = camera_utils.transform_poses_pca(poses)
+      self.colmap_to_world_transform = transform
+    self.poses = poses
+    all_indices = np.arange(images.shape[0])
+    train_indices = all_indices if config.llff_use_all_images_for_training else all_indices % config.llffhold != 0
+    indices = {'test': all_indices[all_indices % config.llffhold == 0], 'train': train_indices}[self.split]
+    self.images = images[indices]
+    self.camtoworlds = poses[indices]
+    self.height, self.width = self.images.shape[1:3]
+
+
+dataset_dict = {'blender': Blender, 'llff': LLFF, 'procedural': Procedural}
 
 
 def load_dataset(split, train_dir, config, device='cuda'):

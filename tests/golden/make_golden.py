@@ -381,6 +381,27 @@ def main():
   g['cam_undistort_in'] = np.stack([xd_in, yd_in])
   g['cam_undistort_out'] = np.stack([xu, yu])
 
+  # pose utilities (pure NumPy in the reference)
+  rp = np.random.RandomState(99)
+  poses = []
+  for i in range(9):
+    q, _ = np.linalg.qr(rp.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+      q[:, 0] = -q[:, 0]
+    ang = 2 * np.pi * i / 9
+    pos = np.array([3 * np.cos(ang), 2 * np.sin(ang), 0.3 * rp.normal()]) + np.array([5., -2., 1.])
+    poses.append(np.concatenate([0.7 * q + 0.3 * np.eye(3), pos[:, None]], 1))
+  poses = np.stack(poses, 0)
+  g['pose_in'] = poses
+  g['pose_pad'] = camera_utils.pad_poses(poses)
+  g['pose_average'] = camera_utils.average_pose(poses)
+  rc_p, rc_t = camera_utils.recenter_poses(poses)
+  g['pose_recenter_poses'], g['pose_recenter_transform'] = rc_p, rc_t
+  g['pose_focus_point'] = camera_utils.focus_point_fn(poses)
+  pca_p, pca_t = camera_utils.transform_poses_pca(poses)
+  g['pose_pca_poses'], g['pose_pca_transform'] = pca_p, pca_t
+  g['pose_viewmatrix'] = camera_utils.viewmatrix(np.array([0.2, -0.3, 0.9]), np.array([0., 1., 0.1]), np.array([1., 2., 3.]))
+
   g = {k: np.asarray(v) for k, v in g.items() if v is not None}
   np.savez_compressed(OUT, **g)
   print(f'wrote {OUT}: {len(g)} arrays, {os.path.getsize(OUT)} bytes')

@@ -636,3 +636,24 @@ def test_weight_decay(ops):
   want = g0.clone()
   want[100:4100] += 0.5 * p[100:4100]
   np.testing.assert_allclose(grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_resample_nan_logits(ops):
+  """train_frac = 0 (anneal = 0) with an exactly-zero weight: 0 * log(0) = NaN propagates through softmax / CDF as
+  in the reference (jnp.max / jnp.minimum keep NaN) and sorted_interp then returns the first fence-post."""
+  gen = torch.Generator().manual_seed(11)
+  B, np_, n = 70, 64, 32
+  sd, w = rand_stepfun(gen, B, np_)
+  w = w * 0.9
+  w[::2, 7] = 0.0                                   # every other ray has a zero weight
+  near, far = torch.full((B, 1), 2.0), torch.full((B, 1), 6.0)
+  u_base, mj = _u_base(n, False)
+  s_ref, t_ref, idx_ref = _resample_ref(sd, w, None, near, far, n=n, use_dil=False, dil=0.0, anneal=0.0, pad=0.0,
+                                        single=True, raydist=None)
+  s, t, idx = ops.resample_level(dev(sd), dev(w), dev(u_base), None, dev(near), dev(far), n_samples=n,
+                                 use_dilation=False, dilation=0.0, domain=(0., 1.), anneal=0.0, resample_padding=0.0,
+                                 single_jitter=True, max_jitter=mj, raydist_fn=None, want_idx=True)
+  assert torch.isfinite(s_ref).all()              # the reference resolves the NaN CDF to the first fence-post
+  np.testing.assert_allclose(s.cpu().numpy(), s_ref.numpy(), atol=2e-6)
+  assert (s.cpu()[::2] == sd[::2, :1]).all()      # NaN rays: every fence-post equals t[0]
+  assert torch.equal(idx.cpu(), idx_ref)

@@ -50,3 +50,20 @@ def test_undistort_matches_reference(golden):
   xd, yd = (torch.as_tensor(v) for v in golden['cam_undistort_in'])
   x, y = ocam._radial_and_tangential_undistort(xd, yd, **dist)
   np.testing.assert_allclose(torch.stack([x, y]).numpy(), golden['cam_undistort_out'], rtol=1e-12)
+
+
+def test_pose_utilities_match_reference(golden):
+  """multinerf_amd.camera_utils pose helpers (host-side NumPy, dataset load time) vs the reference's own."""
+  from multinerf_amd import camera_utils as cu
+  poses = golden['pose_in']
+  np.testing.assert_allclose(cu.pad_poses(poses), golden['pose_pad'], rtol=0, atol=0)
+  np.testing.assert_allclose(cu.average_pose(poses), golden['pose_average'], rtol=1e-12)
+  p, t = cu.recenter_poses(poses)
+  np.testing.assert_allclose(p, golden['pose_recenter_poses'], rtol=1e-10, atol=1e-12)
+  np.testing.assert_allclose(t, golden['pose_recenter_transform'], rtol=1e-10, atol=1e-12)
+  np.testing.assert_allclose(cu.focus_point_fn(poses), golden['pose_focus_point'], rtol=1e-10)
+  p, t = cu.transform_poses_pca(poses.copy())
+  np.testing.assert_allclose(p, golden['pose_pca_poses'], rtol=1e-9, atol=1e-12)
+  np.testing.assert_allclose(t, golden['pose_pca_transform'], rtol=1e-9, atol=1e-12)
+  np.testing.assert_allclose(cu.viewmatrix(np.array([0.2, -0.3, 0.9]), np.array([0., 1., 0.1]), np.array([1., 2., 3.])),
+                             golden['pose_viewmatrix'], rtol=1e-12)
