@@ -225,27 +225,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
       }
   }
 
-  // ReLU-mask bits of the output chunks this thread will write in the epilogue, fetched now: loading
-  // them inside the store loop serialises 16 L2/HBM round trips per tile behind the MFMA phase
-  // (measured: dX layers 20% slower than forward layers with identical operands).
-  constexpr int EPI_PASSES = BM / CFG::EPI_ROWS;
-  constexpr int EPI_CPR = BN / 8;
-  constexpr int EPI_ITERS = CFG::EPI_ROWS * EPI_CPR / CFG::THREADS;
-  unsigned mbits[BITS_IN ? EPI_PASSES : 1][BITS_IN ? EPI_ITERS : 1];
-  if (BITS_IN) {
-#pragma unroll
-    for (int h = 0; h < EPI_PASSES; ++h)
-#pragma unroll
-      for (int it = 0; it < EPI_ITERS; ++it) {
-        const int c = it * CFG::THREADS + tid;
-        const int row = c / EPI_CPR, ch = c % EPI_CPR;
-        int64_t mrow = m0 + h * CFG::EPI_ROWS + row;
-        if (p.bits_row_mod > 0) mrow %= p.bits_row_mod;
-        const int64_t idx = mrow * (int64_t)p.ld_bits_in + ((n0 + ch * 8) >> 3);
-        mbits[h][it] = p.mask_bits_in[idx];
-      }
-  }
-
   f32x16 acc[NJ][MI];
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
@@ -595,6 +574,27 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
   }
   }   // !phased
   if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+  // ReLU-mask bits of the output chunks this thread will write in the epilogue.  Fetched here, after the K loop and
+  // before the LDS staging (whose ~4k cycles hide the latency): loading them inside the store loop serialises 16
+  // L2/HBM round trips per tile, and fetching them before the K loop keeps 16 registers live across it, which
+  // the register allocator spills around every load (measured: 3.8k-cycle prologue instead of 1.4k).
+  constexpr int EPI_PASSES = BM / CFG::EPI_ROWS;
+  constexpr int EPI_CPR = BN / 8;
+  constexpr int EPI_ITERS = CFG::EPI_ROWS * EPI_CPR / CFG::THREADS;
+  unsigned mbits[BITS_IN ? EPI_PASSES : 1][BITS_IN ? EPI_ITERS : 1];
+  if (BITS_IN) {
+#pragma unroll
+    for (int h = 0; h < EPI_PASSES; ++h)
+#pragma unroll
+      for (int it = 0; it < EPI_ITERS; ++it) {
+        const int c = it * CFG::THREADS + tid;
+        const int row = c / EPI_CPR, ch = c % EPI_CPR;
+        int64_t mrow = m0 + h * CFG::EPI_ROWS + row;
+        if (p.bits_row_mod > 0) mrow %= p.bits_row_mod;
+        const int64_t idx = mrow * (int64_t)p.ld_bits_in + ((n0 + ch * 8) >> 3);
+        mbits[h][it] = p.mask_bits_in[idx];
+      }
+  }
   __syncthreads();      // every wave is done with the operand buffers: reuse them for the epilogue
 
   // Epilogue.  acc[j][i][r]: n = n0 + wn*32*NJ + j*32 + (r&3) + 8*(r>>2) + 4*khalf,
@@ -647,56 +647,65 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
       }
       __syncthreads();
       if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 8 + 2 * h] = __builtin_amdgcn_s_memtime();
-#pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        const int c = it * CFG::THREADS + tid;
-        const int row = c / CHUNKS_PER_ROW, ch = c % CHUNKS_PER_ROW;
-        const int64_t m = m0 + h * CFG::EPI_ROWS + row;
+      {
+        // Store loop, unswitched on the epilogue flavour (the flags are kernel-uniform; left inside the loop they
+        // cost branches and selects per chunk).  Iteration `it` handles chunk ch of row row0 + it * ROW_STEP.
+        constexpr int ROW_STEP = CFG::THREADS / CHUNKS_PER_ROW;
+        const int row0 = tid / CHUNKS_PER_ROW, ch = tid % CHUNKS_PER_ROW;
+        const int64_t mfirst = m0 + h * CFG::EPI_ROWS + row0;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 w = *(const u32x4*)(cs + row * CFG::CPITCH + ch * 16);     // 8 bf16 as 4 dwords
-        if (BITS_IN) {
-          // 1 bit per element, written by the forward epilogue of the layer whose ReLU this undoes.  Dword d
-          // holds elements 2d (low half) and 2d+1: sign-extended 1-bit fields select the halves (v_bfe_i32, v_bfi).
-          const int mb = (int)mbits[BITS_IN ? h : 0][BITS_IN ? it : 0];
+        auto store_loop = [&](auto bits_out_c, auto mask_c) {
+          constexpr bool BITS_OUT = decltype(bits_out_c)::value, MASK = decltype(mask_c)::value;
+          bf16* cptr = Cb + mfirst * p.ldcb + n0 + ch * 8;
+          const bf16* mptr = MASK ? mask + mfirst * p.ldmask + n0 + ch * 8 : nullptr;
+          uint8_t* bptr = BITS_OUT ? p.mask_bits_out + mfirst * p.ld_bits_out + ((n0 + ch * 8) >> 3) : nullptr;
+          const char* lptr = cs + row0 * CFG::CPITCH + ch * 16;
 #pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(mb, 2 * d, 1);
-            const unsigned hi = (unsigned)__builtin_amdgcn_sbfe(mb, 2 * d + 1, 1);
-            w[d] &= (lo & 0xffffu) | (hi & 0xffff0000u);
-          }
-        } else if (mask) {
-          const bf16x8 mk = *(const bf16x8*)(mask + m * p.ldmask + n0 + ch * 8);
-          bf16x8 v = __builtin_bit_cast(bf16x8, w);
+          for (int it = 0; it < ITERS; ++it) {
+            u32x4 w = *(const u32x4*)(lptr + it * ROW_STEP * CFG::CPITCH);     // 8 bf16 as 4 dwords
+            if (BITS_IN) {
+              // 1 bit per element, written by the forward epilogue of the layer whose ReLU this undoes.  Dword d holds
+              // elements 2d (low half) and 2d+1: sign-extended 1-bit fields select the halves (v_bfe_i32, v_bfi).
+              const int mb = (int)mbits[BITS_IN ? h : 0][BITS_IN ? it : 0];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = ((float)mk[e] > 0.0f) ? v[e] : (bf16)0.0f;
-          w = __builtin_bit_cast(u32x4, v);
-        }
-        if (p.mask_bits_out) {
-          // bit e = (element e > 0).  The outputs of a ReLU layer are >= 0, so "> 0" is "bits != 0" per 16-bit
-          // half: a packed unsigned min with 1 gives 0/1 in bit 0 and bit 16 of every dword; fold the 4 dwords
-          // into 8 bits.  4 neighbouring lanes (same row, consecutive chunks) combine theirs into one aligned
-          // 32-bit store (byte stores cost ~an order of magnitude more per byte).
-          typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-          unsigned f = 0;
+              for (int d = 0; d < 4; ++d) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(mb, 2 * d, 1);
+                const unsigned hi = (unsigned)__builtin_amdgcn_sbfe(mb, 2 * d + 1, 1);
+                w[d] &= (lo & 0xffffu) | (hi & 0xffff0000u);
+              }
+            } else if (MASK) {
+              const bf16x8 mk = *(const bf16x8*)(mptr + (int64_t)it * ROW_STEP * p.ldmask);
+              bf16x8 v = __builtin_bit_cast(bf16x8, w);
 #pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            const unsigned wd = w[d];     // (bit_cast straight from the vector element reads element 0: clang bug)
-            u16x2 hv = __builtin_bit_cast(u16x2, wd);
-            if (!p.relu) {                                               // general case: test the sign as well
-              typedef short s16x2b __attribute__((ext_vector_type(2)));
-              const s16x2b z = {0, 0};
-              hv = __builtin_bit_cast(u16x2, __builtin_elementwise_max(__builtin_bit_cast(s16x2b, hv), z));
+              for (int e = 0; e < 8; ++e) v[e] = ((float)mk[e] > 0.0f) ? v[e] : (bf16)0.0f;
+              w = __builtin_bit_cast(u32x4, v);
             }
-            const u16x2 one = {1, 1};
-            f |= __builtin_bit_cast(unsigned, __builtin_elementwise_min(hv, one)) << (2 * d);
+            if (BITS_OUT) {
+              // bit e = (element e > 0).  Clamp the halves at 0 as signed 16-bit (no-op after a ReLU), then
+              // "> 0" is "bits != 0": adding 0x7fff to a half in [0, 0x7fff] sets its bit 15 exactly when it is
+              // non-zero, and the low half cannot carry into the high one.  Fold the 8 flags into one byte; the 4
+              // lanes of a quad (same row, consecutive chunks) combine theirs with DPP quad_perm moves into one
+              // aligned 32-bit store (byte stores cost ~an order of magnitude more per byte).
+              typedef short s16x2b __attribute__((ext_vector_type(2)));
+              unsigned f = 0;
+#pragma unroll
+              for (int d = 0; d < 4; ++d) {
+                const unsigned wd = w[d];     // (bit_cast straight from the vector element reads element 0: clang bug)
+                const s16x2b z = {0, 0};
+                const unsigned pos = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2b, wd), z));
+                f |= ((pos + 0x7fff7fffu) & 0x80008000u) >> (15 - 2 * d);
+              }
+              unsigned mb = (f | (f >> 15)) & 0xffu;
+              mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xF5, 0xf, 0xf, false) << 8;     // quad_perm [1,1,3,3]
+              mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xAA, 0xf, 0xf, false) << 16;    // quad_perm [2,2,2,2]
+              if ((ch & 3) == 0) *(unsigned*)(bptr + (int64_t)it * ROW_STEP * p.ld_bits_out) = mb;
+            }
+            *(u32x4*)(cptr + (int64_t)it * ROW_STEP * p.ldcb) = w;
           }
-          unsigned mb = (f | (f >> 15)) & 0xffu;
-          mb |= __shfl_down(mb, 1, 64) << 8;
-          mb |= __shfl_down(mb, 2, 64) << 16;
-          if ((ch & 3) == 0)
-            *(unsigned*)(p.mask_bits_out + m * p.ld_bits_out + ((n0 + ch * 8) >> 3)) = mb;
-        }
-        *(u32x4*)(Cb + m * p.ldcb + n0 + ch * 8) = w;
+        };
+        if (p.mask_bits_out) store_loop(std::true_type(), std::false_type());
+        else if (!BITS_IN && mask) store_loop(std::false_type(), std::true_type());
+        else store_loop(std::false_type(), std::false_type());
       }
       if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 9 + 2 * h] = __builtin_amdgcn_s_memtime();
       if (h + 1 < PASSES) __syncthreads();
@@ -853,6 +862,7 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   MNR_CHECK_ARG(!a->Cb || a->ldcb % 4 == 0, "mnr_gemm_nt_bf16: ldcb must be a multiple of 4");
   MNR_CHECK_ARG(!a->mask || a->ldmask % 4 == 0, "mnr_gemm_nt_bf16: ldmask must be a multiple of 4");
   MNR_CHECK_ARG(a->Cb || a->Cf, "mnr_gemm_nt_bf16: no output");
+  MNR_CHECK_ARG(!(a->mask_bits_out && a->mask), "mnr_gemm_nt_bf16: mask_bits_out cannot be combined with a bf16 mask");
   MNR_CHECK_ARG(!a->bias || a->n_bias >= 1, "mnr_gemm_nt_bf16: bias needs n_bias >= 1");
   MNR_CHECK_ARG(!a->mask_bits_out || (a->Cb && a->nb == a->N && a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0 &&
                                       a->ld_bits_out % 4 == 0 && ((uintptr_t)a->mask_bits_out % 4) == 0),
