@@ -54,11 +54,13 @@ struct NtCfg {
   // FRAGPIPE >= 6: weights straight from global memory in fragment-major order, LDS ring holds activation
   // half-tiles only: 3 + PH_D slots for the first halves, 2 + PH_D for the second halves.
   static constexpr int PH_D = FRAGPIPE_ >= 6 ? FRAGPIPE_ - 6 : 0;
-  static constexpr int LDS_BYTES = FRAGPIPE_ >= 6 ? ((5 + 2 * PH_D) * 16384 < 128 * (BN * 2 + NT_CPAD) ? 128 * (BN * 2 + NT_CPAD) : (5 + 2 * PH_D) * 16384)
-                                   : FRAGPIPE_ >= 2 ? PH_S * 16384 : STAGES * STAGE_BYTES;
+  static constexpr int LDS_OPERANDS = FRAGPIPE_ >= 6 ? (5 + 2 * PH_D) * 16384 : FRAGPIPE_ >= 2 ? PH_S * 16384 : STAGES * STAGE_BYTES;
   static constexpr int LOADS_PER_STAGE = STAGE_BYTES / 16 / THREADS;   // LDS-DMA instructions per wave per stage
   static constexpr int CPITCH = BN * 2 + NT_CPAD;     // bytes per staged output row
-  static constexpr int EPI_ROWS = (128 * CPITCH <= LDS_BYTES) ? 128 : 64;   // rows staged per epilogue pass
+  // Rows staged per epilogue pass: the whole tile when it fits the 160 KiB of LDS (one pass, every wave converts
+  // and writes at once: 135 KiB for the 256x256 tile), else 128 or 64 rows inside the operand buffers.
+  static constexpr int EPI_ROWS = (BM * CPITCH <= 160 * 1024) ? BM : (128 * CPITCH <= LDS_OPERANDS) ? 128 : 64;
+  static constexpr int LDS_BYTES = LDS_OPERANDS > EPI_ROWS * CPITCH ? LDS_OPERANDS : EPI_ROWS * CPITCH;
   static_assert(EPI_ROWS * CPITCH <= LDS_BYTES, "epilogue staging must fit in the operand buffers");
   static_assert(BM % EPI_ROWS == 0 && (32 * MI) <= EPI_ROWS && EPI_ROWS % (32 * MI) == 0, "epilogue pass shape");
   static_assert((BM * SLOTS) % THREADS == 0 && (BN * SLOTS) % THREADS == 0, "stage loop shape");
