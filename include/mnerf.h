@@ -195,7 +195,7 @@ int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* args, void* stream);
  * multiple of 256 (`cfg_big`) and otherwise (`cfg_small`; must be a 128x128 configuration). */
 /* Profiling hook: device buffer of 16 uint64 per workgroup (s_memtime at entry, K-loop start, K-loop end, exit;
  * s_memrealtime at entry, exit; XCC_ID<<32|HW_ID; unused; epilogue pass stamps) written by
- * every following mnr_gemm_nt_bf16 launch; NULL switches it off. */
+ * every following mnr_gemm_nt_bf16 / mnr_gemm_tn_bf16 launch (TN: [7] = steps << 32 | does-bias); NULL switches it off. */
 int mnr_debug_gemm_timeline(unsigned long long* device_buffer);
 int mnr_gemm_nt_set_config(int cfg_big, int cfg_small);
 

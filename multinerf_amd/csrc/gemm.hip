@@ -162,9 +162,11 @@ __device__ __forceinline__ bf16x8 nt_read_half(const char* ht, int lrow, int ksl
 // kernel entry, K-loop start, K-loop end and kernel exit into g_nt_timeline[16 * blockIdx.x + 0..3], s_memrealtime
 // (100 MHz) at entry / exit into [4], [5], XCC_ID << 32 | HW_ID into [6]; epilogue pass h: staged [8+2h], stored [9+2h].
 __device__ unsigned long long* g_nt_timeline = nullptr;
+__device__ unsigned long long* g_tn_timeline = nullptr;
 
 extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_nt_timeline), &device_buffer, sizeof(device_buffer));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_tn_timeline), &device_buffer, sizeof(device_buffer));
   if (e != hipSuccess) {
     mnr_set_error("mnr_debug_gemm_timeline: %s", hipGetErrorString(e));
     return MNR_ERR_HIP;
@@ -810,6 +812,8 @@ typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 4> NtC24;   //   no ds_reads
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 6> NtC25;   //   MFMA + barriers only
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 5> NtC26;   //   DMA + barriers only
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 7> NtC27;   //   barriers only
+typedef NtCfg<4, 2, 2, 4, 32, 4> NtC4;             // 256x256, 8 waves, 4 stages of BK=32 (three K half-tiles in flight)
+typedef NtCfg<4, 2, 2, 4, 32, 3> NtC7;             // 256x256, 8 waves, 3 stages of BK=32
 typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
 typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register double-buffered fragments
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 6> NtC30;      // 256x256 phased, weights direct from the fragment-major image (needs args.Bp)
@@ -828,6 +832,8 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
   switch (cfg) {
     case 0: return nt_launch<NtC0>(a, fast_epi, stream);
     case 2: return nt_launch<NtC2>(a, fast_epi, stream);
+    case 4: return nt_launch<NtC4>(a, fast_epi, stream);
+    case 7: return nt_launch<NtC7>(a, fast_epi, stream);
     case 12: return nt_launch<NtC12>(a, fast_epi, stream);
     case 14: return nt_launch<NtC14>(a, fast_epi, stream);
     case 15: return nt_launch<NtC15>(a, fast_epi, stream);
@@ -957,6 +963,11 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave / CFG::WN, wn = wave % CFG::WN;
+  unsigned long long* const tl = g_tn_timeline;          // profiling hook, same layout as the NT kernel's
+  if (tl && tid == 0) {
+    tl[16 * (int64_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    tl[16 * (int64_t)blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();
+  }
 
   const int ktiles = p.K / BKO, ntiles = p.N / BNO;
   const int tiles = ktiles * ntiles;
@@ -1005,7 +1016,30 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
 
   stage(s_begin, 0);
   __syncthreads();
+  if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
   const int khalf = lane >> 5;
+  // Loop-invariant fragment addresses (see tn_read_frag for the layout): with p = lane & 15 the row of a transpose
+  // read is ks*16 + khalf*8 + (p >> 2) (+4 for the second half), whose low two bits are (p >> 2) & 3 for every ks,
+  // and the 64-B block index of a fragment's columns is wave-uniform, so
+  //   offset = lane part + ((block ^ x) << 6) + ks * 16 * ROWB (+ 4 * ROWB)
+  // and the loop needs one address register per fragment column block plus immediate offsets.  Left to
+  // tn_read_frag() the swizzle arithmetic is redone for all 24 fragments of every step (~350 VALU instructions per
+  // step competing with the MFMA issue: measured 4950 cycles per step against 3850 for the NT kernel's K tile).
+  constexpr int ROWB_A = BKO * 2, ROWB_B = BNO * 2;
+  const int pl = lane & 15, xsw = (pl >> 2) & 3;
+  const int lane_col = (((lane >> 4) & 1) * 16 + (pl & 3) * 4) * 2;
+  const int lane_row = khalf * 8 + (pl >> 2);
+  int a_off[KI], b_off[NJ];
+#pragma unroll
+  for (int i = 0; i < KI; ++i) a_off[i] = lane_row * ROWB_A + (((wk * KI + i) ^ xsw) << 6) + lane_col;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) b_off[j] = lane_row * ROWB_B + (((wn * NJ + j) ^ xsw) << 6) + lane_col;
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  auto tr_frag = [&](const char* ptr, int rowb) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr + 4 * rowb));
+    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
   for (int s = s_begin; s < s_end; ++s) {
     const int cur = (s - s_begin) & 1;
     if (s + 1 < s_end) stage(s + 1, cur ^ 1);
@@ -1013,12 +1047,11 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
     const char* Bs = As + CFG::A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int mbase = ks * 16 + khalf * 8;
       bf16x8 fa[KI], fb[NJ];
 #pragma unroll
-      for (int i = 0; i < KI; ++i) fa[i] = tn_read_frag<BKO>(As, mbase, wk * 32 * KI + i * 32, lane);
+      for (int i = 0; i < KI; ++i) fa[i] = tr_frag(As + a_off[i] + ks * 16 * ROWB_A, ROWB_A);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = tn_read_frag<BNO>(Bs, mbase, wn * 32 * NJ + j * 32, lane);
+      for (int j = 0; j < NJ; ++j) fb[j] = tr_frag(Bs + b_off[j] + ks * 16 * ROWB_B, ROWB_B);
 #pragma unroll
       for (int i = 0; i < KI; ++i)
 #pragma unroll
@@ -1033,6 +1066,10 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
     __syncthreads();
   }
 
+  if (tl && tid == 0) {
+    tl[16 * (int64_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    tl[16 * (int64_t)blockIdx.x + 7] = ((unsigned long long)(s_end - s_begin) << 32) | (unsigned)(k0 == 0 && p.bias_out != nullptr);
+  }
   if (do_bias && lane < 32) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -1053,6 +1090,10 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
         if (k < p.k_valid && n < p.n_valid) unsafeAtomicAdd(p.C + (int64_t)k * p.ldc + n, acc[i][j][r]);
       }
     }
+  if (tl && tid == 0) {
+    tl[16 * (int64_t)blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
+    tl[16 * (int64_t)blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 template <class CFG>
