@@ -1134,7 +1134,15 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
   // The 256x256 tile halves operand traffic per MFMA but issues 4x the atomics per workgroup: use it
   // when the output has enough tiles (the 1024-wide trunk); the narrow proposal layers keep 128x128.
   const bool big = (a->K % 256 == 0) && (a->N % 256 == 0) && ((a->K / 256) * (a->N / 256) >= g_tn_big_min_tiles);
-  if (big) return tn_launch<TnBig>(a, 512, stream);
+  static int tn_target = -1;                             // tuning hook: workgroups per launch of the 256x256 tile
+  if (tn_target < 0) {
+    const char* e = getenv("MNR_TN_TARGET_WGS");
+    // one workgroup per CU: every workgroup ends with a 256 KiB fp32 atomic epilogue (21-88k cycles, bound by the
+    // L2's atomic rate, tools/step_timeline.py), so a second round of workgroups only adds epilogues:
+    // 512 -> 256 workgroups = 398k -> 407k rays/s end to end, 1024: 390k.
+    tn_target = e ? atoi(e) : 256;
+  }
+  if (big) return tn_launch<TnBig>(a, tn_target, stream);
   return tn_launch<TnSmall>(a, 768, stream);
 }
 
