@@ -1143,7 +1143,12 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
     tn_target = e ? atoi(e) : 256;
   }
   if (big) return tn_launch<TnBig>(a, tn_target, stream);
-  return tn_launch<TnSmall>(a, 768, stream);
+  static int tn_small_target = -1;
+  if (tn_small_target < 0) {
+    const char* e = getenv("MNR_TN_SMALL_TARGET_WGS");
+    tn_small_target = e ? atoi(e) : 768;
+  }
+  return tn_launch<TnSmall>(a, tn_small_target, stream);
 }
 
 // ---------------------------------------------------------------------------
