@@ -45,3 +45,25 @@ def test_train_then_eval(tmp_path):
   assert r3.returncode == 0 and 'Evaluating checkpoint at step 60' in r3.stdout
   assert 'Average test psnr over 2 images' in r3.stdout
   assert os.path.exists(os.path.join(ck, 'test_preds', 'color_001.png'))
+
+
+def test_bench_json_contract():
+  """bench.py prints ONE JSON line with the driver's keys (+ roofline); cpu_baseline / aux legs are skipped here."""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--no_cpu_baseline',
+                      '--no_aux'], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.strip()]
+  assert len(lines) == 1
+  d = json.loads(lines[0])
+  for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+    assert k in d, k
+  assert d['metric'] == 'train_rays_per_sec' and d['unit'] == 'rays/s' and d['n_gpus'] == 1 and d['steps'] == 2
+  assert d['scaling'] == 'weak' and d['higher_is_better'] is True and d['vs_baseline'] is None
+  assert '360.gin' in d['config']['workload'] and d['config']['global_batch'] == 16384
+  rf = d['roofline']
+  assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+  assert 0.05 < rf['frac'] < 1.0 and d['value'] > 1e5
+  assert abs(d['value'] - 16384 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
