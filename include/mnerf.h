@@ -247,7 +247,9 @@ int mnr_small_head_bwd(int64_t M, int K, int C, const uint16_t* H, int ldh, cons
                        const float* W, uint16_t* dX, int lddx, int apply_relu_mask,
                        float* dW, float* db,
                        const uint8_t* mask_bits /* optional 1-bit mask [*, ld_bits], row m %% bits_row_mod */,
-                       int ld_bits, int64_t bits_row_mod, void* stream);
+                       int ld_bits, int64_t bits_row_mod,
+                       float* scratch /* optional workspace for per-workgroup dW/db partials (else fp32 atomics) */,
+                       int64_t scratch_floats, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Compositing  (replaces the density/rgb activations models.py:506,584-602,

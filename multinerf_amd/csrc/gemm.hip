@@ -1283,7 +1283,8 @@ __global__ __launch_bounds__(256) void small_head_bwd_kernel(int64_t M, int K, i
                                                               const float* __restrict__ W, bf16* __restrict__ dX,
                                                               int lddx, int relu_mask, float* dW, float* db,
                                                               int rows_per_block, const uint8_t* __restrict__ mbits,
-                                                              int ld_bits, int64_t bits_row_mod) {
+                                                              int ld_bits, int64_t bits_row_mod,
+                                                              float* __restrict__ partials) {
   // Thread (rl, cg): column group cg of 8 consecutive k (16-byte accesses), row lane rl; the block's
   // rows are strided over the row lanes.  dW partials are reduced across row lanes through LDS.
   __shared__ float red[256 * 8];
@@ -1354,20 +1355,50 @@ __global__ __launch_bounds__(256) void small_head_bwd_kernel(int64_t M, int K, i
         for (int e = 0; e < 8; ++e) {
           float sum = 0.0f;
           for (int k2 = 0; k2 < row_lanes; ++k2) sum += red[(k2 * groups + cg) * 8 + e];
-          unsafeAtomicAdd(dW + (int64_t)(cg * 8 + e) * C + c, sum);
+          // with a scratch buffer: this workgroup's partial (reduced by small_head_reduce_kernel); without: K*C
+          // atomics per workgroup onto the same few cache lines, which bounds the kernel once there are >~512 of them
+          if (partials) partials[(int64_t)blockIdx.x * (K * C + C) + (cg * 8 + e) * C + c] = sum;
+          else unsafeAtomicAdd(dW + (int64_t)(cg * 8 + e) * C + c, sum);
         }
       }
     }
   }
-  if (db && cg == 0 && rl < row_lanes) {
+  if (partials && db) {
+    // bias partial of this workgroup: reduce the row lanes' sums through LDS
+    __syncthreads();
+    if (cg == 0 && rl < row_lanes)
+      for (int c = 0; c < C; ++c) red[rl * 4 + c] = sb[c];
+    __syncthreads();
+    if (threadIdx.x < C) {
+      float sum = 0.0f;
+      for (int k2 = 0; k2 < row_lanes; ++k2) sum += red[k2 * 4 + threadIdx.x];
+      partials[(int64_t)blockIdx.x * (K * C + C) + K * C + threadIdx.x] = sum;
+    }
+  } else if (db && cg == 0 && rl < row_lanes) {
     for (int c = 0; c < C; ++c) unsafeAtomicAdd(db + c, sb[c]);
+  }
+}
+
+// out[i] += sum_b partials[b * n + i]: blockIdx.y splits the workgroup partials 16 ways.
+__global__ void small_head_reduce_kernel(int nblk, int n, int n_dw, const float* __restrict__ partials, float* dW,
+                                         float* db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float sum = 0.0f;
+  for (int b = b0; b < b1; ++b) sum += partials[(int64_t)b * n + i];
+  if (i < n_dw) {
+    if (dW) unsafeAtomicAdd(dW + i, sum);
+  } else if (db) {
+    unsafeAtomicAdd(db + (i - n_dw), sum);
   }
 }
 
 extern "C" int mnr_small_head_bwd(int64_t M, int K, int C, const uint16_t* H, int ldh, const float* g,
                                   const float* W, uint16_t* dX, int lddx, int apply_relu_mask, float* dW,
                                   float* db, const uint8_t* mask_bits, int ld_bits, int64_t bits_row_mod,
-                                  void* stream) {
+                                  float* scratch, int64_t scratch_floats, void* stream) {
   MNR_CHECK_ARG(M > 0 && K > 0 && C >= 1 && C <= 4 && H && g && W, "mnr_small_head_bwd: bad arguments (1 <= C <= 4)");
   MNR_CHECK_ARG(K % 8 == 0 && K / 8 <= 256 && ldh % 8 == 0 && (!dX || lddx % 8 == 0),
                 "mnr_small_head_bwd: K must be a multiple of 8 (<= 2048) and the pitches multiples of 8");
@@ -1383,17 +1414,39 @@ extern "C" int mnr_small_head_bwd(int64_t M, int K, int C, const uint16_t* H, in
   // fewer than ~256 and it loses memory parallelism.  tools/head_probe.py.
   int rows_auto = (int)(((M + 511) / 512 + 63) / 64 * 64);
   if (rows_auto < 512) rows_auto = 512;
-  const int rows_per_block = rows_env > 0 ? rows_env : rows_auto;
+  int rows_per_block = rows_env > 0 ? rows_env : rows_auto;
   const int unroll = u_env > 0 ? u_env : 4;
+  // With scratch for per-workgroup partials (reduced by small_head_reduce_kernel) instead of K*C atomics per
+  // workgroup: 295 -> 253-267 us (K = 256, C = 1), 245 -> 98 us (K = 128, C = 3).
+  float* partials = nullptr;
+  if (scratch && dW && rows_env <= 0) {
+    static int blocks_env = -1;
+    if (blocks_env < 0) {
+      const char* e = getenv("MNR_SHB_BLOCKS");
+      blocks_env = e ? atoi(e) : 512;              // tools/head_probe.py: 256: 347 us, 512: 253-267, 1024: 291, 2048: 313 (M = 2^20, K = 256)
+    }
+    int rows_p = (int)(((M + blocks_env - 1) / blocks_env + 63) / 64 * 64);
+    if (rows_p < 256) rows_p = 256;
+    if ((int64_t)mnr_cdiv(M, rows_p) * (K * C + C) <= scratch_floats) {
+      rows_per_block = rows_p;
+      partials = scratch;
+    }
+  }
   const int grid = mnr_cdiv(M, rows_per_block);
 #define MNR_SHB_LAUNCH(UU)                                                                                          \
   hipLaunchKernelGGL(small_head_bwd_kernel<UU>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, C,             \
                      (const bf16*)H, ldh, g, W, (bf16*)dX, lddx, apply_relu_mask, dW, db, rows_per_block, mask_bits, \
-                     ld_bits, bits_row_mod)
+                     ld_bits, bits_row_mod, partials)
   if (unroll >= 4) MNR_SHB_LAUNCH(4);
   else if (unroll >= 2) MNR_SHB_LAUNCH(2);
   else MNR_SHB_LAUNCH(1);
 #undef MNR_SHB_LAUNCH
   MNR_CHECK_LAUNCH();
+  if (partials) {
+    const int n = K * C + C;
+    hipLaunchKernelGGL(small_head_reduce_kernel, dim3(mnr_cdiv(n, 128), 16), dim3(128), 0, (hipStream_t)stream, grid, n,
+                       K * C, partials, dW, db);
+    MNR_CHECK_LAUNCH();
+  }
   return MNR_OK;
 }

@@ -327,6 +327,17 @@ def cast_f32_to_bf16(src, ld_src, M, n, dst, ld_dst, col0):
   L.check(lib().mnr_cast_f32_to_bf16(_ptr(src), ld_src, M, n, _ptr(dst), ld_dst, col0, _stream()))
 
 
+_HEAD_SCRATCH = {}
+
+
+def _head_scratch(device):
+  """Workspace for the per-workgroup dW / db partials of mnr_small_head_bwd (4 MiB per device, allocated once)."""
+  t = _HEAD_SCRATCH.get(device)
+  if t is None:
+    t = _HEAD_SCRATCH[device] = torch.empty(1 << 20, dtype=f32, device=device)
+  return t
+
+
 def small_head_bwd(H, ldh, g, W, *, M, K, Cn, dX=None, lddx=0, relu_mask=True, dW=None, db=None, bits=None,
                    bits_row_mod=0):
   _chk(bits, torch.uint8, 'bits', allow_none=True)
@@ -334,9 +345,10 @@ def small_head_bwd(H, ldh, g, W, *, M, K, Cn, dX=None, lddx=0, relu_mask=True, d
   _chk(g, f32, 'g')
   _chk(W, f32, 'W')
   _e = PROFILE.start()
+  scratch = _head_scratch(H.device)
   L.check(lib().mnr_small_head_bwd(M, K, Cn, _ptr(H), ldh, _ptr(g), _ptr(W), _ptr(dX), lddx, int(relu_mask),
                                    _ptr(dW), _ptr(db), _ptr(bits), bits.stride(0) if bits is not None else 0,
-                                   bits_row_mod, _stream()))
+                                   bits_row_mod, _ptr(scratch), scratch.numel(), _stream()))
   PROFILE.stop(_e, 'small_head_bwd', 2 * M * K * (2 if dX is not None else 1) + 4 * M * Cn)
 
 
