@@ -1035,10 +1035,17 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
 #pragma unroll
   for (int j = 0; j < NJ; ++j) b_off[j] = lane_row * ROWB_B + (((wn * NJ + j) ^ xsw) << 6) + lane_col;
   typedef short s16x8 __attribute__((ext_vector_type(8)));
-  auto tr_frag = [&](const char* ptr, int rowb) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr + 4 * rowb));
-    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  // The transpose reads are issued from inline asm.  Through the builtin, hipcc cannot tell that they read the
+  // OTHER stage than the LDS-DMA just issued writes, and puts `s_waitcnt vmcnt(0)` between stage(s+1) and the first
+  // read of stage s: the next tile's DMA then has to land before this tile's compute starts (measured: 4.9k cycles
+  // per step = DMA + compute in series, against 3.85k for the NT kernel's K tile).  As asm the reads are opaque:
+  // ordering is the explicit lgkmcnt wait below (operands tied to it) and the __syncthreads() at the end of the
+  // step, which still drains vmcnt for the DMA builtin.
+  auto tr_read = [&](const char* ptr, int imm_rows, int rowb) {
+    s16x4 v;
+    const unsigned a = (unsigned)(uintptr_t)(ptr + (size_t)imm_rows * rowb);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
   };
   for (int s = s_begin; s < s_end; ++s) {
     const int cur = (s - s_begin) & 1;
@@ -1047,11 +1054,39 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
     const char* Bs = As + CFG::A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      // One lgkmcnt(0) per k sub-step, operands tied to it so that the MFMAs stay behind it.  (Waiting fragment by
+      // fragment, lgkmcnt(6)/(4)/(2)/(0) with the issue order pinned, measured 4% slower per step.)
+      s16x4 al[KI], ah[KI], bl[NJ], bh[NJ];
+#pragma unroll
+      for (int i = 0; i < KI; ++i) {
+        al[i] = tr_read(As + a_off[i], ks * 16, ROWB_A);
+        ah[i] = tr_read(As + a_off[i], ks * 16 + 4, ROWB_A);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        bl[j] = tr_read(Bs + b_off[j], ks * 16, ROWB_B);
+        bh[j] = tr_read(Bs + b_off[j], ks * 16 + 4, ROWB_B);
+      }
+      static_assert((KI == 4 || KI == 2) && NJ == 2, "wait operand lists below");
+      if constexpr (KI == 4) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]),
+                       "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
+                     :
+                     : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
+                     :
+                     : "memory");
+      }
       bf16x8 fa[KI], fb[NJ];
 #pragma unroll
-      for (int i = 0; i < KI; ++i) fa[i] = tr_frag(As + a_off[i] + ks * 16 * ROWB_A, ROWB_A);
+      for (int i = 0; i < KI; ++i)
+        fa[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = tr_frag(Bs + b_off[j] + ks * 16 * ROWB_B, ROWB_B);
+      for (int j = 0; j < NJ; ++j)
+        fb[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
       for (int i = 0; i < KI; ++i)
 #pragma unroll
