@@ -3,13 +3,23 @@
 //   gemm_nt : C[M,N] = epi([A1|A2][M,K] * Bt[N,K]^T)   forward layers and dX
 //   gemm_tn : C[K,N] += A[M,K]^T * B[M,N]               weight gradients
 //
-// Both: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, each wave a
-// 64x64 block = 2x2 MFMA tiles of 32x32, fp32 accumulators in 64 VGPRs),
-// operand tiles streamed HBM -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4,
-// double-buffered, one barrier per K step), XOR-swizzled through the SOURCE
-// address so the linear DMA image is conflict-free for the fragment reads.
-// Workgroup ids are remapped so that the tiles sharing an operand panel run
-// back to back on one XCD (block b lands on XCD b%8; each XCD has a private L2).
+// Both: 256x256 output tile per 512-thread workgroup (8 waves, each a 128x64 block = 4x2 MFMA tiles of
+// 32x32, fp32 accumulators in 128 VGPRs; a 128x128 / 4-wave variant serves shapes that are not multiples
+// of 256), operand tiles streamed L2 -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4, double-buffered,
+// one barrier per K step), XOR-swizzled through the SOURCE address so the linear DMA image is conflict-free
+// for the fragment reads.  Workgroup ids are remapped so that the tiles sharing an operand panel run together
+// on one XCD (block b lands on XCD b%8; each XCD has a private L2).
+//
+// What the measurements in DESIGN.md section 6 say about these loops, for whoever tunes them next:
+//   * one K step (64 KiB of operands, 256x256x64 MACs) costs ~3.8k cycles; the MFMAs alone 2.05k, the LDS-DMA
+//     alone ~2.8k (23-30 B/clk per CU, independent of prefetch depth), and they overlap only partially;
+//   * hipcc puts `s_waitcnt vmcnt(0)` in front of LDS reads it cannot separate from an in-flight LDS-DMA
+//     (seen with the ds_read_tr builtins in the TN loop: fixed by issuing them from inline asm) and forces
+//     vmcnt(0) when register loads and LDS-DMA are in flight together; always check the ISA of the K loop;
+//   * per-tile fixed costs matter: the NT epilogue was 15.6k cycles of a ~75k-cycle tile before it was reworked,
+//     the TN atomic epilogue makes a second round of workgroups a loss.
+// Optional configurations (phase-interleaved loop, direct-to-register weights, 4-wave 128x128, probes) are kept
+// for tools/gemm_probe.py; none beats the default end to end.
 #include <stdlib.h>
 #include <type_traits>
 
@@ -32,7 +42,7 @@
 //   big  : 256x256 tile, 8 waves (2 along M x 4 along N), 128x64 per wave -- the trunk layers.
 // The big tile halves both the L2->LDS bytes and the LDS fragment reads per MFMA
 // (6 ds_read_b128 per 8 MFMAs instead of 4 per 4); at 128x128 the LDS array is
-// busy ~as long as the matrix pipe (measured 400-560 TF/s, profiles/r1_c).
+// busy ~as long as the matrix pipe (measured 400-560 TF/s).
 
 #define NT_CPAD 16                                   // epilogue staging: 16 B pad per row
 
