@@ -63,8 +63,8 @@ struct NtCfg {
   static constexpr int PH_L = FRAGPIPE_ == 2 ? 6 : FRAGPIPE_ == 3 ? 8 : FRAGPIPE_ == 5 ? 4 : 0;
   // FRAGPIPE >= 6: weights straight from global memory in fragment-major order, LDS ring holds activation
   // half-tiles only: 3 + PH_D slots for the first halves, 2 + PH_D for the second halves.
-  static constexpr int PH_D = FRAGPIPE_ >= 6 ? FRAGPIPE_ - 6 : 0;
-  static constexpr int LDS_OPERANDS = FRAGPIPE_ >= 6 ? (5 + 2 * PH_D) * 16384 : FRAGPIPE_ >= 2 ? PH_S * 16384 : STAGES * STAGE_BYTES;
+  static constexpr int PH_D = (FRAGPIPE_ == 6 || FRAGPIPE_ == 7) ? FRAGPIPE_ - 6 : 0;
+  static constexpr int LDS_OPERANDS = FRAGPIPE_ == 8 ? 2 * A_BYTES : FRAGPIPE_ >= 6 ? (5 + 2 * PH_D) * 16384 : FRAGPIPE_ >= 2 ? PH_S * 16384 : STAGES * STAGE_BYTES;
   static constexpr int LOADS_PER_STAGE = STAGE_BYTES / 16 / THREADS;   // LDS-DMA instructions per wave per stage
   static constexpr int CPITCH = BN * 2 + NT_CPAD;     // bytes per staged output row
   // Rows staged per epilogue pass: the whole tile when it fits the 160 KiB of LDS (one pass, every wave converts
@@ -264,7 +264,52 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
   // proves every wave is done reading tile kt-1, whose buffer the new DMA overwrites), issue tile
   // kt+STAGES-1, compute tile kt.  __syncthreads() would drain vmcnt to 0 and serialise HBM latency
   // with the MFMA phase (measured on the 2-stage version: waves parked 57% of their cycles).
-  if constexpr (CFG::FRAGPIPE >= 6) {
+  if constexpr (CFG::FRAGPIPE == 8) {
+    // 1x8 wave layout, weights direct: every wave owns all 256 rows x 32 columns, so its weight fragments (4 KiB per K
+    // tile, one 1-KiB fully coalesced load per k sub-step from the fragment-major image p.Bp) are private to it: no
+    // duplication across waves, and only the 32 KiB activation tile goes through LDS-DMA (half the bytes of the
+    // default loop, whose measured bound is that fill).  Same two-stage structure: everything issued during step
+    // kt-1 (activation tile kt + weight fragments kt) is waited for at the top of step kt.
+    static_assert(NJ == 1 && CFG::WM == 1 && MI == 8 && BK == 64 && STAGES == 2, "direct-weights loop is built for the 1x8 layout");
+    const bf16* bfrag = (const bf16*)p.Bp + ((int64_t)((n0 >> 5) + wn) * (K / 16)) * 512 + lane * 8;
+    bf16x8 fbn0, fbn1, fbn2, fbn3;                        // weight fragments of the NEXT K tile (inline-asm loads)
+    auto load_B = [&](int kt) {
+      const bf16* src = bfrag + (int64_t)kt * 4 * 512;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fbn0) : "v"(src) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(fbn1) : "v"(src) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(fbn2) : "v"(src) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(fbn3) : "v"(src) : "memory");
+    };
+    auto stage_A = [&](int kt) {
+      const int k0 = kt * BK;
+      char* base = smem + (kt & 1) * CFG::A_BYTES;
+      if (k0 < p.K1) nt_stage_tile<CFG, BM>(A1, p.lda1, m0, k0, base, wave, lane);
+      else nt_stage_tile<CFG, BM>(A2, p.lda2, m0, k0 - p.K1, base, wave, lane);
+    };
+    stage_A(0);
+    load_B(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      // the weight fragments are asm outputs: tie them to the wait so that their first use stays behind it
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(fbn0), "+v"(fbn1), "+v"(fbn2), "+v"(fbn3) : : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const bf16x8 fb[4] = {fbn0, fbn1, fbn2, fbn3};
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) {
+        stage_A(kt + 1);
+        load_B(kt + 1);
+      }
+      const char* As = smem + (kt & 1) * CFG::A_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 fa[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = nt_read_frag<CFG>(As, i * 32 + frow, ks * 2 + khalf);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks], fa[i], acc[0][i], 0, 0, 0);
+      }
+    }
+  } else if constexpr (CFG::FRAGPIPE >= 6) {
     // Direct-B phased loop.  The LDS-DMA path sustains ~23-30 B/clk per CU (tools/gemm_probe.py --timeline,
     // DMA-only probe), less than the 64 KiB per K tile the MFMA rate of a 256x256 tile asks for, so the
     // weights bypass it: each wave loads its own 64 n x 64 k of weights per K tile as eight fully coalesced
@@ -824,6 +869,8 @@ typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 5> NtC26;   //   DMA + barriers only
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 7> NtC27;   //   barriers only
 typedef NtCfg<4, 2, 2, 4, 32, 4> NtC4;             // 256x256, 8 waves, 4 stages of BK=32 (three K half-tiles in flight)
 typedef NtCfg<4, 2, 2, 4, 32, 3> NtC7;             // 256x256, 8 waves, 3 stages of BK=32
+typedef NtCfg<8, 1, 1, 8, 64, 2> NtC35;            // 256x256, 8 waves each 256 rows x 32 columns (no weight duplication across waves)
+typedef NtCfg<8, 1, 1, 8, 64, 2, 1, 8> NtC36;      //   same layout, weights global -> registers from the fragment-major image (needs args.Bp)
 typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
 typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register double-buffered fragments
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 6> NtC30;      // 256x256 phased, weights direct from the fragment-major image (needs args.Bp)
@@ -832,7 +879,7 @@ typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 6, 1> NtC32;   //   probe: no MFMA
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 34 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 36 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -860,6 +907,8 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 27: return nt_launch<NtC27>(a, fast_epi, stream);
     case 30: return nt_launch<NtC30>(a, fast_epi, stream);
     case 33: return nt_launch<NtC33>(a, fast_epi, stream);
+    case 35: return nt_launch<NtC35>(a, fast_epi, stream);
+    case 36: return nt_launch<NtC36>(a, fast_epi, stream);
     case 34: return nt_launch<NtC34>(a, fast_epi, stream);
     case 32: return nt_launch<NtC32>(a, fast_epi, stream);
     default:
@@ -890,7 +939,7 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
                        (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));
   const bool big_ok = (a->M % 256 == 0) && (a->N % 256 == 0);
   int cfg = big_ok ? g_nt_cfg_big : g_nt_cfg_small;
-  if (cfg >= 30 && !a->Bp) cfg = 2;                      // the direct-weights loop needs the fragment-major image
+  if ((cfg == 30 || cfg == 32 || cfg == 36) && !a->Bp) cfg = 2;                      // the direct-weights loop needs the fragment-major image
   static int phased_min_k = -1;                          // tuning hook: phased loop for long-K forward GEMMs only
   if (phased_min_k < 0) {
     const char* e = getenv("MNR_NT_PHASED_MIN_K");
