@@ -182,11 +182,6 @@ typedef struct {
   const uint8_t* mask_bits_in; int ld_bits_in;
   int64_t bits_row_mod;               /* > 0: row m reads the bits of row m % bits_row_mod (tangent rows
                                          c*M + s share the primal mask of sample s) */
-  const uint16_t* Bp;                 /* optional: the same Bt in MFMA-fragment-major order (mnr_pack_desc.transpose
-                                         |= 2): element (n, k) at ((n/32 * K/16 + k/16) * 64 + (k%16/8) * 32 + n%32) * 8
-                                         + k%8, K = K1 + K2.  When given and M, N are multiples of 256 the weight
-                                         fragments go global -> registers (1 KiB per load) and only the activation
-                                         tiles are staged through LDS. */
 } mnr_gemm_nt_args;
 
 /* C[M,N] = epilogue([A1|A2] * Bt^T). */

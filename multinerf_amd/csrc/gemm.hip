@@ -18,7 +18,7 @@
 //     vmcnt(0) when register loads and LDS-DMA are in flight together; always check the ISA of the K loop;
 //   * per-tile fixed costs matter: the NT epilogue was 15.6k cycles of a ~75k-cycle tile before it was reworked,
 //     the TN atomic epilogue makes a second round of workgroups a loss.
-// Optional configurations (phase-interleaved loop, direct-to-register weights, 4-wave 128x128, probes) are kept
+// Optional configurations (phase-interleaved loop, 4-wave 128x128, 1x8 wave layout, probes) are kept
 // for tools/gemm_probe.py; none beats the default end to end.
 #include <stdlib.h>
 #include <type_traits>
@@ -61,10 +61,7 @@ struct NtCfg {
   // phase-interleaved loop (FRAGPIPE >= 2): PH_S half-tile slots of 16 KiB, staged PH_L phases ahead
   static constexpr int PH_S = FRAGPIPE_ == 3 ? 10 : 8;
   static constexpr int PH_L = FRAGPIPE_ == 2 ? 6 : FRAGPIPE_ == 3 ? 8 : FRAGPIPE_ == 5 ? 4 : 0;
-  // FRAGPIPE >= 6: weights straight from global memory in fragment-major order, LDS ring holds activation
-  // half-tiles only: 3 + PH_D slots for the first halves, 2 + PH_D for the second halves.
-  static constexpr int PH_D = (FRAGPIPE_ == 6 || FRAGPIPE_ == 7) ? FRAGPIPE_ - 6 : 0;
-  static constexpr int LDS_OPERANDS = FRAGPIPE_ == 8 ? 2 * A_BYTES : FRAGPIPE_ >= 6 ? (5 + 2 * PH_D) * 16384 : FRAGPIPE_ >= 2 ? PH_S * 16384 : STAGES * STAGE_BYTES;
+  static constexpr int LDS_OPERANDS = FRAGPIPE_ >= 2 ? PH_S * 16384 : STAGES * STAGE_BYTES;
   static constexpr int LOADS_PER_STAGE = STAGE_BYTES / 16 / THREADS;   // LDS-DMA instructions per wave per stage
   static constexpr int CPITCH = BN * 2 + NT_CPAD;     // bytes per staged output row
   // Rows staged per epilogue pass: the whole tile when it fits the 160 KiB of LDS (one pass, every wave converts
@@ -264,185 +261,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
   // proves every wave is done reading tile kt-1, whose buffer the new DMA overwrites), issue tile
   // kt+STAGES-1, compute tile kt.  __syncthreads() would drain vmcnt to 0 and serialise HBM latency
   // with the MFMA phase (measured on the 2-stage version: waves parked 57% of their cycles).
-  if constexpr (CFG::FRAGPIPE == 8) {
-    // 1x8 wave layout, weights direct: every wave owns all 256 rows x 32 columns, so its weight fragments (4 KiB per K
-    // tile, one 1-KiB fully coalesced load per k sub-step from the fragment-major image p.Bp) are private to it: no
-    // duplication across waves, and only the 32 KiB activation tile goes through LDS-DMA (half the bytes of the
-    // default loop, whose measured bound is that fill).  Same two-stage structure: everything issued during step
-    // kt-1 (activation tile kt + weight fragments kt) is waited for at the top of step kt.
-    static_assert(NJ == 1 && CFG::WM == 1 && MI == 8 && BK == 64 && STAGES == 2, "direct-weights loop is built for the 1x8 layout");
-    const bf16* bfrag = (const bf16*)p.Bp + ((int64_t)((n0 >> 5) + wn) * (K / 16)) * 512 + lane * 8;
-    bf16x8 fbn0, fbn1, fbn2, fbn3;                        // weight fragments of the NEXT K tile (inline-asm loads)
-    auto load_B = [&](int kt) {
-      const bf16* src = bfrag + (int64_t)kt * 4 * 512;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fbn0) : "v"(src) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(fbn1) : "v"(src) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(fbn2) : "v"(src) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(fbn3) : "v"(src) : "memory");
-    };
-    auto stage_A = [&](int kt) {
-      const int k0 = kt * BK;
-      char* base = smem + (kt & 1) * CFG::A_BYTES;
-      if (k0 < p.K1) nt_stage_tile<CFG, BM>(A1, p.lda1, m0, k0, base, wave, lane);
-      else nt_stage_tile<CFG, BM>(A2, p.lda2, m0, k0 - p.K1, base, wave, lane);
-    };
-    stage_A(0);
-    load_B(0);
-    for (int kt = 0; kt < nk; ++kt) {
-      // the weight fragments are asm outputs: tie them to the wait so that their first use stays behind it
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(fbn0), "+v"(fbn1), "+v"(fbn2), "+v"(fbn3) : : "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const bf16x8 fb[4] = {fbn0, fbn1, fbn2, fbn3};
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 1 < nk) {
-        stage_A(kt + 1);
-        load_B(kt + 1);
-      }
-      const char* As = smem + (kt & 1) * CFG::A_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 fa[MI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i] = nt_read_frag<CFG>(As, i * 32 + frow, ks * 2 + khalf);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks], fa[i], acc[0][i], 0, 0, 0);
-      }
-    }
-  } else if constexpr (CFG::FRAGPIPE >= 6) {
-    // Direct-B phased loop.  The LDS-DMA path sustains ~23-30 B/clk per CU (tools/gemm_probe.py --timeline,
-    // DMA-only probe), less than the 64 KiB per K tile the MFMA rate of a 256x256 tile asks for, so the
-    // weights bypass it: each wave loads its own 64 n x 64 k of weights per K tile as eight fully coalesced
-    // 1-KiB vector loads from the fragment-major image (p.Bp), two K-tile-halves ahead of their use, and
-    // only the activation rows go through LDS.  Quadrant order per K tile t (two wave groups half a phase
-    // apart as above):
-    //   p0: ds_read A0(t)   issue B1(t)     wait B0(t)   mfma q(0,0)
-    //   p1: ds_read A1(t)   issue DMA A1(t+1+D)          mfma q(1,0)
-    //   p2:                 issue B0(t+1)   wait B1(t)   mfma q(1,1)
-    //   p3: ds_read A0(t)   issue DMA A0(t+2+D)          mfma q(0,1)
-    // vmcnt retires in order, so waiting for a weight fragment also proves every activation half-tile
-    // issued before it has landed; each is read at least one phase (two barriers) after such a wait.
-    static_assert(MI == 4 && NJ == 2 && CFG::WM == 2 && CFG::WN == 4 && BK == 64, "phased loop is built for the 256x256 tile");
-    constexpr int D = CFG::PH_D, S0 = 3 + D, S1 = 2 + D;
-    const bf16* Bp = (const bf16*)p.Bp;
-    const int kfr = K / 16;
-    const bf16* bfrag = Bp + ((int64_t)((n0 >> 5) + wn * 2) * kfr) * 512 + lane * 8;
-    bf16x8 fa[2][4], fb[2][4];
-    auto load_B = [&](auto bhc, int t) {
-      constexpr int BH = decltype(bhc)::value;
-      // Issued from inline asm: hipcc's waitcnt insertion forces vmcnt(0) in front of the consuming MFMAs when
-      // register loads and LDS-DMA are in flight together (it treats the counter as out of order), which would
-      // serialise these loads; the counted waits below are the only ordering, pinned by sched_barrier(0).
-      const bf16* src = bfrag + ((int64_t)BH * kfr + t * 4) * 512;
-      bf16x8 v0, v1, v2, v3;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v0) : "v"(src) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(v1) : "v"(src) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(v2) : "v"(src) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(v3) : "v"(src) : "memory");
-      fb[BH][0] = v0;
-      fb[BH][1] = v1;
-      fb[BH][2] = v2;
-      fb[BH][3] = v3;
-    };
-    int w0 = 0, w1 = 0, r0 = 0, r1 = 0;                      // ring positions (write / read) of the two slot groups
-    auto stage_A0 = [&](int t) {
-      nt_stage_half<0>(p, A1, A2, Bt, m0, n0, t, smem + w0 * NT_HT_BYTES, wave, lane);
-      w0 = (w0 + 1 == S0) ? 0 : w0 + 1;
-    };
-    auto stage_A1 = [&](int t) {
-      nt_stage_half<3>(p, A1, A2, Bt, m0, n0, t, smem + (S0 + w1) * NT_HT_BYTES, wave, lane);
-      w1 = (w1 + 1 == S1) ? 0 : w1 + 1;
-    };
-    auto wait_n = [&](int n) {                               // wave-uniform n in {0, 2, 4, 6}
-      if (n >= 6) nt_wait_vmcnt<6>();
-      else if (n >= 4) nt_wait_vmcnt<4>();
-      else if (n >= 2) nt_wait_vmcnt<2>();
-      else nt_wait_vmcnt<0>();
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    // prologue: A0(0 .. 1+D), A1(0 .. D), B0(0)
-#pragma unroll
-    for (int i = 0; i <= 1 + D; ++i)
-      if (i < nk) stage_A0(i);
-#pragma unroll
-    for (int i = 0; i <= D; ++i)
-      if (i < nk) stage_A1(i);
-    load_B(I0(), 0);
-    nt_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    const int arow = wm * 64 + frow;
-    auto read_A = [&](const char* slot) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) fa[ii][ks] = nt_read_half<(CFG::ABLATE & 4) == 0>(slot, arow + ii * 32, ks * 2 + khalf);
-    };
-    auto quadrant = [&](auto ahc, auto bhc) {
-      constexpr int AH = decltype(ahc)::value, BH = decltype(bhc)::value;
-      __builtin_amdgcn_s_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          if constexpr (CFG::ABLATE & 1) {
-            asm volatile("" ::"v"(fb[BH][ks]), "v"(fa[ii][ks]));
-          } else {
-            acc[BH][AH * 2 + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[BH][ks], fa[ii][ks], acc[BH][AH * 2 + ii], 0, 0, 0);
-          }
-        }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    bool a0_prev = false;                                    // an A0 DMA was issued in the previous p3
-    auto tile = [&](auto steady, int t) {
-      // STEADY: every issue of this K tile happens (no tail conditions), so the counted waits are
-      // compile-time constants and hipcc's own waitcnt insertion sees straight-line code (with conditional
-      // issues it falls back to vmcnt(0) in front of the MFMAs, which serialises the weight loads).
-      constexpr bool STEADY = decltype(steady)::value;
-      const char* sA0 = smem + r0 * NT_HT_BYTES;
-      const char* sA1 = smem + (S0 + r1) * NT_HT_BYTES;
-      r0 = (r0 + 1 == S0) ? 0 : r0 + 1;
-      r1 = (r1 + 1 == S1) ? 0 : r1 + 1;
-      // p0
-      read_A(sA0);
-      load_B(I1(), t);
-      if (STEADY) nt_wait_vmcnt<6>();
-      else wait_n(4 + (a0_prev ? 2 : 0));
-      quadrant(I0(), I0());
-      // p1
-      read_A(sA1);
-      const bool a1_now = STEADY || (t + 1 + D < nk);
-      if (a1_now) stage_A1(t + 1 + D);
-      quadrant(I1(), I0());
-      // p2
-      const bool b0_now = STEADY || (t + 1 < nk);
-      if (b0_now) load_B(I0(), t + 1);
-      if (STEADY) nt_wait_vmcnt<6>();
-      else wait_n((b0_now ? 4 : 0) + (a1_now ? 2 : 0));
-      quadrant(I1(), I1());
-      // p3
-      read_A(sA0);
-      a0_prev = STEADY || (t + 2 + D < nk);
-      if (a0_prev) stage_A0(t + 2 + D);
-      quadrant(I0(), I1());
-    };
-    int t = 0;
-    if (nk > 0) {                                            // tile 0: no A0 DMA precedes its p0
-      tile(std::false_type(), 0);
-      t = 1;
-    }
-    for (; t + 2 + D < nk; ++t) tile(std::true_type(), t);
-    for (; t < nk; ++t) tile(std::false_type(), t);
-    if (wm == 0) __builtin_amdgcn_s_barrier();
-  } else if constexpr (CFG::FRAGPIPE >= 2) {
+  if constexpr (CFG::FRAGPIPE >= 2) {
     static_assert(MI == 4 && NJ == 2 && CFG::WM == 2 && CFG::WN == 4 && BK == 64, "phased loop is built for the 256x256 tile");
     constexpr int S = CFG::PH_S, LEAD = CFG::PH_L;
     static_assert(LEAD >= 2 && LEAD <= S - 2, "a slot is restaged two or more phases after its last read");
@@ -870,16 +689,13 @@ typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 7> NtC27;   //   barriers only
 typedef NtCfg<4, 2, 2, 4, 32, 4> NtC4;             // 256x256, 8 waves, 4 stages of BK=32 (three K half-tiles in flight)
 typedef NtCfg<4, 2, 2, 4, 32, 3> NtC7;             // 256x256, 8 waves, 3 stages of BK=32
 typedef NtCfg<8, 1, 1, 8, 64, 2> NtC35;            // 256x256, 8 waves each 256 rows x 32 columns (no weight duplication across waves)
-typedef NtCfg<8, 1, 1, 8, 64, 2, 1, 8> NtC36;      //   same layout, weights global -> registers from the fragment-major image (needs args.Bp)
 typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
 typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register double-buffered fragments
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 6> NtC30;      // 256x256 phased, weights direct from the fragment-major image (needs args.Bp)
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 6, 1> NtC32;   //   probe: no MFMA
 
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 36 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 35 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -905,12 +721,9 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 25: return nt_launch<NtC25>(a, fast_epi, stream);
     case 26: return nt_launch<NtC26>(a, fast_epi, stream);
     case 27: return nt_launch<NtC27>(a, fast_epi, stream);
-    case 30: return nt_launch<NtC30>(a, fast_epi, stream);
     case 33: return nt_launch<NtC33>(a, fast_epi, stream);
     case 35: return nt_launch<NtC35>(a, fast_epi, stream);
-    case 36: return nt_launch<NtC36>(a, fast_epi, stream);
     case 34: return nt_launch<NtC34>(a, fast_epi, stream);
-    case 32: return nt_launch<NtC32>(a, fast_epi, stream);
     default:
       mnr_set_error("mnr_gemm_nt_bf16: configuration %d is not compiled in", cfg);
       return MNR_ERR_INVALID_ARGUMENT;
@@ -939,7 +752,6 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
                        (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));
   const bool big_ok = (a->M % 256 == 0) && (a->N % 256 == 0);
   int cfg = big_ok ? g_nt_cfg_big : g_nt_cfg_small;
-  if ((cfg == 30 || cfg == 32 || cfg == 36) && !a->Bp) cfg = 2;                      // the direct-weights loop needs the fragment-major image
   static int phased_min_k = -1;                          // tuning hook: phased loop for long-K forward GEMMs only
   if (phased_min_k < 0) {
     const char* e = getenv("MNR_NT_PHASED_MIN_K");

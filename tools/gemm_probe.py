@@ -55,8 +55,7 @@ def main():
     buf = torch.zeros((nwg, 16), dtype=torch.int64, device=dev)
     for c in [int(x) for x in (args.cfgs or '2,18').split(',')]:
       ops.L.check(ops.lib().mnr_gemm_nt_set_config(c, 0))
-      fn = lambda: ops.gemm_nt(A, Bt, M=M, N=N, K1=K, bias=bias, n_bias=N, relu=True, Cb=C, ldcb=N + pad, nb=N,
-                               Bp=Bt if c in (30, 32, 36) else None)   # timing only: Bt read as if it were fragment-major
+      fn = lambda: ops.gemm_nt(A, Bt, M=M, N=N, K1=K, bias=bias, n_bias=N, relu=True, Cb=C, ldcb=N + pad, nb=N)
       for _ in range(5):
         fn()
       torch.cuda.synchronize()
