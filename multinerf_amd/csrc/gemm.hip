@@ -104,7 +104,8 @@ __device__ __forceinline__ bf16x8 nt_read_frag(const char* lds_tile, int row, in
 
 template <int N>
 __device__ __forceinline__ void nt_wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  MNR_GPU_ASM(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"));
+  MNR_SIM_HOOK(hipsim::wait_vmcnt(N));
 }
 
 
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
     auto quadrant = [&](auto ahc, auto bhc) {
       constexpr int AH = decltype(ahc)::value, BH = decltype(bhc)::value;
       __builtin_amdgcn_s_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      MNR_GPU_ASM(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
           if constexpr (CFG::ABLATE & 1) {
-            asm volatile("" ::"v"(fb[BH][ks]), "v"(fa[ii][ks]));
+            MNR_GPU_ASM(asm volatile("" ::"v"(fb[BH][ks]), "v"(fa[ii][ks])));
           } else {
             acc[BH][AH * 2 + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[BH][ks], fa[ii][ks], acc[BH][AH * 2 + ii], 0, 0, 0);
           }
@@ -437,9 +438,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_ge
         }
         if constexpr (CFG::ABLATE & 1) {
 #pragma unroll
-          for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(fa[i]));
+          for (int i = 0; i < MI; ++i) MNR_GPU_ASM(asm volatile("" ::"v"(fa[i])));
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(fb[j]));
+          for (int j = 0; j < NJ; ++j) MNR_GPU_ASM(asm volatile("" ::"v"(fb[j])));
         } else {
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
@@ -914,8 +915,9 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
   // step, which still drains vmcnt for the DMA builtin.
   auto tr_read = [&](const char* ptr, int imm_rows, int rowb) {
     s16x4 v;
-    const unsigned a = (unsigned)(uintptr_t)(ptr + (size_t)imm_rows * rowb);
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    MNR_GPU_ASM(const unsigned a = (unsigned)(uintptr_t)(ptr + (size_t)imm_rows * rowb);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory"));
+    MNR_SIM_HOOK(v = hipsim::ds_read_tr16_b64(ptr + (size_t)imm_rows * rowb));
     return v;
   };
   for (int s = s_begin; s < s_end; ++s) {
@@ -940,16 +942,16 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
       }
       static_assert((KI == 4 || KI == 2) && NJ == 2, "wait operand lists below");
       if constexpr (KI == 4) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]),
-                       "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
-                     :
-                     : "memory");
+        MNR_GPU_ASM(asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]),
+                                   "+v"(ah[3]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
+                                 :
+                                 : "memory"));
       } else {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
-                     :
-                     : "memory");
+        MNR_GPU_ASM(asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
+                                 :
+                                 : "memory"));
       }
       bf16x8 fa[KI], fb[NJ];
 #pragma unroll

@@ -1,0 +1,93 @@
+"""Loader for tools/hipsim (the host-side functional simulator of the csrc kernels): test infrastructure only."""
+
+import ctypes as C
+import importlib.util
+import os
+
+import torch
+
+from multinerf_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_sim = None
+
+
+def load_sim():
+  """Build (if stale) and load libmnerf_sim.so; binds every prototype of multinerf_amd._lib it exports."""
+  global _sim
+  if _sim is not None:
+    return _sim
+  spec = importlib.util.spec_from_file_location('hipsim_build', os.path.join(ROOT, 'tools', 'hipsim', 'build.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  lib = C.CDLL(mod.build(verbose=False))
+  lib.mnr_last_error.restype = C.c_char_p
+  lib.hipsim_error.restype = C.c_char_p
+  lib.hipsim_reset.argtypes = [C.c_int, C.c_long]
+  lib.hipsim_stats.argtypes = [C.POINTER(C.c_ulonglong)]
+  for name, (argtypes, restype) in L._PROTOS.items():
+    fn = getattr(lib, name, None)
+    if fn is not None:
+      fn.argtypes = argtypes
+      fn.restype = restype
+  _sim = lib
+  return lib
+
+
+def sim_check(lib, status):
+  if status != 0:
+    raise RuntimeError(f'status {status}: {lib.mnr_last_error().decode()}')
+  if lib.hipsim_failed():
+    raise RuntimeError('hipsim: ' + lib.hipsim_error().decode())
+
+
+def ptr(t):
+  return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def sim_gemm_nt(lib, A1, Bt, A2=None, bias=None, relu=False, mask=None, out_bf16=True, out_f32=None, bits_out=False,
+                bits_in=None, bits_row_mod=0, nb=None):
+  """C = epi([A1|A2] Bt^T) through the simulated mnr_gemm_nt_bf16; returns (Cb, Cf, bits)."""
+  M, K1 = A1.shape
+  N = Bt.shape[0]
+  a = L.GemmNTArgs()
+  a.A1, a.lda1, a.K1 = ptr(A1), A1.stride(0), K1
+  if A2 is not None:
+    a.A2, a.lda2, a.K2 = ptr(A2), A2.stride(0), A2.shape[1]
+  a.Bt, a.ldb, a.M, a.N = ptr(Bt), Bt.stride(0), M, N
+  if bias is not None:
+    a.bias, a.n_bias = ptr(bias), bias.numel()
+  a.relu = int(relu)
+  if mask is not None:
+    a.mask, a.ldmask = ptr(mask), mask.stride(0)
+  Cb = Cf = bits = None
+  if out_bf16:
+    nb = N if nb is None else nb
+    Cb = torch.full((M, nb), float('nan'), dtype=torch.bfloat16)
+    a.Cb, a.ldcb, a.nb = ptr(Cb), Cb.stride(0), nb
+  if out_f32 is not None:
+    f0, nf = out_f32
+    Cf = torch.full((M, nf), float('nan'), dtype=torch.float32)
+    a.Cf, a.ldcf, a.f0, a.nf = ptr(Cf), Cf.stride(0), f0, nf
+  if bits_out:
+    bits = torch.zeros((M, N // 8), dtype=torch.uint8)
+    a.mask_bits_out, a.ld_bits_out = ptr(bits), bits.stride(0)
+  if bits_in is not None:
+    a.mask_bits_in, a.ld_bits_in, a.bits_row_mod = ptr(bits_in), bits_in.stride(0), bits_row_mod
+  sim_check(lib, lib.mnr_gemm_nt_bf16(C.byref(a), None))
+  return Cb, Cf, bits
+
+
+def sim_gemm_tn(lib, A, B, C_acc, bias_out=None, k_valid=None, n_valid=None):
+  """C_acc[K,N] += A^T B (and bias_out += column sums of B) through the simulated mnr_gemm_tn_bf16."""
+  M, K = A.shape
+  N = B.shape[1]
+  a = L.GemmTNArgs()
+  a.A, a.lda, a.K = ptr(A), A.stride(0), K
+  a.B, a.ldb, a.N = ptr(B), B.stride(0), N
+  a.M, a.C, a.ldc = M, ptr(C_acc), C_acc.stride(0)
+  a.k_valid = K if k_valid is None else k_valid
+  a.n_valid = N if n_valid is None else n_valid
+  if bias_out is not None:
+    a.bias_out, a.bias_n_valid = ptr(bias_out), bias_out.numel()
+  sim_check(lib, lib.mnr_gemm_tn_bf16(C.byref(a), None))

@@ -1,0 +1,167 @@
+"""The GEMM kernels' SOURCE (multinerf_amd/csrc/gemm.hip) run through tools/hipsim, the host-side functional simulator.
+
+What this is: index arithmetic, LDS swizzles, fragment layouts, K-loop pipeline bookkeeping (counted vmcnt waits, raw
+barriers) and the epilogues of the shipped kernels, executed lane by lane on the CPU against a plain fp32 reference, with
+LDS-DMA landing as early and as late as the hardware may deliver it and with different wave orders.  What it is not: a
+product path (the package never loads the simulator) or evidence about the hardware; tests/test_gpu_kernels.py is that.
+The kernels here are the ones the GPU suite validates, so agreement also pins the simulator's restated instruction
+semantics (MFMA lane layout, ds_read_b64_tr_b16, DPP quad_perm, global_load_lds).
+"""
+
+import ctypes as C
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from tests import sim_helpers as S
+
+pytestmark = pytest.mark.skipif(
+    not (shutil.which('clang++') or __import__('os').path.exists('/opt/rocm/lib/llvm/bin/clang++')), reason='needs clang++')
+
+# (LDS-DMA lands late, fiber order): eager/forward, late/forward, eager/reverse, late/shuffled
+MODES = [(0, 0), (1, 0), (0, -1), (1, 11)]
+
+
+@pytest.fixture(scope='module')
+def sim():
+  lib = S.load_sim()
+  yield lib
+  lib.mnr_gemm_nt_set_config(2, 0)
+
+
+def _packbits(x):
+  return torch.from_numpy(np.packbits((x > 0).numpy(), axis=1, bitorder='little'))
+
+
+@pytest.mark.parametrize('cfg', [2, 12, 4, 7, 18, 19, 33, 35])
+@pytest.mark.parametrize('mode', MODES)
+def test_nt_forward_layer(sim, cfg, mode):
+  """Forward layer: [A1|A2] W^T + b, ReLU, bf16 output + 1-bit ReLU masks; every compiled 256x256 configuration."""
+  g = torch.Generator().manual_seed(cfg)
+  M, N, K1, K2 = 512, 256, 192, 64
+  A1 = torch.randn((M, K1), generator=g).bfloat16()
+  A2 = torch.randn((M, K2), generator=g).bfloat16()
+  Bt = (torch.randn((N, K1 + K2), generator=g) * 0.1).bfloat16()
+  bias = torch.randn(N, generator=g)
+  sim.mnr_gemm_nt_set_config(cfg, 0)
+  sim.hipsim_reset(*mode)
+  Cb, _, bits = S.sim_gemm_nt(sim, A1, Bt, A2=A2, bias=bias, relu=True, bits_out=True)
+  ref = torch.relu(torch.cat([A1, A2], 1).float() @ Bt.float().T + bias)
+  np.testing.assert_allclose(Cb.float().numpy(), ref.numpy(), atol=2e-2, rtol=1e-2)       # bf16 output rounding
+  assert torch.equal(bits, _packbits(Cb.float()))
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_nt_dx_layer_with_bit_masks(sim, mode):
+  """dX layer: (dY W) masked by the forward layer's bits (with the tangent rows' modulo), fp32 side output."""
+  g = torch.Generator().manual_seed(5)
+  M, N, K = 512, 256, 128
+  dY = torch.randn((M, K), generator=g).bfloat16()
+  Wt = (torch.randn((N, K), generator=g) * 0.1).bfloat16()
+  keep = torch.rand((256, N), generator=g) > 0.5
+  bits = _packbits(keep.float())
+  sim.mnr_gemm_nt_set_config(2, 0)
+  sim.hipsim_reset(*mode)
+  Cb, Cf, _ = S.sim_gemm_nt(sim, dY, Wt, bits_in=bits, bits_row_mod=256, out_f32=(8, 11))
+  ref = (dY.float() @ Wt.float().T) * keep.repeat(2, 1)
+  np.testing.assert_allclose(Cb.float().numpy(), ref.numpy(), atol=2e-2, rtol=1e-2)
+  np.testing.assert_allclose(Cf.numpy(), ref[:, 8:19].numpy(), atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize('mode', MODES[:2])
+def test_nt_small_tile_heads(sim, mode):
+  """128x128 tile (N not a multiple of 256): partial-width bf16 output, bf16 mask operand, no bias."""
+  g = torch.Generator().manual_seed(6)
+  M, N, K = 384, 128, 320
+  A = torch.randn((M, K), generator=g).bfloat16()
+  Bt = (torch.randn((N, K), generator=g) * 0.1).bfloat16()
+  mask = torch.randn((M, N), generator=g).bfloat16()
+  sim.hipsim_reset(*mode)
+  Cb, _, _ = S.sim_gemm_nt(sim, A, Bt, mask=mask, nb=96)
+  ref = (A.float() @ Bt.float().T) * (mask.float() > 0)
+  np.testing.assert_allclose(Cb.float().numpy(), ref[:, :96].numpy(), atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize('shape', [(512, 256, 256), (1024, 128, 384), (320, 128, 128)])
+@pytest.mark.parametrize('mode', MODES)
+def test_tn_weight_gradient(sim, shape, mode):
+  """dW += X^T dY and db += column sums (the all-ones MFMA), both tile sizes, M not a multiple of the split."""
+  M, K, N = shape
+  g = torch.Generator().manual_seed(M)
+  A = torch.randn((M, K), generator=g).bfloat16()
+  B = torch.randn((M, N), generator=g).bfloat16()
+  acc = torch.ones((K, N))
+  db = torch.zeros(N)
+  sim.hipsim_reset(*mode)
+  S.sim_gemm_tn(sim, A, B, acc, bias_out=db, k_valid=K - 3, n_valid=N - 5)
+  ref = 1.0 + A.float().T @ B.float()
+  ref[K - 3:, :] = 1.0
+  ref[:, N - 5:] = 1.0
+  np.testing.assert_allclose(acc.numpy(), ref.numpy(), atol=1e-3, rtol=1e-5)
+  np.testing.assert_allclose(db.numpy(), B.float().sum(0).numpy(), atol=1e-3, rtol=1e-5)
+
+
+def test_small_head_bwd_and_colsum(sim):
+  """The non-MFMA kernels of gemm.hip: rgb-head VJP (dX with bit masks, dW / db through workgroup partials), colsum."""
+  g = torch.Generator().manual_seed(8)
+  M, K, Cn = 1000, 128, 3
+  H = torch.randn((M, K), generator=g).bfloat16()
+  gr = torch.randn((M, Cn), generator=g)
+  W = torch.randn((K, Cn), generator=g)
+  keep = torch.rand((M, K), generator=g) > 0.3
+  bits = _packbits(keep.float())
+  dX = torch.zeros((M, K), dtype=torch.bfloat16)
+  dW, db = torch.zeros((K, Cn)), torch.zeros(Cn)
+  scratch = torch.zeros(1 << 16)
+  sim.hipsim_reset(0, 0)
+  S.sim_check(sim, sim.mnr_small_head_bwd(M, K, Cn, S.ptr(H), K, S.ptr(gr), S.ptr(W), S.ptr(dX), K, 0, S.ptr(dW), S.ptr(db),
+                                            S.ptr(bits), bits.stride(0), 0, S.ptr(scratch), scratch.numel(), None))
+  np.testing.assert_allclose(dX.float().numpy(), ((gr @ W.T) * keep).numpy(), atol=2e-2, rtol=1e-2)
+  np.testing.assert_allclose(dW.numpy(), (H.float().T @ gr).numpy(), atol=1e-3, rtol=1e-4)
+  np.testing.assert_allclose(db.numpy(), gr.sum(0).numpy(), atol=1e-3, rtol=1e-4)
+  out = torch.zeros(K)
+  S.sim_check(sim, sim.mnr_colsum_bf16(S.ptr(H), K, M, K - 2, S.ptr(out), None))
+  np.testing.assert_allclose(out[:K - 2].numpy(), H.float().sum(0)[:K - 2].numpy(), atol=1e-3, rtol=1e-4)
+  assert float(out[K - 2:].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- the simulator catches what it claims to
+
+
+def _selftest(sim, bug, mode, rounds=4):
+  src = torch.randn(rounds * 1024, generator=torch.Generator().manual_seed(1))
+  s = src.view(rounds, 4, 64, 4)
+  want = torch.stack([s[:, (t // 64 + 1) % 4, t % 64, 0].sum() + s[:, (t // 64 + 1) % 4, t % 64, 3].sum() for t in range(256)])
+  dst = torch.zeros(256)
+  sim.hipsim_reset(*mode)
+  sim.hipsim_selftest(bug, S.ptr(src), S.ptr(dst), rounds, 1)
+  failed = bool(sim.hipsim_failed())
+  msg = sim.hipsim_error().decode()
+  sim.hipsim_reset(0, 0)
+  return bool(torch.allclose(dst, want, atol=1e-5)) and not failed, msg
+
+
+def test_simulator_detects_seeded_synchronisation_bugs(sim):
+  """tools/hipsim/selftest.hip: the correct kernel passes in every mode; a read without the vmcnt wait shows with DMA
+  landing late; a missing barrier and an early restage show through run-ahead scheduling; a lane-varying LDS-DMA base
+  is flagged."""
+  for mode in MODES:
+    assert _selftest(sim, 0, mode)[0]
+  assert _selftest(sim, 1, (0, 0))[0]                  # invisible while DMA lands at issue ...
+  assert not _selftest(sim, 1, (1, 0))[0]              # ... stale LDS when it lands at the wait
+  for mode in MODES:
+    assert not _selftest(sim, 2, mode)[0]
+    assert not _selftest(sim, 3, mode)[0]
+    ok, msg = _selftest(sim, 4, mode)
+    assert not ok and 'wave-uniform' in msg
+
+
+def test_simulator_flags_lds_overflow_and_bad_arguments(sim):
+  """The C ABI's argument checks run unchanged on the host build."""
+  A = torch.zeros((100, 64), dtype=torch.bfloat16)
+  Bt = torch.zeros((128, 64), dtype=torch.bfloat16)
+  sim.hipsim_reset(0, 0)
+  with pytest.raises(RuntimeError, match='multiple of 128'):
+    S.sim_gemm_nt(sim, A, Bt)
