@@ -23,10 +23,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define MNR_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // Seams for tools/hipsim, the host-side functional simulator the CPU tests run this source through (it stands in
-// for <hip/hip_runtime.h> and defines both macros the other way round): statements that only exist on the GPU
-// (inline asm) go through MNR_GPU_ASM, their restated semantics through MNR_SIM_HOOK.  Here: asm as written, no hook.
-#ifndef MNR_GPU_ASM
-#define MNR_GPU_ASM(...) __VA_ARGS__
+// for <hip/hip_runtime.h> and defines both macros the other way round): tokens that only exist on the GPU
+// (inline asm, amdgpu attributes) go through MNR_GPU_ONLY, their restated semantics through MNR_SIM_HOOK.  Here: asm as written, no hook.
+#ifndef MNR_GPU_ONLY
+#define MNR_GPU_ONLY(...) __VA_ARGS__
 #define MNR_SIM_HOOK(...)
 #endif
 

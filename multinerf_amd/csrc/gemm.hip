@@ -19,7 +19,10 @@
 //   * per-tile fixed costs matter: the NT epilogue was 15.6k cycles of a ~75k-cycle tile before it was reworked,
 //     the TN atomic epilogue makes a second round of workgroups a loss.
 // Optional configurations (phase-interleaved loop, 4-wave 128x128, 1x8 wave layout, probes) are kept
-// for tools/gemm_probe.py; none beats the default end to end.
+// for tools/gemm_probe.py; none beats the default end to end.  NtC36 / NtC37 (1x8 layout, weights global -> reserved
+// registers, never in LDS) are checked by the kernel-source simulator and by tests/test_isa_checks.py but have not run
+// on hardware yet: not selectable by default.
+// The NT kernel's body lives in gemm_nt_body.inc (two __global__ functions share it textually).
 #include <stdlib.h>
 #include <type_traits>
 
@@ -46,9 +49,13 @@
 
 #define NT_CPAD 16                                   // epilogue staging: 16 B pad per row
 
-template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_, int MINW_ = 1, int FRAGPIPE_ = 0, int ABLATE_ = 0>
+template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_, int MINW_ = 1, int FRAGPIPE_ = 0, int ABLATE_ = 0, int BDIRECT_ = 0>
 struct NtCfg {
   static constexpr int ABLATE = ABLATE_;              // probe only: 1 no MFMA, 2 no in-loop DMA, 4 no ds_reads
+  // 1: the weights never touch LDS.  With one wave per 32 output columns (WM = 1) a wave's weight fragments are
+  // private to it, so it loads them global -> registers itself (double-buffered, one K tile ahead) and only the
+  // activation tile is staged through LDS: half the LDS-DMA bytes and half the LDS footprint per stage.
+  static constexpr int BDIRECT = BDIRECT_;
   static constexpr int FRAGPIPE = FRAGPIPE_;          // 1: explicit register double-buffering of LDS fragments
   static constexpr int MI = MI_, NJ = NJ_, WM = WM_, WN = WN_, BK = BK_, STAGES = STAGES_;
   static constexpr int MINW = MINW_;                  // __launch_bounds__ min waves per SIMD (register cap)
@@ -56,7 +63,7 @@ struct NtCfg {
   static constexpr int THREADS = 64 * WM * WN;
   static constexpr int ROWB = BK * 2;                 // bytes per staged operand row
   static constexpr int SLOTS = ROWB / 16;             // 16-B slots per row (8 at BK=64, 4 at BK=32)
-  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BDIRECT_ ? 0 : BN * ROWB;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   // phase-interleaved loop (FRAGPIPE >= 2): PH_S half-tile slots of 16 KiB, staged PH_L phases ahead
   static constexpr int PH_S = FRAGPIPE_ == 3 ? 10 : 8;
@@ -71,6 +78,7 @@ struct NtCfg {
   static_assert(EPI_ROWS * CPITCH <= LDS_BYTES, "epilogue staging must fit in the operand buffers");
   static_assert(BM % EPI_ROWS == 0 && (32 * MI) <= EPI_ROWS && EPI_ROWS % (32 * MI) == 0, "epilogue pass shape");
   static_assert((BM * SLOTS) % THREADS == 0 && (BN * SLOTS) % THREADS == 0, "stage loop shape");
+  static_assert(!BDIRECT_ || (WM_ == 1 && NJ_ == 1 && BK_ == 64 && FRAGPIPE_ == 0 && STAGES_ >= 2), "direct-weights loop shape");
 };
 
 // Stage one operand tile [ROWS][BK] with 16-B LDS-DMA.  LDS image: row r, slot s stored at slot
@@ -104,7 +112,7 @@ __device__ __forceinline__ bf16x8 nt_read_frag(const char* lds_tile, int row, in
 
 template <int N>
 __device__ __forceinline__ void nt_wait_vmcnt() {
-  MNR_GPU_ASM(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"));
+  MNR_GPU_ONLY(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"));
   MNR_SIM_HOOK(hipsim::wait_vmcnt(N));
 }
 
@@ -184,463 +192,14 @@ extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
 
 template <class CFG, bool BITS_IN>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi) {
-  constexpr int MI = CFG::MI, NJ = CFG::NJ, BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, STAGES = CFG::STAGES;
-  constexpr int LPS = CFG::LOADS_PER_STAGE;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / CFG::WN, wn = wave % CFG::WN;
-  unsigned long long* const tl = g_nt_timeline;
-  if (tl && tid == 0) {
-    tl[16 * (int64_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
-    tl[16 * (int64_t)blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();
-    tl[16 * (int64_t)blockIdx.x + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
-  }
+#include "gemm_nt_body.inc"
+}
 
-  // XCD-aware mapping: the nt N-tiles of one M-tile run consecutively on one XCD.
-  const int nt = p.N / BN;
-  const int64_t mt = p.M / BM;
-  const int xcd = blockIdx.x & 7;
-  const int64_t q = blockIdx.x >> 3;
-  const int64_t m_tile = xcd + 8 * (q / nt);
-  const int n_tile = (int)(q % nt);
-  if (m_tile >= mt) return;
-  const int64_t m0 = m_tile * BM;
-  const int n0 = n_tile * BN;
-
-  const bf16* A1 = (const bf16*)p.A1;
-  const bf16* A2 = (const bf16*)p.A2;
-  const bf16* Bt = (const bf16*)p.Bt;
-  const int K = p.K1 + p.K2;
-  const int nk = K / BK;
-  const int frow = lane & 31;
-  const int khalf = lane >> 5;
-
-  // Bias of this lane's output columns, fetched once up front with clamped indices: per-element
-  // "in range ? load : 0" inside the epilogue makes hipcc branch around every load and wait for it
-  // (128 dependent L2 round trips per lane; measured: forward layers 25% slower than dX layers).
-  float bias_r[NJ][16];
-  {
-    // Branch-free: always load (from a valid address), then select.
-    const float* bp = p.bias ? p.bias : reinterpret_cast<const float*>(p.Bt);
-    const int nbias = p.bias ? p.n_bias : 1;
-    const bool has_bias = p.bias != nullptr;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 32 * NJ + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        // multiply by a 0/1 factor rather than select: a select lets hipcc sink the load into a branch.
-        const float keep = (has_bias && n < nbias) ? 1.0f : 0.0f;
-        bias_r[j][r] = bp[min(n, nbias - 1)] * keep;
-      }
-  }
-
-  f32x16 acc[NJ][MI];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
-
-  if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
-  auto stage = [&](int kt) {
-    const int k0 = kt * BK;
-    char* base = smem + (kt % STAGES) * CFG::STAGE_BYTES;
-    if (k0 < p.K1) {
-      nt_stage_tile<CFG, BM>(A1, p.lda1, m0, k0, base, wave, lane);
-    } else {
-      nt_stage_tile<CFG, BM>(A2, p.lda2, m0, k0 - p.K1, base, wave, lane);
-    }
-    nt_stage_tile<CFG, BN>(Bt, p.ldb, n0, k0, base + CFG::A_BYTES, wave, lane);
-  };
-
-  // Software pipeline, STAGES-1 K-tiles in flight.  Iteration kt: wait until tile kt has landed
-  // (counted vmcnt: the younger tiles stay in flight ACROSS the barrier), one raw s_barrier (it also
-  // proves every wave is done reading tile kt-1, whose buffer the new DMA overwrites), issue tile
-  // kt+STAGES-1, compute tile kt.  __syncthreads() would drain vmcnt to 0 and serialise HBM latency
-  // with the MFMA phase (measured on the 2-stage version: waves parked 57% of their cycles).
-  if constexpr (CFG::FRAGPIPE >= 2) {
-    static_assert(MI == 4 && NJ == 2 && CFG::WM == 2 && CFG::WN == 4 && BK == 64, "phased loop is built for the 256x256 tile");
-    constexpr int S = CFG::PH_S, LEAD = CFG::PH_L;
-    static_assert(LEAD >= 2 && LEAD <= S - 2, "a slot is restaged two or more phases after its last read");
-    constexpr int WAITN = 2 * (LEAD - 2);
-    const int nh = 4 * nk;                                   // half-tiles in this GEMM
-    int ws = 0;                                              // slot of the next half-tile to stage (= H mod S)
-    auto issue = [&](auto cc, int H) {                       // stage half-tile H (type cc = H & 3), then wait
-      constexpr int C = decltype(cc)::value;
-      if constexpr (CFG::ABLATE & 2) {
-        nt_wait_vmcnt<0>();
-      } else if (H < nh) {
-        nt_stage_half<C>(p, A1, A2, Bt, m0, n0, H >> 2, smem + ws * NT_HT_BYTES, wave, lane);
-        ws = (ws + 1 == S) ? 0 : ws + 1;
-        nt_wait_vmcnt<WAITN>();
-      } else {
-        nt_wait_vmcnt<0>();
-      }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    // prologue: half-tiles 0 .. LEAD-1
-    {
-      auto pro = [&](auto cc, int H) {
-        constexpr int C = decltype(cc)::value;
-        if (H < nh) {
-          nt_stage_half<C>(p, A1, A2, Bt, m0, n0, H >> 2, smem + ws * NT_HT_BYTES, wave, lane);
-          ws = (ws + 1 == S) ? 0 : ws + 1;
-        }
-      };
-      pro(I0(), 0);
-      pro(I1(), 1);
-      pro(I2(), 2);
-      pro(I3(), 3);
-      if (LEAD > 4) pro(I0(), 4);
-      if (LEAD > 5) pro(I1(), 5);
-      if (LEAD > 6) pro(I2(), 6);
-      if (LEAD > 7) pro(I3(), 7);
-      if (nh >= LEAD) nt_wait_vmcnt<WAITN>();
-      else nt_wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();               // this half runs half a phase behind
-    __builtin_amdgcn_sched_barrier(0);
-
-    bf16x8 fa[2][4], fb[2][4];
-    const int arow = wm * 64 + frow, brow = wn * 32 + frow;
-    auto quadrant = [&](auto ahc, auto bhc) {
-      constexpr int AH = decltype(ahc)::value, BH = decltype(bhc)::value;
-      __builtin_amdgcn_s_barrier();
-      MNR_GPU_ASM(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          if constexpr (CFG::ABLATE & 1) {
-            MNR_GPU_ASM(asm volatile("" ::"v"(fb[BH][ks]), "v"(fa[ii][ks])));
-          } else {
-            acc[BH][AH * 2 + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[BH][ks], fa[ii][ks], acc[BH][AH * 2 + ii], 0, 0, 0);
-          }
-        }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    int rs = 0;                                              // slot of Af of K tile t
-    auto slot_ptr = [&](int k) {                             // slot (rs + k) mod S
-      int q = rs + k;
-      q = q >= S ? q - S : q;
-      return (const char*)smem + q * NT_HT_BYTES;
-    };
-    for (int t = 0; t < nk; ++t) {
-      const char* sAf = slot_ptr(0);
-      const char* sBf = slot_ptr(1);
-      const char* sBs = slot_ptr(2);
-      const char* sAs = slot_ptr(3);
-      rs = rs + 4 >= S ? rs + 4 - S : rs + 4;
-      // phase 0
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fb[0][ks] = nt_read_half<(CFG::ABLATE & 4) == 0>(sBf, brow, ks * 2 + khalf);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) fa[ii][ks] = nt_read_half<(CFG::ABLATE & 4) == 0>(sAf, arow + ii * 32, ks * 2 + khalf);
-      issue(std::integral_constant<int, (0 + LEAD) & 3>(), 4 * t + 0 + LEAD);
-      quadrant(I0(), I0());
-      // phase 1
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fb[1][ks] = nt_read_half<(CFG::ABLATE & 4) == 0>(sBs, brow, ks * 2 + khalf);
-      issue(std::integral_constant<int, (1 + LEAD) & 3>(), 4 * t + 1 + LEAD);
-      quadrant(I0(), I1());
-      // phase 2
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) fa[ii][ks] = nt_read_half<(CFG::ABLATE & 4) == 0>(sAs, arow + ii * 32, ks * 2 + khalf);
-      issue(std::integral_constant<int, (2 + LEAD) & 3>(), 4 * t + 2 + LEAD);
-      quadrant(I1(), I1());
-      // phase 3
-      issue(std::integral_constant<int, (3 + LEAD) & 3>(), 4 * t + 3 + LEAD);
-      quadrant(I1(), I0());
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();               // re-align the two halves
-  } else {
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) stage(s);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int ahead = min(nk - 1, kt + STAGES - 2) - kt;     // younger tiles already issued
-    if (STAGES >= 4 && ahead >= 2) nt_wait_vmcnt<2 * LPS>();
-    else if (STAGES >= 3 && ahead >= 1) nt_wait_vmcnt<1 * LPS>();
-    else nt_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if ((CFG::ABLATE & 2) == 0 && kt + STAGES - 1 < nk) stage(kt + STAGES - 1);
-    const char* As = smem + (kt % STAGES) * CFG::STAGE_BYTES;
-    const char* Bs = As + CFG::A_BYTES;
-    if constexpr (CFG::FRAGPIPE) {
-      // Fragment registers are double-buffered across the k-sub-steps: the ds_reads of sub-step ks+1
-      // are issued BEFORE the MFMAs of sub-step ks, so LDS latency hides under a full MFMA batch.
-      constexpr int NKS = BK / 16;
-      bf16x8 fa[2][MI], fb[2][NJ];
-  #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[0][i] = nt_read_frag<CFG>(As, wm * 32 * MI + i * 32 + frow, khalf);
-  #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[0][j] = nt_read_frag<CFG>(Bs, wn * 32 * NJ + j * 32 + frow, khalf);
-      __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
-  #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const int cb = ks & 1, nb2 = cb ^ 1;
-        if (ks + 1 < NKS) {
-          const int kslot = (ks + 1) * 2 + khalf;
-  #pragma unroll
-          for (int i = 0; i < MI; ++i) fa[nb2][i] = nt_read_frag<CFG>(As, wm * 32 * MI + i * 32 + frow, kslot);
-  #pragma unroll
-          for (int j = 0; j < NJ; ++j) fb[nb2][j] = nt_read_frag<CFG>(Bs, wn * 32 * NJ + j * 32 + frow, kslot);
-        }
-  #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-  #pragma unroll
-          for (int i = 0; i < MI; ++i)
-            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][j], fa[cb][i], acc[j][i], 0, 0, 0);
-        // Pin the issue order: this sub-step's (next-fragment) ds_reads first, then its MFMAs.  Left to
-        // itself hipcc interleaves them 1:1 and drains lgkmcnt to 0 in front of every MFMA group, i.e.
-        // it waits for reads it has just issued.
-        if (ks + 1 < NKS) __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);
-      }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        const int kslot = ks * 2 + khalf;
-        bf16x8 fa[MI], fb[NJ];
-        if constexpr (CFG::ABLATE & 4) {
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) fa[i][e] = (bf16)(float)(kslot + i);
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) fb[j][e] = (bf16)(float)(kslot - j);
-        } else {
-#pragma unroll
-          for (int i = 0; i < MI; ++i) fa[i] = nt_read_frag<CFG>(As, wm * 32 * MI + i * 32 + frow, kslot);
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) fb[j] = nt_read_frag<CFG>(Bs, wn * 32 * NJ + j * 32 + frow, kslot);
-        }
-        if constexpr (CFG::ABLATE & 1) {
-#pragma unroll
-          for (int i = 0; i < MI; ++i) MNR_GPU_ASM(asm volatile("" ::"v"(fa[i])));
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) MNR_GPU_ASM(asm volatile("" ::"v"(fb[j])));
-        } else {
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-              acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
-        }
-      }
-    }
-  }
-  }   // !phased
-  if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
-  // ReLU-mask bits of the output chunks this thread will write in the epilogue.  Fetched here, after the K loop and
-  // before the LDS staging (whose ~4k cycles hide the latency): loading them inside the store loop serialises 16
-  // L2/HBM round trips per tile, and fetching them before the K loop keeps 16 registers live across it, which
-  // the register allocator spills around every load (measured: 3.8k-cycle prologue instead of 1.4k).
-  constexpr int EPI_PASSES = BM / CFG::EPI_ROWS;
-  constexpr int EPI_CPR = BN / 8;
-  constexpr int EPI_ITERS = CFG::EPI_ROWS * EPI_CPR / CFG::THREADS;
-  unsigned mbits[BITS_IN ? EPI_PASSES : 1][BITS_IN ? EPI_ITERS : 1];
-  if (BITS_IN) {
-#pragma unroll
-    for (int h = 0; h < EPI_PASSES; ++h)
-#pragma unroll
-      for (int it = 0; it < EPI_ITERS; ++it) {
-        const int c = it * CFG::THREADS + tid;
-        const int row = c / EPI_CPR, ch = c % EPI_CPR;
-        int64_t mrow = m0 + h * CFG::EPI_ROWS + row;
-        if (p.bits_row_mod > 0) mrow %= p.bits_row_mod;
-        const int64_t idx = mrow * (int64_t)p.ld_bits_in + ((n0 + ch * 8) >> 3);
-        mbits[h][it] = p.mask_bits_in[idx];
-      }
-  }
-  __syncthreads();      // every wave is done with the operand buffers: reuse them for the epilogue
-
-  // Epilogue.  acc[j][i][r]: n = n0 + wn*32*NJ + j*32 + (r&3) + 8*(r>>2) + 4*khalf,
-  //                           m = m0 + wm*32*MI + i*32 + frow.
-  bf16* Cb = (bf16*)p.Cb;
-  const bf16* mask = (const bf16*)p.mask;
-  // Fast path: the whole tile goes to the bf16 output.  A lane's accumulators cover 4 consecutive
-  // n of 32 different rows, so direct stores would touch 32 cache lines per instruction (and so
-  // would the ReLU-mask loads of the dX GEMMs).  The tile is transposed through LDS instead, EPI_ROWS
-  // rows per pass (row pitch BN*2+16 B: 2-way conflicts at most), and leaves as full row segments,
-  // 16 B per lane; the mask tile is read the same way.
-  const bool fast = fast_epi && Cb && (n0 + BN <= p.nb);
-  if (fast) {
-    char* cs = smem;
-    constexpr int PASSES = BM / CFG::EPI_ROWS;
-    constexpr int CHUNKS_PER_ROW = BN / 8;
-    constexpr int ITERS = CFG::EPI_ROWS * CHUNKS_PER_ROW / CFG::THREADS;
-#pragma unroll
-    for (int h = 0; h < PASSES; ++h) {
-      if ((wm * 32 * MI) / CFG::EPI_ROWS == h) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            const int ml = (wm * 32 * MI) % CFG::EPI_ROWS + i * 32 + frow;
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-              const int nl = wn * 32 * NJ + j * 32 + rq * 8 + khalf * 4;
-              // packed fp32 adds (v_pk_add_f32), one v_cvt_pk_bf16_f32 per pair, ReLU on the bf16 bit
-              // patterns as a packed signed-16-bit max with 0 (negative floats are negative int16; rounding
-              // commutes with the clamp): 6 VALU ops per 4 outputs instead of 10.
-              const f32x2 a0 = {acc[j][i][rq * 4 + 0], acc[j][i][rq * 4 + 1]};
-              const f32x2 a1 = {acc[j][i][rq * 4 + 2], acc[j][i][rq * 4 + 3]};
-              const f32x2 b0 = {bias_r[j][rq * 4 + 0], bias_r[j][rq * 4 + 1]};
-              const f32x2 b1 = {bias_r[j][rq * 4 + 2], bias_r[j][rq * 4 + 3]};
-              const f32x2 s0 = a0 + b0, s1 = a1 + b1;
-              typedef short s16x2 __attribute__((ext_vector_type(2)));
-              s16x2 h0 = __builtin_bit_cast(s16x2, __builtin_convertvector(s0, bf16x2));
-              s16x2 h1 = __builtin_bit_cast(s16x2, __builtin_convertvector(s1, bf16x2));
-              if (p.relu) {
-                const s16x2 z = {0, 0};
-                h0 = __builtin_elementwise_max(h0, z);
-                h1 = __builtin_elementwise_max(h1, z);
-              }
-              typedef int i32x2 __attribute__((ext_vector_type(2)));
-              const i32x2 pk = {__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1)};
-              *(i32x2*)(cs + ml * CFG::CPITCH + nl * 2) = pk;
-            }
-          }
-      }
-      __syncthreads();
-      if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 8 + 2 * h] = __builtin_amdgcn_s_memtime();
-      {
-        // Store loop, unswitched on the epilogue flavour (the flags are kernel-uniform; left inside the loop they
-        // cost branches and selects per chunk).  Iteration `it` handles chunk ch of row row0 + it * ROW_STEP.
-        constexpr int ROW_STEP = CFG::THREADS / CHUNKS_PER_ROW;
-        const int row0 = tid / CHUNKS_PER_ROW, ch = tid % CHUNKS_PER_ROW;
-        const int64_t mfirst = m0 + h * CFG::EPI_ROWS + row0;
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        auto store_loop = [&](auto bits_out_c, auto mask_c) {
-          constexpr bool BITS_OUT = decltype(bits_out_c)::value, MASK = decltype(mask_c)::value;
-          bf16* cptr = Cb + mfirst * p.ldcb + n0 + ch * 8;
-          const bf16* mptr = MASK ? mask + mfirst * p.ldmask + n0 + ch * 8 : nullptr;
-          uint8_t* bptr = BITS_OUT ? p.mask_bits_out + mfirst * p.ld_bits_out + ((n0 + ch * 8) >> 3) : nullptr;
-          const char* lptr = cs + row0 * CFG::CPITCH + ch * 16;
-#pragma unroll
-          for (int it = 0; it < ITERS; ++it) {
-            u32x4 w = *(const u32x4*)(lptr + it * ROW_STEP * CFG::CPITCH);     // 8 bf16 as 4 dwords
-            if (BITS_IN) {
-              // 1 bit per element, written by the forward epilogue of the layer whose ReLU this undoes.  Dword d holds
-              // elements 2d (low half) and 2d+1: sign-extended 1-bit fields select the halves (v_bfe_i32, v_bfi).
-              const int mb = (int)mbits[BITS_IN ? h : 0][BITS_IN ? it : 0];
-#pragma unroll
-              for (int d = 0; d < 4; ++d) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(mb, 2 * d, 1);
-                const unsigned hi = (unsigned)__builtin_amdgcn_sbfe(mb, 2 * d + 1, 1);
-                w[d] &= (lo & 0xffffu) | (hi & 0xffff0000u);
-              }
-            } else if (MASK) {
-              const bf16x8 mk = *(const bf16x8*)(mptr + (int64_t)it * ROW_STEP * p.ldmask);
-              bf16x8 v = __builtin_bit_cast(bf16x8, w);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = ((float)mk[e] > 0.0f) ? v[e] : (bf16)0.0f;
-              w = __builtin_bit_cast(u32x4, v);
-            }
-            if (BITS_OUT) {
-              // bit e = (element e > 0).  Clamp the halves at 0 as signed 16-bit (no-op after a ReLU), then
-              // "> 0" is "bits != 0": adding 0x7fff to a half in [0, 0x7fff] sets its bit 15 exactly when it is
-              // non-zero, and the low half cannot carry into the high one.  Fold the 8 flags into one byte; the 4
-              // lanes of a quad (same row, consecutive chunks) combine theirs with DPP quad_perm moves into one
-              // aligned 32-bit store (byte stores cost ~an order of magnitude more per byte).
-              typedef short s16x2b __attribute__((ext_vector_type(2)));
-              unsigned f = 0;
-#pragma unroll
-              for (int d = 0; d < 4; ++d) {
-                const unsigned wd = w[d];     // (bit_cast straight from the vector element reads element 0: clang bug)
-                const s16x2b z = {0, 0};
-                const unsigned pos = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2b, wd), z));
-                f |= ((pos + 0x7fff7fffu) & 0x80008000u) >> (15 - 2 * d);
-              }
-              unsigned mb = (f | (f >> 15)) & 0xffu;
-              mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xF5, 0xf, 0xf, false) << 8;     // quad_perm [1,1,3,3]
-              mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xAA, 0xf, 0xf, false) << 16;    // quad_perm [2,2,2,2]
-              if ((ch & 3) == 0) *(unsigned*)(bptr + (int64_t)it * ROW_STEP * p.ld_bits_out) = mb;
-            }
-            *(u32x4*)(cptr + (int64_t)it * ROW_STEP * p.ldcb) = w;
-          }
-        };
-        if (p.mask_bits_out) store_loop(std::true_type(), std::false_type());
-        else if (!BITS_IN && mask) store_loop(std::false_type(), std::true_type());
-        else store_loop(std::false_type(), std::false_type());
-      }
-      if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 9 + 2 * h] = __builtin_amdgcn_s_memtime();
-      if (h + 1 < PASSES) __syncthreads();
-    }
-  }
-  if ((Cb && !fast) || p.Cf) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int64_t m = m0 + wm * 32 * MI + i * 32 + frow;
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const int n4 = n0 + wn * 32 * NJ + j * 32 + rq * 8 + khalf * 4;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[j][i][rq * 4 + e] + bias_r[j][rq * 4 + e];
-          if (p.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-          }
-          if (BITS_IN) {
-            const int64_t mrow = p.bits_row_mod > 0 ? m % p.bits_row_mod : m;
-            const unsigned mb = p.mask_bits_in[mrow * p.ld_bits_in + (n4 >> 3)] >> (n4 & 7);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.0f;
-          } else if (mask) {
-            const bf16x4 mk = *(const bf16x4*)(mask + m * p.ldmask + n4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((float)mk[e] > 0.0f) ? v[e] : 0.0f;
-          }
-          if (Cb && !fast) {
-            if (n4 + 3 < p.nb) {
-              f32x4 vv = {v[0], v[1], v[2], v[3]};
-              *(bf16x4*)(Cb + m * p.ldcb + n4) = __builtin_convertvector(vv, bf16x4);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (n4 + e < p.nb) Cb[m * p.ldcb + n4 + e] = (bf16)v[e];
-            }
-          }
-          if (p.Cf) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int nn = n4 + e - p.f0;
-              if (nn >= 0 && nn < p.nf) p.Cf[m * p.ldcf + nn] = v[e];
-            }
-          }
-        }
-      }
-    }
-  }
-  if (tl && tid == 0) {
-    tl[16 * (int64_t)blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
-    tl[16 * (int64_t)blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
-  }
+// The direct-weights configurations keep v224-v255 out of the register allocator's hands (see NtCfg::BDIRECT's loop).
+template <class CFG, bool BITS_IN>
+__global__ __launch_bounds__(CFG::THREADS, CFG::MINW) MNR_GPU_ONLY(__attribute__((amdgpu_num_vgpr(224))))
+void gemm_nt_kernel_r224(mnr_gemm_nt_args p, int fast_epi) {
+#include "gemm_nt_body.inc"
 }
 
 template <class CFG>
@@ -653,19 +212,23 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   const int64_t groups = (mt + 7) / 8;
   const int64_t grid = groups * 8 * nt;
   MNR_CHECK_ARG(grid < (1ll << 31), "mnr_gemm_nt_bf16: grid too large");
+  void (*k_plain)(mnr_gemm_nt_args, int);
+  void (*k_bits)(mnr_gemm_nt_args, int);
+  if constexpr (CFG::BDIRECT) {
+    k_plain = gemm_nt_kernel_r224<CFG, false>;
+    k_bits = gemm_nt_kernel_r224<CFG, true>;
+  } else {
+    k_plain = gemm_nt_kernel<CFG, false>;
+    k_bits = gemm_nt_kernel<CFG, true>;
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)k_plain, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)k_bits, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
     attr_set = true;
   }
-  if (a->mask_bits_in) {
-    hipLaunchKernelGGL((gemm_nt_kernel<CFG, true>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
-                       (hipStream_t)stream, *a, fast_epi);
-  } else {
-    hipLaunchKernelGGL((gemm_nt_kernel<CFG, false>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
-                       (hipStream_t)stream, *a, fast_epi);
-  }
+  hipLaunchKernelGGL(a->mask_bits_in ? k_bits : k_plain, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
+                     (hipStream_t)stream, *a, fast_epi);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
@@ -690,13 +253,15 @@ typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 7> NtC27;   //   barriers only
 typedef NtCfg<4, 2, 2, 4, 32, 4> NtC4;             // 256x256, 8 waves, 4 stages of BK=32 (three K half-tiles in flight)
 typedef NtCfg<4, 2, 2, 4, 32, 3> NtC7;             // 256x256, 8 waves, 3 stages of BK=32
 typedef NtCfg<8, 1, 1, 8, 64, 2> NtC35;            // 256x256, 8 waves each 256 rows x 32 columns (no weight duplication across waves)
+typedef NtCfg<8, 1, 1, 8, 64, 3, 1, 0, 0, 1> NtC36; // 1x8 waves, weights global -> registers (never in LDS), 3 activation stages of 32 KiB
+typedef NtCfg<8, 1, 1, 8, 64, 4, 1, 0, 0, 1> NtC37; //   same, 4 stages
 typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
 typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register double-buffered fragments
 
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 35 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 37 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -725,6 +290,8 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 33: return nt_launch<NtC33>(a, fast_epi, stream);
     case 35: return nt_launch<NtC35>(a, fast_epi, stream);
     case 34: return nt_launch<NtC34>(a, fast_epi, stream);
+    case 36: return nt_launch<NtC36>(a, fast_epi, stream);
+    case 37: return nt_launch<NtC37>(a, fast_epi, stream);
     default:
       mnr_set_error("mnr_gemm_nt_bf16: configuration %d is not compiled in", cfg);
       return MNR_ERR_INVALID_ARGUMENT;
@@ -915,7 +482,7 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
   // step, which still drains vmcnt for the DMA builtin.
   auto tr_read = [&](const char* ptr, int imm_rows, int rowb) {
     s16x4 v;
-    MNR_GPU_ASM(const unsigned a = (unsigned)(uintptr_t)(ptr + (size_t)imm_rows * rowb);
+    MNR_GPU_ONLY(const unsigned a = (unsigned)(uintptr_t)(ptr + (size_t)imm_rows * rowb);
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory"));
     MNR_SIM_HOOK(v = hipsim::ds_read_tr16_b64(ptr + (size_t)imm_rows * rowb));
     return v;
@@ -942,13 +509,13 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
       }
       static_assert((KI == 4 || KI == 2) && NJ == 2, "wait operand lists below");
       if constexpr (KI == 4) {
-        MNR_GPU_ASM(asm volatile("s_waitcnt lgkmcnt(0)"
+        MNR_GPU_ONLY(asm volatile("s_waitcnt lgkmcnt(0)"
                                  : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]),
                                    "+v"(ah[3]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
                                  :
                                  : "memory"));
       } else {
-        MNR_GPU_ASM(asm volatile("s_waitcnt lgkmcnt(0)"
+        MNR_GPU_ONLY(asm volatile("s_waitcnt lgkmcnt(0)"
                                  : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
                                  :
                                  : "memory"));

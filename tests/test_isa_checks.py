@@ -1,0 +1,55 @@
+"""Static checks on the device ISA hipcc produces for the hand-scheduled GEMM loops (no GPU needed, ~10 s of hipcc).
+
+The direct-weights NT configurations (NtC36 / NtC37) load weight fragments with inline asm into registers they reserve
+with amdgpu_num_vgpr(224).  Two things would silently corrupt results and cannot be seen by any functional test on the
+host: hipcc touching a reserved register while those loads are in flight, and hipcc adding its own vmcnt waits (it drains
+to 0 when register loads and LDS-DMA are mixed, which is why the loads are asm in the first place).  tools/isa_report.py
+reads both off the generated assembly.
+"""
+
+import importlib.util
+import os
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.skipif(not os.path.exists('/opt/rocm/bin/hipcc') and not shutil.which('hipcc'), reason='needs hipcc')
+
+
+@pytest.fixture(scope='module')
+def report():
+  spec = importlib.util.spec_from_file_location('isa_report', os.path.join(ROOT, 'tools', 'isa_report.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  asm, tmp = mod.compile_selected([2, 36, 37])
+  yield mod, mod.kernel_bodies(asm)
+  shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_reserved_registers_are_left_alone_while_weight_loads_fly(report):
+  mod, bodies = report
+  r224 = {n: b for n, b in bodies.items() if 'r224' in n}
+  assert len(r224) == 4                                  # NtC36 / NtC37, with and without bit-mask input
+  for name, body in r224.items():
+    loads = [l for l in body if l.startswith('\tglobal_load_dwordx4') and 'v[2' in l.split(',')[0]]
+    assert len(loads) >= 8, name                         # the asm loads are there (both parities)
+    assert mod.reserved_register_violations(body) == [], name
+
+
+def test_k_loops_carry_only_the_hand_counted_vmcnt_waits(report):
+  mod, bodies = report
+  for name, body in bodies.items():
+    mfma = [k for k, l in enumerate(body) if 'v_mfma' in l]
+    # from the first to the last MFMA of the kernel = K loop (the epilogue has none)
+    seg = body[mfma[0]:mfma[-1] + 1]
+    assert mod.compiler_vmcnt_waits(seg) == [], name
+
+
+def test_no_spills_inside_the_k_loops(report):
+  """(The default forward kernel spills two registers around its prologue; none may sit between the MFMAs.)"""
+  mod, bodies = report
+  for name, body in bodies.items():
+    mfma = [k for k, l in enumerate(body) if 'v_mfma' in l]
+    assert not any('scratch_' in l for l in body[mfma[0]:mfma[-1] + 1]), name

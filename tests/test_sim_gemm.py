@@ -35,7 +35,7 @@ def _packbits(x):
   return torch.from_numpy(np.packbits((x > 0).numpy(), axis=1, bitorder='little'))
 
 
-@pytest.mark.parametrize('cfg', [2, 12, 4, 7, 18, 19, 33, 35])
+@pytest.mark.parametrize('cfg', [2, 12, 4, 7, 18, 19, 33, 35, 36, 37])
 @pytest.mark.parametrize('mode', MODES)
 def test_nt_forward_layer(sim, cfg, mode):
   """Forward layer: [A1|A2] W^T + b, ReLU, bf16 output + 1-bit ReLU masks; every compiled 256x256 configuration."""
@@ -53,8 +53,9 @@ def test_nt_forward_layer(sim, cfg, mode):
   assert torch.equal(bits, _packbits(Cb.float()))
 
 
+@pytest.mark.parametrize('cfg', [2, 36, 37])
 @pytest.mark.parametrize('mode', MODES)
-def test_nt_dx_layer_with_bit_masks(sim, mode):
+def test_nt_dx_layer_with_bit_masks(sim, cfg, mode):
   """dX layer: (dY W) masked by the forward layer's bits (with the tangent rows' modulo), fp32 side output."""
   g = torch.Generator().manual_seed(5)
   M, N, K = 512, 256, 128
@@ -62,12 +63,27 @@ def test_nt_dx_layer_with_bit_masks(sim, mode):
   Wt = (torch.randn((N, K), generator=g) * 0.1).bfloat16()
   keep = torch.rand((256, N), generator=g) > 0.5
   bits = _packbits(keep.float())
-  sim.mnr_gemm_nt_set_config(2, 0)
+  sim.mnr_gemm_nt_set_config(cfg, 0)
   sim.hipsim_reset(*mode)
   Cb, Cf, _ = S.sim_gemm_nt(sim, dY, Wt, bits_in=bits, bits_row_mod=256, out_f32=(8, 11))
   ref = (dY.float() @ Wt.float().T) * keep.repeat(2, 1)
   np.testing.assert_allclose(Cb.float().numpy(), ref.numpy(), atol=2e-2, rtol=1e-2)
   np.testing.assert_allclose(Cf.numpy(), ref[:, 8:19].numpy(), atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize('cfg', [36, 37])
+@pytest.mark.parametrize('nk', [1, 2, 3, 5])
+def test_nt_direct_weights_short_and_odd_k(sim, cfg, nk):
+  """The direct-weights loop's prologue / tail bookkeeping: fewer K tiles than stages, odd tile counts, late DMA."""
+  g = torch.Generator().manual_seed(nk)
+  M, N, K = 256, 256, 64 * nk
+  A = torch.randn((M, K), generator=g).bfloat16()
+  Bt = (torch.randn((N, K), generator=g) * 0.1).bfloat16()
+  sim.mnr_gemm_nt_set_config(cfg, 0)
+  for mode in MODES:
+    sim.hipsim_reset(*mode)
+    Cb, _, _ = S.sim_gemm_nt(sim, A, Bt)
+    np.testing.assert_allclose(Cb.float().numpy(), (A.float() @ Bt.float().T).numpy(), atol=2e-2, rtol=1e-2)
 
 
 @pytest.mark.parametrize('mode', MODES[:2])

@@ -30,7 +30,7 @@
 #define MNR_HIPSIM 1
 
 // Seams declared by csrc/common.h: GPU-only statements vanish, simulator hooks appear.
-#define MNR_GPU_ASM(...)
+#define MNR_GPU_ONLY(...)
 #define MNR_SIM_HOOK(...) __VA_ARGS__
 
 #define __global__
@@ -107,7 +107,7 @@ unsigned long long clock64();
 #define gridDim (hipsim::cur->gdim3)
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-  hipsim::launch(dim3(grid), dim3(block), (size_t)(shmem), [&]() { kern(__VA_ARGS__); })
+  hipsim::launch(dim3(grid), dim3(block), (size_t)(shmem), [&]() { (kern)(__VA_ARGS__); })
 
 #define __syncthreads() hipsim::syncthreads()
 #define __builtin_amdgcn_s_barrier() hipsim::barrier()

@@ -18,14 +18,14 @@ __global__ __launch_bounds__(256) void selftest_kernel(const float* __restrict__
     char* base = buf + wave * 1024 + (BUG == 4 ? lane : 0);
     __builtin_amdgcn_global_load_lds(MNR_GLOBAL_PTR(g), MNR_LDS_PTR(base), 16, 0, 0);
     if (BUG != 1) {
-      MNR_GPU_ASM(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"));
+      MNR_GPU_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"));
       MNR_SIM_HOOK(hipsim::wait_vmcnt(0));
     }
     if (BUG != 2) __builtin_amdgcn_s_barrier();
     const float* nb = (const float*)(buf + ((wave + 1) & 3) * 1024);
     acc += nb[lane * 4] + nb[lane * 4 + 3];
     if (BUG == 1) {
-      MNR_GPU_ASM(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"));
+      MNR_GPU_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"));
       MNR_SIM_HOOK(hipsim::wait_vmcnt(0));
     }
   }

@@ -1,0 +1,133 @@
+"""Device ISA of selected NT configurations of csrc/gemm.hip, without a GPU: registers, spills, and the K loop.
+
+    python tools/isa_report.py 36 37 [--loop] [--keep]
+
+Compiles a temporary copy of gemm.hip in which nt_dispatch() only instantiates the requested configurations (device
+only, gfx950), then prints per kernel: VGPR / AGPR / SGPR counts, scratch bytes, spilled registers, and the counts of
+MFMA, LDS-DMA, ds_read, global_load and s_waitcnt instructions inside the innermost loops; --loop dumps those loops.
+This is how the waits hipcc inserts around LDS-DMA and register loads are checked before a GPU run (see the notes at
+the top of gemm.hip).
+"""
+
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+RESERVED_LO = 224          # gemm_nt_kernel_r224: v224-v255 belong to the inline-asm weight loads
+
+
+def _vregs(text):
+  out = set()
+  for m in re.finditer(r'\bv\[(\d+):(\d+)\]', text):
+    out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+  for m in re.finditer(r'\bv(\d+)\b', text):
+    out.add(int(m.group(1)))
+  return out
+
+
+def reserved_register_violations(body):
+  """Lines that touch v224+ other than the asm weight loads (as destination) and MFMAs (as source operand), up to the
+  last MFMA that reads them.  amdgpu_num_vgpr(224) is a request, not a cap: hipcc does hand out v224+ when a kernel
+  needs more (seen in the general epilogue path, after the K loop, where the fragments are dead); what must never
+  happen is such a use while weight loads can be in flight, i.e. anywhere before the last MFMA that consumes them."""
+  def is_load(code):
+    if not code.startswith('\tglobal_load_dwordx4'):
+      return False
+    dst, rest = code.split(None, 1)[1].split(',', 1)
+    return all(r >= RESERVED_LO for r in _vregs(dst)) and not any(r >= RESERVED_LO for r in _vregs(rest))
+
+  def is_mfma_src(code):
+    return code.startswith('\tv_mfma') and not any(r >= RESERVED_LO for r in _vregs(code.split(None, 1)[1].split(',')[0]))
+
+  codes = [l.split(';')[0] for l in body]
+  touch = [k for k, c in enumerate(codes) if c.startswith('\t') and any(r >= RESERVED_LO for r in _vregs(c))]
+  last = max((k for k in touch if is_mfma_src(codes[k])), default=-1)
+  return [body[k].strip() for k in touch if k <= last and not is_load(codes[k]) and not is_mfma_src(codes[k])]
+
+
+def compiler_vmcnt_waits(seg):
+  """s_waitcnt with a vmcnt field that hipcc inserted itself (i.e. outside ASMSTART / ASMEND) in a code segment."""
+  out, in_asm = [], False
+  for l in seg:
+    if 'ASMSTART' in l:
+      in_asm = True
+    elif 'ASMEND' in l:
+      in_asm = False
+    elif not in_asm and 's_waitcnt' in l and 'vmcnt' in l:
+      out.append(l.strip())
+  return out
+
+
+def kernel_bodies(asm_text):
+  """{kernel name: list of lines} for every gemm_nt kernel in a device assembly listing."""
+  out = {}
+  for m in re.finditer(r'^(_Z\d+gemm_nt_kernel\w*):', asm_text, flags=re.M):
+    i = m.start()
+    out[m.group(1)] = asm_text[i:asm_text.index('.Lfunc_end', i)].split('\n')
+  return out
+
+
+def mfma_loops(body):
+  """Innermost loops (label .. back-edge) that contain MFMAs."""
+  labels = {l.split(':')[0]: k for k, l in enumerate(body) if l.startswith('.LBB')}
+  loops = []
+  for lab, k0 in labels.items():
+    if 'Loop Header' not in body[k0]:
+      continue
+    k1 = max((k for k, l in enumerate(body) if k > k0 and re.search(r's_c?branch\w*\s+%s\b' % re.escape(lab), l)), default=None)
+    if k1 is not None and any('v_mfma' in l for l in body[k0:k1 + 1]):
+      loops.append((lab, body[k0:k1 + 1]))
+  return loops
+
+
+def compile_selected(cfgs):
+  """Device-only assembly of gemm.hip with nt_dispatch() restricted to `cfgs`; returns (assembly text, temp dir)."""
+  src = open(os.path.join(CSRC, 'gemm.hip')).read()
+  keep = lambda m: m.group(0) if int(m.group(1)) in cfgs else ''
+  src = re.sub(r'^\s*case (\d+): return nt_launch<NtC\d+>\(a, fast_epi, stream\);\n', keep, src, flags=re.M)
+  tmp = tempfile.mkdtemp(prefix='isa_')
+  path = os.path.join(tmp, 'gemm_sel.hip')
+  open(path, 'w').write(src)
+  out = os.path.join(tmp, 'gemm_sel.s')
+  cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '--cuda-device-only', '-S', '-I', CSRC,
+         path, '-o', out]
+  r = subprocess.run(cmd, capture_output=True, text=True)
+  if r.returncode != 0:
+    raise RuntimeError(r.stderr)
+  return open(out).read(), tmp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'multinerf_amd', 'csrc')
+
+
+def main():
+  cfgs = [int(a) for a in sys.argv[1:] if a.isdigit()]
+  show_loop = '--loop' in sys.argv
+  s, tmp = compile_selected(cfgs)
+  meta = {}
+  for m in re.finditer(r'- \.agpr_count:\s+(\d+)(.*?)\.wavefront_size', s, re.S):
+    blk = m.group(0)
+    g = lambda k: re.search(r'\.%s:\s+(\S+)' % k, blk).group(1)
+    meta[g('name')] = (g('vgpr_count'), g('agpr_count'), g('sgpr_count'), g('private_segment_fixed_size'), g('vgpr_spill_count'))
+  for name, body in kernel_bodies(s).items():
+    v, a, sg, scr, sp = meta[name]
+    print(f'{name}\n  vgpr {v} agpr {a} sgpr {sg} scratch {scr} B spilled {sp}')
+    if 'r224' in name:
+      bad = reserved_register_violations(body)
+      print(f'  v{RESERVED_LO}+ touched by anything but the asm loads / MFMA sources before the last consuming MFMA: {len(bad)}' + ''.join('\n    ' + b for b in bad[:8]))
+    for lab, seg in mfma_loops(body):
+      n = lambda pat: sum(1 for l in seg if re.search(pat, l))
+      waits = [l.strip() for l in seg if 's_waitcnt' in l and 'vmcnt' in l]
+      print(f'  loop {lab}: {len(seg)} lines, mfma {n("v_mfma")}, lds-dma {n("global_load_lds")}, ds_read {n("ds_read")}, '
+            f'global_load {n(r"global_load_dwordx")}, scratch {n("scratch_")}, barriers {n("s_barrier")}')
+      print('    vmcnt waits: ' + ' | '.join(waits) + f'   (inserted by hipcc: {len(compiler_vmcnt_waits(seg))})')
+      if show_loop:
+        print('\n'.join(seg))
+  if '--keep' in sys.argv:
+    print('kept', tmp)
+
+
+if __name__ == '__main__':
+  main()
