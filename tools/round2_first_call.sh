@@ -1,0 +1,15 @@
+#!/bin/bash
+# First GPU call of the next round (everything here was prepared without a GPU):
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/round2_first_call.sh'
+# 1. operand-ingest probe: which path / pattern bounds the 64 KiB-per-step operand stream of the GEMM loops
+# 2. direct-weights NT loop (NtC36 / NtC37): bitwise screen against NtC2, then timing next to NtC2 / NtC35
+# 3. the same A/B end to end (MNR_NT_CFG selects the 256x256 configuration for the whole step)
+set -x
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+hipcc --offload-arch=gfx950 -O3 -o /tmp/ingest_probe tools/ingest_probe.hip && timeout 300 /tmp/ingest_probe > gpurun_out/r2_ingest_probe.txt 2>&1
+timeout 600 python tools/gemm_probe.py --cfgs 2,35,36,37 > gpurun_out/r2_gemm_probe_direct.txt 2>&1
+for cfg in 2 36 37; do
+  MNR_NT_CFG=$cfg timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg$cfg.json 2> gpurun_out/r2_bench_cfg$cfg.err
+done
+tail -n 5 gpurun_out/r2_ingest_probe.txt gpurun_out/r2_gemm_probe_direct.txt gpurun_out/r2_bench_cfg*.json
