@@ -23,6 +23,7 @@
 // registers, never in LDS) are checked by the kernel-source simulator and by tests/test_isa_checks.py but have not run
 // on hardware yet: not selectable by default.
 // The NT kernel's body lives in gemm_nt_body.inc (two __global__ functions share it textually).
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -255,13 +256,15 @@ typedef NtCfg<4, 2, 2, 4, 32, 3> NtC7;             // 256x256, 8 waves, 3 stages
 typedef NtCfg<8, 1, 1, 8, 64, 2> NtC35;            // 256x256, 8 waves each 256 rows x 32 columns (no weight duplication across waves)
 typedef NtCfg<8, 1, 1, 8, 64, 3, 1, 0, 0, 1> NtC36; // 1x8 waves, weights global -> registers (never in LDS), 3 activation stages of 32 KiB
 typedef NtCfg<8, 1, 1, 8, 64, 4, 1, 0, 0, 1> NtC37; //   same, 4 stages
+typedef NtCfg<4, 2, 2, 2, 32, 2, 2> NtC38;           // 256x128, 4 waves of 128x64, 48 KiB: TWO workgroups per CU (one's epilogue under the other's K loop)
+typedef NtCfg<4, 2, 2, 2, 32, 3, 2> NtC39;           //   same, 3 stages (72 KiB)
 typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
 typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register double-buffered fragments
 
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 37 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 39 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -291,6 +294,8 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 35: return nt_launch<NtC35>(a, fast_epi, stream);
     case 34: return nt_launch<NtC34>(a, fast_epi, stream);
     case 36: return nt_launch<NtC36>(a, fast_epi, stream);
+    case 38: return nt_launch<NtC38>(a, fast_epi, stream);
+    case 39: return nt_launch<NtC39>(a, fast_epi, stream);
     case 37: return nt_launch<NtC37>(a, fast_epi, stream);
     default:
       mnr_set_error("mnr_gemm_nt_bf16: configuration %d is not compiled in", cfg);
@@ -326,6 +331,13 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
     phased_min_k = e ? atoi(e) : 0;
   }
   if (cfg == 2 && phased_min_k > 0 && a->K1 + a->K2 >= phased_min_k && !a->mask_bits_in && !a->mask) cfg = 18;
+  static int short_k_cfg = -1, short_k_max = 0;          // tuning hook: another configuration for the short-K (proposal) GEMMs
+  if (short_k_cfg < 0) {
+    const char* e = getenv("MNR_NT_SHORTK_CFG");         // "cfg,max_k", e.g. "38,512"
+    short_k_cfg = 0;
+    if (e && sscanf(e, "%d,%d", &short_k_cfg, &short_k_max) != 2) short_k_cfg = 0;
+  }
+  if (big_ok && short_k_cfg > 0 && a->K1 + a->K2 <= short_k_max) cfg = short_k_cfg;
   return nt_dispatch(cfg, a, fast_epi, stream);
 }
 

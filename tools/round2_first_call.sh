@@ -12,4 +12,8 @@ timeout 600 python tools/gemm_probe.py --cfgs 2,35,36,37 > gpurun_out/r2_gemm_pr
 for cfg in 2 36 37; do
   MNR_NT_CFG=$cfg,0 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg$cfg.json 2> gpurun_out/r2_bench_cfg$cfg.err
 done
+# 4. short-K (proposal) GEMMs on 256x128 tiles, two workgroups per CU (one's epilogue under the other's K loop)
+for sk in 38,512 39,512 38,256; do
+  MNR_NT_SHORTK_CFG=$sk timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_shortk_${sk/,/_}.json 2> gpurun_out/r2_bench_shortk_${sk/,/_}.err
+done
 tail -n 5 gpurun_out/r2_ingest_probe.txt gpurun_out/r2_gemm_probe_direct.txt gpurun_out/r2_bench_cfg*.json
