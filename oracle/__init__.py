@@ -13,11 +13,16 @@ Pinning status:
     reference's own tests/ and (b) outputs of the reference's own source files
     executed in this container with a NumPy stand-in for `jax.numpy`
     (tests/golden/make_golden.py -> tests/golden/*.npz).
-  * composed Model.__call__ / MLP.__call__ / train_step: the reference holds no
-    test for them and flax/optax are not installable here, so they are pinned
-    only by the published parameter counts (9,007,493 / 835,205 / 713,230 /
-    615,740) and by being compositions of pinned leaves: PARITY UNPINNED for
-    the composition itself.
+  * composed Model.__call__ / MLP.__call__ / loss terms / clip_gradients: the
+    reference holds no test for them and flax / gin are not installable here;
+    they are pinned against the reference's OWN internal/models.py and
+    internal/train_utils.py executed in this container on small stand-ins for
+    flax.linen / gin / jax.random with exact complex-step derivatives
+    (tests/golden/make_golden_models.py -> tests/golden/models.npz, held at
+    rtol 1e-9 in float64 by tests/test_oracle_models_golden.py), and by the
+    published parameter counts.
+  * PARITY UNPINNED: optax.adam (restated from its published algorithm) and
+    jax's PRNG bit streams (every draw is an explicit input here).
 
 Summation-order contract (bit-exact sample indices): `integrate_weights` and
 the softmax denominator inside `invert_cdf` accumulate strictly left-to-right

@@ -1,9 +1,13 @@
 """Oracle restatement of reference internal/models.py (TEST INFRASTRUCTURE ONLY).
 
-PARITY UNPINNED for the composition: the reference has no test of
-Model.__call__/MLP.__call__ and flax cannot be imported here.  What pins it:
-published parameter counts (tests/test_oracle_models.py) and the fact that every
-leaf it calls is pinned (tests/test_oracle_leaves.py, tests/golden/).
+Pinned: the reference has no test of Model.__call__ / MLP.__call__ and flax cannot be
+imported here, so tests/golden/make_golden_models.py executes the reference's own
+internal/models.py on stand-ins for jax.numpy / flax.linen / gin (complex-step
+derivatives for the Ref-NeRF normals and the contraction's Jacobian) and
+tests/test_oracle_models_golden.py holds model_apply() to every recorded entry of
+`renderings` / `ray_history` at rtol 1e-9 in float64, for the four BASELINE
+configurations, rendering and randomized training.  Also: the published parameter
+counts (tests/test_oracle_models.py).
 
 Differences of FORM (not of arithmetic) from the reference:
   * flax modules -> plain dataclasses + an explicit nested dict of torch

@@ -1,0 +1,477 @@
+#!/usr/bin/env python
+"""Golden vectors for the COMPOSITION: the reference's own internal/models.py executed on seeded rays and weights.
+
+make_golden.py pins the leaves; this script pins `Model.__call__` / `MLP.__call__` (reference models.py:75-312,
+402-612), which the reference itself never tests and which cannot be run as is (no jax / flax / gin here).  As there,
+the reference SOURCE is imported from where it lies and executed; what is replaced is the framework underneath it:
+
+  jax.numpy      NumPy in float64 (make_golden.install_jax_standin); jax.linearize by complex step (exact)
+  flax.linen     ~100 lines below: Module (dataclass-style fields, `setup`), `@compact` scoping with flax's automatic
+                 names (`Dense_0`, ... per parent, counted per class, restarted on every call of the parent so that a
+                 module called twice shares its parameters), Dense = x @ kernel + bias, Embed = table[idx]; parameters
+                 are looked up by path in a nested dict with flax's names instead of being initialised
+  gin            the bindings multinerf_amd.gin parsed from the reference's own configs/*.gin (+ the size overrides
+                 below), handed to the reference classes when they are constructed; `@jnp.reciprocal`-style references
+                 map back to the callables the reference registers (configs.py:29-42, models.py:35-36)
+  jax.random     keys are opaque; every uniform / normal draw comes from one seeded NumPy stream and is LOGGED, and
+                 the log is stored with the goldens so that the oracle can be fed the same noise
+  jax.vmap(jax.value_and_grad(f, has_aux=True))   (Ref-NeRF normals, models.py:478-481) evaluates f on the whole
+                 batch and takes d/d(means) by COMPLEX-STEP differentiation (exact to rounding, no cancellation):
+                 three more evaluations with means + 1e-30j e_k; ReLU acts on the real part and `x % t` of
+                 math.safe_sin on the real part only (both are locally linear / the identity shift there)
+
+Sizes are shrunk (widths, samples per level, ray count) so that the vectors stay small; every flag of the four
+BASELINE configurations (ray shape, distance warp, contraction, basis, dilation, annealing, single_mlp, opaque
+background, GLO, Ref-NeRF heads, RawNeRF exposure) is the config file's own.
+
+Run (build container only):  python tests/golden/make_golden_models.py   ->  tests/golden/models.npz
+"""
+
+import functools
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import make_golden  # noqa: E402  (the jax.numpy stand-in of the leaf goldens)
+
+REF = make_golden.REF
+OUT = os.path.join(HERE, 'models.npz')
+
+# name -> (preset, gin overrides, rays, randomized, train_frac)
+CASES = {
+    '360': ('360', ['NerfMLP.net_width = 32', 'PropMLP.net_width = 16', 'Model.num_prop_samples = 8',
+                    'Model.num_nerf_samples = 5'], 4, False, 0.4),
+    '360_train_glo': ('360', ['NerfMLP.net_width = 32', 'PropMLP.net_width = 16', 'Model.num_prop_samples = 8',
+                              'Model.num_nerf_samples = 5', 'Model.num_glo_features = 4', 'NerfMLP.density_noise = 0.5',
+                              'NerfMLP.bottleneck_noise = 0.2', 'Model.bg_intensity_range = (0.2, 0.9)',
+                              'Model.single_jitter = False', 'Config.compute_disp_metrics = True',
+                              'Config.data_loss_type = "mse"', 'Config.grad_max_val = 0.05'], 4, True, 0.7),
+    'blender_256': ('blender_256', ['NerfMLP.net_width = 32', 'PropMLP.net_width = 16', 'Model.num_prop_samples = 9',
+                                    'Model.num_nerf_samples = 6'], 4, False, 1.0),
+    'blender_256_train': ('blender_256', ['NerfMLP.net_width = 32', 'PropMLP.net_width = 16', 'Model.num_prop_samples = 9',
+                                          'Model.num_nerf_samples = 6'], 4, True, 0.1),
+    'blender_refnerf': ('blender_refnerf', ['NerfMLP.net_width = 32', 'NerfMLP.net_width_viewdirs = 16',
+                                            'NerfMLP.bottleneck_width = 16', 'Model.num_prop_samples = 7',
+                                            'Model.num_nerf_samples = 7'], 3, False, 0.5),
+    'blender_refnerf_train': ('blender_refnerf', ['NerfMLP.net_width = 32', 'NerfMLP.net_width_viewdirs = 16',
+                                                  'NerfMLP.bottleneck_width = 16', 'Model.num_prop_samples = 7',
+                                                  'Model.num_nerf_samples = 7', 'Config.compute_normal_metrics = True'], 3, True, 0.5),
+    'llff_raw': ('llff_raw', ['NerfMLP.net_width = 32', 'Model.num_prop_samples = 8', 'Model.num_nerf_samples = 8'], 4, False, 0.5),
+    'llff_raw_train': ('llff_raw', ['NerfMLP.net_width = 32', 'Model.num_prop_samples = 8', 'Model.num_nerf_samples = 8'], 4, True, 0.25),
+}
+
+_CALLABLE_FIELDS = ('raydist_fn', 'warp_fn', 'net_activation', 'density_activation', 'rgb_activation', 'roughness_activation')
+
+
+# ----------------------------------------------------------------------------- complex-step array
+
+
+class CStep(np.ndarray):
+  """Complex ndarray whose `%` acts on the real part (math.safe_sin's range reduction is a shift by a constant)."""
+  __array_priority__ = 100
+
+  def __mod__(self, t):
+    r = np.asarray(self)
+    return (np.remainder(r.real, t) + 1j * r.imag).view(CStep)
+
+  # comparisons look at the real part (coord.contract's `x_mag_sq <= 1`)
+  def __le__(self, o):
+    return np.asarray(self).real <= np.real(o)
+
+  def __lt__(self, o):
+    return np.asarray(self).real < np.real(o)
+
+  def __ge__(self, o):
+    return np.asarray(self).real >= np.real(o)
+
+  def __gt__(self, o):
+    return np.asarray(self).real > np.real(o)
+
+
+def _as_cstep(x):
+  return np.asarray(x, dtype=np.complex128).view(CStep)
+
+
+# ----------------------------------------------------------------------------- flax.linen
+
+
+class _Scope:
+  stack = []          # modules whose @compact method is running
+  params = None       # nested dict with flax's names
+
+
+def _fields(cls):
+  out = {}
+  for c in reversed(cls.__mro__):
+    for name in getattr(c, '__annotations__', {}):
+      if name in ('name', 'parent'):
+        continue
+      out[name] = getattr(c, name, None) if name in c.__dict__ or name not in out else out[name]
+  return out
+
+
+class Module:
+  _gin_bindings = None     # set per case: {configurable name: {field: value}}
+
+  def __init__(self, *args, **kwargs):
+    fields = _fields(type(self))
+    vals = dict(fields)
+    vals.update(dict(zip(fields, args)))
+    bound = (Module._gin_bindings or {}).get(type(self).__name__, {}) if getattr(type(self), '_gin', False) else {}
+    vals.update(bound)
+    name = kwargs.pop('name', None)
+    for k in kwargs:
+      if k not in fields:
+        raise TypeError(f'{type(self).__name__}: unknown field {k}')
+    vals.update(kwargs)
+    for k, v in vals.items():
+      object.__setattr__(self, k, v)
+    parent = _Scope.stack[-1] if _Scope.stack else None
+    if parent is None:
+      self._path = ()
+    else:
+      if name is None:
+        cname = type(self).__name__
+        i = parent._counters.get(cname, 0)
+        parent._counters[cname] = i + 1
+        name = f'{cname}_{i}'
+      self._path = parent._path + (name,)
+    self._counters = {}
+    if hasattr(self, 'setup'):
+      self.setup()
+
+  def _params(self):
+    p = _Scope.params
+    for k in self._path:
+      p = p[k]
+    return p
+
+
+def compact(fn):
+  @functools.wraps(fn)
+  def wrapped(self, *a, **k):
+    self._counters = {}              # a module called again re-creates the same names: shared parameters
+    _Scope.stack.append(self)
+    try:
+      return fn(self, *a, **k)
+    finally:
+      _Scope.stack.pop()
+  return wrapped
+
+
+class Dense(Module):
+  features: int = 0
+  kernel_init: object = None
+
+  def __call__(self, x):
+    p = self._params()
+    assert p['kernel'].shape == (x.shape[-1], self.features), (self._path, p['kernel'].shape, x.shape, self.features)
+    return np.matmul(x, p['kernel']) + p['bias']
+
+
+class Embed(Module):
+  num_embeddings: int = 0
+  features: int = 0
+  embedding_init: object = None
+
+  def __call__(self, idx):
+    table = self._params()['embedding']
+    assert table.shape == (self.num_embeddings, self.features)
+    return table[idx]
+
+
+def _relu(x):
+  if np.iscomplexobj(x):
+    return np.where(np.asarray(x).real > 0, x, 0)
+  return np.maximum(x, 0)
+
+
+def install_flax_gin_standins(jax):
+  linen = types.ModuleType('flax.linen')
+  linen.Module, linen.compact, linen.Dense, linen.Embed = Module, compact, Dense, Embed
+  linen.relu = _relu
+  linen.softplus = lambda x: np.logaddexp(x, 0)
+  linen.sigmoid = lambda x: 1 / (1 + np.exp(-x))
+  flax = types.ModuleType('flax')
+  flax.linen = linen
+  sys.modules['flax'] = flax
+  sys.modules['flax.linen'] = linen
+
+  gin = types.ModuleType('gin')
+  gin.config = types.ModuleType('gin.config')
+  gin.config.external_configurable = lambda fn, module=None, name=None: fn
+
+  def configurable(cls=None, **_):
+    def mark(c):
+      c._gin = True
+      return c
+    return mark(cls) if cls is not None else mark
+
+  gin.configurable = configurable
+  sys.modules['gin'] = gin
+  sys.modules['gin.config'] = gin.config
+
+  # jax pieces models.py touches beyond the leaf stand-in
+  jax.nn.relu = _relu
+  jax.nn.initializers = types.SimpleNamespace(he_uniform=lambda: None, glorot_uniform=lambda: None, he_normal=lambda: None,
+                                              zeros=None)
+  jax.tree_util = types.SimpleNamespace(tree_map=None)
+
+  class _ValueAndGrad:
+    def __init__(self, fn, has_aux=False):
+      assert has_aux
+      self.fn = fn
+
+  jax.value_and_grad = lambda fn, has_aux=False: _ValueAndGrad(fn, has_aux)
+  leaf_vmap = jax.vmap
+
+  def vmap(fn, in_axes=0, out_axes=0):
+    if not isinstance(fn, _ValueAndGrad):
+      return leaf_vmap(fn, in_axes, out_axes)
+    assert tuple(in_axes) == (0, 0)
+
+    def batched(means, covs):
+      scope = _Scope.stack[-1]
+      snapshot = dict(scope._counters)
+
+      def run(m):
+        scope._counters = dict(snapshot)          # every evaluation creates the same Dense_k again
+        return fn.fn(m, covs)
+
+      val, aux = run(means)
+      grad = np.zeros_like(means)
+      h = 1e-30
+      for k in range(means.shape[-1]):
+        e = np.zeros(means.shape[-1])
+        e[k] = 1.0
+        vk, _ = run(_as_cstep(means + 1j * h * e))
+        grad[..., k] = np.asarray(vk).imag / h
+      return (val, aux), grad
+
+    return batched
+
+  jax.vmap = vmap
+
+  # jax.linearize (coord.track_linearize): J v exactly, by complex step, instead of make_golden.py's central difference
+  # (whose 1e-9 relative error the high IPE degrees amplify to ~1e-6 in the rendered distances).
+  real_maximum = np.maximum
+
+  def maximum(a, b):
+    if np.iscomplexobj(a) or np.iscomplexobj(b):
+      return np.where(np.real(a) >= np.real(b), a, b).view(CStep)
+    return real_maximum(a, b)
+
+  jax.numpy.maximum = maximum
+
+  def linearize(fn, x):
+    y = fn(x)
+    h = 1e-30
+    return y, lambda v: np.asarray(fn(_as_cstep(x + 1j * h * v))).imag / h
+
+  jax.linearize = linearize
+
+  # random: opaque keys, one logged stream
+  rnd = jax.random
+  state = {'rs': None, 'log': []}
+
+  class Key:
+    pass
+
+  rnd.split = lambda key, num=2: tuple(Key() for _ in range(num))
+  rnd.PRNGKey = lambda seed: Key()
+
+  def uniform(key, shape=(), minval=0., maxval=1.):
+    if isinstance(key, make_golden.JitterKey):
+      u = np.broadcast_to(key.u01, shape)
+    else:
+      u = state['rs'].uniform(0.0, 1.0, shape)
+      state['log'].append(('uniform', u))
+    return u * (maxval - minval) + minval
+
+  def normal(key, shape=()):
+    z = state['rs'].standard_normal(shape)
+    state['log'].append(('normal', z))
+    return z
+
+  rnd.uniform, rnd.normal = uniform, normal
+  return state, Key
+
+
+# ----------------------------------------------------------------------------- one case
+
+
+def _tree_to_numpy(tree):
+  return {k: (_tree_to_numpy(v) if isinstance(v, dict) else v.detach().numpy().astype(np.float64)) for k, v in tree.items()}
+
+
+def _flatten(prefix, tree, out):
+  for k, v in tree.items():
+    if isinstance(v, dict):
+      _flatten(f'{prefix}{k}/', v, out)
+    else:
+      out[f'{prefix}{k}'] = v
+
+
+def run_case(case, rmodels, ref_callables, rnd_state, Key):
+  import torch
+  from multinerf_amd import configs, gin as my_gin, models as my_models
+  from oracle import models as omodels
+  from tests import helpers
+
+  preset, extra, B, randomized, train_frac = CASES[case]
+  cfg = configs.load_preset(preset, list(extra))
+  m = my_models.Model(config=cfg)
+  om, on, op = helpers.oracle_hparams(m)
+  seed = sum(map(ord, case))
+  tree = _tree_to_numpy(omodels.init_params(om, on, op, seed=seed))
+  # biases are zero-initialised; make them count, and keep everything float32-representable (stored as float32)
+  rs = np.random.RandomState(seed)
+  def jitter_bias(t):
+    for k, v in t.items():
+      if isinstance(v, dict):
+        jitter_bias(v)
+      elif k == 'bias':
+        t[k] = rs.normal(0, 0.1, v.shape)
+      t[k] = t[k].astype(np.float32).astype(np.float64) if not isinstance(t[k], dict) else t[k]
+  jitter_bias(tree)
+  if 'exposure_scaling_offsets' in tree:
+    tree['exposure_scaling_offsets']['embedding'] = rs.normal(0, 0.1, tree['exposure_scaling_offsets']['embedding'].shape
+                                                              ).astype(np.float32).astype(np.float64)
+
+  near = 0.0 if preset == 'llff_raw' else max(cfg.near, 1e-3)
+  batch = helpers.synthetic_rays(B, seed=seed, near=near, far=cfg.far)
+  r = batch.rays
+  f64 = lambda t: None if t is None else t.numpy().astype(np.float64)
+  rays = types.SimpleNamespace(origins=f64(r.origins), directions=f64(r.directions), viewdirs=f64(r.viewdirs), radii=f64(r.radii),
+                               imageplane=f64(r.imageplane), lossmult=f64(r.lossmult), near=f64(r.near), far=f64(r.far),
+                               cam_idx=r.cam_idx.numpy().astype(np.int64), exposure_idx=None, exposure_values=None)
+  if preset == 'llff_raw':
+    rays.exposure_idx = np.array([[0], [1], [2], [3]][:B], dtype=np.int64)
+    rays.exposure_values = np.full((B, 1), 0.7)
+
+  # gin bindings of this case -> the reference's classes
+  bindings = {}
+  for cname in ('Model', 'NerfMLP', 'PropMLP'):
+    b = dict(my_gin._BINDINGS.get(cname, {}))
+    for k in list(b):
+      if k in _CALLABLE_FIELDS and isinstance(b[k], str):
+        b[k] = ref_callables[b[k]]
+    bindings[cname] = b
+  Module._gin_bindings = bindings
+  _Scope.params = tree
+  _Scope.stack = []
+  rnd_state['rs'] = np.random.RandomState(seed + 1)
+  rnd_state['log'] = []
+
+  g = {}
+  model = rmodels.Model(config=types.SimpleNamespace(vis_num_rays=cfg.vis_num_rays))
+  rng = Key() if randomized else None
+  renderings, history = model(rng, rays, train_frac, True, zero_glo=False)
+
+  flat = {}
+  _flatten('', tree, flat)
+  for k, v in flat.items():
+    g[f'{case}/param/{k}'] = v.astype(np.float32)
+  for k, v in vars(rays).items():
+    if v is not None:
+      g[f'{case}/rays/{k}'] = v
+  g[f'{case}/train_frac'] = np.array(train_frac)
+  for i, (kind, arr) in enumerate(rnd_state['log']):
+    g[f'{case}/noise/{i:02d}_{kind}'] = arr
+  # ---- the loss terms of train_utils.py:72-218 on the reference's own outputs
+  rtrain = ref_callables['train_utils']
+  brs = np.random.RandomState(seed + 2)
+  tbatch = types.SimpleNamespace(rgb=batch.rgb.numpy().astype(np.float64), disps=brs.uniform(0.05, 1.0, (B,)),
+                                 alphas=brs.uniform(0.2, 1.0, (B,)), normals=brs.normal(0, 1, (B, 3)))
+  for k in ('rgb', 'disps', 'alphas', 'normals'):
+    g[f'{case}/batch/{k}'] = getattr(tbatch, k)
+  data_loss, stats = rtrain.compute_data_loss(tbatch, renderings, rays, None, cfg)
+  g[f'{case}/loss/data'] = np.asarray(data_loss)
+  for k, v in stats.items():
+    g[f'{case}/loss/stats_{k}'] = np.asarray(v, dtype=np.float64)
+  g[f'{case}/loss/interlevel'] = np.asarray(rtrain.interlevel_loss(history, cfg))
+  g[f'{case}/loss/distortion'] = np.asarray(rtrain.distortion_loss(history, cfg))
+  if history[-1]['normals'] is not None:
+    g[f'{case}/loss/orientation'] = np.asarray(rtrain.orientation_loss(rays, model, history, cfg))
+  if history[-1]['normals'] is not None and history[-1]['normals_pred'] is not None:
+    g[f'{case}/loss/predicted_normal'] = np.asarray(rtrain.predicted_normal_loss(model, history, cfg))
+  # clip_gradients (train_utils.py:200-218) on a small seeded gradient tree of three "modules" whose scales make the
+  # value clip and the norm clip bite for some and not for others
+  grad = {'params': {}}
+  for i, mod in enumerate(('NerfMLP_0', 'PropMLP_0', 'Embed_0')):
+    sc = 10.0 ** (-(1 + 2 * i))
+    grad['params'][mod] = {'Dense_0': {'kernel': brs.normal(0, sc, (7, 5)), 'bias': brs.normal(0, sc, (5,))},
+                           'Dense_1': {'kernel': brs.normal(0, 3 * sc, (5, 3)), 'bias': brs.normal(0, sc, (3,))}}
+  clipped = rtrain.clip_gradients(grad, cfg)
+  flat_g, flat_c = {}, {}
+  _flatten('', grad['params'], flat_g)
+  _flatten('', clipped['params'], flat_c)
+  for k in flat_g:
+    g[f'{case}/grad/{k}'] = flat_g[k]
+    g[f'{case}/clipped/{k}'] = np.asarray(flat_c[k])
+
+  for lvl, (rend, hist) in enumerate(zip(renderings, history)):
+    for k, v in rend.items():
+      if v is not None:
+        g[f'{case}/rendering{lvl}/{k}'] = np.asarray(v, dtype=np.float64)
+    for k, v in hist.items():
+      if v is not None:
+        g[f'{case}/history{lvl}/{k}'] = np.asarray(np.real(v), dtype=np.float64)
+  return g
+
+
+def main():
+  jax = make_golden.install_jax_standin()
+  rnd_state, Key = install_flax_gin_standins(jax)
+  sys.path.insert(0, REF)
+  # models.py imports internal.configs / internal.utils (absl, flax.core, PIL): only render_image touches them.
+  cfg_stub = types.ModuleType('internal.configs')
+  cfg_stub.Config = object
+  utils_stub = types.ModuleType('internal.utils')
+  utils_stub.Rays = utils_stub.Batch = object          # type annotations only
+  sys.modules['internal.configs'] = cfg_stub
+  sys.modules['internal.utils'] = utils_stub
+  from internal import coord as rcoord
+  from internal import math as rmath
+  from internal import models as rmodels
+  # train_utils.py: its loss functions and clip_gradients only need jnp / jax.tree_util; everything else it imports is stubbed
+  for name in ('flax.core', 'flax.core.scope', 'flax.training', 'flax.training.train_state', 'optax', 'internal.camera_utils',
+               'internal.datasets', 'internal.robustnerf'):
+    sys.modules[name] = types.ModuleType(name)
+  sys.modules['flax.core.scope'].FrozenVariableDict = dict
+  sys.modules['flax.training.train_state'].TrainState = object
+  sys.modules['internal.datasets'].Dataset = object              # annotations only
+  sys.modules['internal.camera_utils'].ProjectionType = object
+
+  def tree_map(fn, tree):
+    return {k: tree_map(fn, v) for k, v in tree.items()} if isinstance(tree, dict) else fn(tree)
+
+  def tree_reduce(fn, tree, initializer=None):
+    acc = initializer
+    for v in (tree.values() if isinstance(tree, dict) else [tree]):
+      acc = tree_reduce(fn, v, acc) if isinstance(v, dict) else fn(acc, v)
+    return acc
+
+  jax.tree_util = types.SimpleNamespace(tree_map=tree_map, tree_reduce=tree_reduce)
+  from internal import train_utils as rtrain
+  jnp = jax.numpy
+  ref_callables = {'reciprocal': jnp.reciprocal, 'log': jnp.log, 'log1p': jnp.log1p, 'exp': jnp.exp, 'sqrt': jnp.sqrt,
+                   'square': jnp.square, 'relu': _relu, 'softplus': jax.nn.softplus, 'safe_exp': rmath.safe_exp,
+                   'contract': rcoord.contract, 'train_utils': rtrain}
+  g = {}
+  for case in CASES:
+    g.update(run_case(case, rmodels, ref_callables, rnd_state, Key))
+    print(case, 'ok')
+  np.savez_compressed(OUT, **g)
+  print(f'wrote {OUT}: {len(g)} arrays, {os.path.getsize(OUT)} bytes')
+
+
+if __name__ == '__main__':
+  main()

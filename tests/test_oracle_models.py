@@ -1,7 +1,7 @@
 """Oracle Model/MLP/train_step: architecture goldens + self-consistency (CPU).
 
-The composition is PARITY UNPINNED against the reference (no reference test,
-flax absent); what IS pinned here: the parameter counts published in the
+(The composition itself is pinned against the reference's own source in
+tests/test_oracle_models_golden.py.)  Pinned here: the parameter counts published in the
 reference's scripts/generate_tables.ipynb (:145, :340/:344, :684, :1050), the
 flax tree naming, output shapes, and train_step mechanics (Adam == torch.optim.Adam
 with optax's epsilon placement, clipping, finite gradients at train_frac = 0).
