@@ -66,7 +66,7 @@ def pixels_to_rays(pix_x_int, pix_y_int, pixtocams, camtoworlds, distortion_para
   L.check(ops.lib().mnr_pixels_to_rays(
       B, p(px), p(py), p(ci), ncam, p(P), p(Cw), C.cast(dist, C.c_void_p) if dist is not None else None, p(ndc),
       1 if ProjectionType(camtype) == ProjectionType.FISHEYE else 0, p(origins), p(directions), p(viewdirs), p(radii),
-      p(imageplane), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+      p(imageplane), ops._stream()))
   r = lambda t, c: t.reshape(shape + (c,))
   return r(origins, 3), r(directions, 3), r(viewdirs, 3), r(radii, 1), r(imageplane, 2)
 

@@ -436,7 +436,7 @@ class Model:
     if p.has_rgb and p.use_viewdirs:
       p.head_bias = torch.zeros(_rup(p.head_cols, 128), dtype=f32, device=self.device)
     if p.ref:
-      p.ide = ops.IdeTablesDev(p.hp.deg_view, self.device) if self.device.type == 'cuda' else None
+      p.ide = ops.IdeTablesDev(p.hp.deg_view, self.device)
 
   def pack_weights(self, flat_params):
     """fp32 master parameters -> bf16 GEMM operands (one launch per MLP)."""

@@ -24,12 +24,16 @@ def _stream():
   return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_device(t):
+  return t.is_cuda
+
+
 def _chk(t, dtype, name, allow_none=False):
   if t is None:
     if allow_none:
       return
     raise ValueError(f'{name} is None')
-  if not t.is_cuda:
+  if not _on_device(t):
     raise ValueError(f'{name} must be a device tensor (the HIP path has no CPU fallback)')
   if t.dtype != dtype:
     raise ValueError(f'{name} must be {dtype}, is {t.dtype}')
@@ -480,7 +484,7 @@ def ref_head_bwd(small, raw_grad, viewdirs, n, tabs, roughness_bias, dvi_a, dvi_
 def add_cols_bf16(a, b, dst, cols):
   """dst[:, :cols] = a[:, :cols] + b[:, :cols] (row strides taken from the tensors)."""
   for x, nm in ((a, 'a'), (dst, 'dst')):
-    if x.dtype != bf16 or not x.is_cuda:
+    if x.dtype != bf16 or not _on_device(x):
       raise ValueError(f'{nm} must be a bf16 device tensor')
   M = a.shape[0]
   L.check(lib().mnr_add_cols_bf16(M, cols, _ptr(a), a.stride(0), _ptr(b), b.stride(0) if b is not None else 0,

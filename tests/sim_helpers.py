@@ -91,3 +91,37 @@ def sim_gemm_tn(lib, A, B, C_acc, bias_out=None, k_valid=None, n_valid=None):
   if bias_out is not None:
     a.bias_out, a.bias_n_valid = ptr(bias_out), bias_out.numel()
   sim_check(lib, lib.mnr_gemm_tn_bf16(C.byref(a), None))
+
+
+class simulated_device:
+  """Context manager: route the package's C-ABI calls to the simulator build and let it take host tensors.
+
+  Test harness only.  Inside it `multinerf_amd._lib.load()` hands out libmnerf_sim.so (same C ABI, every csrc/*.hip
+  compiled for the host against tools/hipsim), launches get a null stream and the "must be a device tensor" checks
+  accept CPU tensors, so that Model.build('cpu') / model.apply / train_step run the product's host orchestration and
+  kernel SOURCE on the CPU.  Nothing in the package knows about this; outside the context everything is as shipped
+  (no CPU fallback)."""
+
+  def __enter__(self):
+    from multinerf_amd import ops
+    self.lib = load_sim()
+    missing = [n for n in L._PROTOS if not hasattr(self.lib, n)]
+    if missing:
+      raise RuntimeError(f'simulator build lacks {missing}')
+    self.saved = (L._lib, ops._stream, ops._on_device, ops._cfg_applied)
+    L._lib = self.lib
+    ops._stream = lambda: None
+    ops._on_device = lambda t: True
+    ops._cfg_applied = True
+    self.lib.hipsim_reset(0, 0)
+    return self
+
+  def check(self):
+    if self.lib.hipsim_failed():
+      raise RuntimeError('hipsim: ' + self.lib.hipsim_error().decode())
+
+  def __exit__(self, *exc):
+    from multinerf_amd import ops
+    L._lib, ops._stream, ops._on_device, ops._cfg_applied = self.saved
+    self.lib.mnr_gemm_nt_set_config(2, 0)
+    return False

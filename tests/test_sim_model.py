@@ -1,0 +1,128 @@
+"""The whole product path on the kernel-source simulator: Model.apply and one train step against the CPU oracle.
+
+tests/test_gpu_model.py is the parity test proper (MI355X).  This is its shadow on the host: the package's own host
+orchestration (multinerf_amd.models / train_utils / ops) driving every csrc/*.hip kernel compiled for the CPU by
+tools/hipsim (tests/sim_helpers.simulated_device), on small configurations, compared with the oracle under the same
+tolerance model (bf16-emulating oracle; the plain-fp32 oracle gives the bf16 cost).  It exists so that changes to layouts,
+launch bookkeeping and kernels can be screened without a GPU; it is not evidence about the hardware and the package never
+takes this route by itself.
+"""
+
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from multinerf_amd import configs, models, train_utils
+from oracle import models as omodels
+from oracle import train_utils as otrain
+from tests import helpers
+from tests import sim_helpers as S
+
+pytestmark = pytest.mark.skipif(not (shutil.which('clang++') or os.path.exists('/opt/rocm/lib/llvm/bin/clang++')),
+                                reason='needs clang++')
+
+CASES = [
+    # contraction, dilation, annealing, three levels, two MLPs (256-wide NeRF MLP: the 256x256 GEMM tile; 128-wide
+    # proposal MLP: the 128x128 tile), GLO vectors
+    ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32',
+             'Model.num_glo_features = 4'], 8),
+    # Ref-NeRF: single MLP, tangent network for the density-gradient normals, IDE, orientation / predicted-normal losses
+    ('blender_refnerf', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 4),
+    # RawNeRF: NDC cylinders, exposure scaling, safe_exp colours, rawnerf loss with a Bayer lossmult
+    ('llff_raw', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 4),
+]
+
+
+def _setup(name, extra, B, seed=3):
+  cfg = configs.load_preset(name, list(extra))
+  model = models.Model(config=cfg)
+  model.build('cpu')
+  om, on, op = helpers.oracle_hparams(model)
+  params = omodels.init_params(om, on, op, seed=seed)
+  g = torch.Generator().manual_seed(seed + 1)
+  for mname, mod in params.items():
+    if mname in ('exposure_scaling_offsets', 'Embed_0'):
+      continue
+    for d in mod.values():
+      d['bias'] = 0.05 * torch.randn(d['bias'].shape, generator=g)
+  batch = helpers.synthetic_rays(B, near=cfg.near, far=cfg.far)
+  if name == 'llff_raw':
+    batch.rays.exposure_idx = torch.randint(0, 5, (B, 1), generator=g).to(torch.int32)
+    batch.rays.exposure_values = 0.5 + torch.rand((B, 1), generator=g)
+    batch.rays.lossmult = (torch.rand((B, 3), generator=g) > 0.4).float()
+    batch.rgb = batch.rgb * 0.3
+    params['exposure_scaling_offsets']['embedding'] = 0.1 * torch.randn((1000, 3), generator=g)
+  if cfg.compute_normal_metrics:
+    batch.alphas = torch.rand((B,), generator=g)
+    batch.normals = torch.randn((B, 3), generator=g)
+  return cfg, model, (om, on, op), params, model.flat_from_tree(params), batch
+
+
+# (NT configuration for the 256x256-tiled GEMMs, LDS-DMA landing late, fiber order): the default as shipped, and the
+# configurations prepared for the next round (direct-weights loop, two workgroups per CU) under the adversarial modes
+VARIANTS = [(2, 0, 0), (37, 1, 5), (36, 1, -1), (38, 1, 3)]
+
+
+@pytest.mark.parametrize('name,extra,B', CASES)
+def test_forward_and_train_step_on_the_simulator(name, extra, B):
+  _run(name, extra, B, VARIANTS[0])
+
+
+@pytest.mark.parametrize('variant', VARIANTS[1:])
+def test_360_step_with_the_prepared_gemm_configurations(variant):
+  _run(*CASES[0], variant)
+
+
+def _run(name, extra, B, variant):
+  nt_cfg, dma_late, order = variant
+  with S.simulated_device() as sim:
+    assert sim.lib.mnr_gemm_nt_set_config(nt_cfg, 0) == 0
+    sim.lib.hipsim_reset(dma_late, order)
+    cfg, model, (om, on, op), params, flat, batch = _setup(name, extra, B)
+    noise = helpers.make_noise(model, B)
+    tf = 0.4
+    # ---- forward
+    r_bf, h_bf = omodels.model_apply(om, on, op, params, batch.rays, tf, True, zero_glo=False, noise=noise, dense_dtype=torch.bfloat16)
+    r_32, h_32 = omodels.model_apply(om, on, op, params, batch.rays, tf, True, zero_glo=False, noise=noise)
+    rend, hist = model.apply({'flat': flat}, None, batch.rays, tf, True, zero_glo=False, noise=noise)
+    sim.check()
+    for lv in range(model.num_levels):
+      cost_s = (h_bf[lv]['sdist'] - h_32[lv]['sdist']).abs().max().item()
+      assert (hist[lv]['sdist'] - h_bf[lv]['sdist']).abs().max().item() <= max(2e-6 if lv == 0 else 2e-3, 3 * cost_s), lv
+      cost_w = (h_bf[lv]['weights'] - h_32[lv]['weights']).abs().max().item()
+      assert (hist[lv]['weights'] - h_bf[lv]['weights']).abs().max().item() <= max(5e-3, 3 * cost_w), lv
+    cost = (r_bf[-1]['rgb'] - r_32[-1]['rgb']).abs().max().item()
+    assert (rend[-1]['rgb'] - r_bf[-1]['rgb']).abs().max().item() <= max(5e-3, 3 * cost)
+    for k in ('acc', 'distance_mean', 'distance_median'):
+      rel = ((rend[-1][k] - r_bf[-1][k]).abs() / r_bf[-1][k].abs().clamp_min(1e-3)).max().item()
+      assert rel < 0.05, (k, rel)
+    # ---- one train step: loss, statistics, gradients per module, Adam update
+    st = otrain.init_opt_state(params)
+    new_p, _, stats_o, grads_o = otrain.train_step(params, st, om, on, op, cfg, batch, tf, noise=noise, dense_dtype=torch.bfloat16)
+    _, _, _, grads_32 = otrain.train_step(params, st, om, on, op, cfg, batch, tf, noise=noise)
+    g_ref = model.flat_from_tree(grads_o, device='cpu')
+    g_32 = model.flat_from_tree(grads_32, device='cpu')
+    state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+    state2, stats, _ = train_utils.create_train_step(model, cfg)(0, state, batch, None, tf, 0.0, noise=noise, return_grads=True)
+    sim.check()
+    s = stats.materialize()
+    assert abs(s['loss'] - float(stats_o['loss'])) <= 0.02 * abs(float(stats_o['loss'])) + 1e-5
+    np.testing.assert_allclose(s['mses'], stats_o['mses'].detach().numpy(), rtol=0.03, atol=1e-5)
+    g = stats['_grads']
+    for mod, b, e in model.modules:
+      a, r, r32 = g[b:e].double(), g_ref[b:e].double(), g_32[b:e].double()
+      if r.norm() < 1e-12:
+        assert a.norm() < 1e-6, mod
+        continue
+      cos = (a @ r / (a.norm() * r.norm() + 1e-30)).item()
+      rel = ((a - r).norm() / (r.norm() + 1e-30)).item()
+      bf16_cost = ((r - r32).norm() / (r32.norm() + 1e-30)).item()
+      print(f'{name} {mod}: grad cos {cos:.6f} rel err {rel:.3e} (bf16 cost {bf16_cost:.3e})')
+      assert cos > 0.995 and rel < max(0.05, 3 * bf16_cost), (mod, cos, rel, bf16_cost)
+    ref_flat = model.flat_from_tree(new_p, device='cpu')
+    big = g_ref.abs() > 1e-3 * g_ref.abs().max()
+    agree = (torch.sign((state2.params['flat'] - flat)[big]) == torch.sign((ref_flat - flat)[big])).float().mean().item()
+    assert agree > 0.97 and state2.step == 1

@@ -50,6 +50,16 @@ struct dim3 {
   constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 
+// HIP's built-in vector structs (only the ones the kernels name)
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+struct float3 { float x, y, z; };
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+
 typedef int hipError_t;
 typedef void* hipStream_t;
 enum { hipSuccess = 0 };
