@@ -1,0 +1,96 @@
+"""Data-parallel train_step, world_size 2, gloo, on the kernel-source simulator.
+
+bench.py's N > 1 path (one rank per GPU, one all-reduce of the flat gradient and of the statistics per step, identical
+clip + Adam on every rank: train_utils.py:319-330 of the reference) cannot be exercised on the single-GPU box.  Here two
+CPU processes each run the PRODUCT train_step on their half of a batch through the simulator build (gloo instead of
+RCCL), and the result must be what one process gets on the whole batch: same averaged gradient, same parameters after
+the Adam step on both ranks.
+"""
+
+import os
+import shutil
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.skipif(not (shutil.which('clang++') or os.path.exists('/opt/rocm/lib/llvm/bin/clang++')),
+                                reason='needs clang++')
+
+PRESET = ('blender_256', ['NerfMLP.net_width = 128', 'PropMLP.net_width = 128', 'Model.num_prop_samples = 32',
+                          'Model.num_nerf_samples = 32'])
+B = 8
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _step(rank, world):
+  """One train step of this rank's shard; returns (averaged flat gradient, new flat parameters, loss)."""
+  from multinerf_amd import configs, dist as mdist, models, train_utils
+  from oracle import models as omodels
+  from tests import helpers
+  from tests import sim_helpers as S
+  with S.simulated_device() as sim:
+    cfg = configs.load_preset(PRESET[0], list(PRESET[1]))
+    model = models.Model(config=cfg)
+    model.build('cpu')
+    om, on, op = helpers.oracle_hparams(model)
+    flat = model.flat_from_tree(omodels.init_params(om, on, op, seed=5))
+    batch = helpers.synthetic_rays(B, near=cfg.near, far=cfg.far)
+    noise = helpers.make_noise(model, B)
+    if world > 1:
+      batch = mdist.shard_batch(batch)
+      per = B // world
+      noise = {k: {lv: t[rank * per:(rank + 1) * per] for lv, t in d.items()} for k, d in noise.items()}
+    state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+    state2, stats, _ = train_utils.create_train_step(model, cfg)(0, state, batch, None, 0.5, 0.0, noise=noise, return_grads=True)
+    sim.check()
+    return stats['_grads'].clone(), state2.params['flat'].clone(), stats.materialize()['loss']
+
+
+def _worker(rank, world, port, q):
+  sys.path.insert(0, ROOT)
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+  import torch.distributed as td
+  from multinerf_amd import dist as mdist
+  mdist.init_from_env(backend='gloo')
+  g, p, loss = _step(rank, world)
+  mdist.barrier()
+  q.put((rank, g.numpy(), p.numpy(), loss))
+  td.destroy_process_group()
+
+
+def test_two_rank_step_equals_the_single_process_step():
+  world = 2
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  g1, p1, loss1 = _step(0, 1)
+  (_, ga, pa, la), (_, gb, pb, lb) = res
+  # every rank holds the same reduced gradient, statistics and parameters
+  assert (ga == gb).all() and (pa == pb).all() and la == lb
+  # ... and they are the single-process ones: rows are independent, only the fp32 summation order of dW differs
+  ga_t, g1d = torch.as_tensor(ga).double(), g1.double()
+  rel = ((ga_t - g1d).norm() / g1d.norm()).item()
+  assert rel < 1e-3, rel
+  assert abs(la - loss1) <= 1e-5 * abs(loss1) + 1e-7
+  # same Adam step: the first step moves every parameter by ~lr * sign(g); only near-zero gradients may flip
+  big = g1.abs() > 1e-3 * g1.abs().max()
+  assert torch.equal(torch.as_tensor(pa)[big], p1[big]) or (torch.as_tensor(pa)[big] - p1[big]).abs().max().item() < 1e-6
