@@ -49,6 +49,23 @@ def all_reduce_mean_(t):
   return t
 
 
+def all_reduce_sum_async(t):
+  """Start summing `t` over ranks; returns a handle for finish_mean_ (None when there is one rank).  Under RCCL the
+  reduction runs on the collective stream behind everything already queued on the current stream, and the kernels
+  queued after this call overlap with it."""
+  if world_size() == 1:
+    return None
+  return td.all_reduce(t, op=td.ReduceOp.SUM, async_op=True)
+
+
+def finish_mean_(t, handle):
+  """Wait for all_reduce_sum_async (the current stream waits, not the host) and turn the sum into the mean."""
+  if handle is not None:
+    handle.wait()
+    t.div_(world_size())
+  return t
+
+
 def all_gather_cat(t):
   """Concatenate every rank's [n_local, ...] block along dim 0 (all_gather + unshard)."""
   if world_size() == 1:

@@ -21,8 +21,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.skipif(not (shutil.which('clang++') or os.path.exists('/opt/rocm/lib/llvm/bin/clang++')),
                                 reason='needs clang++')
 
-PRESET = ('blender_256', ['NerfMLP.net_width = 128', 'PropMLP.net_width = 128', 'Model.num_prop_samples = 32',
-                          'Model.num_nerf_samples = 32'])
+PRESETS = {
+    # two MLPs: the NeRF level's backward goes first and NerfMLP_0's all-reduce overlaps the proposal level's backward
+    'blender_256': ('blender_256', ['NerfMLP.net_width = 128', 'PropMLP.net_width = 128', 'Model.num_prop_samples = 32',
+                                    'Model.num_nerf_samples = 32']),
+    # ... with a GLO table (reduced early as well) and weight decay on both MLPs (added before the early reduce)
+    'glo_decay': ('blender_256', ['NerfMLP.net_width = 128', 'PropMLP.net_width = 128', 'Model.num_prop_samples = 32',
+                                  'Model.num_nerf_samples = 32', 'Model.num_glo_features = 4',
+                                  "Config.weight_decay_mults = {'NerfMLP_0': 3e-4, 'PropMLP_0': 1e-4}"]),
+    # one shared MLP (llff_raw): nothing is final before the last level, single all-reduce at the end
+    'single_mlp': ('llff_raw', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32']),
+}
 B = 8
 
 
@@ -34,8 +43,9 @@ def _free_port():
   return p
 
 
-def _step(rank, world):
+def _step(rank, world, case):
   """One train step of this rank's shard; returns (averaged flat gradient, new flat parameters, loss)."""
+  PRESET = PRESETS[case]
   from multinerf_amd import configs, dist as mdist, models, train_utils
   from oracle import models as omodels
   from tests import helpers
@@ -47,6 +57,10 @@ def _step(rank, world):
     om, on, op = helpers.oracle_hparams(model)
     flat = model.flat_from_tree(omodels.init_params(om, on, op, seed=5))
     batch = helpers.synthetic_rays(B, near=cfg.near, far=cfg.far)
+    if cfg.rawnerf_mode:
+      batch.rays.exposure_idx = torch.arange(B, dtype=torch.int32).reshape(B, 1) % 3
+      batch.rays.exposure_values = torch.full((B, 1), 0.8)
+      batch.rgb = batch.rgb * 0.3
     noise = helpers.make_noise(model, B)
     if world > 1:
       batch = mdist.shard_batch(batch)
@@ -58,31 +72,32 @@ def _step(rank, world):
     return stats['_grads'].clone(), state2.params['flat'].clone(), stats.materialize()['loss']
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, case):
   sys.path.insert(0, ROOT)
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
   import torch.distributed as td
   from multinerf_amd import dist as mdist
   mdist.init_from_env(backend='gloo')
-  g, p, loss = _step(rank, world)
+  g, p, loss = _step(rank, world, case)
   mdist.barrier()
   q.put((rank, g.numpy(), p.numpy(), loss))
   td.destroy_process_group()
 
 
-def test_two_rank_step_equals_the_single_process_step():
+@pytest.mark.parametrize('case', list(PRESETS))
+def test_two_rank_step_equals_the_single_process_step(case):
   world = 2
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
   port = _free_port()
-  procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+  procs = [ctx.Process(target=_worker, args=(r, world, port, q, case)) for r in range(world)]
   for p in procs:
     p.start()
   res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
   for p in procs:
     p.join(timeout=60)
     assert p.exitcode == 0
-  g1, p1, loss1 = _step(0, 1)
+  g1, p1, loss1 = _step(0, 1, case)
   (_, ga, pa, la), (_, gb, pb, lb) = res
   # every rank holds the same reduced gradient, statistics and parameters
   assert (ga == gb).all() and (pa == pb).all() and la == lb
