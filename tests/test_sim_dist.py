@@ -109,3 +109,56 @@ def test_two_rank_step_equals_the_single_process_step(case):
   # same Adam step: the first step moves every parameter by ~lr * sign(g); only near-zero gradients may flip
   big = g1.abs() > 1e-3 * g1.abs().max()
   assert torch.equal(torch.as_tensor(pa)[big], p1[big]) or (torch.as_tensor(pa)[big] - p1[big]).abs().max().item() < 1e-6
+
+
+def _render(rank, world):
+  """Image rendering split over `world` ranks (models.py:625-706 + the all-gather of pixel buffers)."""
+  from multinerf_amd import configs, models, train_utils
+  from oracle import models as omodels
+  from tests import helpers
+  from tests import sim_helpers as S
+  with S.simulated_device() as sim:
+    name, extra = PRESETS['blender_256']
+    cfg = configs.load_preset(name, list(extra) + ['Config.render_chunk_size = 16'])
+    model = models.Model(config=cfg)
+    model.build('cpu')
+    om, on, op = helpers.oracle_hparams(model)
+    flat = model.flat_from_tree(omodels.init_params(om, on, op, seed=6))
+    H, W = 5, 7                                    # 35 rays: chunks of 16, 16, 3 -> the last one is padded to 4 for two ranks
+    b = helpers.synthetic_rays(H * W, near=cfg.near, far=cfg.far)
+    rays = b.rays.map(lambda t: t.reshape(H, W, -1))
+    fn = train_utils.create_render_fn(model)
+    out = models.render_image(lambda rng, r: fn({'flat': flat}, 1.0, None, r), rays, None, cfg, verbose=False,
+                              world_size=world, rank=rank)
+    sim.check()
+    return out['rgb'].clone(), out['acc'].clone(), out['distance_median'].clone()
+
+
+def _render_worker(rank, world, port, q):
+  sys.path.insert(0, ROOT)
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+  import torch.distributed as td
+  from multinerf_amd import dist as mdist
+  mdist.init_from_env(backend='gloo')
+  rgb, acc, dist = _render(rank, world)
+  mdist.barrier()
+  q.put((rank, rgb.numpy(), acc.numpy(), dist.numpy()))
+  td.destroy_process_group()
+
+
+def test_two_rank_render_image_equals_the_single_process_image():
+  world = 2
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_render_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  rgb1, acc1, dist1 = _render(0, 1)
+  for _, rgb, acc, dist in res:                    # every rank ends up with the whole image
+    assert rgb.shape == (5, 7, 3)
+    assert (torch.as_tensor(rgb) == rgb1).all() and (torch.as_tensor(acc) == acc1).all() and (torch.as_tensor(dist) == dist1).all()
