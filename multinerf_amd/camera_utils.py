@@ -30,7 +30,7 @@ def pixels_to_rays(pix_x_int, pix_y_int, pixtocams, camtoworlds, distortion_para
   (origins, directions, viewdirs, radii, imageplane) out, shaped like the pixel arrays."""
   shape = tuple(pix_x_int.shape)
   dev = pix_x_int.device
-  if dev.type != 'cuda':
+  if not ops._on_device(pix_x_int):
     raise ValueError('pixels_to_rays: device tensors required (the HIP path has no CPU fallback)')
   px = pix_x_int.reshape(-1).to(torch.int32).contiguous()
   py = pix_y_int.reshape(-1).to(torch.int32).contiguous()

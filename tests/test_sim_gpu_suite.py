@@ -1,0 +1,45 @@
+"""The `-m gpu` tests' own code, run on the kernel-source simulator in a child pytest (MNR_TESTS_ON_SIMULATOR=1).
+
+tests/conftest.py then keeps 'cuda' tensors on the host and hands the package the simulator build of the C ABI, so the
+parity tests written for the MI355X (every kernel against the oracle, bit-exact sample indices, Ref-NeRF heads, camera
+rays against the reference goldens, composed model cases) execute unchanged against the kernel SOURCE.  The default CPU
+run takes the kernel-level files and the quick composed cases; everything, including all of tests/test_gpu_model.py
+(26 cases, ~12 min), runs with
+
+    MNR_TESTS_ON_SIMULATOR=1 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_refnerf.py tests/test_gpu_camera.py tests/test_gpu_model.py -m gpu
+
+A development screen, not evidence about the hardware: host libm instead of the device's transcendental units, no timing,
+sequentially consistent memory apart from the LDS-DMA landing modes of tools/hipsim.
+"""
+
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.skipif(not (shutil.which('clang++') or os.path.exists('/opt/rocm/lib/llvm/bin/clang++')),
+                                reason='needs clang++')
+
+
+def _child(args, timeout):
+  env = dict(os.environ, MNR_TESTS_ON_SIMULATOR='1')
+  cmd = [sys.executable, '-m', 'pytest', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', '-n', '4'] + args
+  r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+  tail = '\n'.join((r.stdout + r.stderr).splitlines()[-25:])
+  assert r.returncode == 0, tail
+  return tail
+
+
+def test_kernel_level_gpu_tests_pass_on_the_simulator():
+  tail = _child(['tests/test_gpu_kernels.py', 'tests/test_gpu_refnerf.py', 'tests/test_gpu_camera.py'], 1500)
+  assert ' passed' in tail and 'failed' not in tail and 'skipped' not in tail, tail
+
+
+def test_quick_composed_gpu_tests_pass_on_the_simulator():
+  sel = 'test_tiny_and_ragged_batches or test_leading_dims or test_unsupported or (test_forward_parity and blender_256 and extra1)'
+  tail = _child(['tests/test_gpu_model.py', '-k', sel], 1500)
+  assert ' passed' in tail and 'failed' not in tail, tail
