@@ -53,3 +53,21 @@ def test_no_spills_inside_the_k_loops(report):
   for name, body in bodies.items():
     mfma = [k for k, l in enumerate(body) if 'v_mfma' in l]
     assert not any('scratch_' in l for l in body[mfma[0]:mfma[-1] + 1]), name
+
+
+def test_default_gemm_kernels_are_the_ones_validated_on_the_gpu(report):
+  """profiles/r1_validated_isa.json holds digests of the device code of the default kernels of gemm.hip (NtC0, NtC2, both
+  TN tiles, the small kernels) as they ran the round-1 GPU suite and bench.  Work on the optional configurations, the
+  simulator seams or the host side must not change them; an intended change re-validates on the GPU and rewrites the file
+  (tools/isa_report.py: normalized_digest)."""
+  import json
+  mod, _ = report
+  want = json.load(open(os.path.join(ROOT, 'profiles', 'r1_validated_isa.json')))['kernels']
+  asm, tmp = mod.compile_selected([0, 2])
+  try:
+    got = {n: mod.normalized_digest(b) for n, b in mod.all_kernel_bodies(asm).items()}
+  finally:
+    shutil.rmtree(tmp, ignore_errors=True)
+  assert set(want) <= set(got), sorted(set(want) - set(got))
+  changed = [n for n in want if got[n] != want[n]]
+  assert not changed, changed

@@ -69,6 +69,31 @@ def kernel_bodies(asm_text):
   return out
 
 
+def normalized_digest(body):
+  """sha1 of a kernel's instructions with labels, symbol names and comments normalised: equal digests = same device code."""
+  import hashlib
+  h = hashlib.sha1()
+  for l in body[1:]:
+    c = re.sub(r';.*', '', l).rstrip()
+    if not c.strip():
+      continue
+    c = re.sub(r'\.LBB\d+_', '.LBB_', c)
+    c = re.sub(r'_Z\w+', 'SYM', c)
+    h.update(c.encode() + b'\n')
+  return h.hexdigest()
+
+
+def all_kernel_bodies(asm_text):
+  """{kernel name: lines} for EVERY kernel of a device assembly listing."""
+  out = {}
+  for m in re.finditer(r'^(_Z\w+):', asm_text, flags=re.M):
+    i = m.start()
+    j = asm_text.find('.Lfunc_end', i)
+    if j > 0:
+      out[m.group(1)] = asm_text[i:j].split('\n')
+  return out
+
+
 def mfma_loops(body):
   """Innermost loops (label .. back-edge) that contain MFMAs."""
   labels = {l.split(':')[0]: k for k, l in enumerate(body) if l.startswith('.LBB')}
