@@ -56,8 +56,8 @@ def test_no_spills_inside_the_k_loops(report):
 
 
 def test_default_gemm_kernels_are_the_ones_validated_on_the_gpu(report):
-  """profiles/r1_validated_isa.json holds digests of the device code of the default kernels of gemm.hip (NtC0, NtC2, both
-  TN tiles, the small kernels) as they ran the round-1 GPU suite and bench.  Work on the optional configurations, the
+  """profiles/r1_validated_isa.json holds digests of the device code of every kernel of the default path (gemm.hip: NtC0,
+  NtC2, both TN tiles, the small kernels; all kernels of the other csrc files) as they ran the round-1 GPU suite and bench.  Work on the optional configurations, the
   simulator seams or the host side must not change them; an intended change re-validates on the GPU and rewrites the file
   (tools/isa_report.py: normalized_digest)."""
   import json
@@ -68,6 +68,8 @@ def test_default_gemm_kernels_are_the_ones_validated_on_the_gpu(report):
     got = {n: mod.normalized_digest(b) for n, b in mod.all_kernel_bodies(asm).items()}
   finally:
     shutil.rmtree(tmp, ignore_errors=True)
+  for f in ('resample.hip', 'features.hip', 'render.hip', 'losses.hip', 'optim.hip', 'refnerf.hip', 'camera.hip'):
+    got.update({n: mod.normalized_digest(b) for n, b in mod.all_kernel_bodies(mod.compile_file(f)).items()})
   assert set(want) <= set(got), sorted(set(want) - set(got))
   changed = [n for n in want if got[n] != want[n]]
   assert not changed, changed

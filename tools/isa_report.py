@@ -107,6 +107,21 @@ def mfma_loops(body):
   return loops
 
 
+def compile_file(name):
+  """Device-only assembly text of csrc/<name> (any kernel file but gemm.hip, which compile_selected handles)."""
+  tmp = tempfile.mkdtemp(prefix='isa_')
+  out = os.path.join(tmp, name + '.s')
+  cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '--cuda-device-only', '-S',
+         os.path.join(CSRC, name), '-o', out]
+  r = subprocess.run(cmd, capture_output=True, text=True)
+  if r.returncode != 0:
+    raise RuntimeError(r.stderr)
+  text = open(out).read()
+  import shutil
+  shutil.rmtree(tmp, ignore_errors=True)
+  return text
+
+
 def compile_selected(cfgs):
   """Device-only assembly of gemm.hip with nt_dispatch() restricted to `cfgs`; returns (assembly text, temp dir)."""
   src = open(os.path.join(CSRC, 'gemm.hip')).read()
