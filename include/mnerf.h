@@ -192,6 +192,11 @@ int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* args, void* stream);
  * s_memrealtime at entry, exit; XCC_ID<<32|HW_ID; unused; epilogue pass stamps) written by
  * every following mnr_gemm_nt_bf16 / mnr_gemm_tn_bf16 launch (TN: [7] = steps << 32 | does-bias); NULL switches it off. */
 int mnr_debug_gemm_timeline(unsigned long long* device_buffer);
+/* Probe hooks for the direct-weights NT configurations (csrc/gemm.hip NtC36 / NtC37; tools/gemm_probe.py): build the
+ * fragment-major image [N/32][K/64][4][64 lanes][8] of a weight operand Bt [N, ldb] (out: N*K bf16), and make every
+ * following direct-weights launch read its weights from such an image instead of args->Bt (NULL switches it off). */
+int mnr_pack_w_frag_bf16(const uint16_t* Bt, int ldb, int N, int K, uint16_t* out, void* stream);
+int mnr_debug_gemm_wfrag(const uint16_t* image);
 int mnr_gemm_nt_set_config(int cfg_big, int cfg_small);
 
 typedef struct {

@@ -179,6 +179,7 @@ __device__ __forceinline__ bf16x8 nt_read_half(const char* ht, int lrow, int ksl
 // kernel entry, K-loop start, K-loop end and kernel exit into g_nt_timeline[16 * blockIdx.x + 0..3], s_memrealtime
 // (100 MHz) at entry / exit into [4], [5], XCC_ID << 32 | HW_ID into [6]; epilogue pass h: staged [8+2h], stored [9+2h].
 __device__ unsigned long long* g_nt_timeline = nullptr;
+__device__ const uint16_t* g_nt_wfrag = nullptr;           // probe hook: fragment-major weight image for the direct-weights loop
 __device__ unsigned long long* g_tn_timeline = nullptr;
 
 extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
@@ -188,6 +189,41 @@ extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
     mnr_set_error("mnr_debug_gemm_timeline: %s", hipGetErrorString(e));
     return MNR_ERR_HIP;
   }
+  return MNR_OK;
+}
+
+// Probe hook (tools/gemm_probe.py): the direct-weights configurations (NtC36 / NtC37) read the weights of every
+// following launch from this fragment-major image (see mnr_pack_w_frag_bf16) instead of args->Bt; NULL switches it off.
+extern "C" int mnr_debug_gemm_wfrag(const uint16_t* image) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_nt_wfrag), &image, sizeof(image));
+  if (e != hipSuccess) {
+    mnr_set_error("mnr_debug_gemm_wfrag: %s", hipGetErrorString(e));
+    return MNR_ERR_HIP;
+  }
+  return MNR_OK;
+}
+
+// out[(((n/32) * (K/64) + k/64) * 4 + ks) * 64 + lane][0..7] = Bt[(n/32)*32 + lane%32][(k/64)*64 + ks*16 + (lane/32)*8 + 0..7]:
+// the MFMA A-operand fragments of the NT kernel's weight side, one contiguous KiB per (32 columns, 16 k) block.
+__global__ void pack_w_frag_kernel(const bf16* __restrict__ Bt, int ldb, int N, int K, bf16* __restrict__ out) {
+  const int nk = K / 64;
+  const int64_t total = (int64_t)(N / 32) * nk * 4 * 64;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(c & 63), ks = (int)((c >> 6) & 3);
+    const int64_t t = c >> 8;
+    const int kt = (int)(t % nk), ntile = (int)(t / nk);
+    *(bf16x8*)(out + c * 8) = *(const bf16x8*)(Bt + (int64_t)(ntile * 32 + (lane & 31)) * ldb + kt * 64 + ks * 16 + (lane >> 5) * 8);
+  }
+}
+
+extern "C" int mnr_pack_w_frag_bf16(const uint16_t* Bt, int ldb, int N, int K, uint16_t* out, void* stream) {
+  MNR_CHECK_ARG(Bt && out && N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0 && ldb % 8 == 0,
+                "mnr_pack_w_frag_bf16: need N %% 32 == 0, K %% 64 == 0, ldb %% 8 == 0");
+  const int64_t total = (int64_t)(N / 32) * (K / 64) * 256;
+  int grid = mnr_cdiv(total, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(pack_w_frag_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)Bt, ldb, N, K, (bf16*)out);
+  MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
 

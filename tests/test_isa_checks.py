@@ -41,9 +41,8 @@ def test_reserved_registers_are_left_alone_while_weight_loads_fly(report):
 def test_k_loops_carry_only_the_hand_counted_vmcnt_waits(report):
   mod, bodies = report
   for name, body in bodies.items():
-    mfma = [k for k, l in enumerate(body) if 'v_mfma' in l]
-    # from the first to the last MFMA of the kernel = K loop (the epilogue has none)
-    seg = body[mfma[0]:mfma[-1] + 1]
+    seg = mod.k_loop_lines(body)
+    assert sum('v_mfma' in l for l in seg) >= 32, name
     assert mod.compiler_vmcnt_waits(seg) == [], name
 
 
@@ -51,8 +50,7 @@ def test_no_spills_inside_the_k_loops(report):
   """(The default forward kernel spills two registers around its prologue; none may sit between the MFMAs.)"""
   mod, bodies = report
   for name, body in bodies.items():
-    mfma = [k for k, l in enumerate(body) if 'v_mfma' in l]
-    assert not any('scratch_' in l for l in body[mfma[0]:mfma[-1] + 1]), name
+    assert not any('scratch_' in l for l in mod.k_loop_lines(body)), name
 
 
 def test_default_gemm_kernels_are_the_ones_validated_on_the_gpu(report):

@@ -86,6 +86,29 @@ def test_nt_direct_weights_short_and_odd_k(sim, cfg, nk):
     np.testing.assert_allclose(Cb.float().numpy(), (A.float() @ Bt.float().T).numpy(), atol=2e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize('cfg', [36, 37])
+def test_nt_direct_weights_from_a_fragment_major_image(sim, cfg):
+  """mnr_pack_w_frag_bf16 + the probe hook mnr_debug_gemm_wfrag: same result, and the row-major operand is not read."""
+  g = torch.Generator().manual_seed(9)
+  M, N, K = 256, 512, 192
+  A = torch.randn((M, K), generator=g).bfloat16()
+  Bt = (torch.randn((N, K + 24), generator=g) * 0.1).bfloat16()[:, :K]         # pitch != K
+  bias = torch.randn(N, generator=g)
+  img = torch.zeros(N * K, dtype=torch.bfloat16)
+  sim.hipsim_reset(0, 0)
+  S.sim_check(sim, sim.mnr_pack_w_frag_bf16(S.ptr(Bt), Bt.stride(0), N, K, S.ptr(img), None))
+  sim.mnr_gemm_nt_set_config(cfg, 0)
+  ref, _, _ = S.sim_gemm_nt(sim, A, Bt, bias=bias, relu=True)
+  for mode in MODES:
+    sim.hipsim_reset(*mode)
+    S.sim_check(sim, sim.mnr_debug_gemm_wfrag(S.ptr(img)))
+    try:
+      got, _, _ = S.sim_gemm_nt(sim, A, torch.full_like(Bt, float('nan')), bias=bias, relu=True)
+    finally:
+      sim.mnr_debug_gemm_wfrag(None)
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize('mode', MODES[:2])
 def test_nt_small_tile_heads(sim, mode):
   """128x128 tile (N not a multiple of 256): partial-width bf16 output, bf16 mask operand, no bias."""

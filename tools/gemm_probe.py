@@ -141,6 +141,28 @@ def main():
       time_it(f'cfg {c} nt fwd  1024', lambda: ops.gemm_nt(A, Bt, M=M, N=N, K1=K, bias=bias, n_bias=N, relu=True, Cb=C, ldcb=N, nb=N), 2.0 * M * N * K)
       time_it(f'cfg {c} nt dX   1024', lambda: ops.gemm_nt(A, Bt, M=M, N=N, K1=K, mask=mask, ldmask=N, Cb=C, ldcb=N, nb=N), 2.0 * M * N * K)
       time_it(f'cfg {c} nt prop  256', lambda: ops.gemm_nt(A2, B2, M=M2, N=K2, K1=K2, bias=b2, n_bias=K2, relu=True, Cb=C2, ldcb=K2, nb=K2), 2.0 * M2 * K2 * K2)
+      if c in (36, 37):
+        # the direct-weights loop reading its weights from a fragment-major image (one contiguous KiB per instruction)
+        import ctypes
+        lib = ops.lib()
+        img = torch.empty(N * K, dtype=bf, device=dev)
+        ops.L.check(lib.mnr_pack_w_frag_bf16(ctypes.c_void_p(Bt.data_ptr()), K, N, K, ctypes.c_void_p(img.data_ptr()), None))
+        img2 = torch.empty(K2 * K2, dtype=bf, device=dev)
+        ops.L.check(lib.mnr_pack_w_frag_bf16(ctypes.c_void_p(B2.data_ptr()), K2, K2, K2, ctypes.c_void_p(img2.data_ptr()), None))
+        torch.cuda.synchronize()
+        ops.L.check(lib.mnr_debug_gemm_wfrag(ctypes.c_void_p(img.data_ptr())))
+        Cw = torch.empty((M, N), dtype=bf, device=dev)
+        ops.gemm_nt(A, Bt, M=M, N=N, K1=K, bias=bias, n_bias=N, relu=True, Cb=Cw, ldcb=N, nb=N)
+        ops.L.check(lib.mnr_debug_gemm_wfrag(None))
+        ops.gemm_nt(A, Bt, M=M, N=N, K1=K, bias=bias, n_bias=N, relu=True, Cb=C, ldcb=N, nb=N)
+        torch.cuda.synchronize()
+        print(f'cfg {c} fragment-major weights: ' + ('bitwise equal to the row-major run' if torch.equal(Cw, C) else 'MISMATCH'), flush=True)
+        ops.L.check(lib.mnr_debug_gemm_wfrag(ctypes.c_void_p(img.data_ptr())))
+        time_it(f'cfg {c} nt fwd  1024 wfrag', lambda: ops.gemm_nt(A, Bt, M=M, N=N, K1=K, bias=bias, n_bias=N, relu=True, Cb=C, ldcb=N, nb=N), 2.0 * M * N * K)
+        time_it(f'cfg {c} nt dX   1024 wfrag', lambda: ops.gemm_nt(A, Bt, M=M, N=N, K1=K, mask=mask, ldmask=N, Cb=C, ldcb=N, nb=N), 2.0 * M * N * K)
+        ops.L.check(lib.mnr_debug_gemm_wfrag(ctypes.c_void_p(img2.data_ptr())))
+        time_it(f'cfg {c} nt prop  256 wfrag', lambda: ops.gemm_nt(A2, B2, M=M2, N=K2, K1=K2, bias=b2, n_bias=K2, relu=True, Cb=C2, ldcb=K2, nb=K2), 2.0 * M2 * K2 * K2)
+        ops.L.check(lib.mnr_debug_gemm_wfrag(None))
     return
   if 'nt' in which:
     C = torch.empty((M, N), dtype=bf, device=dev)

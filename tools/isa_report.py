@@ -27,11 +27,34 @@ def _vregs(text):
   return out
 
 
+def _basic_blocks(body):
+  """[(label, first line, last line + 1, successor labels, falls through)] of a kernel listing."""
+  starts = [k for k, l in enumerate(body) if re.match(r'^\.LBB\d+_\d+:', l)]
+  bounds = [0] + starts + [len(body)]
+  blocks = []
+  for a, b in zip(bounds[:-1], bounds[1:]):
+    if a == b:
+      continue
+    label = body[a].split(':')[0] if body[a].startswith('.LBB') else '<entry>'
+    succ, fall = [], True
+    for l in body[a:b]:
+      code = l.split(';')[0]
+      m = re.match(r'^\ts_(c?branch\w*)\s+(\.LBB\d+_\d+)', code)
+      if m:
+        succ.append(m.group(2))
+        if m.group(1) == 'branch':
+          fall = False
+      if re.match(r'^\ts_endpgm', code):
+        fall = False
+    blocks.append((label, a, b, succ, fall))
+  return blocks
+
+
 def reserved_register_violations(body):
-  """Lines that touch v224+ other than the asm weight loads (as destination) and MFMAs (as source operand), up to the
-  last MFMA that reads them.  amdgpu_num_vgpr(224) is a request, not a cap: hipcc does hand out v224+ when a kernel
-  needs more (seen in the general epilogue path, after the K loop, where the fragments are dead); what must never
-  happen is such a use while weight loads can be in flight, i.e. anywhere before the last MFMA that consumes them."""
+  """Instructions that touch v224+ other than the asm weight loads (as destination) and MFMAs (as source operand) in
+  any basic block that lies on a path from a weight load to an MFMA consuming one.  amdgpu_num_vgpr(224) is a request,
+  not a cap: hipcc does hand out v224+ when a kernel needs more (seen in the general epilogue path, where the fragments
+  are dead); what must never happen is such a use where weight loads can still be in flight."""
   def is_load(code):
     if not code.startswith('\tglobal_load_dwordx4'):
       return False
@@ -39,12 +62,80 @@ def reserved_register_violations(body):
     return all(r >= RESERVED_LO for r in _vregs(dst)) and not any(r >= RESERVED_LO for r in _vregs(rest))
 
   def is_mfma_src(code):
-    return code.startswith('\tv_mfma') and not any(r >= RESERVED_LO for r in _vregs(code.split(None, 1)[1].split(',')[0]))
+    return code.startswith('\tv_mfma') and not any(r >= RESERVED_LO for r in _vregs(code.split(None, 1)[1].split(',')[0])) \
+        and any(r >= RESERVED_LO for r in _vregs(code))
 
   codes = [l.split(';')[0] for l in body]
-  touch = [k for k, c in enumerate(codes) if c.startswith('\t') and any(r >= RESERVED_LO for r in _vregs(c))]
-  last = max((k for k in touch if is_mfma_src(codes[k])), default=-1)
-  return [body[k].strip() for k in touch if k <= last and not is_load(codes[k]) and not is_mfma_src(codes[k])]
+  blocks = _basic_blocks(body)
+  index = {lab: i for i, (lab, *_rest) in enumerate(blocks)}
+  succ = []
+  for i, (lab, a, b, targets, fall) in enumerate(blocks):
+    out = [index[t] for t in targets if t in index]
+    if fall and i + 1 < len(blocks):
+      out.append(i + 1)
+    succ.append(out)
+  pred = [[] for _ in blocks]
+  for i, out in enumerate(succ):
+    for j in out:
+      pred[j].append(i)
+
+  def closure(seeds, edges):
+    seen, todo = set(seeds), list(seeds)
+    while todo:
+      i = todo.pop()
+      for j in edges[i]:
+        if j not in seen:
+          seen.add(j)
+          todo.append(j)
+    return seen
+
+  load_blocks = [i for i, (_, a, b, *_r) in enumerate(blocks) if any(is_load(c) for c in codes[a:b])]
+  use_blocks = [i for i, (_, a, b, *_r) in enumerate(blocks) if any(is_mfma_src(c) for c in codes[a:b])]
+  hot = closure(load_blocks, succ) & closure(use_blocks, pred)
+  bad = []
+  for i in sorted(hot):
+    _, a, b, *_r = blocks[i]
+    for k in range(a, b):
+      c = codes[k]
+      if c.startswith('\t') and any(r >= RESERVED_LO for r in _vregs(c)) and not is_load(c) and not is_mfma_src(c):
+        bad.append(body[k].strip())
+  return bad
+
+
+def k_loop_lines(body):
+  """Lines of the basic blocks that lie on a cycle-or-path between MFMAs (reachable from a block with MFMAs and reaching
+  one): the K loops, without prologue and epilogue, however hipcc lays the blocks out or duplicates the loop."""
+  codes = [l.split(';')[0] for l in body]
+  blocks = _basic_blocks(body)
+  index = {lab: i for i, (lab, *_r) in enumerate(blocks)}
+  succ = []
+  for i, (lab, a, b, targets, fall) in enumerate(blocks):
+    out = [index[t] for t in targets if t in index]
+    if fall and i + 1 < len(blocks):
+      out.append(i + 1)
+    succ.append(out)
+  pred = [[] for _ in blocks]
+  for i, out in enumerate(succ):
+    for j in out:
+      pred[j].append(i)
+
+  def closure(seeds, edges):
+    seen, todo = set(seeds), list(seeds)
+    while todo:
+      i = todo.pop()
+      for j in edges[i]:
+        if j not in seen:
+          seen.add(j)
+          todo.append(j)
+    return seen
+
+  mf = [i for i, (_, a, b, *_r) in enumerate(blocks) if any(c.startswith('\tv_mfma') for c in codes[a:b])]
+  hot = closure(mf, succ) & closure(mf, pred)
+  out = []
+  for i in sorted(hot):
+    _, a, b, *_r = blocks[i]
+    out.extend(body[a:b])
+  return out
 
 
 def compiler_vmcnt_waits(seg):
@@ -156,7 +247,7 @@ def main():
     print(f'{name}\n  vgpr {v} agpr {a} sgpr {sg} scratch {scr} B spilled {sp}')
     if 'r224' in name:
       bad = reserved_register_violations(body)
-      print(f'  v{RESERVED_LO}+ touched by anything but the asm loads / MFMA sources before the last consuming MFMA: {len(bad)}' + ''.join('\n    ' + b for b in bad[:8]))
+      print(f'  v{RESERVED_LO}+ touched by anything but the asm loads / MFMA sources on a path from a weight load to its MFMAs: {len(bad)}' + ''.join('\n    ' + b for b in bad[:8]))
     for lab, seg in mfma_loops(body):
       n = lambda pat: sum(1 for l in seg if re.search(pat, l))
       waits = [l.strip() for l in seg if 's_waitcnt' in l and 'vmcnt' in l]
