@@ -56,6 +56,9 @@ struct NtCfg {
   // 1: the weights never touch LDS.  With one wave per 32 output columns (WM = 1) a wave's weight fragments are
   // private to it, so it loads them global -> registers itself (double-buffered, one K tile ahead) and only the
   // activation tile is staged through LDS: half the LDS-DMA bytes and half the LDS footprint per stage.
+  // 2: split operand paths.  Layout and LDS image as the default loop, but the weight tile of the next K step travels
+  // global -> registers -> ds_write (each thread four 16-byte chunks) while only the activation tile uses the LDS-DMA:
+  // the two halves of a step's 64 KiB come in through different paths at the same time.
   static constexpr int BDIRECT = BDIRECT_;
   static constexpr int FRAGPIPE = FRAGPIPE_;          // 1: explicit register double-buffering of LDS fragments
   static constexpr int MI = MI_, NJ = NJ_, WM = WM_, WN = WN_, BK = BK_, STAGES = STAGES_;
@@ -64,7 +67,7 @@ struct NtCfg {
   static constexpr int THREADS = 64 * WM * WN;
   static constexpr int ROWB = BK * 2;                 // bytes per staged operand row
   static constexpr int SLOTS = ROWB / 16;             // 16-B slots per row (8 at BK=64, 4 at BK=32)
-  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BDIRECT_ ? 0 : BN * ROWB;
+  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BDIRECT_ == 1 ? 0 : BN * ROWB;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   // phase-interleaved loop (FRAGPIPE >= 2): PH_S half-tile slots of 16 KiB, staged PH_L phases ahead
   static constexpr int PH_S = FRAGPIPE_ == 3 ? 10 : 8;
@@ -75,11 +78,19 @@ struct NtCfg {
   // Rows staged per epilogue pass: the whole tile when it fits the 160 KiB of LDS (one pass, every wave converts
   // and writes at once: 135 KiB for the 256x256 tile), else 128 or 64 rows inside the operand buffers.
   static constexpr int EPI_ROWS = (BM * CPITCH <= 160 * 1024) ? BM : (128 * CPITCH <= LDS_OPERANDS) ? 128 : 64;
-  static constexpr int LDS_BYTES = LDS_OPERANDS > EPI_ROWS * CPITCH ? LDS_OPERANDS : EPI_ROWS * CPITCH;
+  // The split-path loop gives 16 registers to its in-flight weight chunks and cannot also hold the bias of the
+  // lane's columns (NJ x 16 registers) across the K loop: there the tile's bias row waits in LDS, behind everything else.
+  static constexpr bool BIAS_LDS = BDIRECT_ == 2;
+  static constexpr int LDS_MAIN = LDS_OPERANDS > EPI_ROWS * CPITCH ? LDS_OPERANDS : EPI_ROWS * CPITCH;
+  static constexpr int BIAS_OFF = (LDS_MAIN + 15) / 16 * 16;
+  static constexpr int LDS_BYTES = BIAS_LDS ? BIAS_OFF + BN * 4 : LDS_MAIN;
   static_assert(EPI_ROWS * CPITCH <= LDS_BYTES, "epilogue staging must fit in the operand buffers");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   static_assert(BM % EPI_ROWS == 0 && (32 * MI) <= EPI_ROWS && EPI_ROWS % (32 * MI) == 0, "epilogue pass shape");
   static_assert((BM * SLOTS) % THREADS == 0 && (BN * SLOTS) % THREADS == 0, "stage loop shape");
-  static_assert(!BDIRECT_ || (WM_ == 1 && NJ_ == 1 && BK_ == 64 && FRAGPIPE_ == 0 && STAGES_ >= 2), "direct-weights loop shape");
+  static_assert(BDIRECT_ != 1 || (WM_ == 1 && NJ_ == 1 && BK_ == 64 && FRAGPIPE_ == 0 && STAGES_ >= 2), "direct-weights loop shape");
+  static_assert(BDIRECT_ != 2 || (BK_ == 64 && FRAGPIPE_ == 0 && STAGES_ == 2 && A_BYTES / 16 / THREADS == 4 && B_BYTES / 16 / THREADS == 4),
+                "split-path loop shape");
 };
 
 // Stage one operand tile [ROWS][BK] with 16-B LDS-DMA.  LDS image: row r, slot s stored at slot
@@ -239,6 +250,13 @@ void gemm_nt_kernel_r224(mnr_gemm_nt_args p, int fast_epi) {
 #include "gemm_nt_body.inc"
 }
 
+// ... the split-path configurations v240-v255.
+template <class CFG, bool BITS_IN>
+__global__ __launch_bounds__(CFG::THREADS, CFG::MINW) MNR_GPU_ONLY(__attribute__((amdgpu_num_vgpr(240))))
+void gemm_nt_kernel_r240(mnr_gemm_nt_args p, int fast_epi) {
+#include "gemm_nt_body.inc"
+}
+
 template <class CFG>
 static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   MNR_CHECK_ARG(a->M % CFG::BM == 0 && a->N % CFG::BN == 0, "mnr_gemm_nt_bf16: M=%lld / N=%d not multiples of the %dx%d tile",
@@ -251,9 +269,12 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   MNR_CHECK_ARG(grid < (1ll << 31), "mnr_gemm_nt_bf16: grid too large");
   void (*k_plain)(mnr_gemm_nt_args, int);
   void (*k_bits)(mnr_gemm_nt_args, int);
-  if constexpr (CFG::BDIRECT) {
+  if constexpr (CFG::BDIRECT == 1) {
     k_plain = gemm_nt_kernel_r224<CFG, false>;
     k_bits = gemm_nt_kernel_r224<CFG, true>;
+  } else if constexpr (CFG::BDIRECT == 2) {
+    k_plain = gemm_nt_kernel_r240<CFG, false>;
+    k_bits = gemm_nt_kernel_r240<CFG, true>;
   } else {
     k_plain = gemm_nt_kernel<CFG, false>;
     k_bits = gemm_nt_kernel<CFG, true>;
@@ -292,6 +313,7 @@ typedef NtCfg<4, 2, 2, 4, 32, 3> NtC7;             // 256x256, 8 waves, 3 stages
 typedef NtCfg<8, 1, 1, 8, 64, 2> NtC35;            // 256x256, 8 waves each 256 rows x 32 columns (no weight duplication across waves)
 typedef NtCfg<8, 1, 1, 8, 64, 3, 1, 0, 0, 1> NtC36; // 1x8 waves, weights global -> registers (never in LDS), 3 activation stages of 32 KiB
 typedef NtCfg<8, 1, 1, 8, 64, 4, 1, 0, 0, 1> NtC37; //   same, 4 stages
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 2> NtC40; // = NtC2 with split operand paths: activations by LDS-DMA, weights global -> registers -> ds_write
 typedef NtCfg<4, 2, 2, 2, 32, 2, 2> NtC38;           // 256x128, 4 waves of 128x64, 48 KiB: TWO workgroups per CU (one's epilogue under the other's K loop)
 typedef NtCfg<4, 2, 2, 2, 32, 3, 2> NtC39;           //   same, 3 stages (72 KiB)
 typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
@@ -300,7 +322,7 @@ typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register doubl
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 39 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 40 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -331,6 +353,7 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 34: return nt_launch<NtC34>(a, fast_epi, stream);
     case 36: return nt_launch<NtC36>(a, fast_epi, stream);
     case 38: return nt_launch<NtC38>(a, fast_epi, stream);
+    case 40: return nt_launch<NtC40>(a, fast_epi, stream);
     case 39: return nt_launch<NtC39>(a, fast_epi, stream);
     case 37: return nt_launch<NtC37>(a, fast_epi, stream);
     default:

@@ -23,19 +23,47 @@ def report():
   spec = importlib.util.spec_from_file_location('isa_report', os.path.join(ROOT, 'tools', 'isa_report.py'))
   mod = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(mod)
-  asm, tmp = mod.compile_selected([2, 36, 37])
+  asm, tmp = mod.compile_selected([2, 36, 37, 40])
   yield mod, mod.kernel_bodies(asm)
   shutil.rmtree(tmp, ignore_errors=True)
 
 
 def test_reserved_registers_are_left_alone_while_weight_loads_fly(report):
+  import re
   mod, bodies = report
-  r224 = {n: b for n, b in bodies.items() if 'r224' in n}
-  assert len(r224) == 4                                  # NtC36 / NtC37, with and without bit-mask input
-  for name, body in r224.items():
-    loads = [l for l in body if l.startswith('\tglobal_load_dwordx4') and 'v[2' in l.split(',')[0]]
-    assert len(loads) >= 8, name                         # the asm loads are there (both parities)
-    assert mod.reserved_register_violations(body) == [], name
+  res = {n: b for n, b in bodies.items() if re.search(r'kernel_r2\d\d', n)}
+  assert len(res) == 6                                   # NtC36 / NtC37 (v224+), NtC40 (v240+), with and without bit-mask input
+  for name, body in res.items():
+    lo = int(re.search(r'kernel_r(2\d\d)', name).group(1))
+    loads = [l for l in body if l.startswith('\tglobal_load_dwordx4') and min(mod._vregs(l.split(',')[0])) >= lo]
+    assert len(loads) >= 4, name                         # the asm loads are there
+    assert mod.reserved_register_violations(body, lo) == [], name
+
+
+def test_the_in_flight_analysis_sees_a_seeded_violation():
+  """The checker itself, on a hand-written listing: a copy out of a reserved register between the load and its wait
+  (what hipcc did with ordinary asm outputs), a fragment read INTO one inside the loop (what it did when the kernel
+  needed more registers than amdgpu_num_vgpr left it), and the clean pattern."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('isa_report', os.path.join(ROOT, 'tools', 'isa_report.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  def listing(middle, after):
+    return ['_Zk:', '\ts_mov_b32 s0, 0', '.LBB0_1:                  ; =>This Inner Loop Header: Depth=1', '\t;;#ASMSTART',
+            '\tglobal_load_dwordx4 v[240:243], v[2:3], off', '\t;;#ASMEND'] + middle + [
+                '\t;;#ASMSTART', '\ts_waitcnt vmcnt(4)', '\t;;#ASMEND'] + after + ['\ts_cbranch_scc1 .LBB0_1', '\ts_endpgm']
+  clean = listing(['\tv_mfma_f32_32x32x16_bf16 v[0:15], v[20:23], v[24:27], v[0:15]'], ['\tds_write_b128 v9, v[240:243]'])
+  assert mod.reserved_register_violations(clean, 240) == []
+  copied = listing(['\tv_mov_b64_e32 v[10:11], v[240:241]'], ['\tds_write_b128 v9, v[10:13]'])
+  assert len(mod.reserved_register_violations(copied, 240)) == 1
+  reused = listing(['\tds_read_b128 v[240:243], v201 offset:8192'], [])
+  assert len(mod.reserved_register_violations(reused, 240)) == 1
+  # in flight around the back-edge: a use at the top of the next iteration, before the wait, is seen through the loop
+  late = listing([], [])
+  late.insert(3, '\tv_add_u32_e32 v5, v241, v6')
+  assert len(mod.reserved_register_violations(late, 240)) == 0     # the wait precedes the back-edge here ...
+  nowait = [l for l in late if 's_waitcnt' not in l]
+  assert len(mod.reserved_register_violations(nowait, 240)) == 1     # ... without it the use is in flight
 
 
 def test_k_loops_carry_only_the_hand_counted_vmcnt_waits(report):

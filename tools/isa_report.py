@@ -50,55 +50,72 @@ def _basic_blocks(body):
   return blocks
 
 
-def reserved_register_violations(body):
-  """Instructions that touch v224+ other than the asm weight loads (as destination) and MFMAs (as source operand) in
-  any basic block that lies on a path from a weight load to an MFMA consuming one.  amdgpu_num_vgpr(224) is a request,
-  not a cap: hipcc does hand out v224+ when a kernel needs more (seen in the general epilogue path, where the fragments
-  are dead); what must never happen is such a use where weight loads can still be in flight."""
-  def is_load(code):
-    if not code.startswith('\tglobal_load_dwordx4'):
-      return False
-    dst, rest = code.split(None, 1)[1].split(',', 1)
-    return all(r >= RESERVED_LO for r in _vregs(dst)) and not any(r >= RESERVED_LO for r in _vregs(rest))
+def reserved_register_violations(body, RESERVED_LO=RESERVED_LO):
+  """Instructions that touch a reserved register (v224+ / v240+) while an inline-asm load into it may still be in flight.
 
-  def is_mfma_src(code):
-    return code.startswith('\tv_mfma') and not any(r >= RESERVED_LO for r in _vregs(code.split(None, 1)[1].split(',')[0])) \
-        and any(r >= RESERVED_LO for r in _vregs(code))
-
+  Forward may-analysis over the kernel's basic blocks.  State: the reserved registers with a load in flight.  An asm
+  `global_load_dwordx4` (between ASMSTART / ASMEND) into reserved registers adds them; an asm `s_waitcnt vmcnt(..)` lands
+  them all (the counted waits of these loops only ever leave younger LDS-DMAs outstanding); anything else that reads or
+  writes a register of the state is reported.  amdgpu_num_vgpr(N) is a request, not a cap: hipcc does hand out the
+  reserved registers when a kernel needs more than N (seen: fragment ds_reads into v240+ inside the K loop of a variant
+  that held the bias row in registers), which no functional test on the host can notice."""
   codes = [l.split(';')[0] for l in body]
+  in_asm, flag = False, []
+  for l in body:
+    if 'ASMSTART' in l:
+      in_asm = True
+    elif 'ASMEND' in l:
+      in_asm = False
+    flag.append(in_asm)
+
+  def load_dst(k):
+    c = codes[k]
+    if flag[k] and c.startswith('\tglobal_load_dwordx4'):
+      d = _vregs(c.split(None, 1)[1].split(',', 1)[0])
+      if d and all(r >= RESERVED_LO for r in d):
+        return d
+    return None
+
+  def is_wait(k):
+    return flag[k] and 's_waitcnt' in codes[k] and 'vmcnt' in codes[k]
+
   blocks = _basic_blocks(body)
-  index = {lab: i for i, (lab, *_rest) in enumerate(blocks)}
+  index = {lab: i for i, (lab, *_r) in enumerate(blocks)}
   succ = []
   for i, (lab, a, b, targets, fall) in enumerate(blocks):
     out = [index[t] for t in targets if t in index]
     if fall and i + 1 < len(blocks):
       out.append(i + 1)
     succ.append(out)
-  pred = [[] for _ in blocks]
-  for i, out in enumerate(succ):
-    for j in out:
-      pred[j].append(i)
 
-  def closure(seeds, edges):
-    seen, todo = set(seeds), list(seeds)
-    while todo:
-      i = todo.pop()
-      for j in edges[i]:
-        if j not in seen:
-          seen.add(j)
-          todo.append(j)
-    return seen
-
-  load_blocks = [i for i, (_, a, b, *_r) in enumerate(blocks) if any(is_load(c) for c in codes[a:b])]
-  use_blocks = [i for i, (_, a, b, *_r) in enumerate(blocks) if any(is_mfma_src(c) for c in codes[a:b])]
-  hot = closure(load_blocks, succ) & closure(use_blocks, pred)
-  bad = []
-  for i in sorted(hot):
+  def transfer(i, state, report=None):
     _, a, b, *_r = blocks[i]
+    state = set(state)
     for k in range(a, b):
       c = codes[k]
-      if c.startswith('\t') and any(r >= RESERVED_LO for r in _vregs(c)) and not is_load(c) and not is_mfma_src(c):
-        bad.append(body[k].strip())
+      if not c.startswith('\t'):
+        continue
+      d = load_dst(k)
+      if d is not None:
+        state |= d
+      elif is_wait(k):
+        state.clear()
+      elif state and report is not None and (_vregs(c) & state):
+        report.append(body[k].strip())
+    return state
+
+  entry = [set() for _ in blocks]
+  todo = list(range(len(blocks)))
+  while todo:
+    i = todo.pop()
+    out = transfer(i, entry[i])
+    for j in succ[i]:
+      if not out <= entry[j]:
+        entry[j] |= out
+        todo.append(j)
+  bad = []
+  for i in range(len(blocks)):
+    transfer(i, entry[i], bad)
   return bad
 
 
@@ -245,9 +262,16 @@ def main():
   for name, body in kernel_bodies(s).items():
     v, a, sg, scr, sp = meta[name]
     print(f'{name}\n  vgpr {v} agpr {a} sgpr {sg} scratch {scr} B spilled {sp}')
-    if 'r224' in name:
-      bad = reserved_register_violations(body)
-      print(f'  v{RESERVED_LO}+ touched by anything but the asm loads / MFMA sources on a path from a weight load to its MFMAs: {len(bad)}' + ''.join('\n    ' + b for b in bad[:8]))
+    m_res = re.search(r'kernel_r(2\d\d)', name)
+    if m_res:
+      lo = int(m_res.group(1))
+      bad = reserved_register_violations(body, lo)
+      print(f'  v{lo}+ touched while an asm load into it may be in flight: {len(bad)}' + ''.join('\n    ' + b for b in bad[:8]))
+    kl = k_loop_lines(body)
+    cnt = lambda pat: sum(1 for l in kl if re.search(pat, l.split(';')[0]))
+    print(f'  K-loop blocks: {len(kl)} lines, mfma {cnt("v_mfma")}, lds-dma {cnt("global_load_lds")}, ds_read {cnt("ds_read")}, '
+          f'ds_write {cnt("ds_write")}, global_load {cnt(r"global_load_dwordx")}, scratch {cnt("scratch_")}, barriers {cnt("s_barrier")}, '
+          f'vmcnt waits by hipcc {len(compiler_vmcnt_waits(kl))}')
     for lab, seg in mfma_loops(body):
       n = lambda pat: sum(1 for l in seg if re.search(pat, l))
       waits = [l.strip() for l in seg if 's_waitcnt' in l and 'vmcnt' in l]
