@@ -214,6 +214,8 @@ int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* args, void* stream);
 /* Tuning hook: the 256x256 output tile is used when K,N are multiples of 256 and the output has at
  * least `big_min_tiles` such tiles (a huge value disables it). */
 int mnr_gemm_tn_set_config(int big_min_tiles);
+/* Probe hook: 1 = the 256x256-tile launches use the split-path kernel (activations by LDS-DMA, dY through registers). */
+int mnr_gemm_tn_set_split(int on);
 
 /* out[n] += sum_m X[m,n] for n < n_valid (bias gradient). X bf16 [M, ld]. */
 int mnr_colsum_bf16(const uint16_t* X, int ld, int64_t M, int n_valid, float* out, void* stream);

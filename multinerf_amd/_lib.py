@@ -105,6 +105,7 @@ _PROTOS = {
     'mnr_gemm_nt_set_config': ([i32, i32], i32),
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
     'mnr_gemm_tn_set_config': ([i32], i32),
+    'mnr_gemm_tn_set_split': ([i32], i32),
     'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),
     'mnr_pack_weights_bf16': ([vp, vp, i32, i32, vp, vp], i32),
     'mnr_scatter_add_f32': ([vp, i32, i32, i32, i32, i32, vp, i32, vp], i32),

@@ -415,9 +415,10 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
 
 #define TN_BM 64       // reduction rows per step
 
-template <int KI_, int NJ_, int WK_, int WN_>
+template <int KI_, int NJ_, int WK_, int WN_, int SPLIT_ = 0>
 struct TnCfg {
   static constexpr int KI = KI_, NJ = NJ_, WK = WK_, WN = WN_;
+  static constexpr int SPLIT = SPLIT_;                // 1: dY tile global -> registers -> ds_write, activations by LDS-DMA
   static constexpr int BKO = 32 * KI * WK;            // output rows (columns of A)
   static constexpr int BNO = 32 * NJ * WN;            // output cols (columns of B)
   static constexpr int THREADS = 64 * WK * WN;
@@ -427,6 +428,7 @@ struct TnCfg {
 };
 typedef TnCfg<2, 2, 2, 2> TnSmall;   // 128x128 output tile, 4 waves,  64 KiB
 typedef TnCfg<4, 2, 2, 4> TnBig;     // 256x256 output tile, 8 waves, 128 KiB
+typedef TnCfg<4, 2, 2, 4, 1> TnBigSplit;   // same with split operand paths (not default; mnr_gemm_tn_set_split)
 
 // Stage a [64 m][COLS] tile; 64-B block b of row r is stored at block position b ^ (r & 3).
 template <int COLS, int THREADS>
@@ -467,179 +469,14 @@ __device__ __forceinline__ bf16x8 tn_read_frag(const char* lds_tile, int mbase, 
 
 template <class CFG>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
-  constexpr int KI = CFG::KI, NJ = CFG::NJ, BKO = CFG::BKO, BNO = CFG::BNO;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wk = wave / CFG::WN, wn = wave % CFG::WN;
-  unsigned long long* const tl = g_tn_timeline;          // profiling hook, same layout as the NT kernel's
-  if (tl && tid == 0) {
-    tl[16 * (int64_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
-    tl[16 * (int64_t)blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();
-  }
+#include "gemm_tn_body.inc"
+}
 
-  const int ktiles = p.K / BKO, ntiles = p.N / BNO;
-  const int tiles = ktiles * ntiles;
-  // All tiles of one M-split run consecutively on one XCD (operand rows shared through its L2).
-  const int xcd = blockIdx.x & 7;
-  const int q = blockIdx.x >> 3;
-  const int split = xcd + 8 * (q / tiles);
-  const int tile = q % tiles;
-  if (split >= splits) return;
-  const int k0 = (tile / ntiles) * BKO;
-  const int n0 = (tile % ntiles) * BNO;
-  const int total_steps = (int)(p.M / TN_BM);
-  const int s_begin = split * steps_per_split;
-  const int s_end = min(total_steps, s_begin + steps_per_split);
-  if (s_begin >= s_end) return;
-
-  const bf16* A = (const bf16*)p.A;
-  const bf16* B = (const bf16*)p.B;
-
-  f32x16 acc[KI][NJ];
-#pragma unroll
-  for (int i = 0; i < KI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  // Bias gradient db[n] = sum_m B[m,n]: the k-tile-0 workgroups multiply an all-ones A fragment
-  // with the B fragments they already hold (every row of the 32x32 result is the column sum), so
-  // dY is not read from HBM a second time.
-  const bool do_bias = (p.bias_out != nullptr) && (k0 == 0) && (wk == 0);
-  f32x16 accb[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[j][r] = 0.0f;
-  bf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
-
-  auto stage = [&](int step, int buf) {
-    char* base = smem + buf * CFG::STAGE_BYTES;
-    const int64_t row0 = (int64_t)step * TN_BM;
-    tn_stage_tile<BKO, CFG::THREADS>(A, p.lda, row0, k0, base, wave, lane);
-    tn_stage_tile<BNO, CFG::THREADS>(B, p.ldb, row0, n0, base + CFG::A_BYTES, wave, lane);
-  };
-
-  stage(s_begin, 0);
-  __syncthreads();
-  if (tl && tid == 0) tl[16 * (int64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
-  const int khalf = lane >> 5;
-  // Loop-invariant fragment addresses (see tn_read_frag for the layout): with p = lane & 15 the row of a transpose
-  // read is ks*16 + khalf*8 + (p >> 2) (+4 for the second half), whose low two bits are (p >> 2) & 3 for every ks,
-  // and the 64-B block index of a fragment's columns is wave-uniform, so
-  //   offset = lane part + ((block ^ x) << 6) + ks * 16 * ROWB (+ 4 * ROWB)
-  // and the loop needs one address register per fragment column block plus immediate offsets.  Left to
-  // tn_read_frag() the swizzle arithmetic is redone for all 24 fragments of every step (~350 VALU instructions per
-  // step competing with the MFMA issue: measured 4950 cycles per step against 3850 for the NT kernel's K tile).
-  constexpr int ROWB_A = BKO * 2, ROWB_B = BNO * 2;
-  const int pl = lane & 15, xsw = (pl >> 2) & 3;
-  const int lane_col = (((lane >> 4) & 1) * 16 + (pl & 3) * 4) * 2;
-  const int lane_row = khalf * 8 + (pl >> 2);
-  int a_off[KI], b_off[NJ];
-#pragma unroll
-  for (int i = 0; i < KI; ++i) a_off[i] = lane_row * ROWB_A + (((wk * KI + i) ^ xsw) << 6) + lane_col;
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) b_off[j] = lane_row * ROWB_B + (((wn * NJ + j) ^ xsw) << 6) + lane_col;
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  // The transpose reads are issued from inline asm.  Through the builtin, hipcc cannot tell that they read the
-  // OTHER stage than the LDS-DMA just issued writes, and puts `s_waitcnt vmcnt(0)` between stage(s+1) and the first
-  // read of stage s: the next tile's DMA then has to land before this tile's compute starts (measured: 4.9k cycles
-  // per step = DMA + compute in series, against 3.85k for the NT kernel's K tile).  As asm the reads are opaque:
-  // ordering is the explicit lgkmcnt wait below (operands tied to it) and the __syncthreads() at the end of the
-  // step, which still drains vmcnt for the DMA builtin.
-  auto tr_read = [&](const char* ptr, int imm_rows, int rowb) {
-    s16x4 v;
-    MNR_GPU_ONLY(const unsigned a = (unsigned)(uintptr_t)(ptr + (size_t)imm_rows * rowb);
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory"));
-    MNR_SIM_HOOK(v = hipsim::ds_read_tr16_b64(ptr + (size_t)imm_rows * rowb));
-    return v;
-  };
-  for (int s = s_begin; s < s_end; ++s) {
-    const int cur = (s - s_begin) & 1;
-    if (s + 1 < s_end) stage(s + 1, cur ^ 1);
-    const char* As = smem + cur * CFG::STAGE_BYTES;
-    const char* Bs = As + CFG::A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      // One lgkmcnt(0) per k sub-step, operands tied to it so that the MFMAs stay behind it.  (Waiting fragment by
-      // fragment, lgkmcnt(6)/(4)/(2)/(0) with the issue order pinned, measured 4% slower per step.)
-      s16x4 al[KI], ah[KI], bl[NJ], bh[NJ];
-#pragma unroll
-      for (int i = 0; i < KI; ++i) {
-        al[i] = tr_read(As + a_off[i], ks * 16, ROWB_A);
-        ah[i] = tr_read(As + a_off[i], ks * 16 + 4, ROWB_A);
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        bl[j] = tr_read(Bs + b_off[j], ks * 16, ROWB_B);
-        bh[j] = tr_read(Bs + b_off[j], ks * 16 + 4, ROWB_B);
-      }
-      static_assert((KI == 4 || KI == 2) && NJ == 2, "wait operand lists below");
-      if constexpr (KI == 4) {
-        MNR_GPU_ONLY(asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]),
-                                   "+v"(ah[3]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
-                                 :
-                                 : "memory"));
-      } else {
-        MNR_GPU_ONLY(asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
-                                 :
-                                 : "memory"));
-      }
-      bf16x8 fa[KI], fb[NJ];
-#pragma unroll
-      for (int i = 0; i < KI; ++i)
-        fa[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        fb[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-      for (int i = 0; i < KI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      if (do_bias) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fb[j], accb[j], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
-
-  if (tl && tid == 0) {
-    tl[16 * (int64_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
-    tl[16 * (int64_t)blockIdx.x + 7] = ((unsigned long long)(s_end - s_begin) << 32) | (unsigned)(k0 == 0 && p.bias_out != nullptr);
-  }
-  if (do_bias && lane < 32) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + wn * 32 * NJ + j * 32 + lane;     // row 0 of the result: reg 0 of lanes 0..31
-      if (n < p.bias_n_valid) unsafeAtomicAdd(p.bias_out + n, accb[j][0]);
-    }
-  }
-
-  // acc[i][j][r]: k = k0 + wk*32*KI + i*32 + (r&3) + 8*(r>>2) + 4*khalf; n = n0 + wn*32*NJ + j*32 + (lane&31).
-#pragma unroll
-  for (int i = 0; i < KI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + wn * 32 * NJ + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = k0 + wk * 32 * KI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (k < p.k_valid && n < p.n_valid) unsafeAtomicAdd(p.C + (int64_t)k * p.ldc + n, acc[i][j][r]);
-      }
-    }
-  if (tl && tid == 0) {
-    tl[16 * (int64_t)blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
-    tl[16 * (int64_t)blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
-  }
+// The split-path configuration keeps v240-v255 out of the register allocator's hands (see gemm_tn_body.inc).
+template <class CFG>
+__global__ __launch_bounds__(CFG::THREADS) MNR_GPU_ONLY(__attribute__((amdgpu_num_vgpr(240))))
+void gemm_tn_kernel_r240(mnr_gemm_tn_args p, int splits, int steps_per_split) {
+#include "gemm_tn_body.inc"
 }
 
 template <class CFG>
@@ -652,18 +489,28 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   while (splits > 8 && (total_steps + splits - 1) / splits < 4) splits -= 8;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   const int64_t grid = (int64_t)splits * tiles;
+  void (*kern)(mnr_gemm_tn_args, int, int);
+  if constexpr (CFG::SPLIT) kern = gemm_tn_kernel_r240<CFG>;
+  else kern = gemm_tn_kernel<CFG>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_tn_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
                      *a, splits, steps_per_split);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
 
 static int g_tn_big_min_tiles = 1;
+static int g_tn_split = 0;
+
+// Probe hook: 1 = the 256x256-tile launches use the split-path kernel (TnBigSplit).
+extern "C" int mnr_gemm_tn_set_split(int on) {
+  g_tn_split = on ? 1 : 0;
+  return MNR_OK;
+}
 
 extern "C" int mnr_gemm_tn_set_config(int big_min_tiles) {
   g_tn_big_min_tiles = big_min_tiles;
@@ -688,6 +535,7 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
     // 512 -> 256 workgroups = 398k -> 407k rays/s end to end, 1024: 390k.
     tn_target = e ? atoi(e) : 256;
   }
+  if (big && g_tn_split) return tn_launch<TnBigSplit>(a, tn_target, stream);
   if (big) return tn_launch<TnBig>(a, tn_target, stream);
   static int tn_small_target = -1;
   if (tn_small_target < 0) {

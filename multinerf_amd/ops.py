@@ -52,6 +52,8 @@ def lib():
     if c:
       big, small = (int(x) for x in c.split(','))
       L.check(L.load().mnr_gemm_nt_set_config(big, small))
+    if os.environ.get('MNR_TN_SPLIT') == '1':   # tuning hook: split-path weight-gradient kernel (csrc/gemm.hip TnBigSplit)
+      L.check(L.load().mnr_gemm_tn_set_split(1))
   return L.load()
 
 

@@ -142,6 +142,29 @@ def test_tn_weight_gradient(sim, shape, mode):
   np.testing.assert_allclose(db.numpy(), B.float().sum(0).numpy(), atol=1e-3, rtol=1e-5)
 
 
+@pytest.mark.parametrize('shape', [(512, 256, 256), (1024, 256, 512), (64, 256, 256), (320, 512, 256)])
+def test_tn_split_path_equals_the_default_kernel(sim, shape):
+  """TnBigSplit (dY tile global -> registers -> ds_write, activations by LDS-DMA): the same LDS image, so the same bits."""
+  M, K, N = shape
+  g = torch.Generator().manual_seed(K)
+  A = torch.randn((M, K), generator=g).bfloat16()
+  B = torch.randn((M, N), generator=g).bfloat16()
+  sim.hipsim_reset(0, 0)
+  sim.mnr_gemm_tn_set_split(0)
+  want, wb = torch.zeros((K, N)), torch.zeros(N)
+  S.sim_gemm_tn(sim, A, B, want, bias_out=wb)
+  np.testing.assert_allclose(want.numpy(), (A.float().T @ B.float()).numpy(), atol=1e-3, rtol=1e-5)
+  try:
+    for mode in MODES:
+      sim.hipsim_reset(*mode)
+      sim.mnr_gemm_tn_set_split(1)
+      got, gb = torch.zeros((K, N)), torch.zeros(N)
+      S.sim_gemm_tn(sim, A, B, got, bias_out=gb)
+      assert torch.equal(got, want) and torch.equal(gb, wb), mode
+  finally:
+    sim.mnr_gemm_tn_set_split(0)
+
+
 def test_small_head_bwd_and_colsum(sim):
   """The non-MFMA kernels of gemm.hip: rgb-head VJP (dX with bit masks, dW / db through workgroup partials), colsum."""
   g = torch.Generator().manual_seed(8)

@@ -63,7 +63,7 @@ def _setup(name, extra, B, seed=3):
 
 # (NT configuration for the 256x256-tiled GEMMs, LDS-DMA landing late, fiber order): the default as shipped, and the
 # configurations prepared for the next round (direct-weights loop, two workgroups per CU) under the adversarial modes
-VARIANTS = [(2, 0, 0), (37, 1, 5), (36, 1, -1), (38, 1, 3), (40, 1, 9)]
+VARIANTS = [(2, 0, 0), (37, 1, 5), (36, 1, -1), (38, 1, 3), (40, 1, 9), (-40, 1, 2)]      # -40: NtC40 + the split-path TN kernel
 
 
 @pytest.mark.parametrize('name,extra,B', CASES)
@@ -79,7 +79,8 @@ def test_360_step_with_the_prepared_gemm_configurations(variant):
 def _run(name, extra, B, variant):
   nt_cfg, dma_late, order = variant
   with S.simulated_device() as sim:
-    assert sim.lib.mnr_gemm_nt_set_config(nt_cfg, 0) == 0
+    assert sim.lib.mnr_gemm_nt_set_config(abs(nt_cfg), 0) == 0
+    assert sim.lib.mnr_gemm_tn_set_split(1 if nt_cfg < 0 else 0) == 0
     sim.lib.hipsim_reset(dma_late, order)
     cfg, model, (om, on, op), params, flat, batch = _setup(name, extra, B)
     noise = helpers.make_noise(model, B)

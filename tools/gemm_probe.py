@@ -191,6 +191,17 @@ def main():
     Cw = torch.zeros((K, N), device=dev)
     bb = torch.zeros(N, device=dev)
     time_it(f'tn  dW   M={M} K={K} N={N}', lambda: ops.gemm_tn(A, Bm, Cw, M=M, K=K, N=N, bias_out=bb, bias_n_valid=N), 2.0 * M * N * K)
+    # split operand paths (TnBigSplit): dY through registers + ds_write, activations by LDS-DMA; screened against the default
+    Cs = torch.zeros((K, N), device=dev)
+    Cd = torch.zeros((K, N), device=dev)
+    ops.gemm_tn(A, Bm, Cd, M=M, K=K, N=N)
+    ops.L.check(ops.lib().mnr_gemm_tn_set_split(1))
+    ops.gemm_tn(A, Bm, Cs, M=M, K=K, N=N)
+    torch.cuda.synchronize()
+    rel = ((Cs - Cd).norm() / Cd.norm()).item()          # fp32 atomics: the order differs from run to run, not the terms
+    print(f'tn split vs default: relative difference {rel:.2e} ' + ('(ok)' if rel < 1e-5 else '(MISMATCH)'), flush=True)
+    time_it(f'tn  dW   M={M} K={K} N={N} split', lambda: ops.gemm_tn(A, Bm, Cw, M=M, K=K, N=N, bias_out=bb, bias_n_valid=N), 2.0 * M * N * K)
+    ops.L.check(ops.lib().mnr_gemm_tn_set_split(0))
   if 'prop' in which:
     M2, K2 = 2 * M, 256
     A2 = rnd(M2, K2)
