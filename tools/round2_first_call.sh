@@ -1,6 +1,6 @@
 #!/bin/bash
 # First GPU call of the next round (everything here was prepared without a GPU):
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/round2_first_call.sh'
+#   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/round2_first_call.sh'
 # 1. operand-ingest probe: which path / pattern bounds the 64 KiB-per-step operand stream of the GEMM loops
 # 2. direct-weights NT loop (NtC36 / NtC37): bitwise screen against NtC2, then timing next to NtC2 / NtC35
 # 3. the same A/B end to end (MNR_NT_CFG selects the 256x256 configuration for the whole step)
