@@ -3,8 +3,8 @@
 tests/conftest.py then keeps 'cuda' tensors on the host and hands the package the simulator build of the C ABI, so the
 parity tests written for the MI355X (every kernel against the oracle, bit-exact sample indices, Ref-NeRF heads, camera
 rays against the reference goldens, composed model cases) execute unchanged against the kernel SOURCE.  The default CPU
-run takes the kernel-level files and the quick composed cases; everything, including all of tests/test_gpu_model.py
-(26 cases, ~12 min), runs with
+run takes the kernel-level files (the composed path is tests/test_sim_model.py's); everything, including all of
+tests/test_gpu_model.py (26 cases, ~12 min), runs with
 
     MNR_TESTS_ON_SIMULATOR=1 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_refnerf.py tests/test_gpu_camera.py tests/test_gpu_model.py -m gpu
 
@@ -37,9 +37,3 @@ def _child(args, timeout):
 def test_kernel_level_gpu_tests_pass_on_the_simulator():
   tail = _child(['tests/test_gpu_kernels.py', 'tests/test_gpu_refnerf.py', 'tests/test_gpu_camera.py'], 1500)
   assert ' passed' in tail and 'failed' not in tail and 'skipped' not in tail, tail
-
-
-def test_quick_composed_gpu_tests_pass_on_the_simulator():
-  sel = 'test_tiny_and_ragged_batches or test_leading_dims or test_unsupported or (test_forward_parity and blender_256 and extra1)'
-  tail = _child(['tests/test_gpu_model.py', '-k', sel], 1500)
-  assert ' passed' in tail and 'failed' not in tail, tail
