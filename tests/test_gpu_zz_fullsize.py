@@ -1,0 +1,146 @@
+"""BASELINE.json's full size (configs/360.gin as is, 16384 rays per step) on the GPU.  -m gpu.  (Named to run last.)
+
+The oracle cannot run 16384 rays of the 9 M-parameter model in test time, so the full-size run is tied to it through
+properties that do not depend on the size:
+  * rays are independent: the full batch's outputs for its first rays ARE the outputs of a small batch of those rays
+    (bit for bit: same per-row arithmetic in every kernel), and that small batch is compared with the oracle at the FULL
+    model width;
+  * the domain's invariants on every ray of the full batch: sorted sample distances inside [0, 1], non-negative weights
+    that sum to the accumulated opacity (1 behind an opaque background), ordered distance percentiles, colours in range,
+    nothing non-finite; deterministic rendering is reproducible bit for bit;
+  * every loss term is a mean over rays, so the gradient of the full batch is the mean of the gradients of its quarters
+    (a checksum of checksums over 9 M parameters), and one Adam step moves every parameter by at most the learning rate.
+MNR_FULLSIZE_RAYS / MNR_FULLSIZE_BINDINGS shrink the batch and the model so that this file's logic can be screened on the
+kernel-source simulator (it passes there with 48 rays and a 256 / 128-wide model):
+  MNR_FULLSIZE_RAYS=48 MNR_FULLSIZE_BINDINGS="NerfMLP.net_width = 256;PropMLP.net_width = 128;Model.num_prop_samples = 32;Model.num_nerf_samples = 32" \
+    MNR_TESTS_ON_SIMULATOR=1 python -m pytest tests/test_gpu_zz_fullsize.py -m gpu
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multinerf_amd import configs, models, train_utils
+from oracle import models as omodels
+from tests import helpers
+
+B_FULL = int(os.environ.get('MNR_FULLSIZE_RAYS', '16384'))
+EXTRA = [b for b in os.environ.get('MNR_FULLSIZE_BINDINGS', '').split(';') if b]
+N_ORACLE = 16
+
+
+@pytest.fixture(scope='module')
+def setup():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  cfg = configs.load_preset('360', EXTRA)
+  model = models.Model(config=cfg)
+  model.build('cuda')
+  om, on, op = helpers.oracle_hparams(model)
+  params = omodels.init_params(om, on, op, seed=11)
+  g = torch.Generator().manual_seed(12)
+  for mname, mod in params.items():
+    for d in mod.values():
+      if isinstance(d, dict) and 'bias' in d:
+        d['bias'] = 0.05 * torch.randn(d['bias'].shape, generator=g)
+  flat = model.flat_from_tree(params)
+  batch = helpers.synthetic_rays(B_FULL, near=cfg.near, far=cfg.far)
+  return cfg, model, (om, on, op), params, flat, batch
+
+
+def _dev(batch_or_rays):
+  return batch_or_rays.map(lambda t: t.cuda())
+
+
+def test_full_batch_rows_are_the_small_batch_and_the_small_batch_is_the_oracle(setup):
+  cfg, model, (om, on, op), params, flat, batch = setup
+  rays = _dev(batch.rays)
+  rend, hist = model.apply({'flat': flat}, None, rays, 0.5, True)
+  rend2, hist2 = model.apply({'flat': flat}, None, rays, 0.5, True)
+  torch.cuda.synchronize()
+  for lv in range(model.num_levels):                      # deterministic rendering is reproducible bit for bit
+    assert torch.equal(hist[lv]['sdist'], hist2[lv]['sdist']) and torch.equal(hist[lv]['weights'], hist2[lv]['weights'])
+  assert torch.equal(rend[-1]['rgb'], rend2[-1]['rgb'])
+  n = N_ORACLE
+  small_rays = batch.rays.map(lambda t: t[:n])
+  rs, hs = model.apply({'flat': flat}, None, _dev(small_rays), 0.5, True)
+  torch.cuda.synchronize()
+  for lv in range(model.num_levels):
+    assert torch.equal(hist[lv]['sdist'][:n], hs[lv]['sdist']), lv
+    assert torch.equal(hist[lv]['weights'][:n], hs[lv]['weights']), lv
+  for k in ('rgb', 'acc', 'distance_mean', 'distance_median'):
+    assert torch.equal(rend[-1][k][:n], rs[-1][k]), k
+  # ... and the small batch against the oracle at the full width (tolerance model of tests/test_gpu_model.py)
+  r_bf, h_bf = omodels.model_apply(om, on, op, params, small_rays, 0.5, True, dense_dtype=torch.bfloat16)
+  r_32, h_32 = omodels.model_apply(om, on, op, params, small_rays, 0.5, True)
+  for lv in range(model.num_levels):
+    cost = (h_bf[lv]['weights'] - h_32[lv]['weights']).abs().max().item()
+    err = (hs[lv]['weights'].cpu() - h_bf[lv]['weights']).abs().max().item()
+    print(f'level {lv}: |weights - oracle_bf16| = {err:.2e} (bf16 cost {cost:.2e})')
+    assert err <= max(5e-3, 3 * cost), lv
+  cost = (r_bf[-1]['rgb'] - r_32[-1]['rgb']).abs().max().item()
+  err = (rs[-1]['rgb'].cpu() - r_bf[-1]['rgb']).abs().max().item()
+  print(f'rgb: |kernel - oracle_bf16| = {err:.2e} (bf16 cost {cost:.2e})')
+  assert err <= max(5e-3, 3 * cost)
+
+
+def test_invariants_hold_on_every_ray_of_the_full_batch(setup):
+  cfg, model, _, params, flat, batch = setup
+  noise = helpers.make_noise(model, B_FULL)
+  rend, hist = model.apply({'flat': flat}, None, _dev(batch.rays), 0.3, True, noise={k: {lv: t.cuda() for lv, t in d.items()} for k, d in noise.items()})
+  torch.cuda.synchronize()
+  for lv in range(model.num_levels):
+    s, w = hist[lv]['sdist'], hist[lv]['weights']
+    n = model.num_prop_samples if lv < model.num_levels - 1 else model.num_nerf_samples
+    assert s.shape == (B_FULL, n + 1) and w.shape == (B_FULL, n)
+    assert torch.isfinite(s).all() and torch.isfinite(w).all()
+    assert (s[:, 1:] >= s[:, :-1]).all() and (s >= 0).all() and (s <= 1).all()
+    assert (w >= 0).all()
+    acc = rend[lv]['acc']
+    np.testing.assert_allclose(w.sum(-1).cpu().numpy(), acc.cpu().numpy(), atol=2e-5)
+    if model.opaque_background:                            # the last interval is opaque: all of the ray is accounted for
+      np.testing.assert_allclose(acc.cpu().numpy(), 1.0, atol=2e-5)
+    rgb = rend[lv]['rgb']
+    pad = model.nerf_hp.rgb_padding
+    assert torch.isfinite(rgb).all() and (rgb >= -pad - 1e-6).all() and (rgb <= 1 + pad + 1e-6).all()
+  last = rend[-1]
+  assert (last['distance_percentile_5'] <= last['distance_median'] + 1e-6).all()
+  assert (last['distance_median'] <= last['distance_percentile_95'] + 1e-6).all()
+  assert torch.isfinite(last['distance_mean']).all() and (last['distance_mean'] >= cfg.near - 1e-6).all()
+
+
+def test_full_batch_gradient_is_the_mean_of_its_quarters(setup):
+  cfg, model, _, params, flat, batch = setup
+  assert B_FULL % 4 == 0
+  noise = helpers.make_noise(model, B_FULL)
+  step = train_utils.create_train_step(model, cfg)
+
+  def grads_of(lo, hi):
+    sub = batch.map(lambda t: t[lo:hi])
+    nz = {k: {lv: t[lo:hi] for lv, t in d.items()} for k, d in noise.items()}
+    state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})
+    state2, stats, _ = step(0, state, _dev(sub), None, 0.4, 0.0, noise={k: {lv: t.cuda() for lv, t in d.items()} for k, d in nz.items()},
+                            return_grads=True)
+    torch.cuda.synchronize()
+    return stats['_grads'].double().cpu(), stats.materialize(), state2
+
+  g_full, s_full, state2 = grads_of(0, B_FULL)
+  q = B_FULL // 4
+  parts = [grads_of(i * q, (i + 1) * q) for i in range(4)]
+  g_mean = sum(p[0] for p in parts) / 4
+  assert np.isfinite(s_full['loss'])
+  np.testing.assert_allclose(s_full['loss'], np.mean([p[1]['loss'] for p in parts]), rtol=1e-4)
+  for name, b, e in model.modules:
+    a, r = g_full[b:e], g_mean[b:e]
+    rel = ((a - r).norm() / (r.norm() + 1e-30)).item()
+    print(f'{name}: |g(full) - mean g(quarters)| / |g| = {rel:.2e}  (|g| = {r.norm().item():.3e})')
+    assert rel < 1e-3, (name, rel)
+  # one Adam step from zero moments: |update| <= lr / (1 - eps-ish), nothing non-finite
+  new = state2.params['flat'].double().cpu()
+  lr = train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})[1](0)
+  assert torch.isfinite(new).all()
+  assert (new - flat.double()).abs().max().item() <= 1.001 * lr
