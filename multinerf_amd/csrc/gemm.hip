@@ -267,26 +267,41 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   const int64_t groups = (mt + 7) / 8;
   const int64_t grid = groups * 8 * nt;
   MNR_CHECK_ARG(grid < (1ll << 31), "mnr_gemm_nt_bf16: grid too large");
-  void (*k_plain)(mnr_gemm_nt_args, int);
-  void (*k_bits)(mnr_gemm_nt_args, int);
-  if constexpr (CFG::BDIRECT == 1) {
-    k_plain = gemm_nt_kernel_r224<CFG, false>;
-    k_bits = gemm_nt_kernel_r224<CFG, true>;
-  } else if constexpr (CFG::BDIRECT == 2) {
-    k_plain = gemm_nt_kernel_r240<CFG, false>;
-    k_bits = gemm_nt_kernel_r240<CFG, true>;
+  if constexpr (CFG::BDIRECT == 0) {
+    // (the shipped path: direct launches of the named kernels, as validated on the GPU)
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+      attr_set = true;
+    }
+    if (a->mask_bits_in) {
+      hipLaunchKernelGGL((gemm_nt_kernel<CFG, true>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
+                         (hipStream_t)stream, *a, fast_epi);
+    } else {
+      hipLaunchKernelGGL((gemm_nt_kernel<CFG, false>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
+                         (hipStream_t)stream, *a, fast_epi);
+    }
   } else {
-    k_plain = gemm_nt_kernel<CFG, false>;
-    k_bits = gemm_nt_kernel<CFG, true>;
+    // reserved-register variants of the kernel (see gemm_nt_kernel_r224 / _r240)
+    void (*k_plain)(mnr_gemm_nt_args, int);
+    void (*k_bits)(mnr_gemm_nt_args, int);
+    if constexpr (CFG::BDIRECT == 1) {
+      k_plain = gemm_nt_kernel_r224<CFG, false>;
+      k_bits = gemm_nt_kernel_r224<CFG, true>;
+    } else {
+      k_plain = gemm_nt_kernel_r240<CFG, false>;
+      k_bits = gemm_nt_kernel_r240<CFG, true>;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)k_plain, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)k_bits, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(a->mask_bits_in ? k_bits : k_plain, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
+                       (hipStream_t)stream, *a, fast_epi);
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_plain, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)k_bits, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(a->mask_bits_in ? k_bits : k_plain, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
-                     (hipStream_t)stream, *a, fast_epi);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
@@ -489,16 +504,24 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   while (splits > 8 && (total_steps + splits - 1) / splits < 4) splits -= 8;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   const int64_t grid = (int64_t)splits * tiles;
-  void (*kern)(mnr_gemm_tn_args, int, int);
-  if constexpr (CFG::SPLIT) kern = gemm_tn_kernel_r240<CFG>;
-  else kern = gemm_tn_kernel<CFG>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-    attr_set = true;
+  if constexpr (!CFG::SPLIT) {
+    // (the shipped path: a direct launch of the named kernel, as validated on the GPU)
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
+                       *a, splits, steps_per_split);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_tn_kernel_r240<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel_r240<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
+                       *a, splits, steps_per_split);
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
-                     *a, splits, steps_per_split);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
