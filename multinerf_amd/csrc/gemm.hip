@@ -50,8 +50,14 @@
 
 #define NT_CPAD 16                                   // epilogue staging: 16 B pad per row
 
-template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_, int MINW_ = 1, int FRAGPIPE_ = 0, int ABLATE_ = 0, int BDIRECT_ = 0>
+template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_, int MINW_ = 1, int FRAGPIPE_ = 0, int ABLATE_ = 0, int BDIRECT_ = 0,
+          int EPI_BATCH_ = 0>
 struct NtCfg {
+  // n > 0: the epilogue's store loop reads its staged chunks from LDS n at a time (n ds_read_b128 in flight per thread)
+  // instead of one read per iteration waited for on the spot, and the fp32 side outputs (which read the accumulators)
+  // are written before the store loop instead of after it, so that the accumulators' 128 registers are free for the
+  // batch (with them alive, 16 reads at once spilled 85 registers).
+  static constexpr int EPI_BATCH = EPI_BATCH_;
   static constexpr int ABLATE = ABLATE_;              // probe only: 1 no MFMA, 2 no in-loop DMA, 4 no ds_reads
   // 1: the weights never touch LDS.  With one wave per 32 output columns (WM = 1) a wave's weight fragments are
   // private to it, so it loads them global -> registers itself (double-buffered, one K tile ahead) and only the
@@ -329,6 +335,8 @@ typedef NtCfg<8, 1, 1, 8, 64, 2> NtC35;            // 256x256, 8 waves each 256 
 typedef NtCfg<8, 1, 1, 8, 64, 3, 1, 0, 0, 1> NtC36; // 1x8 waves, weights global -> registers (never in LDS), 3 activation stages of 32 KiB
 typedef NtCfg<8, 1, 1, 8, 64, 4, 1, 0, 0, 1> NtC37; //   same, 4 stages
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 2> NtC40; // = NtC2 with split operand paths: activations by LDS-DMA, weights global -> registers -> ds_write
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 0, 16> NtC41; // = NtC2 with the epilogue's 16 LDS reads per thread issued together
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 2, 16> NtC42; // = NtC40 (split operand paths) with the same
 typedef NtCfg<4, 2, 2, 2, 32, 2, 2> NtC38;           // 256x128, 4 waves of 128x64, 48 KiB: TWO workgroups per CU (one's epilogue under the other's K loop)
 typedef NtCfg<4, 2, 2, 2, 32, 3, 2> NtC39;           //   same, 3 stages (72 KiB)
 typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
@@ -337,7 +345,7 @@ typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register doubl
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 40 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 42 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -369,6 +377,8 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 36: return nt_launch<NtC36>(a, fast_epi, stream);
     case 38: return nt_launch<NtC38>(a, fast_epi, stream);
     case 40: return nt_launch<NtC40>(a, fast_epi, stream);
+    case 41: return nt_launch<NtC41>(a, fast_epi, stream);
+    case 42: return nt_launch<NtC42>(a, fast_epi, stream);
     case 39: return nt_launch<NtC39>(a, fast_epi, stream);
     case 37: return nt_launch<NtC37>(a, fast_epi, stream);
     default:

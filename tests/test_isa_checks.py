@@ -95,11 +95,11 @@ def test_default_gemm_kernels_are_the_ones_validated_on_the_gpu(report):
   want = json.load(open(os.path.join(ROOT, 'profiles', 'r1_validated_isa.json')))['kernels']
   asm, tmp = mod.compile_selected([0, 2])
   try:
-    got = {n: mod.normalized_digest(b) for n, b in mod.all_kernel_bodies(asm).items()}
+    got = {mod.canonical_kernel_name(n): mod.normalized_digest(b) for n, b in mod.all_kernel_bodies(asm).items()}
   finally:
     shutil.rmtree(tmp, ignore_errors=True)
   for f in ('resample.hip', 'features.hip', 'render.hip', 'losses.hip', 'optim.hip', 'refnerf.hip', 'camera.hip'):
-    got.update({n: mod.normalized_digest(b) for n, b in mod.all_kernel_bodies(mod.compile_file(f)).items()})
+    got.update({mod.canonical_kernel_name(n): mod.normalized_digest(b) for n, b in mod.all_kernel_bodies(mod.compile_file(f)).items()})
   assert set(want) <= set(got), sorted(set(want) - set(got))
   changed = [n for n in want if got[n] != want[n]]
   assert not changed, changed

@@ -191,6 +191,14 @@ def normalized_digest(body):
   return h.hexdigest()
 
 
+def canonical_kernel_name(name):
+  """Kernel name without trailing zero-valued template parameters of NtCfg / TnCfg (parameters added with a default of 0
+  do not rename the configurations that do not use them)."""
+  name = re.sub(r'(NtCfgI(?:Li\d+E)+?)(?:Li0E)*(ELb[01]E)', r'\1\2', name)
+  name = re.sub(r'(TnCfgI(?:Li\d+E)+?)(?:Li0E)*(EEv16mnr_gemm_tn)', r'\1\2', name)
+  return name
+
+
 def all_kernel_bodies(asm_text):
   """{kernel name: lines} for EVERY kernel of a device assembly listing."""
   out = {}
