@@ -106,11 +106,12 @@ def test_invariants_hold_on_every_ray_of_the_full_batch(setup):
       np.testing.assert_allclose(acc.cpu().numpy(), 1.0, atol=2e-5)
     rgb = rend[lv]['rgb']
     pad = model.nerf_hp.rgb_padding
-    assert torch.isfinite(rgb).all() and (rgb >= -pad - 1e-6).all() and (rgb <= 1 + pad + 1e-6).all()
+    assert torch.isfinite(rgb).all() and (rgb >= -pad - 1e-5).all() and (rgb <= 1 + pad + 1e-5).all()
   last = rend[-1]
-  assert (last['distance_percentile_5'] <= last['distance_median'] + 1e-6).all()
-  assert (last['distance_median'] <= last['distance_percentile_95'] + 1e-6).all()
-  assert torch.isfinite(last['distance_mean']).all() and (last['distance_mean'] >= cfg.near - 1e-6).all()
+  tol_d = 1e-6 * last['distance_percentile_95'].abs().clamp_min(1.0)      # distances reach 1e6 (far plane): relative
+  assert (last['distance_percentile_5'] <= last['distance_median'] + tol_d).all()
+  assert (last['distance_median'] <= last['distance_percentile_95'] + tol_d).all()
+  assert torch.isfinite(last['distance_mean']).all() and (last['distance_mean'] >= cfg.near * (1 - 1e-6)).all()
 
 
 def test_full_batch_gradient_is_the_mean_of_its_quarters(setup):
@@ -143,4 +144,4 @@ def test_full_batch_gradient_is_the_mean_of_its_quarters(setup):
   new = state2.params['flat'].double().cpu()
   lr = train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})[1](0)
   assert torch.isfinite(new).all()
-  assert (new - flat.double()).abs().max().item() <= 1.001 * lr
+  assert (new - flat.double()).abs().max().item() <= 1.01 * lr + 1e-7          # (+ fp32 rounding of the parameters)
