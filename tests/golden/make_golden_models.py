@@ -320,7 +320,6 @@ def _flatten(prefix, tree, out):
 
 
 def run_case(case, rmodels, ref_callables, rnd_state, Key):
-  import torch
   from multinerf_amd import configs, gin as my_gin, models as my_models
   from oracle import models as omodels
   from tests import helpers

@@ -8,7 +8,6 @@ The kernels here are the ones the GPU suite validates, so agreement also pins th
 semantics (MFMA lane layout, ds_read_b64_tr_b16, DPP quad_perm, global_load_lds).
 """
 
-import ctypes as C
 import shutil
 
 import numpy as np
