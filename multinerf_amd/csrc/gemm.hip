@@ -51,7 +51,7 @@
 #define NT_CPAD 16                                   // epilogue staging: 16 B pad per row
 
 template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_, int MINW_ = 1, int FRAGPIPE_ = 0, int ABLATE_ = 0, int BDIRECT_ = 0,
-          int EPI_BATCH_ = 0>
+          int EPI_BATCH_ = 0, int BIAS_LDS_ = 0>
 struct NtCfg {
   // n > 0: the epilogue's store loop reads its staged chunks from LDS n at a time (n ds_read_b128 in flight per thread)
   // instead of one read per iteration waited for on the spot, and the fp32 side outputs (which read the accumulators)
@@ -86,7 +86,9 @@ struct NtCfg {
   static constexpr int EPI_ROWS = (BM * CPITCH <= 160 * 1024) ? BM : (128 * CPITCH <= LDS_OPERANDS) ? 128 : 64;
   // The split-path loop gives 16 registers to its in-flight weight chunks and cannot also hold the bias of the
   // lane's columns (NJ x 16 registers) across the K loop: there the tile's bias row waits in LDS, behind everything else.
-  static constexpr bool BIAS_LDS = BDIRECT_ == 2;
+  // (BIAS_LDS_ = 1 asks for the same on any loop: one coalesced load per thread in the prologue instead of NJ x 16
+  // scalar loads per lane, and NJ x 16 fewer registers alive across the K loop.)
+  static constexpr bool BIAS_LDS = BDIRECT_ == 2 || BIAS_LDS_ != 0;
   static constexpr int LDS_MAIN = LDS_OPERANDS > EPI_ROWS * CPITCH ? LDS_OPERANDS : EPI_ROWS * CPITCH;
   static constexpr int BIAS_OFF = (LDS_MAIN + 15) / 16 * 16;
   static constexpr int LDS_BYTES = BIAS_LDS ? BIAS_OFF + BN * 4 : LDS_MAIN;
@@ -337,6 +339,7 @@ typedef NtCfg<8, 1, 1, 8, 64, 4, 1, 0, 0, 1> NtC37; //   same, 4 stages
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 2> NtC40; // = NtC2 with split operand paths: activations by LDS-DMA, weights global -> registers -> ds_write
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 0, 16> NtC41; // = NtC2 with the epilogue's 16 LDS reads per thread issued together
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 2, 16> NtC42; // = NtC40 (split operand paths) with the same
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 0, 16, 1> NtC43; // = NtC41 with the bias row parked in LDS (cheaper prologue, 32 registers fewer in the loop)
 typedef NtCfg<4, 2, 2, 2, 32, 2, 2> NtC38;           // 256x128, 4 waves of 128x64, 48 KiB: TWO workgroups per CU (one's epilogue under the other's K loop)
 typedef NtCfg<4, 2, 2, 2, 32, 3, 2> NtC39;           //   same, 3 stages (72 KiB)
 typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
@@ -345,7 +348,7 @@ typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register doubl
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 42 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 43 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -379,6 +382,7 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 40: return nt_launch<NtC40>(a, fast_epi, stream);
     case 41: return nt_launch<NtC41>(a, fast_epi, stream);
     case 42: return nt_launch<NtC42>(a, fast_epi, stream);
+    case 43: return nt_launch<NtC43>(a, fast_epi, stream);
     case 39: return nt_launch<NtC39>(a, fast_epi, stream);
     case 37: return nt_launch<NtC37>(a, fast_epi, stream);
     default:

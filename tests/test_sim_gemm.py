@@ -34,7 +34,7 @@ def _packbits(x):
   return torch.from_numpy(np.packbits((x > 0).numpy(), axis=1, bitorder='little'))
 
 
-@pytest.mark.parametrize('cfg', [2, 12, 4, 7, 18, 19, 33, 35, 36, 37, 38, 39, 40, 41, 42])
+@pytest.mark.parametrize('cfg', [2, 12, 4, 7, 18, 19, 33, 35, 36, 37, 38, 39, 40, 41, 42, 43])
 @pytest.mark.parametrize('mode', MODES)
 def test_nt_forward_layer(sim, cfg, mode):
   """Forward layer: [A1|A2] W^T + b, ReLU, bf16 output + 1-bit ReLU masks; every compiled 256x256 configuration."""
@@ -52,7 +52,7 @@ def test_nt_forward_layer(sim, cfg, mode):
   assert torch.equal(bits, _packbits(Cb.float()))
 
 
-@pytest.mark.parametrize('cfg', [2, 36, 37, 40, 41, 42])
+@pytest.mark.parametrize('cfg', [2, 36, 37, 40, 41, 42, 43])
 @pytest.mark.parametrize('mode', MODES)
 def test_nt_dx_layer_with_bit_masks(sim, cfg, mode):
   """dX layer: (dY W) masked by the forward layer's bits (with the tangent rows' modulo), fp32 side output."""
