@@ -34,8 +34,12 @@ def _packbits(x):
   return torch.from_numpy(np.packbits((x > 0).numpy(), axis=1, bitorder='little'))
 
 
-@pytest.mark.parametrize('cfg', [2, 12, 4, 7, 18, 19, 33, 35, 36, 37, 38, 39, 40, 41, 42, 43])
-@pytest.mark.parametrize('mode', MODES)
+# every compiled 256-row configuration; the default in all four modes, the others eager/reverse and late/shuffled
+_FWD_CASES = [(2, m) for m in MODES] + [(c, m) for c in (12, 4, 7, 18, 19, 33, 35, 36, 37, 38, 39, 40, 41, 42, 43)
+                                        for m in (MODES[2], MODES[3])]
+
+
+@pytest.mark.parametrize('cfg,mode', _FWD_CASES)
 def test_nt_forward_layer(sim, cfg, mode):
   """Forward layer: [A1|A2] W^T + b, ReLU, bf16 output + 1-bit ReLU masks; every compiled 256x256 configuration."""
   g = torch.Generator().manual_seed(cfg)
@@ -52,8 +56,7 @@ def test_nt_forward_layer(sim, cfg, mode):
   assert torch.equal(bits, _packbits(Cb.float()))
 
 
-@pytest.mark.parametrize('cfg', [2, 36, 37, 40, 41, 42, 43])
-@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('cfg,mode', [(2, m) for m in MODES] + [(c, m) for c in (36, 37, 40, 41, 42, 43) for m in (MODES[2], MODES[3])])
 def test_nt_dx_layer_with_bit_masks(sim, cfg, mode):
   """dX layer: (dY W) masked by the forward layer's bits (with the tangent rows' modulo), fp32 side output."""
   g = torch.Generator().manual_seed(5)
