@@ -26,4 +26,5 @@ MNR_NT_CFG=42,0 MNR_TN_SPLIT=1 timeout 300 python bench.py --steps 10 --warmup 3
 for sk in 38,512 39,512 38,256; do
   MNR_NT_SHORTK_CFG=$sk timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_shortk_${sk/,/_}.json 2> gpurun_out/r2_bench_shortk_${sk/,/_}.err
 done
-tail -n 5 gpurun_out/r2_ingest_probe.txt gpurun_out/r2_gemm_probe_direct.txt gpurun_out/r2_bench_cfg*.json
+
+python tools/round2_summary.py gpurun_out > gpurun_out/r2_summary.txt 2>&1; cat gpurun_out/r2_summary.txt
