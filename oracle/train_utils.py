@@ -3,7 +3,8 @@
 The loss terms (compute_data_loss, interlevel / distortion / orientation /
 predicted-normal losses) and clip_gradients are pinned against the reference's own
 internal/train_utils.py executed on stand-ins (tests/golden/make_golden_models.py,
-tests/test_oracle_models_golden.py, rtol 1e-9 in float64).
+tests/test_oracle_models_golden.py, rtol 1e-9 in float64); so is the gradient of loss_fn, against the
+reference's forward + losses differentiated by complex step along seeded directions.
 PARITY UNPINNED: optax.adam (train_utils.py:372) is restated from its published algorithm
 (scale_by_adam with eps outside the sqrt, eps_root=0, bias correction by
 1-b^t with t = count+1; scale_by_schedule evaluates lr at the PRE-increment

@@ -187,6 +187,38 @@ class Embed(Module):
     return table[idx]
 
 
+def _softplus(x):
+  if np.iscomplexobj(x):                          # np.logaddexp has no complex loop
+    big = np.asarray(x).real > 30
+    return np.where(big, x, np.log1p(np.exp(np.where(big, 0, x))))
+  return np.logaddexp(x, 0)
+
+
+class _StopGradient:
+  """jax.lax.stop_gradient for the derivative goldens.  'real': the value without its complex-step perturbation (what
+  autodiff's zero tangent is); 'record' / 'replay': the base run's values handed back in call order during the finite-
+  difference runs, so that what the reference holds constant stays constant there too."""
+  mode = 'real'
+  tape = []
+  pos = 0
+
+  @classmethod
+  def __call__(cls, x):
+    return cls.apply(x)
+
+  @classmethod
+  def apply(cls, x):
+    if cls.mode == 'record':
+      cls.tape.append(np.array(x, copy=True))
+      return x
+    if cls.mode == 'replay':
+      v = cls.tape[cls.pos]
+      cls.pos += 1
+      assert np.shape(v) == np.shape(x)
+      return v
+    return np.real(x) if np.iscomplexobj(x) else x
+
+
 def _relu(x):
   if np.iscomplexobj(x):
     return np.where(np.asarray(x).real > 0, x, 0)
@@ -197,7 +229,7 @@ def install_flax_gin_standins(jax):
   linen = types.ModuleType('flax.linen')
   linen.Module, linen.compact, linen.Dense, linen.Embed = Module, compact, Dense, Embed
   linen.relu = _relu
-  linen.softplus = lambda x: np.logaddexp(x, 0)
+  linen.softplus = _softplus
   linen.sigmoid = lambda x: 1 / (1 + np.exp(-x))
   flax = types.ModuleType('flax')
   flax.linen = linen
@@ -220,6 +252,8 @@ def install_flax_gin_standins(jax):
 
   # jax pieces models.py touches beyond the leaf stand-in
   jax.nn.relu = _relu
+  jax.nn.softplus = _softplus
+  jax.lax.stop_gradient = _StopGradient.apply
   jax.nn.initializers = types.SimpleNamespace(he_uniform=lambda: None, glorot_uniform=lambda: None, he_normal=lambda: None,
                                               zeros=None)
   jax.tree_util = types.SimpleNamespace(tree_map=None)
@@ -382,6 +416,7 @@ def run_case(case, rmodels, ref_callables, rnd_state, Key):
     if v is not None:
       g[f'{case}/rays/{k}'] = v
   g[f'{case}/train_frac'] = np.array(train_frac)
+  g[f'{case}/seed'] = np.array(seed)
   for i, (kind, arr) in enumerate(rnd_state['log']):
     g[f'{case}/noise/{i:02d}_{kind}'] = arr
   # ---- the loss terms of train_utils.py:72-218 on the reference's own outputs
@@ -401,6 +436,77 @@ def run_case(case, rmodels, ref_callables, rnd_state, Key):
     g[f'{case}/loss/orientation'] = np.asarray(rtrain.orientation_loss(rays, model, history, cfg))
   if history[-1]['normals'] is not None and history[-1]['normals_pred'] is not None:
     g[f'{case}/loss/predicted_normal'] = np.asarray(rtrain.predicted_normal_loss(model, history, cfg))
+  # ---- directional derivatives of the total loss (the sum train_utils.py:265-314 differentiates) along three seeded
+  # directions in parameter space, THROUGH the reference's own forward and loss code: complex step (exact; stop_gradient
+  # = drop the perturbation), or, where the forward already uses the complex step itself (Ref-NeRF normals), a 4-point
+  # central difference with every stop_gradient value replayed from the base run.
+  import copy
+  cfg_nm = copy.copy(cfg)
+  cfg_nm.compute_disp_metrics = cfg_nm.compute_normal_metrics = False
+
+  def total_loss(tree_x):
+    _Scope.params = tree_x
+    _Scope.stack = []
+    rnd_state['rs'] = np.random.RandomState(seed + 1)      # the same draws as the recorded run
+    rnd_state['log'] = []
+    mdl = rmodels.Model(config=types.SimpleNamespace(vis_num_rays=cfg.vis_num_rays))
+    rend, hist = mdl(Key() if randomized else None, rays, train_frac, False, zero_glo=False)
+    total, _ = rtrain.compute_data_loss(tbatch, rend, rays, None, cfg_nm)
+    if cfg.interlevel_loss_mult > 0:
+      total = total + rtrain.interlevel_loss(hist, cfg)
+    if cfg.distortion_loss_mult > 0:
+      total = total + rtrain.distortion_loss(hist, cfg)
+    if cfg.orientation_coarse_loss_mult > 0 or cfg.orientation_loss_mult > 0:
+      total = total + rtrain.orientation_loss(rays, mdl, hist, cfg)
+    if cfg.predicted_normal_coarse_loss_mult > 0 or cfg.predicted_normal_loss_mult > 0:
+      total = total + rtrain.predicted_normal_loss(mdl, hist, cfg)
+    return total
+
+  def axpy(t, v, a):
+    return {k: (axpy(t[k], v[k], a) if isinstance(t[k], dict) else t[k] + a * v[k]) for k in t}
+
+  drs = np.random.RandomState(seed + 3)
+
+  def direction(t):
+    """Seeded direction, drawn over the SORTED flat parameter names so that the test can redraw it (float32 values)."""
+    flat_t = {}
+    _flatten('', t, flat_t)
+    out = {}
+    for k in sorted(flat_t):
+      v = flat_t[k]
+      d = (drs.normal(0, 1, v.shape) * (np.abs(v).mean() + 1e-3)).astype(np.float32).astype(np.float64)
+      node = out
+      parts = k.split('/')
+      for q in parts[:-1]:
+        node = node.setdefault(q, {})
+      node[parts[-1]] = d
+    return out
+
+  uses_inner_cstep = preset == 'blender_refnerf'
+  for d in range(3):
+    V = direction(tree)
+    if not uses_inner_cstep:
+      _StopGradient.mode = 'real'
+      h = 1e-30
+      dl = np.imag(total_loss(axpy(tree, V, 1j * h))) / h
+    else:
+      _StopGradient.mode, _StopGradient.tape = 'record', []
+      base = total_loss(tree)
+      def at(a):
+        _StopGradient.mode, _StopGradient.pos = 'replay', 0
+        return total_loss(axpy(tree, V, a))
+
+      # the loss is only piecewise smooth in the parameters (ReLU, clips): the step must stay inside one piece, which
+      # two step sizes agreeing to 1e-6 show (2e-5 did not: a kink inside the stencil)
+      est = []
+      for h in (1e-6, 2e-6):
+        est.append((8 * (at(h) - at(-h)) - (at(2 * h) - at(-2 * h))) / (12 * h))
+      assert abs(est[0] - est[1]) <= 1e-6 * max(1.0, abs(est[0])), (case, d, est)
+      dl = est[0]
+      _StopGradient.mode = 'real'
+    g[f'{case}/dloss{d}'] = np.array(dl)
+  _Scope.params = tree
+
   # clip_gradients (train_utils.py:200-218) on a small seeded gradient tree of three "modules" whose scales make the
   # value clip and the norm clip bite for some and not for others
   grad = {'params': {}}

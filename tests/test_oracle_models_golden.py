@@ -6,7 +6,8 @@ complex-step derivatives for the Ref-NeRF normals, and logs every random draw.  
 configuration, weights, rays and draws, in float64, and must reproduce every entry of `renderings` and `ray_history` of
 every level: deterministic rendering and randomized training for 360 (contraction, dilation, annealing, GLO, density /
 bottleneck noise, random background), blender_256, blender_refnerf (density-gradient normals, predicted normals, IDE,
-tint, roughness, diffuse) and llff_raw (NDC cylinders, single MLP, exposure scaling, safe_exp colours).
+tint, roughness, diffuse) and llff_raw (NDC cylinders, single MLP, exposure scaling, safe_exp colours).  The loss terms, clip_gradients and the
+gradient of the total loss (directional derivatives through the reference's code) are held the same way.
 """
 
 import importlib.util
@@ -144,3 +145,64 @@ def test_loss_terms_match_the_reference_source(case):
     np.testing.assert_allclose(node.numpy(), w, err_msg=name, rtol=1e-12, atol=0)
     changed += int(not np.array_equal(w, GOLD[f'{case}/grad/{name}']))
   assert changed > 0                                       # the clip did bite somewhere
+
+
+def _direction(params_flat, rs):
+  """The generator's seeded direction (make_golden_models.py: drawn over the sorted flat names, float32 values)."""
+  out = {}
+  for k in sorted(params_flat):
+    v = params_flat[k].astype(np.float64)
+    out[k] = (rs.normal(0, 1, v.shape) * (np.abs(v).mean() + 1e-3)).astype(np.float32).astype(np.float64)
+  return out
+
+
+@pytest.mark.parametrize('case', list(CASES))
+def test_gradient_matches_the_reference_forward_differentiated(case):
+  """d(total loss)/d(parameters) along three seeded directions.  Golden: complex-step differentiation THROUGH the
+  reference's own models.py + train_utils.py with stop_gradient = "drop the perturbation" (for Ref-NeRF, whose forward
+  already uses the complex step, a 4-point central difference with the stop_gradient values replayed).  Here: the
+  oracle's autograd gradient of `train_utils.loss_fn` dotted with the same directions.  This pins where gradients flow
+  (stop_level_grad, the interlevel loss's detached targets, RawNeRF's detached scaling) as well as the arithmetic."""
+  from oracle import train_utils as otrain
+  preset, extra, B, randomized, train_frac = CASES[case]
+  cfg = configs.load_preset(preset, list(extra))
+  cfg.compute_disp_metrics = cfg.compute_normal_metrics = False        # metrics never enter the loss
+  cfg.randomized = randomized
+  m = models.Model(config=cfg)
+  om, on, op = helpers.oracle_hparams(m)
+  flat = _sub(f'{case}/param/')
+  params = _tree(flat)
+  leaves = []
+  def req(t):
+    for k, v in t.items():
+      if isinstance(v, dict):
+        req(v)
+      else:
+        t[k] = v.clone().requires_grad_(True)
+        leaves.append(t[k])
+  req(params)
+  r = _sub(f'{case}/rays/')
+  f = lambda k: torch.as_tensor(r[k]) if k in r else None
+  rays = utils.Rays(origins=f('origins'), directions=f('directions'), viewdirs=f('viewdirs'), radii=f('radii'),
+                    imageplane=f('imageplane'), lossmult=f('lossmult'), near=f('near'), far=f('far'), cam_idx=f('cam_idx'),
+                    exposure_idx=f('exposure_idx'), exposure_values=f('exposure_values'))
+  b = _sub(f'{case}/batch/')
+  batch = utils.Batch(rays=rays, rgb=torch.as_tensor(b['rgb']), disps=torch.as_tensor(b['disps']),
+                      alphas=torch.as_tensor(b['alphas']), normals=torch.as_tensor(b['normals']))
+  loss, _, _ = otrain.loss_fn(params, om, on, op, cfg, batch, float(GOLD[f'{case}/train_frac']), _noise_from_log(case, B))
+  loss.backward()
+  grads = {}
+  def collect(t, prefix=''):
+    for k, v in t.items():
+      if isinstance(v, dict):
+        collect(v, f'{prefix}{k}/')
+      else:
+        grads[f'{prefix}{k}'] = torch.zeros_like(v) if v.grad is None else v.grad
+  collect(params)
+  rs = np.random.RandomState(int(GOLD[f'{case}/seed']) + 3)
+  tol = 2e-5 if preset == 'blender_refnerf' else 1e-8
+  for d in range(3):
+    V = _direction(flat, rs)
+    got = sum(float((grads[k] * torch.as_tensor(V[k])).sum()) for k in V)
+    want = float(GOLD[f'{case}/dloss{d}'])
+    assert abs(got - want) <= tol * max(1.0, abs(want)), (case, d, got, want)
