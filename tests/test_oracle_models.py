@@ -17,6 +17,7 @@ from oracle import train_utils as otrain
 from tests import helpers
 
 PUBLISHED = {'360': 9007493, 'blender_256': 835205, 'blender_refnerf': 713230, 'llff_raw': 615740}
+PUBLISHED_FILES = {'blender_512.gin': 3065733, 'llff_512.gin': 3065733, 'llff_256.gin': 835205}     # generate_tables.ipynb:349
 
 
 @pytest.mark.parametrize('name', list(PUBLISHED))
@@ -38,6 +39,24 @@ def test_param_counts_match_published(name):
           assert tree[mod][dn].shape == params[mod][dn].shape
         else:
           assert tree[mod][dn]['kernel'].shape == params[mod][dn]['kernel'].shape
+
+
+@pytest.mark.parametrize('fname', list(PUBLISHED_FILES))
+def test_param_counts_of_the_other_reference_configs(fname):
+  """Read from the reference's own gin files when they are at hand (build container), else skipped."""
+  import os
+  path = os.path.join(os.environ.get('MULTINERF_REFERENCE', '/root/reference'), 'configs', fname)
+  if not os.path.exists(path):
+    pytest.skip('reference configs not present')
+  from multinerf_amd import gin
+  gin.clear_config()
+  cfg = configs.load_config([path], [])
+  m = models.Model(config=cfg)
+  om, on, op = helpers.oracle_hparams(m)
+  assert omodels.param_count(omodels.init_params(om, on, op)) == PUBLISHED_FILES[fname]
+  m.build('cpu')
+  assert m.num_params == PUBLISHED_FILES[fname]
+  gin.clear_config()
 
 
 def test_360_glo4_param_count():

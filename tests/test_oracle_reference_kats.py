@@ -360,3 +360,39 @@ def test_convert_to_ndc_maps_points_on_rays_consistently():
     proj = torch.stack([xm * p[:, 0] / p[:, 2], ym * p[:, 1] / p[:, 2], 1 + 2 * near / p[:, 2]], -1)
     s = (proj[:, 2] - o_ndc[:, 2]) / d_ndc[:, 2]
     np.testing.assert_allclose((o_ndc + s[:, None] * d_ndc).numpy(), proj.numpy(), atol=1e-9)
+
+
+# ----------------------------------------------------------------------------- pos_enc against a stable recursion
+
+
+def _pos_enc_by_angle_doubling(x, n):
+  """sin / cos of 2^k x for k < n by repeated squaring of the rotation by x (coord_test.py:34-43 uses the same idea as
+  its high-degree reference): no large arguments ever reach sin / cos.  Output layout of coord.pos_enc without the
+  identity: [sin(2^0 x) .. sin(2^(n-1) x), cos(2^0 x) .. cos(2^(n-1) x)] per input."""
+  s, c = np.sin(x), np.cos(x)
+  sins, coss = [], []
+  for _ in range(n):
+    sins.append(s)
+    coss.append(c)
+    s, c = 2 * s * c, c * c - s * s
+  return np.stack(sins + coss, -1)
+
+
+def test_angle_doubling_reference_on_multiples_of_half_pi():
+  """coord_test.py:48-59: the recursion itself on x = -pi .. pi in steps of pi/2."""
+  z = _pos_enc_by_angle_doubling(np.linspace(-np.pi, np.pi, 5), 10)
+  want_sin = np.zeros((5, 10))
+  want_cos = np.ones((5, 10))
+  want_sin[:, 0] = [0, -1, 0, 1, 0]
+  want_cos[:, 0] = [-1, 0, 1, 0, -1]
+  want_cos[:, 1] = [1, -1, 1, -1, 1]
+  np.testing.assert_allclose(z, np.concatenate([want_sin, want_cos], -1), atol=1e-10)
+
+
+@pytest.mark.parametrize('n,tol', [(5, 1e-5), (10, 1e-4), (15, 0.005), (20, 0.2)])
+def test_pos_enc_against_the_stable_recursion(n, tol):
+  """coord_test.py:112-127: fp32 pos_enc of degree n stays within the reference's tolerances of the stable recursion
+  (the direct form loses ~2^n ulp of phase; the tolerances are the reference test's own)."""
+  x = np.linspace(-np.pi, np.pi, 10001)
+  z = coord.pos_enc(torch.as_tensor(x, dtype=torch.float32)[:, None], 0, n, append_identity=False).double().numpy()
+  assert np.abs(z - _pos_enc_by_angle_doubling(x, n)).max() < tol
