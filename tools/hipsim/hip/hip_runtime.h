@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <functional>
@@ -77,6 +78,41 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   p->multiProcessorCount = 256;
   p->maxSharedMemoryPerMultiProcessor = 160 * 1024;
   strcpy(p->gcnArchName, "hipsim-gfx950");
+  return hipSuccess;
+}
+// host-side runtime calls of stand-alone probes (tools/cabi_probe.cpp built against the simulator)
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+struct hipsimEvent { double t; };
+typedef hipsimEvent* hipEvent_t;
+template <class T>
+inline hipError_t hipMalloc(T** p, size_t n) {
+  *p = (T*)aligned_alloc(256, (n + 255) / 256 * 256);
+  return *p ? hipSuccess : 1;
+}
+inline hipError_t hipFree(void* p) {
+  free(p);
+  return hipSuccess;
+}
+inline hipError_t hipMemcpy(void* d, const void* s_, size_t n, hipMemcpyKind) {
+  memcpy(d, s_, n);
+  return hipSuccess;
+}
+inline hipError_t hipMemset(void* d, int v, size_t n) {
+  memset(d, v, n);
+  return hipSuccess;
+}
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) {
+  *e = new hipsimEvent{0.0};
+  return hipSuccess;
+}
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
+  e->t = (double)clock() / CLOCKS_PER_SEC;
+  return hipSuccess;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = (float)((b->t - a->t) * 1e3) + 1e-3f;
   return hipSuccess;
 }
 #define HIP_SYMBOL(x) x

@@ -7,6 +7,12 @@
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+# 0. the C-ABI probe (no Python: seconds): bitwise screens + timings of every prepared NT configuration and the TN pair.
+#    Each configuration in its own process under its own timeout: a variant that misbehaves on hardware costs one line.
+hipcc -O2 -std=c++17 -o /tmp/cabi_probe tools/cabi_probe.cpp -Iinclude -Lmultinerf_amd -lmnerf_hip -Wl,-rpath,$PWD/multinerf_amd
+for cfg in 2 43 41 40 42 35 36 37 38 39; do
+  timeout 90 /tmp/cabi_probe $cfg >> gpurun_out/r2_cabi_probe.txt 2>&1 || echo "cfg $cfg: probe exited with $?" >> gpurun_out/r2_cabi_probe.txt
+done
 hipcc --offload-arch=gfx950 -O3 -o /tmp/ingest_probe tools/ingest_probe.hip && timeout 300 /tmp/ingest_probe > gpurun_out/r2_ingest_probe.txt 2>&1
 timeout 600 python tools/gemm_probe.py --cfgs 2,35,36,37 > gpurun_out/r2_gemm_probe_direct.txt 2>&1
 for cfg in 2 36 37; do

@@ -40,6 +40,12 @@ def main():
       print('   ' + l)
     for l in re.findall(r'^(?:cfg \d+ nt|tn ).*TFLOP/s$', text, flags=re.M):
       print('   ' + l)
+  p = os.path.join(d, 'r2_cabi_probe.txt')
+  if os.path.exists(p):
+    print('\n' + os.path.basename(p))
+    for l in open(p):
+      if l.startswith(('cfg', 'tn ')):
+        print('   ' + l.rstrip()[:200])
   p = os.path.join(d, 'r2_ingest_probe.txt')
   if os.path.exists(p):
     print('\n' + os.path.basename(p))
