@@ -341,6 +341,7 @@ typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 0, 16> NtC41; // = NtC2 with the epilo
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 2, 16> NtC42; // = NtC40 (split operand paths) with the same
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 0, 16, 1> NtC43; // = NtC41 with the bias row parked in LDS (cheaper prologue, 32 registers fewer in the loop)
 typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 1, 0, 0, 16, 1> NtC44; // = NtC43 with register double-buffered fragments (NtC12's loop, which spilled while the bias row sat in registers)
+typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 0, 0, 16, 1> NtC45; // = NtC18 (phase-interleaved loop) with the bias row in LDS and the batched epilogue reads
 typedef NtCfg<4, 2, 2, 2, 32, 2, 2> NtC38;           // 256x128, 4 waves of 128x64, 48 KiB: TWO workgroups per CU (one's epilogue under the other's K loop)
 typedef NtCfg<4, 2, 2, 2, 32, 3, 2> NtC39;           //   same, 3 stages (72 KiB)
 typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
@@ -349,7 +350,7 @@ typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register doubl
 static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 44 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
+  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 45 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
   g_nt_cfg_big = cfg_big;
   g_nt_cfg_small = cfg_small;
   return MNR_OK;
@@ -385,6 +386,7 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
     case 42: return nt_launch<NtC42>(a, fast_epi, stream);
     case 43: return nt_launch<NtC43>(a, fast_epi, stream);
     case 44: return nt_launch<NtC44>(a, fast_epi, stream);
+    case 45: return nt_launch<NtC45>(a, fast_epi, stream);
     case 39: return nt_launch<NtC39>(a, fast_epi, stream);
     case 37: return nt_launch<NtC37>(a, fast_epi, stream);
     default:
@@ -420,7 +422,8 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
     const char* e = getenv("MNR_NT_PHASED_MIN_K");
     phased_min_k = e ? atoi(e) : 0;
   }
-  if (cfg == 2 && phased_min_k > 0 && a->K1 + a->K2 >= phased_min_k && !a->mask_bits_in && !a->mask) cfg = 18;
+  if ((cfg == 2 || cfg == 43) && phased_min_k > 0 && a->K1 + a->K2 >= phased_min_k && !a->mask_bits_in && !a->mask)
+    cfg = cfg == 43 ? 45 : 18;
   static int short_k_cfg = -1, short_k_max = 0;          // tuning hook: another configuration for the short-K (proposal) GEMMs
   if (short_k_cfg < 0) {
     const char* e = getenv("MNR_NT_SHORTK_CFG");         // "cfg,max_k", e.g. "38,512"

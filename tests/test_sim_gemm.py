@@ -35,7 +35,7 @@ def _packbits(x):
 
 
 # every compiled 256-row configuration; the default in all four modes, the others eager/reverse and late/shuffled
-_FWD_CASES = [(2, m) for m in MODES] + [(c, m) for c in (12, 4, 7, 18, 19, 33, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44)
+_FWD_CASES = [(2, m) for m in MODES] + [(c, m) for c in (12, 4, 7, 18, 19, 33, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45)
                                         for m in (MODES[2], MODES[3])]
 
 
@@ -56,7 +56,7 @@ def test_nt_forward_layer(sim, cfg, mode):
   assert torch.equal(bits, _packbits(Cb.float()))
 
 
-@pytest.mark.parametrize('cfg,mode', [(2, m) for m in MODES] + [(c, m) for c in (36, 37, 40, 41, 42, 43, 44) for m in (MODES[2], MODES[3])])
+@pytest.mark.parametrize('cfg,mode', [(2, m) for m in MODES] + [(c, m) for c in (36, 37, 40, 41, 42, 43, 44, 45) for m in (MODES[2], MODES[3])])
 def test_nt_dx_layer_with_bit_masks(sim, cfg, mode):
   """dX layer: (dY W) masked by the forward layer's bits (with the tangent rows' modulo), fp32 side output."""
   g = torch.Generator().manual_seed(5)

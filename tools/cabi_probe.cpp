@@ -94,7 +94,7 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[i], "--small")) small = true;
     else cfgs.push_back(atoi(argv[i]));
   }
-  if (cfgs.empty()) cfgs = {2, 43, 44, 41, 40, 42, 35, 36, 37, 38, 39, 18};
+  if (cfgs.empty()) cfgs = {2, 43, 44, 45, 41, 40, 42, 35, 36, 37, 38, 39, 18};
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   printf("%s, %d CUs, ABI %d\n", prop.gcnArchName, prop.multiProcessorCount, mnr_abi_version());

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 # 0. the C-ABI probe (no Python: seconds): bitwise screens + timings of every prepared NT configuration and the TN pair.
 #    Each configuration in its own process under its own timeout: a variant that misbehaves on hardware costs one line.
 hipcc -O2 -std=c++17 -o /tmp/cabi_probe tools/cabi_probe.cpp -Iinclude -Lmultinerf_amd -lmnerf_hip -Wl,-rpath,$PWD/multinerf_amd
-for cfg in 2 43 44 41 40 42 35 36 37 38 39; do
+for cfg in 2 43 44 45 18 41 40 42 35 36 37 38 39; do
   timeout 90 /tmp/cabi_probe $cfg >> gpurun_out/r2_cabi_probe.txt 2>&1 || echo "cfg $cfg: probe exited with $?" >> gpurun_out/r2_cabi_probe.txt
 done
 hipcc --offload-arch=gfx950 -O3 -o /tmp/ingest_probe tools/ingest_probe.hip && timeout 300 /tmp/ingest_probe > gpurun_out/r2_ingest_probe.txt 2>&1
@@ -28,6 +28,8 @@ MNR_NT_CFG=40,0 MNR_TN_SPLIT=1 timeout 300 python bench.py --steps 10 --warmup 3
 MNR_NT_CFG=41,0 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg41.json 2> gpurun_out/r2_bench_cfg41.err
 MNR_NT_CFG=43,0 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg43.json 2> gpurun_out/r2_bench_cfg43.err
 MNR_NT_CFG=44,0 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg44.json 2> gpurun_out/r2_bench_cfg44.err
+MNR_NT_CFG=45,0 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg45.json 2> gpurun_out/r2_bench_cfg45.err
+MNR_NT_CFG=43,0 MNR_NT_PHASED_MIN_K=1024 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg43_phased1024.json 2> gpurun_out/r2_bench_cfg43_phased1024.err
 MNR_NT_CFG=42,0 MNR_TN_SPLIT=1 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg42_tnsplit.json 2> gpurun_out/r2_bench_cfg42_tnsplit.err
 # 4. short-K (proposal) GEMMs on 256x128 tiles, two workgroups per CU (one's epilogue under the other's K loop)
 for sk in 38,512 39,512 38,256; do
