@@ -112,7 +112,7 @@ class simulated_device:
     L._lib = self.lib
     ops._stream = lambda: None
     ops._on_device = lambda t: True
-    ops._cfg_applied = True
+    ops._cfg_applied = False          # the MNR_NT_CFG / MNR_TN_SPLIT hooks, if set, now configure the simulator build
     self.lib.hipsim_reset(0, 0)
     return self
 
