@@ -32,7 +32,7 @@ MNR_NT_CFG=45,0 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_basel
 MNR_NT_CFG=43,0 MNR_NT_PHASED_MIN_K=1024 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg43_phased1024.json 2> gpurun_out/r2_bench_cfg43_phased1024.err
 MNR_NT_CFG=42,0 MNR_TN_SPLIT=1 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg42_tnsplit.json 2> gpurun_out/r2_bench_cfg42_tnsplit.err
 # 4. short-K (proposal) GEMMs on 256x128 tiles, two workgroups per CU (one's epilogue under the other's K loop)
-for sk in 38,512 39,512 38,256; do
+for sk in 38,512 39,512 38,256 36,512 40,512 43,512; do
   MNR_NT_SHORTK_CFG=$sk timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_shortk_${sk/,/_}.json 2> gpurun_out/r2_bench_shortk_${sk/,/_}.err
 done
 
