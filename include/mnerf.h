@@ -214,7 +214,8 @@ int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* args, void* stream);
 /* Tuning hook: the 256x256 output tile is used when K,N are multiples of 256 and the output has at
  * least `big_min_tiles` such tiles (a huge value disables it). */
 int mnr_gemm_tn_set_config(int big_min_tiles);
-/* Probe hook: 1 = the 256x256-tile launches use the split-path kernel (activations by LDS-DMA, dY through registers). */
+/* Probe hook: 1 = the 256x256-tile launches use the split-path kernel (activations by LDS-DMA, dY through registers);
+ * 2 = the default loop with the transpose reads' row offsets as instruction immediates; 0 = default. */
 int mnr_gemm_tn_set_split(int on);
 
 /* out[n] += sum_m X[m,n] for n < n_valid (bias gradient). X bf16 [M, ld]. */

@@ -449,8 +449,9 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
 
 #define TN_BM 64       // reduction rows per step
 
-template <int KI_, int NJ_, int WK_, int WN_, int SPLIT_ = 0>
+template <int KI_, int NJ_, int WK_, int WN_, int SPLIT_ = 0, int IMM_ = 0>
 struct TnCfg {
+  static constexpr int IMM = IMM_ || SPLIT_;           // transpose-read row offsets in the instruction's immediate field
   static constexpr int KI = KI_, NJ = NJ_, WK = WK_, WN = WN_;
   static constexpr int SPLIT = SPLIT_;                // 1: dY tile global -> registers -> ds_write, activations by LDS-DMA
   static constexpr int BKO = 32 * KI * WK;            // output rows (columns of A)
@@ -462,7 +463,8 @@ struct TnCfg {
 };
 typedef TnCfg<2, 2, 2, 2> TnSmall;   // 128x128 output tile, 4 waves,  64 KiB
 typedef TnCfg<4, 2, 2, 4> TnBig;     // 256x256 output tile, 8 waves, 128 KiB
-typedef TnCfg<4, 2, 2, 4, 1> TnBigSplit;   // same with split operand paths (not default; mnr_gemm_tn_set_split)
+typedef TnCfg<4, 2, 2, 4, 1> TnBigSplit;   // same with split operand paths (not default; mnr_gemm_tn_set_split(1))
+typedef TnCfg<4, 2, 2, 4, 0, 1> TnBigImm;  // the default loop with immediate-offset transpose reads only (mnr_gemm_tn_set_split(2))
 
 // Stage a [64 m][COLS] tile; 64-B block b of row r is stored at block position b ^ (r & 3).
 template <int COLS, int THREADS>
@@ -550,7 +552,7 @@ static int g_tn_split = 0;
 
 // Probe hook: 1 = the 256x256-tile launches use the split-path kernel (TnBigSplit).
 extern "C" int mnr_gemm_tn_set_split(int on) {
-  g_tn_split = on ? 1 : 0;
+  g_tn_split = (on == 1 || on == 2) ? on : 0;
   return MNR_OK;
 }
 
@@ -577,7 +579,8 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
     // 512 -> 256 workgroups = 398k -> 407k rays/s end to end, 1024: 390k.
     tn_target = e ? atoi(e) : 256;
   }
-  if (big && g_tn_split) return tn_launch<TnBigSplit>(a, tn_target, stream);
+  if (big && g_tn_split == 1) return tn_launch<TnBigSplit>(a, tn_target, stream);
+  if (big && g_tn_split == 2) return tn_launch<TnBigImm>(a, tn_target, stream);
   if (big) return tn_launch<TnBig>(a, tn_target, stream);
   static int tn_small_target = -1;
   if (tn_small_target < 0) {

@@ -52,8 +52,8 @@ def lib():
     if c:
       big, small = (int(x) for x in c.split(','))
       L.check(L.load().mnr_gemm_nt_set_config(big, small))
-    if os.environ.get('MNR_TN_SPLIT') == '1':   # tuning hook: split-path weight-gradient kernel (csrc/gemm.hip TnBigSplit)
-      L.check(L.load().mnr_gemm_tn_set_split(1))
+    if os.environ.get('MNR_TN_SPLIT') in ('1', '2'):   # tuning hook: csrc/gemm.hip TnBigSplit (1) / TnBigImm (2)
+      L.check(L.load().mnr_gemm_tn_set_split(int(os.environ['MNR_TN_SPLIT'])))
   return L.load()
 
 

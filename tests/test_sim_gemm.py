@@ -157,12 +157,13 @@ def test_tn_split_path_equals_the_default_kernel(sim, shape):
   S.sim_gemm_tn(sim, A, B, want, bias_out=wb)
   np.testing.assert_allclose(want.numpy(), (A.float().T @ B.float()).numpy(), atol=1e-3, rtol=1e-5)
   try:
-    for mode in MODES:
-      sim.hipsim_reset(*mode)
-      sim.mnr_gemm_tn_set_split(1)
-      got, gb = torch.zeros((K, N)), torch.zeros(N)
-      S.sim_gemm_tn(sim, A, B, got, bias_out=gb)
-      assert torch.equal(got, want) and torch.equal(gb, wb), mode
+    for variant in (1, 2):                                # TnBigSplit, TnBigImm
+      for mode in MODES:
+        sim.hipsim_reset(*mode)
+        sim.mnr_gemm_tn_set_split(variant)
+        got, gb = torch.zeros((K, N)), torch.zeros(N)
+        S.sim_gemm_tn(sim, A, B, got, bias_out=gb)
+        assert torch.equal(got, want) and torch.equal(gb, wb), (variant, mode)
   finally:
     sim.mnr_gemm_tn_set_split(0)
 

@@ -194,11 +194,11 @@ int main(int argc, char** argv) {
     printf("tn split vs default at M = %lld: relative difference %.2e %s\n", (long long)Mc, den > 0 ? sqrt(num / den) : -1.0,
            (den > 0 && num / den < 1e-10) ? "(ok: fp32 atomics order only)" : "(MISMATCH)");
   }
-  for (int split = 0; split < 2; ++split) {
+  for (int split = 0; split < 3; ++split) {
     MNR(mnr_gemm_tn_set_split(split));
     const float t = time_us([&] { tn(Mt, W0); }, reps);
-    printf("tn %s: dW 1024x1024 over M = %lld: %7.1f us %6.1f TF/s\n", split ? "split  " : "default", (long long)Mt, t,
-           2.0 * Mt * N * K / t / 1e6);
+    printf("tn %s: dW 1024x1024 over M = %lld: %7.1f us %6.1f TF/s\n", split == 1 ? "split  " : split == 2 ? "imm    " : "default",
+           (long long)Mt, t, 2.0 * Mt * N * K / t / 1e6);
   }
   MNR(mnr_gemm_tn_set_split(0));
   return 0;

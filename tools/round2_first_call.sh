@@ -23,6 +23,7 @@ timeout 600 python tools/gemm_probe.py --cfgs 2,40,41,42,43 > gpurun_out/r2_gemm
 timeout 600 python tools/gemm_probe.py --which tn > gpurun_out/r2_gemm_probe_split_tn.txt 2>&1
 MNR_NT_CFG=40,0 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg40.json 2> gpurun_out/r2_bench_cfg40.err
 MNR_TN_SPLIT=1 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_tnsplit.json 2> gpurun_out/r2_bench_tnsplit.err
+MNR_TN_SPLIT=2 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_tnimm.json 2> gpurun_out/r2_bench_tnimm.err
 MNR_NT_CFG=40,0 MNR_TN_SPLIT=1 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg40_tnsplit.json 2> gpurun_out/r2_bench_cfg40_tnsplit.err
 # 3c. the epilogue with its 16 LDS reads per thread issued together: on the default loop (41) and on the split-path loop (42)
 MNR_NT_CFG=41,0 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_cfg41.json 2> gpurun_out/r2_bench_cfg41.err
