@@ -198,6 +198,10 @@ int mnr_debug_gemm_timeline(unsigned long long* device_buffer);
 int mnr_pack_w_frag_bf16(const uint16_t* Bt, int ldb, int N, int K, uint16_t* out, void* stream);
 int mnr_debug_gemm_wfrag(const uint16_t* image);
 int mnr_gemm_nt_set_config(int cfg_big, int cfg_small);
+/* Probe hook: 0 = off; 1 = eligible short-K launches (N = 256, K1 <= 256, K2 = 0, full-width bf16 output, no fp32 side
+ * output, no bf16 mask) go to the weights-resident persistent kernel (weights in registers, one workgroup per CU walking
+ * the M tiles); n > 1 = the same with at most n workgroups. */
+int mnr_gemm_nt_set_wres(int max_wgs);
 
 typedef struct {
   const uint16_t* A; int lda; int K;   /* A [M, lda] bf16, K columns used, K multiple of 128 */

@@ -395,6 +395,244 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
   }
 }
 
+// ---------------------------------------------------------------------------
+// Weights-resident NT kernel for the short-K layers (N = 256, K <= 256: the proposal MLP's hidden layers and their dX).
+//
+// There a 256x256 tile of the tiled kernel brings in as many weight bytes as activation bytes, runs only four K steps and
+// spends ~40 % of its time in prologue and epilogue.  Here the whole weight matrix (<= 128 KiB) is held in REGISTERS: one
+// wave per 32 output columns (the 1x8 layout), 4 fragments per K tile = 64 VGPRs for K = 256, loaded once per workgroup.
+// The workgroups are persistent (one per CU) and walk over the M tiles; only activation tiles are streamed (LDS-DMA, two
+// 32-KiB slots), as ONE pipeline across tile boundaries: the first activation tile of the next M tile is in flight while
+// this tile's epilogue runs, because the epilogue stages through its own LDS region (two passes of 128 rows).
+// Probe variant (MNR_NT_WRES=1); simulator- and ISA-checked, not run on hardware yet.
+typedef NtCfg<8, 1, 1, 8, 64, 2> WresCfg;            // 256 rows, 8 waves as 1 x 8, for nt_stage_tile / nt_read_frag
+#define WRES_A_BYTES (2 * 32768)
+#define WRES_STAGE_ROWS 128
+#define WRES_CPITCH (256 * 2 + NT_CPAD)
+#define WRES_BIAS_OFF (WRES_A_BYTES + WRES_STAGE_ROWS * WRES_CPITCH)
+#define WRES_LDS_BYTES (WRES_BIAS_OFF + 256 * 4)
+
+template <bool BITS_IN>
+__global__ __launch_bounds__(512) void gemm_nt_wres_kernel(mnr_gemm_nt_args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, khalf = lane >> 5;
+  const bf16* A = (const bf16*)p.A1;
+  const bf16* Bt = (const bf16*)p.Bt;
+  bf16* Cb = (bf16*)p.Cb;
+  const int nk = p.K1 / 64;                               // 1 .. 4
+  const int64_t mt = p.M / 256;
+  const int64_t my_tiles = (mt - blockIdx.x + gridDim.x - 1) / gridDim.x;      // tiles blockIdx.x, + gridDim.x, ...
+  if (my_tiles <= 0) return;
+
+  // bias row -> LDS (read back per tile in the epilogue)
+  {
+    const float* bp = p.bias ? p.bias : reinterpret_cast<const float*>(p.Bt);
+    const int nbias = p.bias ? p.n_bias : 1;
+    if (tid < 256) {
+      const float keep = (p.bias != nullptr && tid < nbias) ? 1.0f : 0.0f;
+      ((float*)(smem + WRES_BIAS_OFF))[tid] = bp[min(tid, nbias - 1)] * keep;
+    }
+  }
+  // this wave's weights: columns 32 * wave + frow, all of K
+  bf16x8 wreg[4][4];
+  {
+    const bf16* wsrc = Bt + (int64_t)(wave * 32 + frow) * p.ldb + khalf * 8;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (bf16)0.0f;
+        wreg[kt][ks] = kt < nk ? *(const bf16x8*)(wsrc + kt * 64 + ks * 16) : z;
+      }
+    // Make hipcc wait for these loads HERE: left pending into the loop, its waitcnt pass re-waits (vmcnt(0)) at every
+    // use, i.e. behind the just-issued LDS-DMA of every step, and serialises the prefetch with the MFMAs (seen in the ISA).
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) MNR_GPU_ONLY(asm volatile("" : "+v"(wreg[kt][ks])));
+  }
+
+  f32x16 acc[8];
+  const int64_t steps = my_tiles * nk;
+  auto stage = [&](int64_t g) {                           // activation tile of global step g into slot g & 1
+    const int64_t tile = blockIdx.x + (g / nk) * gridDim.x;
+    const int kt = (int)(g % nk);
+    nt_stage_tile<WresCfg, 256>(A, p.lda1, tile * 256, kt * 64, smem + (g & 1) * 32768, wave, lane);
+  };
+  stage(0);
+  for (int64_t g = 0; g < steps; ++g) {
+    const int kt = (int)(g % nk);
+    const int64_t m0 = (blockIdx.x + (g / nk) * gridDim.x) * 256;
+    if (kt == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    }
+    nt_wait_vmcnt<0>();                                   // A(g) has landed (A(g+1) is not issued yet)
+    MNR_GPU_ONLY(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (g + 1 < steps) stage(g + 1);
+    const char* As = smem + (g & 1) * 32768;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      // (the register array is indexed by a loop-carried kt: select with a uniform switch, not a dynamic index)
+      bf16x8 w;
+      switch (kt) {
+        case 0: w = wreg[0][ks]; break;
+        case 1: w = wreg[1][ks]; break;
+        case 2: w = wreg[2][ks]; break;
+        default: w = wreg[3][ks]; break;
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {               // four row blocks at a time: 16 fragment registers, not 32
+        bf16x8 fa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = nt_read_frag<WresCfg>(As, (half * 4 + i) * 32 + frow, ks * 2 + khalf);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[half * 4 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, fa[i], acc[half * 4 + i], 0, 0, 0);
+      }
+    }
+    if (kt != nk - 1) continue;
+
+    // ---- epilogue of this M tile: two passes of 128 rows through the staging region (the next tile's DMA flies on)
+    // (the dX flavour has no bias: the launcher only sends bias-free calls to it, which keeps 16 registers out of an
+    // epilogue that otherwise makes hipcc spill weight fragments across the whole loop)
+    float bias_r[16];
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      if constexpr (!BITS_IN) b4 = *(const f32x4*)(smem + WRES_BIAS_OFF + (wave * 32 + rq * 8 + khalf * 4) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias_r[rq * 4 + e] = b4[e];
+    }
+    char* cs = smem + WRES_A_BYTES;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      constexpr int ITERS = WRES_STAGE_ROWS * 32 / 512;     // 8 chunks of 16 B per thread and pass
+      const int row0 = tid / 32, ch = tid % 32;
+      const int64_t mfirst = m0 + h * WRES_STAGE_ROWS + row0;
+      unsigned mbits[BITS_IN ? ITERS : 1];
+      if (BITS_IN) {
+        // row of the bit matrix: m, or m mod bits_row_mod (one 64-bit division per pass, then increments: the pass's
+        // 128 rows wrap at most once because the launcher requires bits_row_mod >= 256 here)
+        const int64_t mod = p.bits_row_mod;
+        int64_t mrow = mod > 0 ? mfirst % mod : mfirst;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          mbits[it] = p.mask_bits_in[mrow * (int64_t)p.ld_bits_in + ch];
+          mrow += 16;
+          if (mod > 0 && mrow >= mod) mrow -= mod;
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = h * 4 + ii;
+        const int ml = ii * 32 + frow;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int nl = wave * 32 + rq * 8 + khalf * 4;
+          const f32x2 s0 = f32x2{acc[i][rq * 4 + 0], acc[i][rq * 4 + 1]} + f32x2{bias_r[rq * 4 + 0], bias_r[rq * 4 + 1]};
+          const f32x2 s1 = f32x2{acc[i][rq * 4 + 2], acc[i][rq * 4 + 3]} + f32x2{bias_r[rq * 4 + 2], bias_r[rq * 4 + 3]};
+          typedef short s16x2 __attribute__((ext_vector_type(2)));
+          s16x2 h0 = __builtin_bit_cast(s16x2, __builtin_convertvector(s0, bf16x2));
+          s16x2 h1 = __builtin_bit_cast(s16x2, __builtin_convertvector(s1, bf16x2));
+          if (p.relu) {
+            const s16x2 z = {0, 0};
+            h0 = __builtin_elementwise_max(h0, z);
+            h1 = __builtin_elementwise_max(h1, z);
+          }
+          typedef int i32x2 __attribute__((ext_vector_type(2)));
+          const i32x2 pk = {__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1)};
+          *(i32x2*)(cs + ml * WRES_CPITCH + nl * 2) = pk;
+        }
+      }
+      MNR_GPU_ONLY(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      bf16* cptr = Cb + mfirst * p.ldcb + ch * 8;
+      uint8_t* bptr = p.mask_bits_out ? p.mask_bits_out + mfirst * p.ld_bits_out + ch : nullptr;
+      const char* lptr = cs + row0 * WRES_CPITCH + ch * 16;
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        u32x4 w = *(const u32x4*)(lptr + it * 16 * WRES_CPITCH);
+        if (BITS_IN) {
+          const int mb = (int)mbits[BITS_IN ? it : 0];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(mb, 2 * d, 1);
+            const unsigned hi = (unsigned)__builtin_amdgcn_sbfe(mb, 2 * d + 1, 1);
+            w[d] &= (lo & 0xffffu) | (hi & 0xffff0000u);
+          }
+        }
+        if (bptr) {                                        // kernel-uniform
+          typedef short s16x2b __attribute__((ext_vector_type(2)));
+          unsigned f = 0;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const unsigned wd = w[d];
+            const s16x2b z = {0, 0};
+            const unsigned pos = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2b, wd), z));
+            f |= ((pos + 0x7fff7fffu) & 0x80008000u) >> (15 - 2 * d);
+          }
+          unsigned mb = (f | (f >> 15)) & 0xffu;
+          mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xF5, 0xf, 0xf, false) << 8;
+          mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xAA, 0xf, 0xf, false) << 16;
+          if ((ch & 3) == 0) *(unsigned*)(bptr + (int64_t)it * 16 * p.ld_bits_out) = mb;
+        }
+        *(u32x4*)(cptr + (int64_t)it * 16 * p.ldcb) = w;
+      }
+      MNR_GPU_ONLY(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
+      __builtin_amdgcn_s_barrier();                         // the staging region is free again
+      asm volatile("" ::: "memory");
+    }
+  }
+}
+
+static int g_nt_wres = 0;
+
+// Probe hook: 0 = off; 1 = eligible short-K launches (N = 256, K <= 256, plain epilogues) go to the weights-resident
+// persistent kernel, one workgroup per CU; n > 1 = the same with at most n workgroups.
+extern "C" int mnr_gemm_nt_set_wres(int max_wgs) {
+  g_nt_wres = max_wgs > 0 ? max_wgs : 0;
+  return MNR_OK;
+}
+
+static bool nt_wres_eligible(const mnr_gemm_nt_args* a, int fast_epi) {
+  return a->N == 256 && a->K2 == 0 && a->K1 <= 256 && a->M % 256 == 0 && !a->mask && !a->Cf && a->Cb && a->nb == a->N && fast_epi &&
+         (!a->mask_bits_out || (a->ld_bits_out % 4 == 0)) && (!a->mask_bits_in || ((a->bits_row_mod == 0 || a->bits_row_mod >= 256) && !a->bias && !a->relu && !a->mask_bits_out));
+}
+
+static int nt_wres_launch(const mnr_gemm_nt_args* a, int max_wgs, void* stream) {
+  static int cus = 0;
+  if (cus == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const int64_t mt = a->M / 256;
+  const int cap = max_wgs > 1 ? max_wgs : cus;            // MNR_NT_WRES = 1: one workgroup per CU; n > 1: at most n workgroups
+  const int grid = (int)(mt < cap ? mt : cap);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_wres_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_wres_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES);
+    attr_set = true;
+  }
+  if (a->mask_bits_in) hipLaunchKernelGGL(gemm_nt_wres_kernel<true>, dim3(grid), dim3(512), WRES_LDS_BYTES, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(gemm_nt_wres_kernel<false>, dim3(grid), dim3(512), WRES_LDS_BYTES, (hipStream_t)stream, *a);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
 extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   MNR_CHECK_ARG(a != nullptr, "mnr_gemm_nt_bf16: null args");
   MNR_CHECK_ARG(a->M > 0 && a->M % 128 == 0, "mnr_gemm_nt_bf16: M=%lld must be a positive multiple of 128", (long long)a->M);
@@ -415,6 +653,7 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   // 16-byte row segments in the epilogue need 8-element-aligned output / mask pitches and bases.
   const int fast_epi = (!a->Cb || (a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0)) &&
                        (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));
+  if (g_nt_wres > 0 && nt_wres_eligible(a, fast_epi)) return nt_wres_launch(a, g_nt_wres, stream);
   const bool big_ok = (a->M % 256 == 0) && (a->N % 256 == 0);
   int cfg = big_ok ? g_nt_cfg_big : g_nt_cfg_small;
   static int phased_min_k = -1;                          // tuning hook: phased loop for long-K forward GEMMs only

@@ -125,4 +125,5 @@ class simulated_device:
     L._lib, ops._stream, ops._on_device, ops._cfg_applied = self.saved
     self.lib.mnr_gemm_nt_set_config(2, 0)
     self.lib.mnr_gemm_tn_set_split(0)
+    self.lib.mnr_gemm_nt_set_wres(0)
     return False

@@ -103,3 +103,22 @@ def test_default_gemm_kernels_are_the_ones_validated_on_the_gpu(report):
   assert set(want) <= set(got), sorted(set(want) - set(got))
   changed = [n for n in want if got[n] != want[n]]
   assert not changed, changed
+
+
+def test_weights_resident_kernel_keeps_its_prefetch_in_flight(report):
+  """gemm_nt_wres_kernel: no spills (a spilled weight fragment is reloaded with scratch_load inside the K step, whose vmcnt
+  wait also drains the activation prefetch: seen while building it), and no hipcc vmcnt wait between the LDS-DMA issue of a
+  step and its last MFMA (weight loads left pending into the loop made hipcc re-wait vmcnt(0) at every use)."""
+  mod, _ = report
+  asm, tmp = mod.compile_selected([2])
+  try:
+    bodies = {n: b for n, b in mod.all_kernel_bodies(asm).items() if 'gemm_nt_wres_kernel' in n}
+  finally:
+    shutil.rmtree(tmp, ignore_errors=True)
+  assert len(bodies) == 2
+  for name, body in bodies.items():
+    assert not any('scratch_' in l for l in body), name
+    mf = [k for k, l in enumerate(body) if 'v_mfma' in l]
+    dma = [k for k, l in enumerate(body) if 'global_load_lds' in l and k < mf[0]]
+    start = max(k for k in dma if mf[0] - k < 400)        # the step's DMA issue in front of its MFMAs
+    assert mod.compiler_vmcnt_waits(body[start:mf[-1] + 1]) == [], name

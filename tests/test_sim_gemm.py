@@ -10,6 +10,8 @@ semantics (MFMA lane layout, ds_read_b64_tr_b16, DPP quad_perm, global_load_lds)
 
 import shutil
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -21,6 +23,7 @@ pytestmark = pytest.mark.skipif(
 
 # (LDS-DMA lands late, fiber order): eager/forward, late/forward, eager/reverse, late/shuffled
 MODES = [(0, 0), (1, 0), (0, -1), (1, 11)]
+C_ULL = ctypes.c_ulonglong
 
 
 @pytest.fixture(scope='module')
@@ -109,6 +112,37 @@ def test_nt_direct_weights_from_a_fragment_major_image(sim, cfg):
     finally:
       sim.mnr_debug_gemm_wfrag(None)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize('K', [64, 128, 192, 256])
+def test_nt_weights_resident_persistent_kernel(sim, K):
+  """gemm_nt_wres_kernel (weights in registers, persistent workgroups walking the M tiles, activation tiles as one
+  pipeline across tile boundaries): bitwise the tiled kernel's result, forward (partial bias, ReLU, bit masks) and dX
+  (bit masks with the tangent rows' modulo), with 1, 2 and 3 workgroups for 5 tiles, in every mode."""
+  g = torch.Generator().manual_seed(K)
+  M, N = 1280, 256
+  A = torch.randn((M, K), generator=g).bfloat16()
+  Bt = (torch.randn((N, K + 8), generator=g) * 0.1).bfloat16()[:, :K]
+  bias = torch.randn(200, generator=g)
+  keep = torch.rand((256, N), generator=g) > 0.5
+  bits_in = _packbits(keep.float())
+  sim.mnr_gemm_nt_set_config(2, 0)
+  sim.mnr_gemm_nt_set_wres(0)
+  sim.hipsim_reset(0, 0)
+  want_f, _, want_b = S.sim_gemm_nt(sim, A, Bt, bias=bias, relu=True, bits_out=True)
+  want_d, _, _ = S.sim_gemm_nt(sim, A, Bt, bits_in=bits_in, bits_row_mod=256)
+  n0 = (C_ULL * 4)()
+  try:
+    for wgs, mode in [(5, MODES[0]), (2, MODES[1]), (3, MODES[2]), (2, MODES[3])]:
+      sim.hipsim_reset(*mode)
+      sim.mnr_gemm_nt_set_wres(wgs)
+      got_f, _, got_b = S.sim_gemm_nt(sim, A, Bt, bias=bias, relu=True, bits_out=True)
+      got_d, _, _ = S.sim_gemm_nt(sim, A, Bt, bits_in=bits_in, bits_row_mod=256)
+      sim.hipsim_stats(n0)
+      assert torch.equal(got_f, want_f) and torch.equal(got_b, want_b) and torch.equal(got_d, want_d), (wgs, mode)
+      assert n0[3] != 0
+  finally:
+    sim.mnr_gemm_nt_set_wres(0)
 
 
 @pytest.mark.parametrize('mode', MODES[:2])

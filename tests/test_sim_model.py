@@ -63,7 +63,8 @@ def _setup(name, extra, B, seed=3):
 
 # (NT configuration for the 256x256-tiled GEMMs, LDS-DMA landing late, fiber order): the default as shipped, and the
 # configurations prepared for the next round (direct-weights loop, two workgroups per CU) under the adversarial modes
-VARIANTS = [(2, 0, 0), (37, 1, 5), (38, 1, 3), (-42, 1, 2)]      # -42: NtC42 (split paths + batched epilogue reads) + the split-path TN kernel
+# -42: NtC42 (split paths + batched epilogue reads) + the split-path TN kernel; 1043: NtC43 + the weights-resident kernel
+VARIANTS = [(2, 0, 0), (37, 1, 5), (38, 1, 3), (-42, 1, 2), (1043, 1, 4)]
 
 
 @pytest.mark.parametrize('name,extra,B', CASES)
@@ -79,8 +80,9 @@ def test_360_step_with_the_prepared_gemm_configurations(variant):
 def _run(name, extra, B, variant):
   nt_cfg, dma_late, order = variant
   with S.simulated_device() as sim:
-    assert sim.lib.mnr_gemm_nt_set_config(abs(nt_cfg), 0) == 0
+    assert sim.lib.mnr_gemm_nt_set_config(abs(nt_cfg) % 1000, 0) == 0
     assert sim.lib.mnr_gemm_tn_set_split(1 if nt_cfg < 0 else 0) == 0
+    assert sim.lib.mnr_gemm_nt_set_wres(2 if nt_cfg >= 1000 else 0) == 0
     sim.lib.hipsim_reset(dma_late, order)
     cfg, model, (om, on, op), params, flat, batch = _setup(name, extra, B)
     noise = helpers.make_noise(model, B)

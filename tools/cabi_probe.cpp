@@ -167,6 +167,28 @@ int main(int argc, char** argv) {
     fflush(stdout);
   }
   MNR(mnr_gemm_nt_set_config(2, 0));
+  {
+    // weights-resident persistent kernel on the proposal shape: bitwise screen at M = Mc rows of it, then timing
+    uint16_t *Pr = dev_zero<uint16_t>(Mc * 256), *Px = dev_zero<uint16_t>(Mc * 256);
+    auto prop_small = [&](uint16_t* out) {
+      mnr_gemm_nt_args a;
+      memset(&a, 0, sizeof(a));
+      a.A1 = A2; a.lda1 = 256; a.K1 = 256; a.Bt = B2; a.ldb = 256; a.M = Mc; a.N = 256; a.bias = bias; a.n_bias = 256; a.relu = 1;
+      a.Cb = out; a.ldcb = 256; a.nb = 256; a.mask_bits_out = bits; a.ld_bits_out = 32;
+      MNR(mnr_gemm_nt_bf16(&a, nullptr));
+    };
+    prop_small(Pr);
+    for (int wgs : {1, 128}) {
+      MNR(mnr_gemm_nt_set_wres(wgs));
+      CHECK(hipMemset(Px, 0xff, Mc * 256 * 2));
+      prop_small(Px);
+      CHECK(hipDeviceSynchronize());
+      const bool ok = same(Px, Pr, Mc * 256 * 2);
+      const float tp = time_us([&] { prop_fwd(); }, reps);
+      printf("wres %3d: %s | prop 256 %7.1f us %6.1f TF/s\n", wgs, ok ? "bitwise = cfg 2" : "MISMATCH      ", tp, 2.0 * Mp * 256 * 256 / tp / 1e6);
+    }
+    MNR(mnr_gemm_nt_set_wres(0));
+  }
 
   // weight gradient: C[K, N] += A^T dY
   float *W0 = dev_zero<float>((size_t)K * N), *W1 = dev_zero<float>((size_t)K * N), *db = dev_zero<float>(N);

@@ -74,6 +74,10 @@ struct hipDeviceProp_t {
 inline const char* hipGetErrorString(hipError_t) { return "hipsim"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) {
+  *d = 0;
+  return hipSuccess;
+}
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   p->multiProcessorCount = 256;
   p->maxSharedMemoryPerMultiProcessor = 160 * 1024;

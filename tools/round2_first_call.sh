@@ -37,4 +37,7 @@ for sk in 38,512 39,512 38,256 36,512 40,512 43,512; do
   MNR_NT_SHORTK_CFG=$sk timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_shortk_${sk/,/_}.json 2> gpurun_out/r2_bench_shortk_${sk/,/_}.err
 done
 
+# 5. weights-resident persistent kernel for the short-K (proposal) layers, alone and with the overhead-trimmed trunk configuration
+MNR_NT_WRES=1 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_wres.json 2> gpurun_out/r2_bench_wres.err
+MNR_NT_WRES=1 MNR_NT_CFG=43,0 timeout 300 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_aux > gpurun_out/r2_bench_wres_cfg43.json 2> gpurun_out/r2_bench_wres_cfg43.err
 python tools/round2_summary.py gpurun_out > gpurun_out/r2_summary.txt 2>&1; cat gpurun_out/r2_summary.txt

@@ -44,7 +44,7 @@ def main():
   if os.path.exists(p):
     print('\n' + os.path.basename(p))
     for l in open(p):
-      if l.startswith(('cfg', 'tn ')):
+      if l.startswith(('cfg', 'tn ', 'wres')):
         print('   ' + l.rstrip()[:200])
   p = os.path.join(d, 'r2_ingest_probe.txt')
   if os.path.exists(p):
