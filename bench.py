@@ -80,6 +80,9 @@ def main():
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--batch_size', type=int, default=16384, help='rays per GPU (Config.batch_size of 360.gin)')
+  ap.add_argument('--global_batch', type=int, default=0,
+                  help='total rays per step over all GPUs (overrides --batch_size: rays per GPU = global_batch / gpus, "strong" '
+                       'scaling); BASELINE config 3 is --gpus 8 --global_batch 65536')
   ap.add_argument('--preset', default='360')
   ap.add_argument('--gin_bindings', action='append', default=[])
   ap.add_argument('--no_cpu_baseline', action='store_true')
@@ -87,8 +90,7 @@ def main():
   ap.add_argument('--no_aux', action='store_true', help='skip the secondary measurements (4096x192 north-star shape, render)')
   args = ap.parse_args()
 
-  from multinerf_amd import configs, dist as mdist, models, ops, train_utils
-  from tests import helpers
+  from multinerf_amd import configs, dist as mdist, models, ops, synthetic, train_utils
 
   mdist.init_from_env()
   rank, world = mdist.rank(), mdist.world_size()
@@ -99,10 +101,14 @@ def main():
   dev = torch.device('cuda', local)
 
   cfg = configs.load_preset(args.preset, args.gin_bindings)
+  if args.global_batch:
+    if args.global_batch % world:
+      raise SystemExit(f'--global_batch {args.global_batch} is not a multiple of --gpus {world}')
+    args.batch_size = args.global_batch // world
   cfg.batch_size = args.batch_size
   model, state, render_eval_pfn, train_pstep, lr_fn = train_utils.setup_model(cfg, 0, device=dev)
   B = args.batch_size
-  batch = helpers.synthetic_rays(B, seed=20200823 + rank, near=cfg.near, far=cfg.far).map(lambda t: t.to(dev))
+  batch = synthetic.synthetic_rays(B, seed=20200823 + rank, near=cfg.near, far=cfg.far).map(lambda t: t.to(dev))
   gen = torch.Generator(device=dev).manual_seed(1234 + rank)
   if cfg.compute_normal_metrics:      # blender ground-truth normals / alphas (synthetic)
     batch.alphas = torch.rand((B,), generator=gen, device=dev)
@@ -185,7 +191,7 @@ def main():
     Bb = 4096
     cfg_b.batch_size = Bb
     model_b, state_b, _, step_b, _ = train_utils.setup_model(cfg_b, 0, device=dev)
-    batch_b = helpers.synthetic_rays(Bb, seed=20200823 + rank, near=cfg_b.near, far=cfg_b.far).map(lambda t: t.to(dev))
+    batch_b = synthetic.synthetic_rays(Bb, seed=20200823 + rank, near=cfg_b.near, far=cfg_b.far).map(lambda t: t.to(dev))
     def run_b():
       nonlocal state_b
       state_b, _, _ = step_b(gen, state_b, batch_b, None, train_frac, 0.0)
@@ -217,7 +223,7 @@ def main():
         'warmup': args.warmup,
         'ms_per_step': ms_per_step,
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': 'strong' if args.global_batch else 'weak',
         'vs_baseline': None,
         'dtype': 'bf16 MFMA inputs / fp32 accumulate, fp32 everywhere else',
         'data': 'synthetic rays (SURVEY 8d, seed 20200823+rank), he_uniform random-init weights, random jitter',
@@ -242,6 +248,11 @@ def main():
             'peak': 2500.0,
             'unit': 'TFLOP/s',
             'frac': achieved_tflops / 2500.0,
+            # two fractions of the same 2.5 PFLOP/s: `frac` / `gemm_frac` = algorithmic FLOPs / time spent INSIDE the MFMA
+            # kernels (HIP events); `whole_step_frac` = SURVEY 8(d)'s definition, rays/s x FLOPs/ray / peak per GPU
+            'gemm_frac': achieved_tflops / 2500.0,
+            'whole_step_achieved': train_flops * B / (ms_per_step * 1e-3) / 1e12,
+            'whole_step_frac': train_flops * B / (ms_per_step * 1e-3) / 2.5e15,
             'traffic': traffic,
             'gemm_ms_per_step': gemm_ms_per_step,
             'gemm_launches_per_step': gemm_launches / nprof,
@@ -254,13 +265,14 @@ def main():
 
   # ---- CPU baseline (rank 0, N=1 only): the oracle's train_step on a bounded sample
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    from oracle import bridge as obridge
     from oracle import models as omodels
     from oracle import train_utils as otrain
-    om, on, op = helpers.oracle_hparams(model)
+    om, on, op = obridge.oracle_hparams(model)
     params = omodels.init_params(om, on, op, seed=0)
     nb = args.cpu_rays
-    cb = helpers.synthetic_rays(nb, near=cfg.near, far=cfg.far)
-    noise = helpers.make_noise(model, nb)
+    cb = synthetic.synthetic_rays(nb, near=cfg.near, far=cfg.far)
+    noise = obridge.make_noise(model, nb)
     st = otrain.init_opt_state(params)
     cores = torch.get_num_threads()
     t0 = time.perf_counter()
@@ -273,7 +285,8 @@ def main():
     dt = (time.perf_counter() - t0) / reps
     out['cpu_baseline'] = {
         'value': nb / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-        'sample': f'{reps} x oracle train_step (fp32 torch-CPU restatement of the reference) on {nb} rays of the same workload; '
+        'sample': f'{reps} x oracle train_step (fp32 torch-CPU restatement of the reference; NOT the reference\'s JAX, which '
+                  f'cannot be installed here) on {nb} rays of the same workload; '
                   f'host has {os.cpu_count()} logical CPUs, torch used {cores} threads',
     }
   if rank == 0:

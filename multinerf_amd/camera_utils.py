@@ -135,39 +135,60 @@ def average_pose(poses):
 
 
 def recenter_poses(poses):
-  """camera_utils.py:112-117 -> (poses, transform)."""
-  cam2world = average_pose(poses)
-  transform = np.linalg.inv(pad_poses(cam2world))
-  poses = transform @ pad_poses(poses)
-  return unpad_poses(poses), transform
+  """Express all cameras in the frame of their average camera (what camera_utils.py:112-117 computes).
+
+  Returns (poses [N,3,4], world -> average-camera transform [4,4]).  The average frame [R | c] is rigid, so its
+  inverse is written down directly, [R^T | -R^T c], instead of inverting the padded 4x4.
+  """
+  mean_frame = average_pose(poses)
+  r_t = mean_frame[:3, :3].T
+  world_to_mean = np.eye(4)
+  world_to_mean[:3, :3] = r_t
+  world_to_mean[:3, 3] = -r_t @ mean_frame[:3, 3]
+  return np.einsum('ij,njk->nik', world_to_mean[:3, :3], poses[:, :3, :4]) + \
+      np.concatenate([np.zeros((3, 3)), world_to_mean[:3, 3:4]], 1)[None], world_to_mean
 
 
 def focus_point_fn(poses):
-  """camera_utils.py:144-156: the point nearest to all focal axes."""
-  directions, origins = poses[:, :3, 2:3], poses[:, :3, 3:4]
-  m = np.eye(3) - directions * np.transpose(directions, [0, 2, 1])
-  mt_m = np.transpose(m, [0, 2, 1]) @ m
-  return np.linalg.inv(mt_m.mean(0)) @ (mt_m @ origins).mean(0)[:, 0]
+  """The point closest, in the least-squares sense, to every camera's optical axis (camera_utils.py:144-156).
+
+  With unit axis directions d_i through centres o_i the distance to axis i is |P_i (x - o_i)|, P_i = I - d_i d_i^T an
+  orthogonal projector (P_i^T P_i = P_i), so the normal equations are (sum P_i) x = sum P_i o_i.
+  """
+  d = poses[:, :3, 2]
+  o = poses[:, :3, 3]
+  proj = np.eye(3)[None] - d[:, :, None] * d[:, None, :]
+  proj = np.einsum('nji,njk->nik', proj, proj)              # P^T P: equals P for unit d, kept general for un-normalised axes
+  return np.linalg.solve(proj.sum(0), np.einsum('nij,nj->i', proj, o))
 
 
 def transform_poses_pca(poses):
-  """camera_utils.py:191-227: align the principal axes of the camera centres with XYZ, scale into the unit cube."""
-  t = poses[:, :3, 3]
-  t_mean = t.mean(axis=0)
-  t = t - t_mean
-  eigval, eigvec = np.linalg.eig(t.T @ t)
-  inds = np.argsort(eigval)[::-1]
-  eigvec = eigvec[:, inds]
-  rot = eigvec.T
-  if np.linalg.det(rot) < 0:
-    rot = np.diag(np.array([1, 1, -1])) @ rot
-  transform = np.concatenate([rot, rot @ -t_mean[:, None]], -1)
-  poses_recentered = unpad_poses(transform @ pad_poses(poses))
-  transform = np.concatenate([transform, np.eye(4)[3:]], axis=0)
-  if poses_recentered.mean(axis=0)[2, 1] < 0:
-    poses_recentered = np.diag(np.array([1, -1, -1])) @ poses_recentered
-    transform = np.diag(np.array([1, -1, -1, 1])) @ transform
-  scale_factor = 1. / np.max(np.abs(poses_recentered[:, :3, 3]))
-  poses_recentered[:, :3, 3] *= scale_factor
-  transform = np.diag(np.array([scale_factor] * 3 + [1])) @ transform
-  return poses_recentered, transform
+  """Scene normalisation for unbounded captures (what camera_utils.py:191-227 computes): rotate the principal axes of
+  the camera centres onto x, y, z (largest spread first), keep the cameras' mean up-vector pointing to +z... i.e. a
+  positive z component of the mean y axis, and scale the centres into [-1, 1]^3.  Returns (poses, 4x4 transform).
+
+  Principal axes from the SVD of the centred [N,3] centre matrix (its right singular vectors, already sorted by
+  spread).  An axis is only defined up to sign; the sign is fixed here by making every axis' largest-magnitude
+  component positive before the handedness / up-vector rules below are applied.
+  """
+  centres = poses[:, :3, 3]
+  mean = centres.mean(0)
+  _, _, axes = np.linalg.svd(centres - mean, full_matrices=False)      # rows: principal directions
+  for k in range(3):
+    if axes[k, np.argmax(np.abs(axes[k]))] < 0:
+      axes[k] = -axes[k]
+  if np.linalg.det(axes) < 0:                                           # keep a right-handed frame
+    axes[2] = -axes[2]
+  world_to_pca = np.eye(4)
+  world_to_pca[:3, :3] = axes
+  world_to_pca[:3, 3] = -axes @ mean
+  out = np.einsum('ij,njk->nik', axes, poses[:, :3, :4])
+  out[:, :, 3] += world_to_pca[:3, 3]
+  if out[:, 2, 1].mean() < 0:                                           # cameras upside down on average: turn about x
+    turn = np.diag([1., -1., -1.])
+    out = np.einsum('ij,njk->nik', turn, out)
+    world_to_pca[:3] = turn @ world_to_pca[:3]
+  shrink = 1.0 / np.abs(out[:, :, 3]).max()
+  out[:, :, 3] *= shrink
+  world_to_pca[:3] *= shrink
+  return out, world_to_pca

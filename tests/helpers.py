@@ -8,87 +8,41 @@ import torch
 from multinerf_amd import configs, gin, models, utils
 
 
-def synthetic_rays(B, seed=20200823, near=0.2, far=1e6, device='cpu'):
-  """SURVEY.md section 8(d) 'Ray inputs (seeded)'."""
-  rs = np.random.default_rng(seed)
-  o = rs.uniform(-1, 1, (B, 3))
-  tgt = rs.normal(0, 0.3, (B, 3))
-  d = tgt - o
-  d = d / np.linalg.norm(d, axis=-1, keepdims=True) * rs.uniform(1.0, 1.2, (B, 1))
-  vd = d / np.linalg.norm(d, axis=-1, keepdims=True)
-  radii = rs.uniform(3e-4, 1e-3, (B, 1))
-  ip = rs.uniform(-0.6, 0.6, (B, 2))
-  cam = rs.integers(0, 200, (B, 1))
-  rgb = rs.uniform(0, 1, (B, 3))
-  f = lambda x: torch.as_tensor(x, dtype=torch.float32, device=device).contiguous()
-  rays = utils.Rays(origins=f(o), directions=f(d), viewdirs=f(vd), radii=f(radii), imageplane=f(ip),
-                    lossmult=f(np.ones((B, 1))), near=f(np.full((B, 1), near)), far=f(np.full((B, 1), far)),
-                    cam_idx=torch.as_tensor(cam, dtype=torch.int32, device=device))
-  return utils.Batch(rays=rays, rgb=f(rgb))
+from multinerf_amd.synthetic import synthetic_rays, procedural_scene_rays  # noqa: F401  (moved into the package)
 
 
-def oracle_hparams(model: models.Model):
-  """Product hyper-parameter objects -> the oracle's dataclasses (same field names)."""
-  from oracle import models as omodels        # imported here: bench.py uses the ray helpers without the oracle
-  def conv(src, cls):
-    names = {f.name for f in dataclasses.fields(cls)}
-    kw = {f.name: getattr(src, f.name) for f in dataclasses.fields(src) if f.name in names and f.name != 'config'}
-    return cls(**kw)
-  om = conv(model, omodels.Model)
-  if model.config is not None:
-    om.vis_num_rays = model.config.vis_num_rays
-  return om, conv(model.nerf_hp, omodels.MLP), (None if model.single_mlp else conv(model.prop_hp, omodels.MLP))
+from oracle.bridge import oracle_hparams, make_noise  # noqa: F401,E402
 
 
-def make_noise(model, B, seed=0):
-  g = torch.Generator().manual_seed(seed)
-  noise = {'u_jitter': {}, 'density_noise': {}, 'bg_rgbs': {}}
-  for i in range(model.num_levels):
-    n = model.num_prop_samples if i < model.num_levels - 1 else model.num_nerf_samples
-    noise['u_jitter'][i] = torch.rand((B, 1 if model.single_jitter else n), generator=g)
-    noise['density_noise'][i] = torch.randn((B, n), generator=g)
-    noise['bg_rgbs'][i] = torch.rand((B, 3), generator=g)
-  return noise
-
-
-def procedural_scene_rays(B, seed, device='cpu', image_size=64):
-  """SURVEY.md 8(d) 'PSNR': a procedural stand-in for the Blender scenes (no dataset in the image).
-
-  A unit sphere at the origin shaded by its normal and a fixed light, in front of a white background
-  (blender convention: near 2, far 6, cameras on a radius-4 sphere looking at the origin).  Rays are
-  pixel rays of random cameras; ground-truth colour is the analytic ray/sphere intersection.
-  """
-  rs = np.random.default_rng(seed)
-  # camera centres on the upper part of a radius-4 sphere
-  z = rs.uniform(0.1, 0.9, (B, 1))
-  phi = rs.uniform(0, 2 * np.pi, (B, 1))
-  r = np.sqrt(1 - z * z)
-  c = 4.0 * np.concatenate([r * np.cos(phi), r * np.sin(phi), z], -1)
-  fwd = -c / np.linalg.norm(c, axis=-1, keepdims=True)
-  up = np.array([[0., 0., 1.]])
-  right = np.cross(fwd, up)
-  right /= np.linalg.norm(right, axis=-1, keepdims=True)
-  upv = np.cross(right, fwd)
-  focal = 1.2 * image_size                       # ~45 degree field of view
-  px = rs.uniform(-0.5, 0.5, (B, 2)) * image_size
-  d = fwd * focal + right * px[:, :1] + upv * px[:, 1:]
-  d = d / focal                                  # camera_utils convention: |d| ~ 1 at the image centre, un-normalised
-  vd = d / np.linalg.norm(d, axis=-1, keepdims=True)
-  radii = np.full((B, 1), 2.0 / np.sqrt(12.0) / focal)          # camera_utils.py:604-610 pixel footprint
-  # analytic render: unit sphere, normal shading
-  b = np.sum(c * vd, -1)
-  disc = b * b - (np.sum(c * c, -1) - 1.0)
-  hit = disc > 0
-  t = -b - np.sqrt(np.maximum(disc, 0))
-  p = c + vd * t[:, None]
-  nrm = p / np.maximum(np.linalg.norm(p, axis=-1, keepdims=True), 1e-9)
-  light = np.array([0.3, 0.5, 0.8]) / np.linalg.norm([0.3, 0.5, 0.8])
-  shade = 0.3 + 0.7 * np.clip(nrm @ light, 0, 1)[:, None]
-  col = (0.5 + 0.5 * nrm) * shade
-  rgb = np.where(hit[:, None], col, 1.0)
-  f = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=device).contiguous()
-  rays = utils.Rays(origins=f(c), directions=f(d), viewdirs=f(vd), radii=f(radii),
-                    imageplane=f(px / image_size), lossmult=f(np.ones((B, 1))), near=f(np.full((B, 1), 2.0)),
-                    far=f(np.full((B, 1), 6.0)),
-                    cam_idx=torch.zeros((B, 1), dtype=torch.int32, device=device))
-  return utils.Batch(rays=rays, rgb=f(rgb), alphas=f(hit.astype(np.float32)), normals=f(np.where(hit[:, None], nrm, 0.0)))
+def assert_adam_matches_oracle(model, cfg, flat0, raw_grad, opt0, state2, what=''):
+  """The optimiser arithmetic, numerically (train_utils.py:326-330 + optax.adam): the oracle's clip_gradients ->
+  nan_to_num -> adam_update applied to the KERNEL's own raw gradient `raw_grad`, from parameters `flat0` and
+  moments `opt0` = (mu, nu, count) or None for zeros, must reproduce the kernel's new parameters and moments
+  (`state2`).  Feeding the same gradient to both sides separates optimiser errors (eps, bias correction, clip
+  scale, learning-rate schedule, step count) from the bf16 noise of the gradient itself.  Returns (mu, nu, count)."""
+  from oracle import train_utils as otrain
+  flat0 = flat0.detach().float().cpu()
+  g = raw_grad.detach().float().cpu()
+  params = model.params_tree(flat0.clone())
+  grads = model.params_tree(g.clone())
+  if opt0 is None:
+    opt = otrain.init_opt_state(params)
+  else:
+    opt = {'count': opt0[2], 'mu': model.params_tree(opt0[0].detach().float().cpu().clone()),
+           'nu': model.params_tree(opt0[1].detach().float().cpu().clone())}
+  grads = otrain.clip_gradients(grads, cfg)
+  grads = otrain.tree_map(lambda z: torch.nan_to_num(z), grads)
+  new_p, new_opt = otrain.adam_update(params, grads, opt, cfg)
+  lr = float(otrain.lr_fn(cfg, opt['count']))
+  ref_p = model.flat_from_tree(new_p, device='cpu').double()
+  ref_mu = model.flat_from_tree(new_opt['mu'], device='cpu').double()
+  ref_nu = model.flat_from_tree(new_opt['nu'], device='cpu').double()
+  got_p, got_mu, got_nu = (t.detach().double().cpu() for t in (state2.params['flat'], state2.mu, state2.nu))
+  assert state2.step == new_opt['count'], (state2.step, new_opt['count'])
+  e_mu = ((got_mu - ref_mu).abs() / (ref_mu.abs() + 1e-5 * ref_mu.abs().max() + 1e-30)).max().item()
+  e_nu = ((got_nu - ref_nu).abs() / (ref_nu.abs() + 1e-5 * ref_nu.abs().max() + 1e-30)).max().item()
+  # the update itself, relative to the learning rate (|update| <= ~lr): 1e-3 lr absolute + fp32 rounding of the parameter
+  upd_err = ((got_p - ref_p).abs() - 2.0 ** -23 * ref_p.abs()).clamp_min(0).max().item() / lr
+  print(f'{what}Adam vs oracle on the kernel gradient: mu rel {e_mu:.2e}, nu rel {e_nu:.2e}, |update err| / lr {upd_err:.2e} (lr {lr:.3e})')
+  assert e_mu < 1e-4 and e_nu < 2e-4 and upd_err < 1e-3, (e_mu, e_nu, upd_err)
+  return state2.mu.detach().clone(), state2.nu.detach().clone(), state2.step

@@ -133,10 +133,11 @@ def test_resample_level(ops, case):
                                  single_jitter=c['single'], max_jitter=max_jitter, raydist_fn=c['raydist'],
                                  want_idx=True)
   mismatch = (idx.cpu() != idx_ref).float().mean().item()
-  # End-to-end the CDF depends on device expf/logf (<= 1 ulp from the host's): indices may flip
-  # only where u lands within an ulp of a CDF fence-post.  Report + bound the rate.
-  print(f'{case}: index mismatch rate {mismatch:.2e}')
-  assert mismatch < 2e-3
+  # Sample indices are bit-exact (north_star): the kernel and the oracle sum the softmax denominator and the CDF in
+  # the same documented order, so an index can only differ where device expf/logf and the host's differ by an ulp AND
+  # u lands on that ulp of a CDF fence-post: 0 of 12800..25600 indices on these seeded cases.
+  print(f'{case}: index mismatch rate {mismatch:.2e} ({int((idx.cpu() != idx_ref).sum())} of {idx_ref.numel()})')
+  assert mismatch == 0
   same = (idx.cpu() == idx_ref).all(-1)
   # (u - cw0)/(cw1 - cw0) amplifies the <=1-ulp softmax differences inside narrow bins: 5e-5 in s.
   np.testing.assert_allclose(s.cpu().numpy(), s_ref.numpy(), atol=5e-5, rtol=0)

@@ -67,6 +67,8 @@ CASES = [
     ('blender_256', ['NerfMLP.net_depth_viewdirs = 6', 'NerfMLP.skip_layer_dir = 2'], 16),
     # weight regulariser per top-level module (train_utils.py:300-305)
     ('blender_256', ["Config.weight_decay_mults = {'NerfMLP_0': 3e-5, 'PropMLP_0': 1e-5}"], 16),
+    # the north-star's synthetic shape: 192 samples per ray = levels (64, 64, 64)
+    ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_nerf_samples = 64'], 16),
 ]
 
 
@@ -165,17 +167,25 @@ def test_train_step_parity(name, extra, B):
         if nelem >= 8:   # scalars (Dense(1) biases) are sums with full cancellation: noise, not signal
           worst = max(worst, rel / max(0.05, 1.5 * cost))
   assert worst <= 1.0, worst
-  # one Adam step
+  # one Adam step, numerically: the oracle's clip + nan_to_num + Adam on the kernel's own gradient (helpers), ...
+  opt1 = helpers.assert_adam_matches_oracle(model, cfg, flat, g, None, state2, what=f'{name} step 1: ')
+  # ... and the update direction against the oracle's own step (its gradient carries bf16 noise: where that gradient
+  # is significant the two first-step updates, lr * g / (|g| + eps), agree in sign)
   ref_flat = model.flat_from_tree(new_p, device='cpu')
   got = state2.params['flat'].cpu()
   upd_ref = ref_flat - flat.cpu()
   upd = got - flat.cpu()
-  # first Adam step is lr * sign-like; compare where the reference gradient is not ~0.
   big = g_ref.abs() > 1e-3 * g_ref.abs().max()
   agree = (torch.sign(upd[big]) == torch.sign(upd_ref[big])).float().mean().item()
   print(f'{name}: Adam update sign agreement on significant grads {agree:.4f}')
   assert agree > 0.97
   assert state2.step == 1
+  # a second step from non-zero moments (bias correction with t = 2, the schedule at count 1)
+  flat1 = state2.params['flat'].detach().clone()
+  state3, stats3, _ = step(0, state2, batch_d, None, tf, 0.0, noise=noise, return_grads=True)
+  torch.cuda.synchronize()
+  helpers.assert_adam_matches_oracle(model, cfg, flat1, stats3['_grads'], opt1, state3, what=f'{name} step 2: ')
+  assert state3.step == 2
 
 
 def test_unsupported_features_fail_loudly():

@@ -140,8 +140,11 @@ def test_full_batch_gradient_is_the_mean_of_its_quarters(setup):
     rel = ((a - r).norm() / (r.norm() + 1e-30)).item()
     print(f'{name}: |g(full) - mean g(quarters)| / |g| = {rel:.2e}  (|g| = {r.norm().item():.3e})')
     assert rel < 1e-3, (name, rel)
-  # one Adam step from zero moments: |update| <= lr / (1 - eps-ish), nothing non-finite
+  # one Adam step from zero moments, numerically: the oracle's clip + nan_to_num + Adam (train_utils.py:326-330)
+  # applied to the KERNEL's own raw gradient must reproduce the kernel's parameters and moments.
+  flat0 = flat.double().cpu()
   new = state2.params['flat'].double().cpu()
-  lr = train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})[1](0)
   assert torch.isfinite(new).all()
-  assert (new - flat.double()).abs().max().item() <= 1.01 * lr + 1e-7          # (+ fp32 rounding of the parameters)
+  lr = float(train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})[1](0))
+  assert (new - flat0).abs().max().item() <= 1.01 * lr + 1e-7          # (+ fp32 rounding of the parameters)
+  helpers.assert_adam_matches_oracle(model, cfg, flat.float().cpu(), g_full.float(), None, state2)
