@@ -203,6 +203,40 @@ int mnr_gemm_nt_set_config(int cfg_big, int cfg_small);
  * the M tiles); n > 1 = the same with at most n workgroups. */
 int mnr_gemm_nt_set_wres(int max_wgs);
 
+/* ---- Fused Dense chain (csrc/fused_mlp.hip): the proposal MLP of internal/models.py:441-465 (net_depth <= skip_layer:
+ * Dense + ReLU layers without a skip concat) and its Dense(1) density head (:460) as ONE persistent kernel per sampling
+ * level; replaces depth + 1 mnr_gemm_nt_bf16 launches (forward) / the dX chain (backward).  The activation tile of a
+ * 256-row block stays in LDS between layers; weights go global -> registers. */
+#define MNR_CHAIN_MAX_DEPTH 8
+typedef struct {
+  int64_t M;                  /* rows (samples of the level): a multiple of 256 */
+  int W;                      /* layer width: 128 or 256 */
+  int depth;                  /* number of Dense + ReLU layers, 1..MNR_CHAIN_MAX_DEPTH */
+  const uint16_t* feat;       /* [M, ld_feat] bf16: input of layer 0 (IPE features), columns >= fan_in zero */
+  int ld_feat; int K0;        /* K0 = padded fan_in of layer 0, a multiple of 64 */
+  const uint16_t* Bt[MNR_CHAIN_MAX_DEPTH];   /* layer i: [W, ldb[i]] bf16 = kernel^T (row = output column) */
+  int ldb[MNR_CHAIN_MAX_DEPTH];
+  const float* bias[MNR_CHAIN_MAX_DEPTH];    /* [W] fp32 */
+  const uint16_t* w_head;     /* [W] bf16 Dense(1) kernel applied to the last activation; NULL: no head */
+  const float* b_head;        /* [1] fp32 on the device (NULL: 0) */
+  float* head_out;            /* [M] fp32: x_last . w_head + b_head */
+  uint16_t* acts[MNR_CHAIN_MAX_DEPTH];       /* optional out: activation of layer i, [M, W] bf16 (training: dW inputs) */
+  uint8_t* bits[MNR_CHAIN_MAX_DEPTH];        /* optional out: its ReLU mask, 1 bit per element, [M, W/8] */
+} mnr_mlp_chain_fwd_args;
+int mnr_mlp_chain_fwd(const mnr_mlp_chain_fwd_args* args, void* stream);
+
+typedef struct {
+  int64_t M; int W; int depth;
+  const float* g_head;        /* [M] fp32: gradient w.r.t. the head output (from mnr_composite_bwd) */
+  const float* w_head;        /* [W] fp32 head kernel */
+  const uint8_t* bits[MNR_CHAIN_MAX_DEPTH];  /* ReLU masks written by the forward pass */
+  const uint16_t* Bw[MNR_CHAIN_MAX_DEPTH];   /* layer i >= 1: [W, ldb[i]] bf16 = kernel as flax stores it (row = input) */
+  int ldb[MNR_CHAIN_MAX_DEPTH];
+  uint16_t* dY[MNR_CHAIN_MAX_DEPTH];         /* out: gradient w.r.t. layer i's pre-activation, [M, W] bf16
+                                                (dY[depth-1] = mask * (g_head (x) w_head) may be NULL: not stored) */
+} mnr_mlp_chain_bwd_args;
+int mnr_mlp_chain_bwd(const mnr_mlp_chain_bwd_args* args, void* stream);
+
 typedef struct {
   const uint16_t* A; int lda; int K;   /* A [M, lda] bf16, K columns used, K multiple of 128 */
   const uint16_t* B; int ldb; int N;   /* B [M, ldb] bf16, N columns used, N multiple of 128 */

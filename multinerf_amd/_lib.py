@@ -61,6 +61,24 @@ class GemmTNArgs(C.Structure):
               ('bias_out', vp), ('bias_n_valid', C.c_int)]
 
 
+CHAIN_MAX_DEPTH = 8
+
+
+class MlpChainFwdArgs(C.Structure):
+  _fields_ = [('M', C.c_int64), ('W', C.c_int), ('depth', C.c_int),
+              ('feat', vp), ('ld_feat', C.c_int), ('K0', C.c_int),
+              ('Bt', vp * CHAIN_MAX_DEPTH), ('ldb', C.c_int * CHAIN_MAX_DEPTH), ('bias', vp * CHAIN_MAX_DEPTH),
+              ('w_head', vp), ('b_head', vp), ('head_out', vp),
+              ('acts', vp * CHAIN_MAX_DEPTH), ('bits', vp * CHAIN_MAX_DEPTH)]
+
+
+class MlpChainBwdArgs(C.Structure):
+  _fields_ = [('M', C.c_int64), ('W', C.c_int), ('depth', C.c_int),
+              ('g_head', vp), ('w_head', vp),
+              ('bits', vp * CHAIN_MAX_DEPTH), ('Bw', vp * CHAIN_MAX_DEPTH), ('ldb', C.c_int * CHAIN_MAX_DEPTH),
+              ('dY', vp * CHAIN_MAX_DEPTH)]
+
+
 class PackDesc(C.Structure):
   _fields_ = [('src_off', C.c_int64), ('rows_in', C.c_int), ('cols_out', C.c_int),
               ('dst_off', C.c_int64), ('ld', C.c_int), ('row0', C.c_int), ('col0', C.c_int),
@@ -105,6 +123,8 @@ _PROTOS = {
     'mnr_gemm_nt_set_config': ([i32, i32], i32),
     'mnr_gemm_nt_set_wres': ([i32], i32),
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
+    'mnr_mlp_chain_fwd': ([C.POINTER(MlpChainFwdArgs), vp], i32),
+    'mnr_mlp_chain_bwd': ([C.POINTER(MlpChainBwdArgs), vp], i32),
     'mnr_gemm_tn_set_config': ([i32], i32),
     'mnr_gemm_tn_set_split': ([i32], i32),
     'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),

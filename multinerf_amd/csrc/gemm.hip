@@ -347,7 +347,7 @@ typedef NtCfg<4, 2, 2, 2, 32, 3, 2> NtC39;           //   same, 3 stages (72 KiB
 typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
 typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register double-buffered fragments
 
-static int g_nt_cfg_big = 2, g_nt_cfg_small = 0;
+static int g_nt_cfg_big = 43, g_nt_cfg_small = 0;   // NtC43: round-2 A/B winner (bias row in LDS, batched epilogue reads)
 
 extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
   MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 45 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
@@ -787,11 +787,11 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
 }
 
 static int g_tn_big_min_tiles = 1;
-static int g_tn_split = 0;
+static int g_tn_split = 2;                        // TnBigImm: round-2 A/B winner (immediate-offset transpose reads)
 
 // Probe hook: 1 = the 256x256-tile launches use the split-path kernel (TnBigSplit).
 extern "C" int mnr_gemm_tn_set_split(int on) {
-  g_tn_split = (on == 1 || on == 2) ? on : 0;
+  g_tn_split = (on == 1 || on == 2) ? on : 0;     // 0: the round-1 loop
   return MNR_OK;
 }
 

@@ -37,6 +37,7 @@ def _rup(x, m):
 
 import os as _os
 _USE_BITS = _os.environ.get('MNR_RELU_BITS', '1') != '0'   # A/B switch: 1-bit ReLU masks vs re-reading activations
+_USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused per-level Dense chain vs one GEMM per layer
 
 
 # =============================================================================
@@ -718,9 +719,33 @@ class Model:
     """A [rows, ld] view into the packed bf16 operand buffer."""
     return plan.wbf[off:off + rows * ld].view(rows, ld)
 
+  @staticmethod
+  def _chain_ok(plan: MLPPlan):
+    """The fused per-level kernel (csrc/fused_mlp.hip) covers density-only MLPs without a skip concat: PropMLP."""
+    return (_USE_CHAIN and not plan.has_rgb and not plan.ref and plan.W in (128, 256) and
+            1 <= len(plan.trunk) <= L.CHAIN_MAX_DEPTH and not any(c for _, c in plan.trunk))
+
+  def _chain_forward(self, plan: MLPPlan, flat, feat, M, tag, keep):
+    """models.py:441-465 for a density-only MLP as ONE launch: every Dense + ReLU layer and the density head."""
+    W, D = plan.W, len(plan.trunk)
+    acts = [self._buf((tag, 'act', i), (M, W), bf16) for i in range(D)] if keep else None
+    bits = [self._buf((tag, 'bits', i), (M, W // 8), torch.uint8) for i in range(D)] if keep else None
+    layers = []
+    for i, (d, _) in enumerate(plan.trunk):
+      e = plan.packed[('trunk', i)]
+      layers.append((self._w(plan, e['f_off'], e['n_pad'], e['f_ld']), flat[d.bias_off:d.bias_off + d.fan_out]))
+    e = plan.packed['density']
+    d = plan.density
+    raw_density = self._buf((tag, 'raw_density'), (M,), f32)
+    ops.mlp_chain_fwd(feat, plan.ldF, layers, M=M, W=W, w_head=self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])[0],
+                      b_head=flat[d.bias_off:d.bias_off + 1], head_out=raw_density, acts=acts, bits=bits)
+    return dict(acts=acts or [], bits=bits or [], raw_density=raw_density, chain=True)
+
   def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep, tdist=None):
     """MLP.__call__ (models.py:402-612) for the M = B*n samples of one level."""
     hp = plan.hp
+    if self._chain_ok(plan):
+      return self._chain_forward(plan, flat, feat, M, tag, keep)
     need_bits = (keep and _USE_BITS) or plan.ref
     acts, bits = [], []
     x = None
@@ -845,8 +870,9 @@ class Model:
     acts = mlp['acts']
     x_last = acts[-1]
     W = plan.W
-    dA = self._buf(('bwd', 'dA', W), (M, W), bf16)       # ping-pong dY buffers (shared across levels)
-    dB = self._buf(('bwd', 'dB', W), (M, W), bf16)
+    if not mlp.get('chain'):
+      dA = self._buf(('bwd', 'dA', W), (M, W), bf16)     # ping-pong dY buffers (shared across levels)
+      dB = self._buf(('bwd', 'dB', W), (M, W), bf16)
 
     def gslice(off, size):
       return grads[off:off + size]
@@ -956,6 +982,22 @@ class Model:
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], density_noise=lv['dnoise'],
           bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights, want_f32=True)
       d = plan.density
+      if mlp.get('chain'):
+        # fused dX chain: head dW / db from the last activation, then every dY_i in one launch; dW_i = x_{i-1}^T dY_i below
+        w_head = flat[d.kernel_off:d.kernel_off + W]
+        ops.small_head_bwd(x_last, W, g_raw_density.view(M, 1), w_head.view(W, 1), M=M, K=W, Cn=1, dX=None,
+                           relu_mask=False, dW=gslice(d.kernel_off, W), db=gslice(d.bias_off, 1))
+        D = len(plan.trunk)
+        dYs = [self._buf(('bwd', 'dYc', W, i), (M, W), bf16) for i in range(D)]
+        Bws = [None] + [self._w(plan, plan.packed[('trunk', i)]['b_off'], _rup(W, 128), plan.packed[('trunk', i)]['b_ld'])
+                        for i in range(1, D)]
+        ops.mlp_chain_bwd(g_raw_density.view(M), w_head, mlp['bits'], Bws, dYs, M=M, W=W)
+        feat = lv['feat']
+        for i, (dl, _) in enumerate(plan.trunk):
+          inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
+          ops.gemm_tn(inp, dYs[i], gslice(dl.kernel_off, kv * W), M=M, K=in_w, N=W, lda=in_w, ldb=W, ldc=W,
+                      k_valid=kv, n_valid=W, bias_out=gslice(dl.bias_off, W), bias_n_valid=W)
+        return
       ops.small_head_bwd(x_last, W, g_raw_density.view(M, 1), flat[d.kernel_off:d.kernel_off + W].view(W, 1),
                          M=M, K=W, Cn=1, dX=dA, lddx=W, relu_mask=True,
                          dW=gslice(d.kernel_off, W), db=gslice(d.bias_off, 1))

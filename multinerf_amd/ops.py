@@ -54,7 +54,7 @@ def lib():
       L.check(L.load().mnr_gemm_nt_set_config(big, small))
     if os.environ.get('MNR_NT_WRES'):           # tuning hook: weights-resident kernel for the short-K layers (csrc/gemm.hip)
       L.check(L.load().mnr_gemm_nt_set_wres(int(os.environ['MNR_NT_WRES'])))
-    if os.environ.get('MNR_TN_SPLIT') in ('1', '2'):   # tuning hook: csrc/gemm.hip TnBigSplit (1) / TnBigImm (2)
+    if os.environ.get('MNR_TN_SPLIT') in ('0', '1', '2'):   # tuning hook: csrc/gemm.hip TnBigSplit (1) / TnBigImm (2)
       L.check(L.load().mnr_gemm_tn_set_split(int(os.environ['MNR_TN_SPLIT'])))
   return L.load()
 
@@ -306,6 +306,67 @@ def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, 
   a.bias_n_valid = bias_n_valid
   _e = PROFILE.start()
   L.check(lib().mnr_gemm_tn_bf16(C.byref(a), _stream()))
+  PROFILE.stop(_e)
+
+
+def mlp_chain_fwd(feat, K0, layers, *, M, W, w_head=None, b_head=None, head_out=None, acts=None, bits=None):
+  """Fused Dense + ReLU chain with a Dense(1) head (csrc/fused_mlp.hip): `layers` = [(Bt [W, ldb] bf16, bias [W] fp32)],
+  layer 0 reading feat [M, ld_feat] over K0 columns.  acts / bits: optional per-layer outputs (training)."""
+  depth = len(layers)
+  if not 1 <= depth <= L.CHAIN_MAX_DEPTH:
+    raise ValueError(f'mlp_chain_fwd: depth {depth}')
+  _chk(feat, bf16, 'feat')
+  _chk(w_head, bf16, 'w_head', allow_none=True)
+  _chk(b_head, f32, 'b_head', allow_none=True)
+  _chk(head_out, f32, 'head_out', allow_none=True)
+  a = L.MlpChainFwdArgs()
+  a.M, a.W, a.depth = M, W, depth
+  a.feat, a.ld_feat, a.K0 = feat.data_ptr(), feat.stride(0), K0
+  for i, (Bt, bias) in enumerate(layers):
+    _chk(Bt, bf16, f'Bt[{i}]')
+    _chk(bias, f32, f'bias[{i}]')
+    assert Bt.shape[0] >= W and bias.numel() == W
+    a.Bt[i], a.ldb[i], a.bias[i] = Bt.data_ptr(), Bt.stride(0), bias.data_ptr()
+    if acts is not None and acts[i] is not None:
+      _chk(acts[i], bf16, f'acts[{i}]')
+      assert acts[i].shape == (M, W)
+      a.acts[i] = acts[i].data_ptr()
+    if bits is not None and bits[i] is not None:
+      _chk(bits[i], torch.uint8, f'bits[{i}]')
+      assert bits[i].shape == (M, W // 8)
+      a.bits[i] = bits[i].data_ptr()
+  if w_head is not None:
+    assert w_head.numel() >= W and head_out is not None and head_out.numel() == M
+    a.w_head, a.head_out = w_head.data_ptr(), head_out.data_ptr()
+    a.b_head = b_head.data_ptr() if b_head is not None else None
+  _e = PROFILE.start()
+  L.check(lib().mnr_mlp_chain_fwd(C.byref(a), _stream()))
+  PROFILE.stop(_e)
+
+
+def mlp_chain_bwd(g_head, w_head, bits, Bws, dYs, *, M, W):
+  """The dX chain of the fused Dense stack: dY[last] = mask * (g_head (x) w_head), dY[i-1] = mask_{i-1} * (dY[i] W_i^T).
+  Bws[i] (i >= 1): [W, ldb] bf16 kernel as stored (rows = inputs); Bws[0] unused."""
+  depth = len(bits)
+  _chk(g_head, f32, 'g_head')
+  _chk(w_head, f32, 'w_head')
+  assert g_head.numel() == M and w_head.numel() == W and len(dYs) == depth and len(Bws) == depth
+  a = L.MlpChainBwdArgs()
+  a.M, a.W, a.depth = M, W, depth
+  a.g_head, a.w_head = g_head.data_ptr(), w_head.data_ptr()
+  for i in range(depth):
+    _chk(bits[i], torch.uint8, f'bits[{i}]')
+    assert bits[i].shape == (M, W // 8)
+    a.bits[i] = bits[i].data_ptr()
+    if dYs[i] is not None:
+      _chk(dYs[i], bf16, f'dY[{i}]')
+      assert dYs[i].shape == (M, W)
+      a.dY[i] = dYs[i].data_ptr()
+    if i >= 1:
+      _chk(Bws[i], bf16, f'Bw[{i}]')
+      a.Bw[i], a.ldb[i] = Bws[i].data_ptr(), Bws[i].stride(0)
+  _e = PROFILE.start()
+  L.check(lib().mnr_mlp_chain_bwd(C.byref(a), _stream()))
   PROFILE.stop(_e)
 
 

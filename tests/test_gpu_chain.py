@@ -1,0 +1,107 @@
+"""The fused per-level Dense chain (csrc/fused_mlp.hip) against the per-layer GEMM path it replaces.  -m gpu.
+
+Both paths feed the same bf16 operands to the same MFMA instruction in the same k order and apply the same bias / ReLU /
+rounding, so the layer activations, their 1-bit masks and the dX chain must agree BIT FOR BIT; the Dense(1) head sums
+256 products in a different order (fp32) and the weight gradients go through fp32 atomics: those are held to 1e-5.
+The composed tests (tests/test_gpu_model.py) hold the fused path to the oracle.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multinerf_amd import configs, models, train_utils
+from oracle import models as omodels
+from tests import helpers
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _gpu():
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+
+
+def _run(use_chain, cfg, flat, batch, noise, monkeypatch):
+  monkeypatch.setattr(models, '_USE_CHAIN', use_chain)
+  model = models.Model(config=cfg).build('cuda')
+  state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})
+  step = train_utils.create_train_step(model, cfg)
+  _, stats, _ = step(0, state, batch.map(lambda t: t.cuda()), None, 0.4, 0.0,
+                     noise={k: {lv: t.cuda() for lv, t in d.items()} for k, d in noise.items()}, return_grads=True)
+  torch.cuda.synchronize()
+  saved = model._saved['levels']
+  out = dict(grads=stats['_grads'].cpu(), loss=stats.materialize()['loss'], model=model)
+  for li, lv in enumerate(saved[:-1]):
+    assert bool(lv['mlp'].get('chain')) == use_chain
+    out[li] = dict(acts=[a.cpu().clone() for a in lv['mlp']['acts']], bits=[b.cpu().clone() for b in lv['mlp']['bits']],
+                   raw=lv['mlp']['raw_density'].cpu().clone(), sdist=lv['sdist'].cpu().clone(), weights=lv['weights'].cpu().clone())
+  return out
+
+
+@pytest.mark.parametrize('W,bindings,B', [
+    (256, ['NerfMLP.net_width = 128'], 24),                                            # 360.gin's PropMLP as is: K0 = 512
+    (128, ['NerfMLP.net_width = 128', 'PropMLP.net_width = 128', 'PropMLP.net_depth = 3'], 16),
+    (256, ['NerfMLP.net_width = 128', 'PropMLP.basis_shape = "octahedron"', 'PropMLP.basis_subdivisions = 1',
+           'PropMLP.max_deg_point = 16', 'PropMLP.net_depth = 2'], 8),                 # K0 = 128, two layers
+])
+def test_fused_chain_equals_per_layer_path(W, bindings, B, monkeypatch):
+  cfg = configs.load_preset('360', bindings)
+  m0 = models.Model(config=cfg).build('cuda')
+  assert m0.prop_plan.W == W and models.Model._chain_ok(m0.prop_plan)
+  om, on, op = helpers.oracle_hparams(m0)
+  params = omodels.init_params(om, on, op, seed=5)
+  g = torch.Generator().manual_seed(6)
+  for mod in params.values():
+    for d in mod.values():
+      if isinstance(d, dict) and 'bias' in d:
+        d['bias'] = 0.05 * torch.randn(d['bias'].shape, generator=g)
+  flat = m0.flat_from_tree(params)
+  batch = helpers.synthetic_rays(B, near=cfg.near, far=cfg.far)
+  noise = helpers.make_noise(m0, B)
+  a = _run(True, cfg, flat, batch, noise, monkeypatch)
+  b = _run(False, cfg, flat, batch, noise, monkeypatch)
+  # level 0 sees identical inputs on both paths: bitwise activations and masks, head to fp32 rounding
+  for i, (x, y) in enumerate(zip(a[0]['acts'], b[0]['acts'])):
+    assert torch.equal(x.view(torch.int16), y.view(torch.int16)), f'level 0 activation {i}'
+  for i, (x, y) in enumerate(zip(a[0]['bits'], b[0]['bits'])):
+    assert torch.equal(x, y), f'level 0 mask bits {i}'
+  scale = b[0]['raw'].abs().max().item()
+  err = (a[0]['raw'] - b[0]['raw']).abs().max().item()
+  print(f'W={W}: head |fused - per-layer| = {err:.2e} (|raw| <= {scale:.2e})')
+  assert err <= 2e-6 * max(scale, 1.0)
+  # the dX chain on identical inputs (level 0's saved masks, a seeded head gradient): bitwise against
+  # small_head_bwd + one masked NT GEMM per layer
+  model = a['model']
+  plan = model.prop_plan
+  lv = model._saved['levels'][0]
+  M, D = lv['M'], len(plan.trunk)
+  bits = lv['mlp']['bits']
+  acts = lv['mlp']['acts']
+  g_head = (torch.randn((M,), generator=torch.Generator().manual_seed(7)) * 0.01).cuda()
+  w_head = flat.cuda()[plan.density.kernel_off:plan.density.kernel_off + W].contiguous()
+  dYs = [torch.empty((M, W), dtype=torch.bfloat16, device='cuda') for _ in range(D)]
+  Bws = [None] + [model._w(plan, plan.packed[('trunk', i)]['b_off'], models._rup(W, 128), plan.packed[('trunk', i)]['b_ld'])
+                  for i in range(1, D)]
+  ops = models.ops
+  ops.mlp_chain_bwd(g_head, w_head, bits, Bws, dYs, M=M, W=W)
+  ref = torch.empty((M, W), dtype=torch.bfloat16, device='cuda')
+  ops.small_head_bwd(acts[-1], W, g_head.view(M, 1), w_head.view(W, 1), M=M, K=W, Cn=1, dX=ref, lddx=W, relu_mask=True)
+  torch.cuda.synchronize()
+  assert torch.equal(ref.view(torch.int16), dYs[-1].view(torch.int16)), 'dY of the last layer'
+  for i in reversed(range(1, D)):
+    nxt = torch.empty((M, W), dtype=torch.bfloat16, device='cuda')
+    ops.gemm_nt(ref, Bws[i], M=M, N=models._rup(W, 128), K1=plan.packed[('trunk', i)]['b_ld'], Cb=nxt, ldcb=W, nb=W,
+                bits_in=bits[i - 1])
+    torch.cuda.synchronize()
+    assert torch.equal(nxt.view(torch.int16), dYs[i - 1].view(torch.int16)), f'dY of layer {i - 1}'
+    ref = nxt
+  # end to end: downstream of the head's last-ulp differences everything stays close
+  np.testing.assert_allclose(a[1]['sdist'].numpy(), b[1]['sdist'].numpy(), atol=2e-5)
+  assert abs(a['loss'] - b['loss']) <= 1e-3 * abs(b['loss'])
+  for name, lo, hi in model.modules:
+    x, y = a['grads'][lo:hi].double(), b['grads'][lo:hi].double()
+    rel = ((x - y).norm() / (y.norm() + 1e-30)).item()
+    print(f'W={W} {name}: |g(fused) - g(per-layer)| / |g| = {rel:.2e}')
+    assert rel < 5e-2, (name, rel)       # (samples move with the head's last ulp: not bitwise, but small)
