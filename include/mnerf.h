@@ -198,6 +198,8 @@ int mnr_debug_gemm_timeline(unsigned long long* device_buffer);
 int mnr_pack_w_frag_bf16(const uint16_t* Bt, int ldb, int N, int K, uint16_t* out, void* stream);
 int mnr_debug_gemm_wfrag(const uint16_t* image);
 int mnr_gemm_nt_set_config(int cfg_big, int cfg_small);
+/* Tuning hook: 0 = one workgroup per output tile; n > 0 = persistent launches (n workgroups per CU walk the tiles). */
+int mnr_gemm_nt_set_persistent(int wgs_per_cu);
 /* Probe hook: 0 = off; 1 = eligible short-K launches (N = 256, K1 <= 256, K2 = 0, full-width bf16 output, no fp32 side
  * output, no bf16 mask) go to the weights-resident persistent kernel (weights in registers, one workgroup per CU walking
  * the M tiles); n > 1 = the same with at most n workgroups. */
@@ -236,6 +238,9 @@ typedef struct {
                                                 (dY[depth-1] = mask * (g_head (x) w_head) may be NULL: not stored) */
 } mnr_mlp_chain_bwd_args;
 int mnr_mlp_chain_bwd(const mnr_mlp_chain_bwd_args* args, void* stream);
+/* Profiling hook: device buffer of 32 uint64 per workgroup, stamped (s_memtime per phase of the workgroup's second tile,
+ * see csrc/fused_mlp.hip) by every following mnr_mlp_chain_fwd / _bwd launch; NULL switches it off. */
+int mnr_debug_chain_timeline(unsigned long long* device_buffer);
 
 typedef struct {
   const uint16_t* A; int lda; int K;   /* A [M, lda] bf16, K columns used, K multiple of 128 */

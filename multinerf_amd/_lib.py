@@ -121,10 +121,12 @@ _PROTOS = {
     'mnr_pack_w_frag_bf16': ([vp, i32, i32, i32, vp, vp], i32),
     'mnr_debug_gemm_wfrag': ([vp], i32),
     'mnr_gemm_nt_set_config': ([i32, i32], i32),
+    'mnr_gemm_nt_set_persistent': ([i32], i32),
     'mnr_gemm_nt_set_wres': ([i32], i32),
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
     'mnr_mlp_chain_fwd': ([C.POINTER(MlpChainFwdArgs), vp], i32),
     'mnr_mlp_chain_bwd': ([C.POINTER(MlpChainBwdArgs), vp], i32),
+    'mnr_debug_chain_timeline': ([vp], i32),
     'mnr_gemm_tn_set_config': ([i32], i32),
     'mnr_gemm_tn_set_split': ([i32], i32),
     'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),

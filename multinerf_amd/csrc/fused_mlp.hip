@@ -27,20 +27,29 @@
 #define FM_ROWS 256
 #define FM_KT_BYTES 32768                     // one [256][64] bf16 K-tile
 
+// Address arithmetic derived from fm_opaque(tid) cannot be hoisted out of the enclosing loops: hipcc otherwise keeps the
+// lane-dependent addresses of EVERY phase (stage, fragments, epilogue, copy-out) live across the MFMA loops, runs out of
+// its 256 registers and spills them; a reload is a vector-memory operation, and the wait for it (vmcnt(0)) also waits
+// for every LDS-DMA / store issued before it.
+__device__ __forceinline__ int fm_opaque(int v) {
+  MNR_GPU_ONLY(asm volatile("" : "+v"(v)));
+  return v;
+}
+
 __device__ __forceinline__ int fm_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
 // LDS-DMA of a [ROWS][64] bf16 tile (rows row0.., columns k0.. of the row-major matrix g) into lds_tile; the swizzle is
 // applied to the SOURCE address, the DMA image itself is lane-linear (see gemm.hip nt_stage_tile).
 template <int ROWS>
-__device__ __forceinline__ void fm_stage_tile(const bf16* __restrict__ g, int ld, int64_t row0, int k0, char* lds_tile,
-                                              int wave, int lane) {
+__device__ __forceinline__ void fm_stage_tile(const bf16* __restrict__ tile_base, int ld, char* lds_tile, int wave, int lane) {
+  // tile_base (wave-uniform) = &g[row0][k0]; per lane only a 32-bit element offset
 #pragma unroll
   for (int i = 0; i < ROWS * 8 / 512; ++i) {
     const int cbase = (i * 8 + wave) * 64;
     const int c = cbase + lane;
     const int r = c >> 3;
     const int slot = (c & 7) ^ ((r >> 1) & 7);
-    const bf16* src = g + (row0 + r) * (int64_t)ld + k0 + slot * 8;
+    const bf16* src = tile_base + (unsigned)(r * ld + slot * 8);
     __builtin_amdgcn_global_load_lds(MNR_GLOBAL_PTR(src), MNR_LDS_PTR(lds_tile + cbase * 16), 16, 0, 0);
   }
 }
@@ -48,6 +57,26 @@ __device__ __forceinline__ void fm_stage_tile(const bf16* __restrict__ g, int ld
 __device__ __forceinline__ bf16x8 fm_read_frag(const char* kt_tile, int row, int kslot) {
   return *(const bf16x8*)(kt_tile + fm_off(row, kslot));
 }
+
+// Profiling hook (tools/chain_probe.py --timeline): when set, thread 0 of every workgroup stamps s_memtime into
+// g_fm_timeline[32 * blockIdx.x + slot] during its SECOND tile (steady state): slot 0 tile start, 1 layer-0 stream done,
+// 2 + 3*li: layer li's MFMAs done, 3 + 3*li: its epilogue done (tile in LDS), 4 + 3*li: its copy-out issued;
+// s_memrealtime (100 MHz) in slots 30 / 31 at tile start / end.
+__device__ unsigned long long* g_fm_timeline = nullptr;
+
+extern "C" int mnr_debug_chain_timeline(unsigned long long* device_buffer) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_fm_timeline), &device_buffer, sizeof(device_buffer));
+  if (e != hipSuccess) {
+    mnr_set_error("mnr_debug_chain_timeline: %s", hipGetErrorString(e));
+    return MNR_ERR_HIP;
+  }
+  return MNR_OK;
+}
+
+#define FM_STAMP(slot)                                                                                  \
+  do {                                                                                                  \
+    if (tl_on) g_fm_timeline[32 * (int64_t)blockIdx.x + (slot)] = __builtin_amdgcn_s_memtime();         \
+  } while (0)
 
 template <int W>
 struct FmCfg {
@@ -57,7 +86,9 @@ struct FmCfg {
   static constexpr int NKT = W / 64;                   // K-tiles of the resident activation
   static constexpr int X_BYTES = NKT * FM_KT_BYTES;
   static constexpr int STAGE_BYTES = FM_KT_BYTES + W * 128;       // layer 0: feature tile + weight tile [W][64]
-  static constexpr int LDS_BYTES = X_BYTES > 2 * STAGE_BYTES ? X_BYTES : 2 * STAGE_BYTES;
+  static constexpr int LDS_MAIN = X_BYTES > 2 * STAGE_BYTES ? X_BYTES : 2 * STAGE_BYTES;
+  static constexpr int BIAS_OFF = LDS_MAIN;                        // [MNR_CHAIN_MAX_DEPTH][W] fp32 bias rows
+  static constexpr int LDS_BYTES = BIAS_OFF + MNR_CHAIN_MAX_DEPTH * W * 4;
   static constexpr int CPR = W / 8;                    // 16-byte chunks per activation row
   static constexpr int COPY_ITERS = FM_ROWS * CPR / 512;
   static constexpr int ROW_STEP = 512 / CPR;
@@ -69,52 +100,89 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
-// One layer whose input sits in LDS: acc[rb] += X[rows of this wave] * Bt[cols of this wave]^T.
+// One layer whose input sits in LDS: acc[rb] = X[rows of this wave] * Bt[cols of this wave]^T.
 // The wave's weight fragments come global -> registers in chunks of four k-steps (16 registers), the next chunk in
 // flight while this one multiplies; chunk 0 arrives preloaded (`w0`, issued before the previous layer's epilogue).
+// The activation fragments are double-buffered by hand, four row blocks (16 registers) at a time: left to itself hipcc
+// (at ~250 live registers) reads one fragment, waits, multiplies, reads the next.
 #define FM_WCHUNK 4
 __device__ __forceinline__ void fm_load_wchunk(const bf16* __restrict__ Bt, int ldb, int cw, int frow, int khalf, int chunk,
                                                bf16x8 (&w)[FM_WCHUNK]) {
-  const bf16* wsrc = Bt + (int64_t)(cw * 32 + frow) * ldb + khalf * 8 + chunk * (FM_WCHUNK * 16);
+  // (wave-uniform row block + 32-bit lane offset)
+  const bf16* wsrc = Bt + (int64_t)(cw * 32) * ldb + chunk * (FM_WCHUNK * 16) + (unsigned)(frow * ldb + khalf * 8);
 #pragma unroll
   for (int j = 0; j < FM_WCHUNK; ++j) w[j] = *(const bf16x8*)(wsrc + j * 16);
 }
 
 template <int W>
-__device__ __forceinline__ void fm_layer_mfma(const char* X, const bf16* __restrict__ Bt, int ldb, int cw, int rg, int frow,
-                                              int khalf, const bf16x8 (&w0)[FM_WCHUNK], f32x16 (&acc)[FmCfg<W>::RB]) {
+__device__ __forceinline__ void fm_layer_mfma(const char* X, const bf16* __restrict__ Bt, int ldb, int cw, int rg, int lane_,
+                                              const bf16x8 (&w0)[FM_WCHUNK], f32x16 (&acc)[FmCfg<W>::RB]) {
   typedef FmCfg<W> C;
-  constexpr int NCH = W / 16 / FM_WCHUNK;
+  const int lane = fm_opaque(lane_), frow = lane & 31, khalf = lane >> 5;
+  constexpr int NKS = W / 16;
+  constexpr int NCH = NKS / FM_WCHUNK;
+  constexpr int HB = C::RB > 4 ? 4 : C::RB;            // row blocks per fragment batch
+  constexpr int NH = C::RB / HB;
+  constexpr int STEPS = NKS * NH;
+#pragma unroll
+  for (int rb = 0; rb < C::RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+  // lane part of the fragment address: row = (rg*RB + rb)*32 + frow, slot = (ks&3)*2 + khalf; the swizzle term
+  // (row >> 1) & 7 = (frow >> 1) & 7 does not depend on the row block
+  const int sw = (frow >> 1) & 7;
+  const char* xrow = X + (rg * C::RB * 32 + frow) * 128;
+  auto read_batch = [&](int step, bf16x8 (&fa)[HB]) {
+    const int ks = step / NH, h = step % NH;
+    const char* base = xrow + (ks >> 2) * FM_KT_BYTES + h * HB * 4096 + ((((ks & 3) * 2 + khalf) ^ sw) << 4);
+#pragma unroll
+    for (int i = 0; i < HB; ++i) fa[i] = *(const bf16x8*)(base + i * 4096);
+  };
   bf16x8 wq[2][FM_WCHUNK];
 #pragma unroll
   for (int j = 0; j < FM_WCHUNK; ++j) wq[0][j] = w0[j];
+  bf16x8 fa[2][HB];
+  read_batch(0, fa[0]);
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    if (c + 1 < NCH) fm_load_wchunk(Bt, ldb, cw, frow, khalf, c + 1, wq[(c + 1) & 1]);
-#pragma unroll
-    for (int j = 0; j < FM_WCHUNK; ++j) {
-      const int ks = c * FM_WCHUNK + j;
-      const char* kt = X + (ks >> 2) * FM_KT_BYTES;
-      constexpr int HB = C::RB > 4 ? 4 : C::RB;          // four row blocks at a time: 16 fragment registers
-#pragma unroll
-      for (int h = 0; h < C::RB / HB; ++h) {
-        bf16x8 fa[HB];
-#pragma unroll
-        for (int i = 0; i < HB; ++i) fa[i] = fm_read_frag(kt, (rg * C::RB + h * HB + i) * 32 + frow, (ks & 3) * 2 + khalf);
-#pragma unroll
-        for (int i = 0; i < HB; ++i)
-          acc[h * HB + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[c & 1][j], fa[i], acc[h * HB + i], 0, 0, 0);
-      }
+  for (int step = 0; step < STEPS; ++step) {
+    const int ks = step / NH, h = step % NH;
+    const int c = ks / FM_WCHUNK, j = ks % FM_WCHUNK;
+    if (j == 1 && h == 0 && c + 1 < NCH) {
+      // issue the next chunk's four loads HERE, one k-step into this chunk (at the chunk's first step hipcc would wait
+      // vmcnt(0), i.e. for these loads too, before the first MFMA; they have three k-steps to land) (left to the scheduler they sink to their first use, one L2 round trip
+      // per k-step in front of its MFMAs)
+      __builtin_amdgcn_sched_barrier(0);
+      fm_load_wchunk(Bt, ldb, cw, frow, khalf, c + 1, wq[(c + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (step + 1 < STEPS) {
+      read_batch(step + 1, fa[(step + 1) & 1]);
+      __builtin_amdgcn_sched_group_barrier(0x100, HB, 0);          // this step's (next-batch) ds_reads first ...
+    }
+#pragma unroll
+    for (int i = 0; i < HB; ++i)
+      acc[h * HB + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[c & 1][j], fa[step & 1][i], acc[h * HB + i], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, HB, 0);            // ... then its MFMAs
   }
 }
 
 // acc -> bf16 -> the LDS activation tile.  Forward: + bias, ReLU.  Backward: ReLU mask bits of the layer below.
 // acc[rb][r]: column n = cw*32 + (r&3) + 8*(r>>2) + 4*khalf, row m = (rg*RB + rb)*32 + frow.
 template <int W, bool BWD>
-__device__ __forceinline__ void fm_epilogue(char* X, int cw, int rg, int frow, int khalf, f32x16 (&acc)[FmCfg<W>::RB],
-                                            const float (&bias_r)[16], const unsigned (&mbits)[FmCfg<W>::RB]) {
+__device__ __forceinline__ void fm_epilogue(char* X, int cw, int rg, int lane_, f32x16 (&acc)[FmCfg<W>::RB],
+                                            const float* __restrict__ bias, const unsigned (&mbits)[FmCfg<W>::RB]) {
   typedef FmCfg<W> C;
+  const int lane = fm_opaque(lane_), frow = lane & 31, khalf = lane >> 5;
+  float bias_r[16];
+  if constexpr (!BWD) {                                  // `bias`: this layer's row in LDS (parked there once per kernel)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 b4 = *(const f32x4*)(bias + cw * 32 + rq * 8 + khalf * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias_r[rq * 4 + e] = b4[e];
+    }
+  }
+  const int sw = (frow >> 1) & 7;
 #pragma unroll
   for (int rb = 0; rb < C::RB; ++rb) {
     const int ml = (rg * C::RB + rb) * 32 + frow;
@@ -143,47 +211,85 @@ __device__ __forceinline__ void fm_epilogue(char* X, int cw, int rg, int frow, i
         d1 &= (b2 & 0xffffu) | (b3 & 0xffff0000u);
       }
       const i32x2 pk = {(int)d0, (int)d1};
-      *(i32x2*)(X + (nl >> 6) * FM_KT_BYTES + fm_off(ml, (nl & 63) >> 3) + (nl & 7) * 2) = pk;
+      *(i32x2*)(X + (nl >> 6) * FM_KT_BYTES + ml * 128 + ((((nl & 63) >> 3) ^ sw) << 4) + (nl & 7) * 2) = pk;
     }
   }
 }
 
 // The LDS activation tile -> global memory in full rows (16 B per lane), the 1-bit "> 0" masks, and (forward, last
 // layer) the Dense(1) head: 8-element partial dot products reduced over the W/8 lanes that share a row.
-template <int W>
-__device__ __forceinline__ void fm_copy_out(const char* X, int tid, int64_t m0, bf16* __restrict__ dst, uint8_t* __restrict__ bits,
-                                            const float (&whead)[8], bool do_head, float b_head, float* __restrict__ head_out) {
+// A rolled loop over batches of four rows with running pointers: fully unrolled, hipcc hoists the 16 x 2 addresses out
+// of the tile loop, spills them, and every reload (a vmcnt operation) then waits for the stores before it.
+template <int W, bool DST, bool BITS, bool HEAD>
+__device__ __forceinline__ void fm_copy_out(const char* X, int tid_, int64_t m0, bf16* __restrict__ dst, uint8_t* __restrict__ bits,
+                                            const bf16* __restrict__ w_head, float b_head, float* __restrict__ head_out) {
   typedef FmCfg<W> C;
+  constexpr int UB = 4;
+  static_assert(C::COPY_ITERS % UB == 0, "copy-out batch");
+  const int tid = fm_opaque(tid_);
   const int row0 = tid / C::CPR, ch = tid % C::CPR;
-  const char* lptr = X + (ch >> 3) * FM_KT_BYTES;
+  // (row >> 1) & 7 is the same for every row this thread touches (they are ROW_STEP = 16 or 32 apart)
+  const char* lptr = X + (ch >> 3) * FM_KT_BYTES + row0 * 128 + (((ch & 7) ^ ((row0 >> 1) & 7)) << 4);
+  int64_t e0 = (m0 + row0) * (int64_t)W + ch * 8;                  // element offset of this thread's first chunk
+  int64_t bo = (m0 + row0) * (int64_t)(W / 8) + ch;
+  int64_t ro = m0 + row0;
+  float whead[8];
+  if constexpr (HEAD) {
+    const bf16x8 wh = *(const bf16x8*)(w_head + ch * 8);
 #pragma unroll
-  for (int it = 0; it < C::COPY_ITERS; ++it) {
-    const int row = row0 + it * C::ROW_STEP;
-    const u32x4 w = *(const u32x4*)(lptr + fm_off(row, ch & 7));
-    if (bits) {                                           // (kernel-uniform)
-      unsigned f = 0;
+    for (int e = 0; e < 8; ++e) whead[e] = (float)wh[e];
+  }
+#pragma unroll 1
+  for (int it0 = 0; it0 < C::COPY_ITERS; it0 += UB) {
+    u32x4 w[UB];
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const unsigned wd = w[d];
-        const s16x2 z = {0, 0};
-        const unsigned pos = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, wd), z));
-        f |= ((pos + 0x7fff7fffu) & 0x80008000u) >> (15 - 2 * d);
+    for (int u = 0; u < UB; ++u) w[u] = *(const u32x4*)(lptr + (it0 + u) * C::ROW_STEP * 128);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if constexpr (BITS) {
+        unsigned f = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const unsigned wd = w[u][d];
+          const s16x2 z = {0, 0};
+          const unsigned pos = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, wd), z));
+          f |= ((pos + 0x7fff7fffu) & 0x80008000u) >> (15 - 2 * d);
+        }
+        unsigned mb = (f | (f >> 15)) & 0xffu;
+        mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xF5, 0xf, 0xf, false) << 8;     // quad_perm [1,1,3,3]
+        mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xAA, 0xf, 0xf, false) << 16;    // quad_perm [2,2,2,2]
+        if ((ch & 3) == 0) *(unsigned*)(bits + bo + (int64_t)u * C::ROW_STEP * (W / 8)) = mb;
       }
-      unsigned mb = (f | (f >> 15)) & 0xffu;
-      mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xF5, 0xf, 0xf, false) << 8;     // quad_perm [1,1,3,3]
-      mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xAA, 0xf, 0xf, false) << 16;    // quad_perm [2,2,2,2]
-      if ((ch & 3) == 0) *(unsigned*)(bits + (m0 + row) * (int64_t)(W / 8) + ch) = mb;
-    }
-    if (dst) *(u32x4*)(dst + (m0 + row) * (int64_t)W + ch * 8) = w;
-    if (do_head) {
-      const bf16x8 v = __builtin_bit_cast(bf16x8, w);
-      float s = 0.0f;
+      if constexpr (DST) *(u32x4*)(dst + e0 + (int64_t)u * C::ROW_STEP * W) = w[u];
+      if constexpr (HEAD) {
+        const bf16x8 v = __builtin_bit_cast(bf16x8, w[u]);
+        float s = 0.0f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += (float)v[e] * whead[e];
+        for (int e = 0; e < 8; ++e) s += (float)v[e] * whead[e];
 #pragma unroll
-      for (int d = C::CPR / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-      if (ch == 0) head_out[m0 + row] = s + b_head;
+        for (int d = C::CPR / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        if (ch == 0) head_out[ro + u * C::ROW_STEP] = s + b_head;
+      }
     }
+    e0 += (int64_t)UB * C::ROW_STEP * W;
+    bo += (int64_t)UB * C::ROW_STEP * (W / 8);
+    ro += UB * C::ROW_STEP;
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void fm_copy_out_dispatch(const char* X, int tid, int64_t m0, bf16* dst, uint8_t* bits,
+                                                     const bf16* w_head, float b_head, float* head_out) {
+  // (all flags are kernel-uniform)
+  if (w_head) {
+    if (dst && bits) fm_copy_out<W, true, true, true>(X, tid, m0, dst, bits, w_head, b_head, head_out);
+    else if (dst) fm_copy_out<W, true, false, true>(X, tid, m0, dst, bits, w_head, b_head, head_out);
+    else if (bits) fm_copy_out<W, false, true, true>(X, tid, m0, dst, bits, w_head, b_head, head_out);
+    else fm_copy_out<W, false, false, true>(X, tid, m0, dst, bits, w_head, b_head, head_out);
+  } else {
+    if (dst && bits) fm_copy_out<W, true, true, false>(X, tid, m0, dst, bits, w_head, b_head, head_out);
+    else if (dst) fm_copy_out<W, true, false, false>(X, tid, m0, dst, bits, w_head, b_head, head_out);
+    else if (bits) fm_copy_out<W, false, true, false>(X, tid, m0, dst, bits, w_head, b_head, head_out);
   }
 }
 
@@ -194,16 +300,19 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(mnr_mlp_chain_fwd_ar
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cw = wave % C::NW, rg = wave / C::NW;
-  const int frow = lane & 31, khalf = lane >> 5;
   const int64_t tiles = p.M / FM_ROWS;
   const bf16* feat = (const bf16*)p.feat;
   const int nk0 = p.K0 / 64;
   const unsigned no_bits[C::RB] = {};
-
   const float b_head = (p.w_head && p.b_head) ? p.b_head[0] : 0.0f;
+  // bias rows -> LDS, once (an epilogue then reads its 16 values with four ds_read_b128 instead of waiting on L2)
+  for (int i = tid; i < p.depth * W; i += 512) ((float*)(smem + C::BIAS_OFF))[i] = p.bias[i / W][i % W];
 
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t m0 = tile * FM_ROWS;
+    const bool tl_on = g_fm_timeline != nullptr && tid == 0 && tile == (int64_t)blockIdx.x + gridDim.x;
+    FM_STAMP(0);
+    if (tl_on) g_fm_timeline[32 * (int64_t)blockIdx.x + 30] = __builtin_amdgcn_s_memrealtime();
     f32x16 acc[C::RB];
 #pragma unroll
     for (int rb = 0; rb < C::RB; ++rb)
@@ -214,11 +323,17 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(mnr_mlp_chain_fwd_ar
     __syncthreads();                                    // the previous tile's copy-out is done reading the buffer
     {
       const bf16* Bt0 = (const bf16*)p.Bt[0];
+      const bf16* feat_tile = feat + m0 * (int64_t)p.ld_feat;
       auto stage = [&](int kt) {
         char* base = smem + (kt & 1) * C::STAGE_BYTES;
-        fm_stage_tile<FM_ROWS>(feat, p.ld_feat, m0, kt * 64, base, wave, lane);
-        fm_stage_tile<W>(Bt0, p.ldb[0], 0, kt * 64, base + FM_KT_BYTES, wave, lane);
+        const int ln = fm_opaque(lane);
+        fm_stage_tile<FM_ROWS>(feat_tile + kt * 64, p.ld_feat, base, wave, ln);
+        fm_stage_tile<W>(Bt0 + kt * 64, p.ldb[0], base + FM_KT_BYTES, wave, ln);
       };
+      constexpr int HB = C::RB > 4 ? 4 : C::RB;
+      constexpr int NH = C::RB / HB;
+      const int ln0 = fm_opaque(lane), frow = ln0 & 31, khalf = ln0 >> 5;
+      const int sw = (frow >> 1) & 7;
       stage(0);
       for (int kt = 0; kt < nk0; ++kt) {
         MNR_GPU_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"));
@@ -226,56 +341,60 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(mnr_mlp_chain_fwd_ar
         __builtin_amdgcn_s_barrier();                   // step kt has landed everywhere; step kt-1's buffer is free
         asm volatile("" ::: "memory");
         if (kt + 1 < nk0) stage(kt + 1);
-        const char* As = smem + (kt & 1) * C::STAGE_BYTES;
-        const char* Ws = As + FM_KT_BYTES;
+        const char* As = smem + (kt & 1) * C::STAGE_BYTES + (rg * C::RB * 32 + frow) * 128;
+        const char* Ws = smem + (kt & 1) * C::STAGE_BYTES + FM_KT_BYTES + (cw * 32 + frow) * 128;
+        bf16x8 wf[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 wf = fm_read_frag(Ws, cw * 32 + frow, ks * 2 + khalf);
-          constexpr int HB = C::RB > 4 ? 4 : C::RB;
+        for (int ks = 0; ks < 4; ++ks) wf[ks] = *(const bf16x8*)(Ws + (((ks * 2 + khalf) ^ sw) << 4));
+        bf16x8 fa[2][HB];
+        auto read_batch = [&](int step, bf16x8 (&f)[HB]) {
+          const int ks = step / NH, h = step % NH;
+          const char* base = As + h * HB * 4096 + (((ks * 2 + khalf) ^ sw) << 4);
 #pragma unroll
-          for (int h = 0; h < C::RB / HB; ++h) {
-            bf16x8 fa[HB];
+          for (int i = 0; i < HB; ++i) f[i] = *(const bf16x8*)(base + i * 4096);
+        };
+        read_batch(0, fa[0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + HB, 0);
 #pragma unroll
-            for (int i = 0; i < HB; ++i) fa[i] = fm_read_frag(As, (rg * C::RB + h * HB + i) * 32 + frow, ks * 2 + khalf);
-#pragma unroll
-            for (int i = 0; i < HB; ++i)
-              acc[h * HB + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, fa[i], acc[h * HB + i], 0, 0, 0);
+        for (int step = 0; step < 4 * NH; ++step) {
+          const int ks = step / NH, h = step % NH;
+          if (step + 1 < 4 * NH) {
+            read_batch(step + 1, fa[(step + 1) & 1]);
+            __builtin_amdgcn_sched_group_barrier(0x100, HB, 0);
           }
+#pragma unroll
+          for (int i = 0; i < HB; ++i)
+            acc[h * HB + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], fa[step & 1][i], acc[h * HB + i], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, HB, 0);
         }
       }
     }
 
+    FM_STAMP(1);
     bf16x8 w0[FM_WCHUNK];
-    if (p.depth > 1) fm_load_wchunk((const bf16*)p.Bt[1], p.ldb[1], cw, frow, khalf, 0, w0);
-    for (int li = 0; li < p.depth; ++li) {
-      if (li > 0) fm_layer_mfma<W>(smem, (const bf16*)p.Bt[li], p.ldb[li], cw, rg, frow, khalf, w0, acc);
-      if (li + 1 < p.depth && li > 0) fm_load_wchunk((const bf16*)p.Bt[li + 1], p.ldb[li + 1], cw, frow, khalf, 0, w0);
-      float bias_r[16];
-      {
-        const float* bp = p.bias[li];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bias_r[r] = bp[cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf];
-      }
-      __syncthreads();                                  // every wave is done reading this layer's input
-      fm_epilogue<W, false>(smem, cw, rg, frow, khalf, acc, bias_r, no_bits);
-#pragma unroll
-      for (int rb = 0; rb < C::RB; ++rb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
-      __syncthreads();                                  // the layer's output is complete in LDS
-      const bool last = li == p.depth - 1;
-      bf16* dst = p.acts[li] ? (bf16*)p.acts[li] : nullptr;
-      if (last && p.w_head) {
-        float whead[8];
-        const bf16x8 wh = *(const bf16x8*)((const bf16*)p.w_head + (tid % C::CPR) * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) whead[e] = (float)wh[e];
-        fm_copy_out<W>(smem, tid, m0, dst, p.bits[li], whead, true, b_head, p.head_out);
-      } else if (dst || p.bits[li]) {
-        const float none[8] = {};
-        fm_copy_out<W>(smem, tid, m0, dst, p.bits[li], none, false, 0.0f, nullptr);
-      }
+    if (p.depth > 1) {
+      const int ln = fm_opaque(lane);
+      fm_load_wchunk((const bf16*)p.Bt[1], p.ldb[1], cw, ln & 31, ln >> 5, 0, w0);
     }
+    for (int li = 0; li < p.depth; ++li) {
+      if (li > 0) {
+        fm_layer_mfma<W>(smem, (const bf16*)p.Bt[li], p.ldb[li], cw, rg, lane, w0, acc);
+        if (li + 1 < p.depth) {
+          const int ln = fm_opaque(lane);
+          fm_load_wchunk((const bf16*)p.Bt[li + 1], p.ldb[li + 1], cw, ln & 31, ln >> 5, 0, w0);
+        }
+      }
+      FM_STAMP(2 + 3 * li);
+      __syncthreads();                                  // every wave is done reading this layer's input
+      fm_epilogue<W, false>(smem, cw, rg, lane, acc, (const float*)(smem + C::BIAS_OFF) + li * W, no_bits);
+      __syncthreads();                                  // the layer's output is complete in LDS
+      FM_STAMP(3 + 3 * li);
+      const bool last = li == p.depth - 1;
+      fm_copy_out_dispatch<W>(smem, tid, m0, (bf16*)p.acts[li], p.bits[li], last ? (const bf16*)p.w_head : nullptr, b_head,
+                              p.head_out);
+      FM_STAMP(4 + 3 * li);
+    }
+    if (tl_on) g_fm_timeline[32 * (int64_t)blockIdx.x + 31] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -286,60 +405,80 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd_kernel(mnr_mlp_chain_bwd_ar
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cw = wave % C::NW, rg = wave / C::NW;
-  const int frow = lane & 31, khalf = lane >> 5;
   const int64_t tiles = p.M / FM_ROWS;
-  const float no_bias[16] = {};
-  const float no_head[8] = {};
-
-  // head kernel: this thread's 8 columns of the rank-1 start dY_last = mask * (g (x) w_head)
-  const int row0 = tid / C::CPR, ch = tid % C::CPR;
-  float wh[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) wh[e] = p.w_head[ch * 8 + e];
 
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t m0 = tile * FM_ROWS;
+    const bool tl_on = g_fm_timeline != nullptr && tid == 0 && tile == (int64_t)blockIdx.x + gridDim.x;
+    FM_STAMP(0);
+    if (tl_on) g_fm_timeline[32 * (int64_t)blockIdx.x + 30] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();                                    // the previous tile's copy-out is done reading the buffer
     {
+      // rank-1 start: dY_last = mask_last * (g (x) w_head), this thread's 8 columns of its COPY_ITERS rows
       const int last = p.depth - 1;
-      const uint8_t* bl = p.bits[last];
-      bf16* dst = (bf16*)p.dY[last];
+      const int t_ = fm_opaque(tid);
+      const int row0 = t_ / C::CPR, ch = t_ % C::CPR;
+      float wh[8];
+      {
+        const f32x4 a = *(const f32x4*)(p.w_head + ch * 8), b = *(const f32x4*)(p.w_head + ch * 8 + 4);
 #pragma unroll
-      for (int it = 0; it < C::COPY_ITERS; ++it) {
-        const int row = row0 + it * C::ROW_STEP;
-        const float g = p.g_head[m0 + row];
-        const unsigned mb = bl[(m0 + row) * (int64_t)(W / 8) + ch];
+        for (int e = 0; e < 4; ++e) wh[e] = a[e], wh[4 + e] = b[e];
+      }
+      char* lptr = smem + (ch >> 3) * FM_KT_BYTES + row0 * 128 + (((ch & 7) ^ ((row0 >> 1) & 7)) << 4);
+      const int64_t ro = m0 + row0;
+      const uint8_t* bl = p.bits[last] + ro * (W / 8) + (ch & ~3);          // the dword holding this chunk's byte
+      const float* gp = p.g_head + ro;
+      bf16* dst = p.dY[last] ? (bf16*)p.dY[last] + ro * W + ch * 8 : nullptr;
+      // every row's head gradient and mask word requested up front (nothing else is live here: 2 x COPY_ITERS registers),
+      // one HBM round trip for the whole start instead of one per batch of rows
+      float g[C::COPY_ITERS];
+      unsigned mb[C::COPY_ITERS];
+#pragma unroll
+      for (int u = 0; u < C::COPY_ITERS; ++u) {
+        g[u] = gp[u * C::ROW_STEP];
+        mb[u] = *(const unsigned*)(bl + (int64_t)u * C::ROW_STEP * (W / 8)) >> ((ch & 3) * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < C::COPY_ITERS; ++u) {
         bf16x8 v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (bf16)(((mb >> e) & 1u) ? g * wh[e] : 0.0f);
-        *(bf16x8*)(smem + (ch >> 3) * FM_KT_BYTES + fm_off(row, ch & 7)) = v;
-        if (dst) *(bf16x8*)(dst + (m0 + row) * (int64_t)W + ch * 8) = v;
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)(((mb[u] >> e) & 1u) ? g[u] * wh[e] : 0.0f);
+        *(bf16x8*)(lptr + u * C::ROW_STEP * 128) = v;
+        if (dst) *(bf16x8*)(dst + (int64_t)u * C::ROW_STEP * W) = v;
       }
     }
     bf16x8 w0[FM_WCHUNK];
-    if (p.depth > 1) fm_load_wchunk((const bf16*)p.Bw[p.depth - 1], p.ldb[p.depth - 1], cw, frow, khalf, 0, w0);
+    if (p.depth > 1) {
+      const int ln = fm_opaque(lane);
+      fm_load_wchunk((const bf16*)p.Bw[p.depth - 1], p.ldb[p.depth - 1], cw, ln & 31, ln >> 5, 0, w0);
+    }
     __syncthreads();
+    FM_STAMP(1);
     for (int li = p.depth - 1; li >= 1; --li) {
-      f32x16 acc[C::RB];
-#pragma unroll
-      for (int rb = 0; rb < C::RB; ++rb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
-      fm_layer_mfma<W>(smem, (const bf16*)p.Bw[li], p.ldb[li], cw, rg, frow, khalf, w0, acc);
-      if (li > 1) fm_load_wchunk((const bf16*)p.Bw[li - 1], p.ldb[li - 1], cw, frow, khalf, 0, w0);
-      // ReLU masks of layer li-1 for this lane's rows: one dword = the 32 columns of this wave
+      // ReLU masks of layer li-1 for this lane's rows (one dword = the 32 columns of this wave), requested ahead of the
+      // MFMAs that hide their latency
       unsigned mbits[C::RB];
       {
-        const uint8_t* bl = p.bits[li - 1];
+        const int frow = fm_opaque(lane) & 31;
+        const uint8_t* bl = p.bits[li - 1] + (m0 + rg * C::RB * 32) * (int64_t)(W / 8) + cw * 4 + (unsigned)(frow * (W / 8));
 #pragma unroll
-        for (int rb = 0; rb < C::RB; ++rb)
-          mbits[rb] = *(const unsigned*)(bl + (m0 + (rg * C::RB + rb) * 32 + frow) * (int64_t)(W / 8) + cw * 4);
+        for (int rb = 0; rb < C::RB; ++rb) mbits[rb] = *(const unsigned*)(bl + (int64_t)rb * 32 * (W / 8));
+      }
+      f32x16 acc[C::RB];
+      fm_layer_mfma<W>(smem, (const bf16*)p.Bw[li], p.ldb[li], cw, rg, lane, w0, acc);
+      FM_STAMP(2 + 3 * li);
+      if (li > 1) {
+        const int ln = fm_opaque(lane);
+        fm_load_wchunk((const bf16*)p.Bw[li - 1], p.ldb[li - 1], cw, ln & 31, ln >> 5, 0, w0);
       }
       __syncthreads();
-      fm_epilogue<W, true>(smem, cw, rg, frow, khalf, acc, no_bias, mbits);
+      fm_epilogue<W, true>(smem, cw, rg, lane, acc, nullptr, mbits);
       __syncthreads();
-      fm_copy_out<W>(smem, tid, m0, (bf16*)p.dY[li - 1], nullptr, no_head, false, 0.0f, nullptr);
+      FM_STAMP(3 + 3 * li);
+      fm_copy_out<W, true, false, false>(smem, tid, m0, (bf16*)p.dY[li - 1], nullptr, nullptr, 0.0f, nullptr);
+      FM_STAMP(4 + 3 * li);
     }
+    if (tl_on) g_fm_timeline[32 * (int64_t)blockIdx.x + 31] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -364,11 +503,12 @@ static int fm_check_common(const char* who, int64_t M, int W, int depth) {
 extern "C" int mnr_mlp_chain_fwd(const mnr_mlp_chain_fwd_args* a, void* stream) {
   MNR_CHECK_ARG(a != nullptr, "mnr_mlp_chain_fwd: null args");
   if (int s = fm_check_common("mnr_mlp_chain_fwd", a->M, a->W, a->depth)) return s;
-  MNR_CHECK_ARG(a->feat && a->K0 > 0 && a->K0 % 64 == 0 && a->ld_feat % 8 == 0 && a->ld_feat >= a->K0,
+  MNR_CHECK_ARG(a->feat && a->K0 > 0 && a->K0 % 64 == 0 && a->ld_feat % 8 == 0 && a->ld_feat >= a->K0 && a->ld_feat <= (1 << 20),
                 "mnr_mlp_chain_fwd: feature matrix needs K0 %% 64 == 0 and ld_feat %% 8 == 0");
   for (int i = 0; i < a->depth; ++i) {
     MNR_CHECK_ARG(a->Bt[i] && a->bias[i] && a->ldb[i] % 8 == 0 && a->ldb[i] >= (i == 0 ? a->K0 : a->W),
                   "mnr_mlp_chain_fwd: layer %d operand", i);
+    MNR_CHECK_ARG(((uintptr_t)a->bias[i] % 16) == 0, "mnr_mlp_chain_fwd: bias[%d] must be 16-byte aligned", i);
     MNR_CHECK_ARG(((uintptr_t)a->Bt[i] % 16) == 0 && (!a->acts[i] || ((uintptr_t)a->acts[i] % 16) == 0) &&
                       (!a->bits[i] || ((uintptr_t)a->bits[i] % 4) == 0),
                   "mnr_mlp_chain_fwd: layer %d pointers must be 16-byte (bits: 4-byte) aligned", i);
@@ -390,7 +530,7 @@ extern "C" int mnr_mlp_chain_fwd(const mnr_mlp_chain_fwd_args* a, void* stream) 
 extern "C" int mnr_mlp_chain_bwd(const mnr_mlp_chain_bwd_args* a, void* stream) {
   MNR_CHECK_ARG(a != nullptr, "mnr_mlp_chain_bwd: null args");
   if (int s = fm_check_common("mnr_mlp_chain_bwd", a->M, a->W, a->depth)) return s;
-  MNR_CHECK_ARG(a->g_head && a->w_head, "mnr_mlp_chain_bwd: head gradient / head kernel missing");
+  MNR_CHECK_ARG(a->g_head && a->w_head && ((uintptr_t)a->w_head % 16) == 0, "mnr_mlp_chain_bwd: head gradient / 16-byte-aligned head kernel missing");
   for (int i = 0; i < a->depth; ++i) {
     MNR_CHECK_ARG(a->bits[i] && ((uintptr_t)a->bits[i] % 4) == 0, "mnr_mlp_chain_bwd: layer %d needs its ReLU mask bits", i);
     MNR_CHECK_ARG(a->dY[i] || i == a->depth - 1, "mnr_mlp_chain_bwd: dY[%d] missing", i);

@@ -247,22 +247,52 @@ extern "C" int mnr_pack_w_frag_bf16(const uint16_t* Bt, int ldb, int N, int K, u
 }
 
 template <class CFG, bool BITS_IN>
-__global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi) {
+__global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
+  for (int64_t vbid = blockIdx.x; vbid < vtotal; vbid += gridDim.x) {
 #include "gemm_nt_body.inc"
+    if (vbid + gridDim.x < vtotal) __syncthreads();      // (persistent launch) this tile's LDS is free for the next one
+  }
 }
 
 // The direct-weights configurations keep v224-v255 out of the register allocator's hands (see NtCfg::BDIRECT's loop).
 template <class CFG, bool BITS_IN>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) MNR_GPU_ONLY(__attribute__((amdgpu_num_vgpr(224))))
-void gemm_nt_kernel_r224(mnr_gemm_nt_args p, int fast_epi) {
+void gemm_nt_kernel_r224(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
+  for (int64_t vbid = blockIdx.x; vbid < vtotal; vbid += gridDim.x) {
 #include "gemm_nt_body.inc"
+    if (vbid + gridDim.x < vtotal) __syncthreads();      // (persistent launch) this tile's LDS is free for the next one
+  }
 }
 
 // ... the split-path configurations v240-v255.
 template <class CFG, bool BITS_IN>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) MNR_GPU_ONLY(__attribute__((amdgpu_num_vgpr(240))))
-void gemm_nt_kernel_r240(mnr_gemm_nt_args p, int fast_epi) {
+void gemm_nt_kernel_r240(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
+  for (int64_t vbid = blockIdx.x; vbid < vtotal; vbid += gridDim.x) {
 #include "gemm_nt_body.inc"
+    if (vbid + gridDim.x < vtotal) __syncthreads();      // (persistent launch) this tile's LDS is free for the next one
+  }
+}
+
+static int g_nt_persist = 1;                             // workgroups per CU of a persistent launch (round-2 A/B: +2 % end to end,
+                                                         // bitwise equal); 0: one workgroup per tile
+
+static int nt_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
+// Tuning hook: 0 = one workgroup per output tile; n > 0 = persistent launches of n workgroups per CU for the
+// single-resident-workgroup (> 80 KiB LDS) configurations.
+extern "C" int mnr_gemm_nt_set_persistent(int wgs_per_cu) {
+  g_nt_persist = wgs_per_cu > 0 ? wgs_per_cu : 0;
+  return MNR_OK;
 }
 
 template <class CFG>
@@ -273,8 +303,16 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   const int nt = a->N / CFG::BN;
   const int64_t mt = a->M / CFG::BM;
   const int64_t groups = (mt + 7) / 8;
-  const int64_t grid = groups * 8 * nt;
-  MNR_CHECK_ARG(grid < (1ll << 31), "mnr_gemm_nt_bf16: grid too large");
+  const int64_t vtotal = groups * 8 * nt;                  // virtual workgroups = tiles (M tiles padded to 8 per XCD group)
+  MNR_CHECK_ARG(vtotal < (1ll << 31), "mnr_gemm_nt_bf16: grid too large");
+  // Persistent launch: one resident workgroup per CU walks the tiles vbid = blockIdx.x, + gridDim.x, ... (a multiple of 8,
+  // so a workgroup keeps its XCD's share of the tile order): the stores of a tile's epilogue drain under the next
+  // tile's K loop instead of in front of the workgroup's retirement, and the per-workgroup launch gap goes away.
+  int64_t grid = vtotal;
+  if (g_nt_persist > 0 && CFG::LDS_BYTES > 80 * 1024) {
+    const int64_t cap = (int64_t)g_nt_persist * nt_cu_count();
+    if (grid > cap) grid = cap / 8 * 8;
+  }
   if constexpr (CFG::BDIRECT == 0) {
     // (the shipped path: direct launches of the named kernels, as validated on the GPU)
     static bool attr_set = false;
@@ -285,15 +323,15 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
     }
     if (a->mask_bits_in) {
       hipLaunchKernelGGL((gemm_nt_kernel<CFG, true>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
-                         (hipStream_t)stream, *a, fast_epi);
+                         (hipStream_t)stream, *a, fast_epi, (long long)vtotal);
     } else {
       hipLaunchKernelGGL((gemm_nt_kernel<CFG, false>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
-                         (hipStream_t)stream, *a, fast_epi);
+                         (hipStream_t)stream, *a, fast_epi, (long long)vtotal);
     }
   } else {
     // reserved-register variants of the kernel (see gemm_nt_kernel_r224 / _r240)
-    void (*k_plain)(mnr_gemm_nt_args, int);
-    void (*k_bits)(mnr_gemm_nt_args, int);
+    void (*k_plain)(mnr_gemm_nt_args, int, long long);
+    void (*k_bits)(mnr_gemm_nt_args, int, long long);
     if constexpr (CFG::BDIRECT == 1) {
       k_plain = gemm_nt_kernel_r224<CFG, false>;
       k_bits = gemm_nt_kernel_r224<CFG, true>;
@@ -308,7 +346,7 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
       attr_set = true;
     }
     hipLaunchKernelGGL(a->mask_bits_in ? k_bits : k_plain, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
-                       (hipStream_t)stream, *a, fast_epi);
+                       (hipStream_t)stream, *a, fast_epi, (long long)vtotal);
   }
   MNR_CHECK_LAUNCH();
   return MNR_OK;

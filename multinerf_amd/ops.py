@@ -52,6 +52,8 @@ def lib():
     if c:
       big, small = (int(x) for x in c.split(','))
       L.check(L.load().mnr_gemm_nt_set_config(big, small))
+    if os.environ.get('MNR_NT_PERSIST'):        # tuning hook: persistent NT launches, workgroups per CU (csrc/gemm.hip)
+      L.check(L.load().mnr_gemm_nt_set_persistent(int(os.environ['MNR_NT_PERSIST'])))
     if os.environ.get('MNR_NT_WRES'):           # tuning hook: weights-resident kernel for the short-K layers (csrc/gemm.hip)
       L.check(L.load().mnr_gemm_nt_set_wres(int(os.environ['MNR_NT_WRES'])))
     if os.environ.get('MNR_TN_SPLIT') in ('0', '1', '2'):   # tuning hook: csrc/gemm.hip TnBigSplit (1) / TnBigImm (2)
