@@ -33,6 +33,11 @@ def main():
       configs.load_config(args.gin_configs, args.gin_bindings, save_config=False)
   dataset = datasets.load_dataset('test', config.data_dir, config, device=dev)
   model, state, render_eval_pfn, _, _ = train_utils.setup_model(config, 20200823, dataset=dataset, device=dev)
+  if not config.checkpoint_dir or not os.path.isdir(config.checkpoint_dir):
+    raise SystemExit(f'eval.py: Config.checkpoint_dir = {config.checkpoint_dir!r} is not a directory')
+  if checkpoints.latest_checkpoint(config.checkpoint_dir) is None:
+    # (the reference polls until train.py writes one, eval.py:92-104; evaluating random-init weights is never wanted)
+    raise SystemExit(f'eval.py: no checkpoint in {config.checkpoint_dir}')
   state = checkpoints.restore_checkpoint(config.checkpoint_dir, model, state)
   step = int(state.step)
   if rank == 0:

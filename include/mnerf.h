@@ -186,23 +186,16 @@ typedef struct {
 
 /* C[M,N] = epilogue([A1|A2] * Bt^T). */
 int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* args, void* stream);
-/* Tuning hook: tile / pipeline configuration ids (see csrc/gemm.hip NtC0..NtC7) used when N is a
- * multiple of 256 (`cfg_big`) and otherwise (`cfg_small`; must be a 128x128 configuration). */
 /* Profiling hook: device buffer of 16 uint64 per workgroup (s_memtime at entry, K-loop start, K-loop end, exit;
  * s_memrealtime at entry, exit; XCC_ID<<32|HW_ID; unused; epilogue pass stamps) written by
  * every following mnr_gemm_nt_bf16 / mnr_gemm_tn_bf16 launch (TN: [7] = steps << 32 | does-bias); NULL switches it off. */
 int mnr_debug_gemm_timeline(unsigned long long* device_buffer);
-/* Probe hooks for the direct-weights NT configurations (csrc/gemm.hip NtC36 / NtC37; tools/gemm_probe.py): build the
- * fragment-major image [N/32][K/64][4][64 lanes][8] of a weight operand Bt [N, ldb] (out: N*K bf16), and make every
- * following direct-weights launch read its weights from such an image instead of args->Bt (NULL switches it off). */
-int mnr_pack_w_frag_bf16(const uint16_t* Bt, int ldb, int N, int K, uint16_t* out, void* stream);
-int mnr_debug_gemm_wfrag(const uint16_t* image);
-int mnr_gemm_nt_set_config(int cfg_big, int cfg_small);
-/* Tuning hook: 0 = one workgroup per output tile; n > 0 = persistent launches (n workgroups per CU walk the tiles). */
+/* A/B switch: 0 = one workgroup per output tile; n > 0 (default 1) = persistent launches, n workgroups per CU walk the
+ * tiles; n < 0 = at most -n workgroups in total. */
 int mnr_gemm_nt_set_persistent(int wgs_per_cu);
-/* Probe hook: 0 = off; 1 = eligible short-K launches (N = 256, K1 <= 256, K2 = 0, full-width bf16 output, no fp32 side
+/* A/B switch: 1 (default) = eligible short-K launches (N = 256, K1 <= 256, K2 = 0, full-width bf16 output, no fp32 side
  * output, no bf16 mask) go to the weights-resident persistent kernel (weights in registers, one workgroup per CU walking
- * the M tiles); n > 1 = the same with at most n workgroups. */
+ * the M tiles); n > 1 = the same with at most n workgroups; 0 = off. */
 int mnr_gemm_nt_set_wres(int max_wgs);
 
 /* ---- Fused Dense chain (csrc/fused_mlp.hip): the proposal MLP of internal/models.py:441-465 (net_depth <= skip_layer:
@@ -257,9 +250,6 @@ int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* args, void* stream);
 /* Tuning hook: the 256x256 output tile is used when K,N are multiples of 256 and the output has at
  * least `big_min_tiles` such tiles (a huge value disables it). */
 int mnr_gemm_tn_set_config(int big_min_tiles);
-/* Probe hook: 1 = the 256x256-tile launches use the split-path kernel (activations by LDS-DMA, dY through registers);
- * 2 = the default loop with the transpose reads' row offsets as instruction immediates; 0 = default. */
-int mnr_gemm_tn_set_split(int on);
 
 /* out[n] += sum_m X[m,n] for n < n_valid (bias gradient). X bf16 [M, ld]. */
 int mnr_colsum_bf16(const uint16_t* X, int ld, int64_t M, int n_valid, float* out, void* stream);

@@ -118,9 +118,6 @@ _PROTOS = {
     'mnr_glo_bwd': ([i64, i32, i32, vp, vp, vp, i32, vp, vp], i32),
     'mnr_gemm_nt_bf16': ([C.POINTER(GemmNTArgs), vp], i32),
     'mnr_debug_gemm_timeline': ([vp], i32),
-    'mnr_pack_w_frag_bf16': ([vp, i32, i32, i32, vp, vp], i32),
-    'mnr_debug_gemm_wfrag': ([vp], i32),
-    'mnr_gemm_nt_set_config': ([i32, i32], i32),
     'mnr_gemm_nt_set_persistent': ([i32], i32),
     'mnr_gemm_nt_set_wres': ([i32], i32),
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
@@ -128,7 +125,6 @@ _PROTOS = {
     'mnr_mlp_chain_bwd': ([C.POINTER(MlpChainBwdArgs), vp], i32),
     'mnr_debug_chain_timeline': ([vp], i32),
     'mnr_gemm_tn_set_config': ([i32], i32),
-    'mnr_gemm_tn_set_split': ([i32], i32),
     'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),
     'mnr_pack_weights_bf16': ([vp, vp, i32, i32, vp, vp], i32),
     'mnr_scatter_add_f32': ([vp, i32, i32, i32, i32, i32, vp, i32, vp], i32),

@@ -140,10 +140,19 @@ def restore_checkpoint(ckpt_dir, model, state, step=None, prefix='checkpoint_'):
   adam = sd['opt_state']['0']
   mu = model.flat_from_tree(to_t(adam['mu']['params']), device=dev)
   nu = model.flat_from_tree(to_t(adam['nu']['params']), device=dev)
+  # validate everything BEFORE touching the live state: a failed restore must leave it as it was
+  step_ = int(np.asarray(sd['step']))
+  counts = [int(np.asarray(adam['count']))]
+  sched = sd['opt_state'].get('1')                      # optax.scale_by_schedule state: its own copy of the count
+  if isinstance(sched, dict) and 'count' in sched:
+    counts.append(int(np.asarray(sched['count'])))
+  if any(c != step_ for c in counts):
+    raise ValueError(f'checkpoint step {step_} and optimiser counts {counts} disagree')
+  want = state.params['flat'].shape
+  for name, t in (('params', flat), ('mu', mu), ('nu', nu)):
+    if t.shape != want or not torch.isfinite(t).all():
+      raise ValueError(f'checkpoint {name}: shape {tuple(t.shape)} vs model {tuple(want)}, or non-finite values')
   state.params['flat'].copy_(flat)
   state.mu.copy_(mu)
   state.nu.copy_(nu)
-  new = type(state)(step=int(np.asarray(sd['step'])), params=state.params, mu=state.mu, nu=state.nu)
-  if int(np.asarray(adam['count'])) != new.step:
-    raise ValueError(f"checkpoint step {new.step} and Adam count {int(np.asarray(adam['count']))} disagree")
-  return new
+  return type(state)(step=step_, params=state.params, mu=state.mu, nu=state.nu)

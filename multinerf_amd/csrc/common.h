@@ -53,6 +53,29 @@ void mnr_set_error(const char* fmt, ...);
 
 static inline int mnr_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// CUs of the current device (cached: the GPUs of one node are identical); persistent kernels size their grids with it.
+static inline int mnr_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
+// hipFuncSetAttribute applies per device: a launcher's "attribute already set" flag is a bit mask over device ordinals
+// (a process that drives a second GPU sets the attribute there too).  True when the current device still needs it.
+static inline bool mnr_attr_needed(unsigned long long* mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (*mask & bit) return false;
+  *mask |= bit;
+  return true;
+}
+
 // nan_to_num(x, nan=0) followed by clip to [0,1] (reference internal/math.py:125).
 __device__ __forceinline__ float mnr_nan0_clip01(float x) {
   if (x != x) return 0.0f;

@@ -483,13 +483,7 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd_kernel(mnr_mlp_chain_bwd_ar
 }
 
 static int fm_grid(int64_t tiles) {
-  static int cus = 0;
-  if (cus == 0) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
+  const int cus = mnr_cu_count();
   return (int)(tiles < cus ? tiles : cus);
 }
 

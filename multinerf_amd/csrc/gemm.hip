@@ -17,12 +17,13 @@
 //     (seen with the ds_read_tr builtins in the TN loop: fixed by issuing them from inline asm) and forces
 //     vmcnt(0) when register loads and LDS-DMA are in flight together; always check the ISA of the K loop;
 //   * per-tile fixed costs matter: the NT epilogue was 15.6k cycles of a ~75k-cycle tile before it was reworked,
-//     the TN atomic epilogue makes a second round of workgroups a loss.
-// Optional configurations (phase-interleaved loop, 4-wave 128x128, 1x8 wave layout, probes) are kept
-// for tools/gemm_probe.py; none beats the default end to end.  NtC36 / NtC37 (1x8 layout, weights global -> reserved
-// registers, never in LDS) are checked by the kernel-source simulator and by tests/test_isa_checks.py but have not run
-// on hardware yet: not selectable by default.
-// The NT kernel's body lives in gemm_nt_body.inc (two __global__ functions share it textually).
+//     the TN atomic epilogue makes a second round of workgroups a loss; persistent NT launches (one workgroup per CU
+//     walking the tiles) let a tile's stores drain under the next tile's K loop: +2 % end to end.
+// Shipped configurations (round-2 A/B on hardware, profiles/r2_gemm_ab.md): NtBig / NtSmall, the weights-resident
+// kernel for N = 256, K <= 256 layers, TnBig / TnSmall.  The thirteen other loop structures tried in rounds 1-2
+// (phase-interleaved, split operand paths, direct weights, 4-wave 128x128, 256x128 two-per-CU, 3/4-stage BK=32)
+// were within +-3 % of these or slower and were removed; DESIGN.md section 6 keeps their numbers.
+// The NT kernel's body lives in gemm_nt_body.inc (textually inside the tile loop of the kernel function).
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -50,45 +51,30 @@
 
 #define NT_CPAD 16                                   // epilogue staging: 16 B pad per row
 
-template <int MI_, int NJ_, int WM_, int WN_, int BK_, int STAGES_, int MINW_ = 1, int FRAGPIPE_ = 0, int ABLATE_ = 0, int BDIRECT_ = 0,
-          int EPI_BATCH_ = 0, int BIAS_LDS_ = 0>
+template <int MI_, int NJ_, int WM_, int WN_, int EPI_BATCH_ = 0, int BIAS_LDS_ = 0>
 struct NtCfg {
   // n > 0: the epilogue's store loop reads its staged chunks from LDS n at a time (n ds_read_b128 in flight per thread)
   // instead of one read per iteration waited for on the spot, and the fp32 side outputs (which read the accumulators)
   // are written before the store loop instead of after it, so that the accumulators' 128 registers are free for the
   // batch (with them alive, 16 reads at once spilled 85 registers).
   static constexpr int EPI_BATCH = EPI_BATCH_;
-  static constexpr int ABLATE = ABLATE_;              // probe only: 1 no MFMA, 2 no in-loop DMA, 4 no ds_reads
-  // 1: the weights never touch LDS.  With one wave per 32 output columns (WM = 1) a wave's weight fragments are
-  // private to it, so it loads them global -> registers itself (double-buffered, one K tile ahead) and only the
-  // activation tile is staged through LDS: half the LDS-DMA bytes and half the LDS footprint per stage.
-  // 2: split operand paths.  Layout and LDS image as the default loop, but the weight tile of the next K step travels
-  // global -> registers -> ds_write (each thread four 16-byte chunks) while only the activation tile uses the LDS-DMA:
-  // the two halves of a step's 64 KiB come in through different paths at the same time.
-  static constexpr int BDIRECT = BDIRECT_;
-  static constexpr int FRAGPIPE = FRAGPIPE_;          // 1: explicit register double-buffering of LDS fragments
-  static constexpr int MI = MI_, NJ = NJ_, WM = WM_, WN = WN_, BK = BK_, STAGES = STAGES_;
-  static constexpr int MINW = MINW_;                  // __launch_bounds__ min waves per SIMD (register cap)
+  static constexpr int MI = MI_, NJ = NJ_, WM = WM_, WN = WN_, BK = 64, STAGES = 2;
+  static constexpr int MINW = 1;                      // __launch_bounds__ min waves per SIMD
   static constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   static constexpr int THREADS = 64 * WM * WN;
   static constexpr int ROWB = BK * 2;                 // bytes per staged operand row
-  static constexpr int SLOTS = ROWB / 16;             // 16-B slots per row (8 at BK=64, 4 at BK=32)
-  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BDIRECT_ == 1 ? 0 : BN * ROWB;
+  static constexpr int SLOTS = ROWB / 16;             // 16-B slots per row (8 at BK=64)
+  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  // phase-interleaved loop (FRAGPIPE >= 2): PH_S half-tile slots of 16 KiB, staged PH_L phases ahead
-  static constexpr int PH_S = FRAGPIPE_ == 3 ? 10 : 8;
-  static constexpr int PH_L = FRAGPIPE_ == 2 ? 6 : FRAGPIPE_ == 3 ? 8 : FRAGPIPE_ == 5 ? 4 : 0;
-  static constexpr int LDS_OPERANDS = FRAGPIPE_ >= 2 ? PH_S * 16384 : STAGES * STAGE_BYTES;
+  static constexpr int LDS_OPERANDS = STAGES * STAGE_BYTES;
   static constexpr int LOADS_PER_STAGE = STAGE_BYTES / 16 / THREADS;   // LDS-DMA instructions per wave per stage
   static constexpr int CPITCH = BN * 2 + NT_CPAD;     // bytes per staged output row
   // Rows staged per epilogue pass: the whole tile when it fits the 160 KiB of LDS (one pass, every wave converts
   // and writes at once: 135 KiB for the 256x256 tile), else 128 or 64 rows inside the operand buffers.
   static constexpr int EPI_ROWS = (BM * CPITCH <= 160 * 1024) ? BM : (128 * CPITCH <= LDS_OPERANDS) ? 128 : 64;
-  // The split-path loop gives 16 registers to its in-flight weight chunks and cannot also hold the bias of the
-  // lane's columns (NJ x 16 registers) across the K loop: there the tile's bias row waits in LDS, behind everything else.
-  // (BIAS_LDS_ = 1 asks for the same on any loop: one coalesced load per thread in the prologue instead of NJ x 16
-  // scalar loads per lane, and NJ x 16 fewer registers alive across the K loop.)
-  static constexpr bool BIAS_LDS = BDIRECT_ == 2 || BIAS_LDS_ != 0;
+  // 1: the tile's bias row waits in LDS during the K loop: one coalesced load per thread in the prologue instead of
+  // NJ x 16 scalar loads per lane, and NJ x 16 fewer registers alive across the K loop.
+  static constexpr bool BIAS_LDS = BIAS_LDS_ != 0;
   static constexpr int LDS_MAIN = LDS_OPERANDS > EPI_ROWS * CPITCH ? LDS_OPERANDS : EPI_ROWS * CPITCH;
   static constexpr int BIAS_OFF = (LDS_MAIN + 15) / 16 * 16;
   static constexpr int LDS_BYTES = BIAS_LDS ? BIAS_OFF + BN * 4 : LDS_MAIN;
@@ -96,9 +82,6 @@ struct NtCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   static_assert(BM % EPI_ROWS == 0 && (32 * MI) <= EPI_ROWS && EPI_ROWS % (32 * MI) == 0, "epilogue pass shape");
   static_assert((BM * SLOTS) % THREADS == 0 && (BN * SLOTS) % THREADS == 0, "stage loop shape");
-  static_assert(BDIRECT_ != 1 || (WM_ == 1 && NJ_ == 1 && BK_ == 64 && FRAGPIPE_ == 0 && STAGES_ >= 2), "direct-weights loop shape");
-  static_assert(BDIRECT_ != 2 || (BK_ == 64 && FRAGPIPE_ == 0 && STAGES_ == 2 && A_BYTES / 16 / THREADS == 4 && B_BYTES / 16 / THREADS == 4),
-                "split-path loop shape");
 };
 
 // Stage one operand tile [ROWS][BK] with 16-B LDS-DMA.  LDS image: row r, slot s stored at slot
@@ -137,68 +120,10 @@ __device__ __forceinline__ void nt_wait_vmcnt() {
 }
 
 
-// ---------------------------------------------------------------------------
-// Phase-interleaved K loop for the 256x256 tile (NtCfg FRAGPIPE_ = 2).
-//
-// The 2-stage loop above tops out near 0.9 PFLOP/s: every wave drains lgkmcnt to 0 in front of each
-// MFMA group and all waves stage, read and multiply in lock step.  Here the two M-halves of the
-// workgroup (waves 0-3 / 4-7, i.e. one wave of each half per SIMD) run half a phase apart: while one
-// half issues its MFMAs the other issues its ds_reads and LDS-DMA, so the matrix pipe of every SIMD
-// always has a wave to run.  A K tile (BK = 64) is four phases, one 64x32 output quadrant each:
-//     phase 0: read Bf, Af   mfma q(0,0)         Af/As = rows {0..63}/{64..127} of each wave's A strip
-//     phase 1: read Bs       mfma q(0,1)         Bf/Bs = cols {0..31}/{32..63}  of each wave's B strip
-//     phase 2: read As       mfma q(1,1)
-//     phase 3: -             mfma q(1,0)         (Bf stays in registers)
-// LDS is a ring of PH_S (8 or 10) half-tile slots of 16 KiB; half-tile H = 4t + {0:Af, 1:Bf, 2:Bs, 3:As} of
-// K tile t lives in slot H mod PH_S.  Half-tiles are staged in
-// consumption order, one half-tile per phase, PH_L phases ahead of its first read.  After its
-// issue each wave waits vmcnt(2*(PH_L-2)): everything up to the half-tile needed in the NEXT
-// phase has landed (2 DMA instructions per wave and half-tile), younger ones stay in flight across
-// the barrier; the read happens one phase (two barriers) after the wait, which also covers the other
-// half's waves.  A slot is restaged two or more phases after its last read retired.
-#define NT_HT_BYTES 16384
-
-template <int C>
-__device__ __forceinline__ void nt_stage_half(const mnr_gemm_nt_args& p, const bf16* __restrict__ A1,
-                                              const bf16* __restrict__ A2, const bf16* __restrict__ Bt, int64_t m0,
-                                              int n0, int t, char* dst, int wave, int lane) {
-  const int k0 = t * 64;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int cbase = (i * 8 + wave) * 64;
-    const int c = cbase + lane;
-    const int lr = c >> 3;                                 // local row 0..127 of the half-tile
-    const int slot = (c & 7) ^ ((lr >> 1) & 7);           // source-side swizzle (see nt_stage_tile)
-    const bf16* src;
-    if (C == 0 || C == 3) {
-      const int64_t grow = m0 + (lr >> 6) * 128 + (C == 3 ? 64 : 0) + (lr & 63);
-      if (k0 < p.K1) src = A1 + grow * (int64_t)p.lda1 + k0 + slot * 8;
-      else src = A2 + grow * (int64_t)p.lda2 + (k0 - p.K1) + slot * 8;
-    } else {
-      const int grow = n0 + (lr >> 5) * 64 + (C == 2 ? 32 : 0) + (lr & 31);
-      src = Bt + grow * (int64_t)p.ldb + k0 + slot * 8;
-    }
-    __builtin_amdgcn_global_load_lds(MNR_GLOBAL_PTR(src), MNR_LDS_PTR(dst + cbase * 16), 16, 0, 0);
-  }
-}
-
-template <bool REAL = true>
-__device__ __forceinline__ bf16x8 nt_read_half(const char* ht, int lrow, int kslot) {
-  if constexpr (!REAL) {                                   // ablation probe: no LDS traffic
-    bf16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (bf16)(float)(kslot + e);
-    return v;
-  } else {
-    return *(const bf16x8*)(ht + lrow * 128 + ((kslot ^ ((lrow >> 1) & 7)) << 4));
-  }
-}
-
-// Profiling hook (tools/gemm_probe.py --timeline): when set, wave 0 of every workgroup records s_memtime at
+// Profiling hook (tools/step_timeline.py): when set, wave 0 of every workgroup records s_memtime at
 // kernel entry, K-loop start, K-loop end and kernel exit into g_nt_timeline[16 * blockIdx.x + 0..3], s_memrealtime
 // (100 MHz) at entry / exit into [4], [5], XCC_ID << 32 | HW_ID into [6]; epilogue pass h: staged [8+2h], stored [9+2h].
 __device__ unsigned long long* g_nt_timeline = nullptr;
-__device__ const uint16_t* g_nt_wfrag = nullptr;           // probe hook: fragment-major weight image for the direct-weights loop
 __device__ unsigned long long* g_tn_timeline = nullptr;
 
 extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
@@ -211,63 +136,8 @@ extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
   return MNR_OK;
 }
 
-// Probe hook (tools/gemm_probe.py): the direct-weights configurations (NtC36 / NtC37) read the weights of every
-// following launch from this fragment-major image (see mnr_pack_w_frag_bf16) instead of args->Bt; NULL switches it off.
-extern "C" int mnr_debug_gemm_wfrag(const uint16_t* image) {
-  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_nt_wfrag), &image, sizeof(image));
-  if (e != hipSuccess) {
-    mnr_set_error("mnr_debug_gemm_wfrag: %s", hipGetErrorString(e));
-    return MNR_ERR_HIP;
-  }
-  return MNR_OK;
-}
-
-// out[(((n/32) * (K/64) + k/64) * 4 + ks) * 64 + lane][0..7] = Bt[(n/32)*32 + lane%32][(k/64)*64 + ks*16 + (lane/32)*8 + 0..7]:
-// the MFMA A-operand fragments of the NT kernel's weight side, one contiguous KiB per (32 columns, 16 k) block.
-__global__ void pack_w_frag_kernel(const bf16* __restrict__ Bt, int ldb, int N, int K, bf16* __restrict__ out) {
-  const int nk = K / 64;
-  const int64_t total = (int64_t)(N / 32) * nk * 4 * 64;
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
-    const int lane = (int)(c & 63), ks = (int)((c >> 6) & 3);
-    const int64_t t = c >> 8;
-    const int kt = (int)(t % nk), ntile = (int)(t / nk);
-    *(bf16x8*)(out + c * 8) = *(const bf16x8*)(Bt + (int64_t)(ntile * 32 + (lane & 31)) * ldb + kt * 64 + ks * 16 + (lane >> 5) * 8);
-  }
-}
-
-extern "C" int mnr_pack_w_frag_bf16(const uint16_t* Bt, int ldb, int N, int K, uint16_t* out, void* stream) {
-  MNR_CHECK_ARG(Bt && out && N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0 && ldb % 8 == 0,
-                "mnr_pack_w_frag_bf16: need N %% 32 == 0, K %% 64 == 0, ldb %% 8 == 0");
-  const int64_t total = (int64_t)(N / 32) * (K / 64) * 256;
-  int grid = mnr_cdiv(total, 256);
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(pack_w_frag_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)Bt, ldb, N, K, (bf16*)out);
-  MNR_CHECK_LAUNCH();
-  return MNR_OK;
-}
-
 template <class CFG, bool BITS_IN>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
-  for (int64_t vbid = blockIdx.x; vbid < vtotal; vbid += gridDim.x) {
-#include "gemm_nt_body.inc"
-    if (vbid + gridDim.x < vtotal) __syncthreads();      // (persistent launch) this tile's LDS is free for the next one
-  }
-}
-
-// The direct-weights configurations keep v224-v255 out of the register allocator's hands (see NtCfg::BDIRECT's loop).
-template <class CFG, bool BITS_IN>
-__global__ __launch_bounds__(CFG::THREADS, CFG::MINW) MNR_GPU_ONLY(__attribute__((amdgpu_num_vgpr(224))))
-void gemm_nt_kernel_r224(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
-  for (int64_t vbid = blockIdx.x; vbid < vtotal; vbid += gridDim.x) {
-#include "gemm_nt_body.inc"
-    if (vbid + gridDim.x < vtotal) __syncthreads();      // (persistent launch) this tile's LDS is free for the next one
-  }
-}
-
-// ... the split-path configurations v240-v255.
-template <class CFG, bool BITS_IN>
-__global__ __launch_bounds__(CFG::THREADS, CFG::MINW) MNR_GPU_ONLY(__attribute__((amdgpu_num_vgpr(240))))
-void gemm_nt_kernel_r240(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
   for (int64_t vbid = blockIdx.x; vbid < vtotal; vbid += gridDim.x) {
 #include "gemm_nt_body.inc"
     if (vbid + gridDim.x < vtotal) __syncthreads();      // (persistent launch) this tile's LDS is free for the next one
@@ -277,21 +147,10 @@ void gemm_nt_kernel_r240(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
 static int g_nt_persist = 1;                             // workgroups per CU of a persistent launch (round-2 A/B: +2 % end to end,
                                                          // bitwise equal); 0: one workgroup per tile
 
-static int nt_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
-  return cus;
-}
-
-// Tuning hook: 0 = one workgroup per output tile; n > 0 = persistent launches of n workgroups per CU for the
-// single-resident-workgroup (> 80 KiB LDS) configurations.
+// A/B switch: 0 = one workgroup per output tile; n > 0 = persistent launches of n workgroups per CU for the
+// single-resident-workgroup (> 80 KiB LDS) configurations; n < 0 = at most -n workgroups in total (tests).
 extern "C" int mnr_gemm_nt_set_persistent(int wgs_per_cu) {
-  g_nt_persist = wgs_per_cu > 0 ? wgs_per_cu : 0;
+  g_nt_persist = wgs_per_cu;
   return MNR_OK;
 }
 
@@ -309,129 +168,29 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   // so a workgroup keeps its XCD's share of the tile order): the stores of a tile's epilogue drain under the next
   // tile's K loop instead of in front of the workgroup's retirement, and the per-workgroup launch gap goes away.
   int64_t grid = vtotal;
-  if (g_nt_persist > 0 && CFG::LDS_BYTES > 80 * 1024) {
-    const int64_t cap = (int64_t)g_nt_persist * nt_cu_count();
-    if (grid > cap) grid = cap / 8 * 8;
+  if (g_nt_persist != 0 && CFG::LDS_BYTES > 80 * 1024) {
+    const int64_t cap = g_nt_persist > 0 ? (int64_t)g_nt_persist * mnr_cu_count() : -(int64_t)g_nt_persist;
+    if (grid > cap && cap >= 8) grid = cap / 8 * 8;
   }
-  if constexpr (CFG::BDIRECT == 0) {
-    // (the shipped path: direct launches of the named kernels, as validated on the GPU)
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-      attr_set = true;
-    }
-    if (a->mask_bits_in) {
-      hipLaunchKernelGGL((gemm_nt_kernel<CFG, true>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
-                         (hipStream_t)stream, *a, fast_epi, (long long)vtotal);
-    } else {
-      hipLaunchKernelGGL((gemm_nt_kernel<CFG, false>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
-                         (hipStream_t)stream, *a, fast_epi, (long long)vtotal);
-    }
+  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if (mnr_attr_needed(&attr_set)) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+  }
+  if (a->mask_bits_in) {
+    hipLaunchKernelGGL((gemm_nt_kernel<CFG, true>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
+                       (hipStream_t)stream, *a, fast_epi, (long long)vtotal);
   } else {
-    // reserved-register variants of the kernel (see gemm_nt_kernel_r224 / _r240)
-    void (*k_plain)(mnr_gemm_nt_args, int, long long);
-    void (*k_bits)(mnr_gemm_nt_args, int, long long);
-    if constexpr (CFG::BDIRECT == 1) {
-      k_plain = gemm_nt_kernel_r224<CFG, false>;
-      k_bits = gemm_nt_kernel_r224<CFG, true>;
-    } else {
-      k_plain = gemm_nt_kernel_r240<CFG, false>;
-      k_bits = gemm_nt_kernel_r240<CFG, true>;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)k_plain, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-      (void)hipFuncSetAttribute((const void*)k_bits, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(a->mask_bits_in ? k_bits : k_plain, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
+    hipLaunchKernelGGL((gemm_nt_kernel<CFG, false>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
                        (hipStream_t)stream, *a, fast_epi, (long long)vtotal);
   }
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
 
-//                 MI NJ WM WN BK STAGES MINW FRAGPIPE ABLATE
-typedef NtCfg<2, 2, 2, 2, 64, 2> NtC0;             // 128x128, 4 waves,  64 KiB: N not a multiple of 256 (heads, view MLP)
-typedef NtCfg<4, 2, 2, 4, 64, 2> NtC2;             // 256x256, 8 waves, 128 KiB: the trunk layers (default)
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 1> NtC12;      // = NtC2 with register double-buffered fragments
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 1> NtC14;   // probes of NtC2 (tools/gemm_probe.py): no MFMAs
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 2> NtC15;   //   no in-loop DMA
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 6> NtC16;   //   MFMAs only (no DMA, no ds_reads)
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 5> NtC17;   //   DMA only (no ds_reads, no MFMAs)
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2> NtC18;      // 256x256, phase-interleaved K loop (two wave groups half a phase apart), 8 slots, lead 6
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 3> NtC19;      //   same, 10 slots (160 KiB), lead 8
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 5> NtC21;      //   same, 8 slots, lead 4 (latency probe)
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 1> NtC22;   // probes of NtC18: no MFMA
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 2> NtC23;   //   no in-loop DMA
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 4> NtC24;   //   no ds_reads
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 6> NtC25;   //   MFMA + barriers only
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 5> NtC26;   //   DMA + barriers only
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 7> NtC27;   //   barriers only
-typedef NtCfg<4, 2, 2, 4, 32, 4> NtC4;             // 256x256, 8 waves, 4 stages of BK=32 (three K half-tiles in flight)
-typedef NtCfg<4, 2, 2, 4, 32, 3> NtC7;             // 256x256, 8 waves, 3 stages of BK=32
-typedef NtCfg<8, 1, 1, 8, 64, 2> NtC35;            // 256x256, 8 waves each 256 rows x 32 columns (no weight duplication across waves)
-typedef NtCfg<8, 1, 1, 8, 64, 3, 1, 0, 0, 1> NtC36; // 1x8 waves, weights global -> registers (never in LDS), 3 activation stages of 32 KiB
-typedef NtCfg<8, 1, 1, 8, 64, 4, 1, 0, 0, 1> NtC37; //   same, 4 stages
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 2> NtC40; // = NtC2 with split operand paths: activations by LDS-DMA, weights global -> registers -> ds_write
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 0, 16> NtC41; // = NtC2 with the epilogue's 16 LDS reads per thread issued together
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 2, 16> NtC42; // = NtC40 (split operand paths) with the same
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 0, 0, 0, 16, 1> NtC43; // = NtC41 with the bias row parked in LDS (cheaper prologue, 32 registers fewer in the loop)
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 1, 0, 0, 16, 1> NtC44; // = NtC43 with register double-buffered fragments (NtC12's loop, which spilled while the bias row sat in registers)
-typedef NtCfg<4, 2, 2, 4, 64, 2, 1, 2, 0, 0, 16, 1> NtC45; // = NtC18 (phase-interleaved loop) with the bias row in LDS and the batched epilogue reads
-typedef NtCfg<4, 2, 2, 2, 32, 2, 2> NtC38;           // 256x128, 4 waves of 128x64, 48 KiB: TWO workgroups per CU (one's epilogue under the other's K loop)
-typedef NtCfg<4, 2, 2, 2, 32, 3, 2> NtC39;           //   same, 3 stages (72 KiB)
-typedef NtCfg<4, 4, 2, 2, 64, 2> NtC33;            // 256x256, 4 waves of 128x128 (one per SIMD, 512 registers per lane)
-typedef NtCfg<4, 4, 2, 2, 64, 2, 1, 1> NtC34;      //   same with register double-buffered fragments
-
-static int g_nt_cfg_big = 43, g_nt_cfg_small = 0;   // NtC43: round-2 A/B winner (bias row in LDS, batched epilogue reads)
-
-extern "C" int mnr_gemm_nt_set_config(int cfg_big, int cfg_small) {
-  MNR_CHECK_ARG(cfg_big >= 0 && cfg_big <= 45 && cfg_small == 0, "mnr_gemm_nt_set_config: unknown configuration (small must be 0)");
-  g_nt_cfg_big = cfg_big;
-  g_nt_cfg_small = cfg_small;
-  return MNR_OK;
-}
-
-static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
-  switch (cfg) {
-    case 0: return nt_launch<NtC0>(a, fast_epi, stream);
-    case 2: return nt_launch<NtC2>(a, fast_epi, stream);
-    case 4: return nt_launch<NtC4>(a, fast_epi, stream);
-    case 7: return nt_launch<NtC7>(a, fast_epi, stream);
-    case 12: return nt_launch<NtC12>(a, fast_epi, stream);
-    case 14: return nt_launch<NtC14>(a, fast_epi, stream);
-    case 15: return nt_launch<NtC15>(a, fast_epi, stream);
-    case 16: return nt_launch<NtC16>(a, fast_epi, stream);
-    case 17: return nt_launch<NtC17>(a, fast_epi, stream);
-    case 18: return nt_launch<NtC18>(a, fast_epi, stream);
-    case 19: return nt_launch<NtC19>(a, fast_epi, stream);
-    case 21: return nt_launch<NtC21>(a, fast_epi, stream);
-    case 22: return nt_launch<NtC22>(a, fast_epi, stream);
-    case 23: return nt_launch<NtC23>(a, fast_epi, stream);
-    case 24: return nt_launch<NtC24>(a, fast_epi, stream);
-    case 25: return nt_launch<NtC25>(a, fast_epi, stream);
-    case 26: return nt_launch<NtC26>(a, fast_epi, stream);
-    case 27: return nt_launch<NtC27>(a, fast_epi, stream);
-    case 33: return nt_launch<NtC33>(a, fast_epi, stream);
-    case 35: return nt_launch<NtC35>(a, fast_epi, stream);
-    case 34: return nt_launch<NtC34>(a, fast_epi, stream);
-    case 36: return nt_launch<NtC36>(a, fast_epi, stream);
-    case 38: return nt_launch<NtC38>(a, fast_epi, stream);
-    case 40: return nt_launch<NtC40>(a, fast_epi, stream);
-    case 41: return nt_launch<NtC41>(a, fast_epi, stream);
-    case 42: return nt_launch<NtC42>(a, fast_epi, stream);
-    case 43: return nt_launch<NtC43>(a, fast_epi, stream);
-    case 44: return nt_launch<NtC44>(a, fast_epi, stream);
-    case 45: return nt_launch<NtC45>(a, fast_epi, stream);
-    case 39: return nt_launch<NtC39>(a, fast_epi, stream);
-    case 37: return nt_launch<NtC37>(a, fast_epi, stream);
-    default:
-      mnr_set_error("mnr_gemm_nt_bf16: configuration %d is not compiled in", cfg);
-      return MNR_ERR_INVALID_ARGUMENT;
-  }
-}
+//            MI NJ WM WN EPI_BATCH BIAS_LDS
+typedef NtCfg<2, 2, 2, 2> NtSmall;                  // 128x128, 4 waves, 64 KiB: N not a multiple of 256 (heads, view MLP)
+typedef NtCfg<4, 2, 2, 4, 16, 1> NtBig;             // 256x256, 8 waves (2 x 4, 128x64 per wave), 128 KiB + bias row: the trunk layers
 
 // ---------------------------------------------------------------------------
 // Weights-resident NT kernel for the short-K layers (N = 256, K <= 256: the proposal MLP's hidden layers and their dX).
@@ -442,8 +201,9 @@ static int nt_dispatch(int cfg, const mnr_gemm_nt_args* a, int fast_epi, void* s
 // The workgroups are persistent (one per CU) and walk over the M tiles; only activation tiles are streamed (LDS-DMA, two
 // 32-KiB slots), as ONE pipeline across tile boundaries: the first activation tile of the next M tile is in flight while
 // this tile's epilogue runs, because the epilogue stages through its own LDS region (two passes of 128 rows).
-// Probe variant (MNR_NT_WRES=1); simulator- and ISA-checked, not run on hardware yet.
-typedef NtCfg<8, 1, 1, 8, 64, 2> WresCfg;            // 256 rows, 8 waves as 1 x 8, for nt_stage_tile / nt_read_frag
+// Round-2 A/B on hardware (bitwise equal to the tiled kernel): the 256-wide layers 282 -> 230 us at M = 2^20; llff_raw +7 %,
+// blender_256 +2.5 % end to end.  On by default for eligible launches (mnr_gemm_nt_set_wres(0) switches it off).
+typedef NtCfg<8, 1, 1, 8> WresCfg;                  // 256 rows, 8 waves as 1 x 8, for nt_stage_tile / nt_read_frag
 #define WRES_A_BYTES (2 * 32768)
 #define WRES_STAGE_ROWS 128
 #define WRES_CPITCH (256 * 2 + NT_CPAD)
@@ -634,9 +394,9 @@ __global__ __launch_bounds__(512) void gemm_nt_wres_kernel(mnr_gemm_nt_args p) {
   }
 }
 
-static int g_nt_wres = 0;
+static int g_nt_wres = 1;
 
-// Probe hook: 0 = off; 1 = eligible short-K launches (N = 256, K <= 256, plain epilogues) go to the weights-resident
+// A/B switch: 0 = off; 1 (default) = eligible short-K launches (N = 256, K <= 256, plain epilogues) go to the weights-resident
 // persistent kernel, one workgroup per CU; n > 1 = the same with at most n workgroups.
 extern "C" int mnr_gemm_nt_set_wres(int max_wgs) {
   g_nt_wres = max_wgs > 0 ? max_wgs : 0;
@@ -649,21 +409,14 @@ static bool nt_wres_eligible(const mnr_gemm_nt_args* a, int fast_epi) {
 }
 
 static int nt_wres_launch(const mnr_gemm_nt_args* a, int max_wgs, void* stream) {
-  static int cus = 0;
-  if (cus == 0) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
+  const int cus = mnr_cu_count();
   const int64_t mt = a->M / 256;
   const int cap = max_wgs > 1 ? max_wgs : cus;            // MNR_NT_WRES = 1: one workgroup per CU; n > 1: at most n workgroups
   const int grid = (int)(mt < cap ? mt : cap);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if (mnr_attr_needed(&attr_set)) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_wres_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_wres_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES);
-    attr_set = true;
   }
   if (a->mask_bits_in) hipLaunchKernelGGL(gemm_nt_wres_kernel<true>, dim3(grid), dim3(512), WRES_LDS_BYTES, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL(gemm_nt_wres_kernel<false>, dim3(grid), dim3(512), WRES_LDS_BYTES, (hipStream_t)stream, *a);
@@ -692,23 +445,8 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   const int fast_epi = (!a->Cb || (a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0)) &&
                        (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));
   if (g_nt_wres > 0 && nt_wres_eligible(a, fast_epi)) return nt_wres_launch(a, g_nt_wres, stream);
-  const bool big_ok = (a->M % 256 == 0) && (a->N % 256 == 0);
-  int cfg = big_ok ? g_nt_cfg_big : g_nt_cfg_small;
-  static int phased_min_k = -1;                          // tuning hook: phased loop for long-K forward GEMMs only
-  if (phased_min_k < 0) {
-    const char* e = getenv("MNR_NT_PHASED_MIN_K");
-    phased_min_k = e ? atoi(e) : 0;
-  }
-  if ((cfg == 2 || cfg == 43) && phased_min_k > 0 && a->K1 + a->K2 >= phased_min_k && !a->mask_bits_in && !a->mask)
-    cfg = cfg == 43 ? 45 : 18;
-  static int short_k_cfg = -1, short_k_max = 0;          // tuning hook: another configuration for the short-K (proposal) GEMMs
-  if (short_k_cfg < 0) {
-    const char* e = getenv("MNR_NT_SHORTK_CFG");         // "cfg,max_k", e.g. "38,512"
-    short_k_cfg = 0;
-    if (e && sscanf(e, "%d,%d", &short_k_cfg, &short_k_max) != 2) short_k_cfg = 0;
-  }
-  if (big_ok && short_k_cfg > 0 && a->K1 + a->K2 <= short_k_max) cfg = short_k_cfg;
-  return nt_dispatch(cfg, a, fast_epi, stream);
+  if (a->M % 256 == 0 && a->N % 256 == 0) return nt_launch<NtBig>(a, fast_epi, stream);
+  return nt_launch<NtSmall>(a, fast_epi, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -726,11 +464,9 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
 
 #define TN_BM 64       // reduction rows per step
 
-template <int KI_, int NJ_, int WK_, int WN_, int SPLIT_ = 0, int IMM_ = 0>
+template <int KI_, int NJ_, int WK_, int WN_>
 struct TnCfg {
-  static constexpr int IMM = IMM_ || SPLIT_;           // transpose-read row offsets in the instruction's immediate field
   static constexpr int KI = KI_, NJ = NJ_, WK = WK_, WN = WN_;
-  static constexpr int SPLIT = SPLIT_;                // 1: dY tile global -> registers -> ds_write, activations by LDS-DMA
   static constexpr int BKO = 32 * KI * WK;            // output rows (columns of A)
   static constexpr int BNO = 32 * NJ * WN;            // output cols (columns of B)
   static constexpr int THREADS = 64 * WK * WN;
@@ -740,8 +476,6 @@ struct TnCfg {
 };
 typedef TnCfg<2, 2, 2, 2> TnSmall;   // 128x128 output tile, 4 waves,  64 KiB
 typedef TnCfg<4, 2, 2, 4> TnBig;     // 256x256 output tile, 8 waves, 128 KiB
-typedef TnCfg<4, 2, 2, 4, 1> TnBigSplit;   // same with split operand paths (not default; mnr_gemm_tn_set_split(1))
-typedef TnCfg<4, 2, 2, 4, 0, 1> TnBigImm;  // the default loop with immediate-offset transpose reads only (mnr_gemm_tn_set_split(2))
 
 // Stage a [64 m][COLS] tile; 64-B block b of row r is stored at block position b ^ (r & 3).
 template <int COLS, int THREADS>
@@ -762,33 +496,8 @@ __device__ __forceinline__ void tn_stage_tile(const bf16* __restrict__ g, int ld
   }
 }
 
-// Fragment of 8 reduction elements for column (colbase + 16*g16 + c) of a [64][COLS] tile.
-template <int COLS>
-__device__ __forceinline__ bf16x8 tn_read_frag(const char* lds_tile, int mbase, int colbase, int lane) {
-  constexpr int ROWB = COLS * 2;
-  const int p = lane & 15;
-  const int g16 = (lane >> 4) & 1;
-  const int col = colbase + g16 * 16 + (p & 3) * 4;
-  const int r0 = mbase + (p >> 2);
-  const int r1 = r0 + 4;
-  const int off0 = r0 * ROWB + ((((col >> 5) ^ (r0 & 3))) << 6) + (col & 31) * 2;
-  const int off1 = r1 * ROWB + ((((col >> 5) ^ (r1 & 3))) << 6) + (col & 31) * 2;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_tile + off0));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_tile + off1));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
-
 template <class CFG>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
-#include "gemm_tn_body.inc"
-}
-
-// The split-path configuration keeps v240-v255 out of the register allocator's hands (see gemm_tn_body.inc).
-template <class CFG>
-__global__ __launch_bounds__(CFG::THREADS) MNR_GPU_ONLY(__attribute__((amdgpu_num_vgpr(240))))
-void gemm_tn_kernel_r240(mnr_gemm_tn_args p, int splits, int steps_per_split) {
 #include "gemm_tn_body.inc"
 }
 
@@ -802,37 +511,17 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   while (splits > 8 && (total_steps + splits - 1) / splits < 4) splits -= 8;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   const int64_t grid = (int64_t)splits * tiles;
-  if constexpr (!CFG::SPLIT) {
-    // (the shipped path: a direct launch of the named kernel, as validated on the GPU)
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_tn_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
-                       *a, splits, steps_per_split);
-  } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)gemm_tn_kernel_r240<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_tn_kernel_r240<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
-                       *a, splits, steps_per_split);
+  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if (mnr_attr_needed(&attr_set)) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
   }
+  hipLaunchKernelGGL(gemm_tn_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
+                     *a, splits, steps_per_split);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
 
 static int g_tn_big_min_tiles = 1;
-static int g_tn_split = 2;                        // TnBigImm: round-2 A/B winner (immediate-offset transpose reads)
-
-// Probe hook: 1 = the 256x256-tile launches use the split-path kernel (TnBigSplit).
-extern "C" int mnr_gemm_tn_set_split(int on) {
-  g_tn_split = (on == 1 || on == 2) ? on : 0;     // 0: the round-1 loop
-  return MNR_OK;
-}
-
 extern "C" int mnr_gemm_tn_set_config(int big_min_tiles) {
   g_tn_big_min_tiles = big_min_tiles;
   return MNR_OK;
@@ -856,8 +545,6 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
     // 512 -> 256 workgroups = 398k -> 407k rays/s end to end, 1024: 390k.
     tn_target = e ? atoi(e) : 256;
   }
-  if (big && g_tn_split == 1) return tn_launch<TnBigSplit>(a, tn_target, stream);
-  if (big && g_tn_split == 2) return tn_launch<TnBigImm>(a, tn_target, stream);
   if (big) return tn_launch<TnBig>(a, tn_target, stream);
   static int tn_small_target = -1;
   if (tn_small_target < 0) {

@@ -245,10 +245,9 @@ static int ls_interlevel_launch(float mult, int64_t B, int64_t B_valid, int n, c
                 "mnr_interlevel_loss: bad arguments");
   const size_t lds = (size_t)(3 * n + 2) * LS_THREADS * 4;
   MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_interlevel_loss: n too large");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if (mnr_attr_needed(&attr_set)) {
     (void)hipFuncSetAttribute((const void*)interlevel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL(interlevel_kernel, dim3(mnr_cdiv(B_valid, LS_THREADS)), dim3(LS_THREADS), lds,
                      (hipStream_t)stream, mult, B, B_valid, n, t, w, ne, te, we, stats, g_we, per_elem);
@@ -310,10 +309,9 @@ static int ls_distortion_launch(float mult, int64_t B, int64_t B_valid, int n, c
   MNR_CHECK_ARG(B > 0 && B_valid > 0 && B_valid <= B && n >= 1 && t && w, "mnr_distortion_loss: bad arguments");
   const size_t lds = (size_t)(2 * n) * LS_THREADS * 4;
   MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_distortion_loss: n too large");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if (mnr_attr_needed(&attr_set)) {
     (void)hipFuncSetAttribute((const void*)distortion_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL(distortion_kernel, dim3(mnr_cdiv(B_valid, LS_THREADS)), dim3(LS_THREADS), lds,
                      (hipStream_t)stream, mult, B, B_valid, n, t, w, stats, g_w, per_ray);

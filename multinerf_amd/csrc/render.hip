@@ -143,10 +143,9 @@ extern "C" int mnr_composite_fwd(const mnr_composite_cfg* cfg, int64_t B, const 
   const int S = cp_rays_per_block(cfg->n, B);
   const size_t lds = cp_lds_bytes(cfg->n, S);
   MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_composite_fwd: n=%d too long for LDS staging", cfg->n);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if (mnr_attr_needed(&attr_set)) {
     (void)hipFuncSetAttribute((const void*)composite_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(mnr_cdiv(B, S)), dim3(CP_THREADS), lds, (hipStream_t)stream,
                      *cfg, B, S, raw_density, density_noise, raw_rgb, tdist, dirs, bg, exposure_scale, density, rgb,
@@ -272,10 +271,9 @@ extern "C" int mnr_composite_bwd(const mnr_composite_cfg* cfg, int64_t B, const 
   const int S = cp_rays_per_block(cfg->n, B);
   const size_t lds = cp_lds_bytes(cfg->n, S);
   MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_composite_bwd: n=%d too long for LDS staging", cfg->n);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if (mnr_attr_needed(&attr_set)) {
     (void)hipFuncSetAttribute((const void*)composite_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL(composite_bwd_kernel, dim3(mnr_cdiv(B, S)), dim3(CP_THREADS), lds, (hipStream_t)stream,
                      *cfg, B, S, raw_density, density_noise, raw_rgb, tdist, dirs, bg, exposure_scale, weights,

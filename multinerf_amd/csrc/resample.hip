@@ -259,11 +259,10 @@ extern "C" int mnr_resample_level(const mnr_resample_cfg* cfg, int64_t B, const 
   while (lay.rpb > 8 && B / lay.rpb < 1024) lay.rpb >>= 1;
   const size_t lds_bytes = (size_t)(lay.a_len + lay.b_len) * lay.rpb * 4;
   MNR_CHECK_ARG(lds_bytes <= 160 * 1024, "mnr_resample_level: step function too long for LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if (mnr_attr_needed(&attr_set)) {
     (void)hipFuncSetAttribute((const void*)resample_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    attr_set = true;
   }
   const int grid = mnr_cdiv(B, lay.rpb);
   hipLaunchKernelGGL(resample_level_kernel, dim3(grid), dim3(RS_THREADS), lds_bytes, (hipStream_t)stream, *cfg,

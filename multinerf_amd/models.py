@@ -585,7 +585,14 @@ class Model:
     randomized = (rng is not None) or (noise is not None)
     gen = None
     if rng is not None and noise is None:
-      gen = rng if isinstance(rng, torch.Generator) else torch.Generator(device=dev).manual_seed(int(rng))
+      if isinstance(rng, torch.Generator):
+        gen = rng
+      elif keep_for_backward:
+        # a bare seed would reproduce the same jitter / noise / background on every training step (the reference splits
+        # its key each step, train_utils.py:263): training takes a torch.Generator, which advances
+        raise TypeError('training needs rng to be a torch.Generator (a reused integer seed repeats the same randomness)')
+      else:
+        gen = torch.Generator(device=dev).manual_seed(int(rng))
 
     renderings, ray_history, saved = [], [], []
     for (i_level, is_prop, n, prod_prev) in self._level_plan():

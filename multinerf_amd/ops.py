@@ -48,16 +48,10 @@ def lib():
   global _cfg_applied
   if not _cfg_applied:
     _cfg_applied = True
-    c = os.environ.get('MNR_NT_CFG')          # tuning hook: 'big,small' NtC* ids (csrc/gemm.hip)
-    if c:
-      big, small = (int(x) for x in c.split(','))
-      L.check(L.load().mnr_gemm_nt_set_config(big, small))
-    if os.environ.get('MNR_NT_PERSIST'):        # tuning hook: persistent NT launches, workgroups per CU (csrc/gemm.hip)
+    if os.environ.get('MNR_NT_PERSIST'):        # A/B switch: persistent NT launches, workgroups per CU (0: off)
       L.check(L.load().mnr_gemm_nt_set_persistent(int(os.environ['MNR_NT_PERSIST'])))
-    if os.environ.get('MNR_NT_WRES'):           # tuning hook: weights-resident kernel for the short-K layers (csrc/gemm.hip)
+    if os.environ.get('MNR_NT_WRES'):           # A/B switch: weights-resident kernel for the short-K layers (0: off)
       L.check(L.load().mnr_gemm_nt_set_wres(int(os.environ['MNR_NT_WRES'])))
-    if os.environ.get('MNR_TN_SPLIT') in ('0', '1', '2'):   # tuning hook: csrc/gemm.hip TnBigSplit (1) / TnBigImm (2)
-      L.check(L.load().mnr_gemm_tn_set_split(int(os.environ['MNR_TN_SPLIT'])))
   return L.load()
 
 

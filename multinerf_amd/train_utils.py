@@ -224,7 +224,8 @@ def create_train_step(model: models.Model, config, dataset=None):
                     grad_max_val=config.grad_max_val, grad_max_norm=config.grad_max_norm)
     new_state = TrainState(step=step_count + 1, params=state.params, mu=state.mu, nu=state.nu)
 
-    out_stats = {'_raw': stats, '_nlev': nlev, 'grad_sqnorms': sq, '_disp': config.compute_disp_metrics,
+    # (copies: `stats` and `sq` are workspace tensors the next step overwrites, and callers keep TrainStats in buffers)
+    out_stats = {'_raw': stats.clone(), '_nlev': nlev, 'grad_sqnorms': sq.clone(), '_disp': config.compute_disp_metrics,
                  '_normal': config.compute_normal_metrics}
     if return_grads:
       out_stats['_grads'] = raw_grads
@@ -257,6 +258,8 @@ class TrainStats(dict):
       out['normal_maes'] = raw[3 * n + 5:4 * n + 5]
     out['loss'] = sum(out['losses'].values())
     out['psnr'] = float(out['psnrs'][-1])
+    # per top-level module, AFTER the clip by value (what clip_adam's norm clip sees); the reference logs the
+    # pre-clip norm (train_utils.py:323-324): identical whenever grad_max_val = 0, as in every shipped config
     out['grad_norms'] = np.sqrt(self['grad_sqnorms'].detach().cpu().numpy())
     return out
 

@@ -112,7 +112,7 @@ class simulated_device:
     L._lib = self.lib
     ops._stream = lambda: None
     ops._on_device = lambda t: True
-    ops._cfg_applied = False          # the MNR_NT_CFG / MNR_TN_SPLIT hooks, if set, now configure the simulator build
+    ops._cfg_applied = False          # the MNR_NT_PERSIST / MNR_NT_WRES switches, if set, now configure the simulator build
     self.lib.hipsim_reset(0, 0)
     return self
 
@@ -123,7 +123,6 @@ class simulated_device:
   def __exit__(self, *exc):
     from multinerf_amd import ops
     L._lib, ops._stream, ops._on_device, ops._cfg_applied = self.saved
-    self.lib.mnr_gemm_nt_set_config(2, 0)
-    self.lib.mnr_gemm_tn_set_split(0)
-    self.lib.mnr_gemm_nt_set_wres(0)
+    self.lib.mnr_gemm_nt_set_persistent(1)
+    self.lib.mnr_gemm_nt_set_wres(1)
     return False

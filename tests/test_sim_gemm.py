@@ -30,88 +30,58 @@ C_ULL = ctypes.c_ulonglong
 def sim():
   lib = S.load_sim()
   yield lib
-  lib.mnr_gemm_nt_set_config(2, 0)
+  lib.mnr_gemm_nt_set_persistent(1)
+  lib.mnr_gemm_nt_set_wres(1)
 
 
 def _packbits(x):
   return torch.from_numpy(np.packbits((x > 0).numpy(), axis=1, bitorder='little'))
 
 
-# every compiled 256-row configuration; the default in all four modes, the others eager/reverse and late/shuffled
-_FWD_CASES = [(2, m) for m in MODES] + [(c, m) for c in (12, 4, 7, 18, 19, 33, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45)
-                                        for m in (MODES[2], MODES[3])]
-
-
-@pytest.mark.parametrize('cfg,mode', _FWD_CASES)
-def test_nt_forward_layer(sim, cfg, mode):
-  """Forward layer: [A1|A2] W^T + b, ReLU, bf16 output + 1-bit ReLU masks; every compiled 256x256 configuration."""
-  g = torch.Generator().manual_seed(cfg)
-  M, N, K1, K2 = 512, 256, 192, 64
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('persist', [0, -8])
+def test_nt_forward_layer(sim, persist, mode):
+  """Forward layer on the 256x256 tile: [A1|A2] W^T + b, ReLU, bf16 output + 1-bit ReLU masks; one workgroup per tile and
+  a persistent launch (8 workgroups walking 16 virtual tiles: the LDS hand-over between a tile's epilogue and the next
+  tile's prologue, the running tile index)."""
+  g = torch.Generator().manual_seed(2)
+  M, N, K1, K2 = 2304, 256, 192, 64                              # 9 M tiles -> 16 virtual workgroups (7 of them idle)
   A1 = torch.randn((M, K1), generator=g).bfloat16()
   A2 = torch.randn((M, K2), generator=g).bfloat16()
   Bt = (torch.randn((N, K1 + K2), generator=g) * 0.1).bfloat16()
   bias = torch.randn(N, generator=g)
-  sim.mnr_gemm_nt_set_config(cfg, 0)
+  sim.mnr_gemm_nt_set_wres(0)
+  sim.mnr_gemm_nt_set_persistent(persist)
   sim.hipsim_reset(*mode)
-  Cb, _, bits = S.sim_gemm_nt(sim, A1, Bt, A2=A2, bias=bias, relu=True, bits_out=True)
+  try:
+    Cb, _, bits = S.sim_gemm_nt(sim, A1, Bt, A2=A2, bias=bias, relu=True, bits_out=True)
+  finally:
+    sim.mnr_gemm_nt_set_persistent(1)
+    sim.mnr_gemm_nt_set_wres(1)
   ref = torch.relu(torch.cat([A1, A2], 1).float() @ Bt.float().T + bias)
   np.testing.assert_allclose(Cb.float().numpy(), ref.numpy(), atol=2e-2, rtol=1e-2)       # bf16 output rounding
   assert torch.equal(bits, _packbits(Cb.float()))
 
 
-@pytest.mark.parametrize('cfg,mode', [(2, m) for m in MODES] + [(c, m) for c in (36, 37, 40, 41, 42, 43, 44, 45) for m in (MODES[2], MODES[3])])
-def test_nt_dx_layer_with_bit_masks(sim, cfg, mode):
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('persist', [0, -8])
+def test_nt_dx_layer_with_bit_masks(sim, persist, mode):
   """dX layer: (dY W) masked by the forward layer's bits (with the tangent rows' modulo), fp32 side output."""
   g = torch.Generator().manual_seed(5)
-  M, N, K = 512, 256, 128
+  M, N, K = 1024, 512, 128
   dY = torch.randn((M, K), generator=g).bfloat16()
   Wt = (torch.randn((N, K), generator=g) * 0.1).bfloat16()
   keep = torch.rand((256, N), generator=g) > 0.5
   bits = _packbits(keep.float())
-  sim.mnr_gemm_nt_set_config(cfg, 0)
+  sim.mnr_gemm_nt_set_persistent(persist)
   sim.hipsim_reset(*mode)
-  Cb, Cf, _ = S.sim_gemm_nt(sim, dY, Wt, bits_in=bits, bits_row_mod=256, out_f32=(8, 11))
-  ref = (dY.float() @ Wt.float().T) * keep.repeat(2, 1)
+  try:
+    Cb, Cf, _ = S.sim_gemm_nt(sim, dY, Wt, bits_in=bits, bits_row_mod=256, out_f32=(8, 11))
+  finally:
+    sim.mnr_gemm_nt_set_persistent(1)
+  ref = (dY.float() @ Wt.float().T) * keep.repeat(4, 1)
   np.testing.assert_allclose(Cb.float().numpy(), ref.numpy(), atol=2e-2, rtol=1e-2)
   np.testing.assert_allclose(Cf.numpy(), ref[:, 8:19].numpy(), atol=1e-4, rtol=1e-5)
-
-
-@pytest.mark.parametrize('cfg', [36, 37])
-@pytest.mark.parametrize('nk', [1, 2, 3, 5])
-def test_nt_direct_weights_short_and_odd_k(sim, cfg, nk):
-  """The direct-weights loop's prologue / tail bookkeeping: fewer K tiles than stages, odd tile counts, late DMA."""
-  g = torch.Generator().manual_seed(nk)
-  M, N, K = 256, 256, 64 * nk
-  A = torch.randn((M, K), generator=g).bfloat16()
-  Bt = (torch.randn((N, K), generator=g) * 0.1).bfloat16()
-  sim.mnr_gemm_nt_set_config(cfg, 0)
-  for mode in MODES:
-    sim.hipsim_reset(*mode)
-    Cb, _, _ = S.sim_gemm_nt(sim, A, Bt)
-    np.testing.assert_allclose(Cb.float().numpy(), (A.float() @ Bt.float().T).numpy(), atol=2e-2, rtol=1e-2)
-
-
-@pytest.mark.parametrize('cfg', [36, 37])
-def test_nt_direct_weights_from_a_fragment_major_image(sim, cfg):
-  """mnr_pack_w_frag_bf16 + the probe hook mnr_debug_gemm_wfrag: same result, and the row-major operand is not read."""
-  g = torch.Generator().manual_seed(9)
-  M, N, K = 256, 512, 192
-  A = torch.randn((M, K), generator=g).bfloat16()
-  Bt = (torch.randn((N, K + 24), generator=g) * 0.1).bfloat16()[:, :K]         # pitch != K
-  bias = torch.randn(N, generator=g)
-  img = torch.zeros(N * K, dtype=torch.bfloat16)
-  sim.hipsim_reset(0, 0)
-  S.sim_check(sim, sim.mnr_pack_w_frag_bf16(S.ptr(Bt), Bt.stride(0), N, K, S.ptr(img), None))
-  sim.mnr_gemm_nt_set_config(cfg, 0)
-  ref, _, _ = S.sim_gemm_nt(sim, A, Bt, bias=bias, relu=True)
-  for mode in MODES:
-    sim.hipsim_reset(*mode)
-    S.sim_check(sim, sim.mnr_debug_gemm_wfrag(S.ptr(img)))
-    try:
-      got, _, _ = S.sim_gemm_nt(sim, A, torch.full_like(Bt, float('nan')), bias=bias, relu=True)
-    finally:
-      sim.mnr_debug_gemm_wfrag(None)
-    assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize('K', [64, 128, 192, 256])
@@ -126,7 +96,6 @@ def test_nt_weights_resident_persistent_kernel(sim, K):
   bias = torch.randn(200, generator=g)
   keep = torch.rand((256, N), generator=g) > 0.5
   bits_in = _packbits(keep.float())
-  sim.mnr_gemm_nt_set_config(2, 0)
   sim.mnr_gemm_nt_set_wres(0)
   sim.hipsim_reset(0, 0)
   want_f, _, want_b = S.sim_gemm_nt(sim, A, Bt, bias=bias, relu=True, bits_out=True)
@@ -142,7 +111,7 @@ def test_nt_weights_resident_persistent_kernel(sim, K):
       assert torch.equal(got_f, want_f) and torch.equal(got_b, want_b) and torch.equal(got_d, want_d), (wgs, mode)
       assert n0[3] != 0
   finally:
-    sim.mnr_gemm_nt_set_wres(0)
+    sim.mnr_gemm_nt_set_wres(1)
 
 
 @pytest.mark.parametrize('mode', MODES[:2])
@@ -176,30 +145,6 @@ def test_tn_weight_gradient(sim, shape, mode):
   ref[:, N - 5:] = 1.0
   np.testing.assert_allclose(acc.numpy(), ref.numpy(), atol=1e-3, rtol=1e-5)
   np.testing.assert_allclose(db.numpy(), B.float().sum(0).numpy(), atol=1e-3, rtol=1e-5)
-
-
-@pytest.mark.parametrize('shape', [(512, 256, 256), (256, 256, 512), (64, 256, 256), (320, 512, 256)])
-def test_tn_split_path_equals_the_default_kernel(sim, shape):
-  """TnBigSplit (dY tile global -> registers -> ds_write, activations by LDS-DMA): the same LDS image, so the same bits."""
-  M, K, N = shape
-  g = torch.Generator().manual_seed(K)
-  A = torch.randn((M, K), generator=g).bfloat16()
-  B = torch.randn((M, N), generator=g).bfloat16()
-  sim.hipsim_reset(0, 0)
-  sim.mnr_gemm_tn_set_split(0)
-  want, wb = torch.zeros((K, N)), torch.zeros(N)
-  S.sim_gemm_tn(sim, A, B, want, bias_out=wb)
-  np.testing.assert_allclose(want.numpy(), (A.float().T @ B.float()).numpy(), atol=1e-3, rtol=1e-5)
-  try:
-    for variant in (1, 2):                                # TnBigSplit, TnBigImm
-      for mode in MODES:
-        sim.hipsim_reset(*mode)
-        sim.mnr_gemm_tn_set_split(variant)
-        got, gb = torch.zeros((K, N)), torch.zeros(N)
-        S.sim_gemm_tn(sim, A, B, got, bias_out=gb)
-        assert torch.equal(got, want) and torch.equal(gb, wb), (variant, mode)
-  finally:
-    sim.mnr_gemm_tn_set_split(0)
 
 
 def test_small_head_bwd_and_colsum(sim):

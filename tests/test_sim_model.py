@@ -61,10 +61,9 @@ def _setup(name, extra, B, seed=3):
   return cfg, model, (om, on, op), params, model.flat_from_tree(params), batch
 
 
-# (NT configuration for the 256x256-tiled GEMMs, LDS-DMA landing late, fiber order): the default as shipped, and the
-# configurations prepared for the next round (direct-weights loop, two workgroups per CU) under the adversarial modes
-# -42: NtC42 (split paths + batched epilogue reads) + the split-path TN kernel; 1043: NtC43 + the weights-resident kernel
-VARIANTS = [(2, 0, 0), (37, 1, 5), (-42, 1, 2), (1043, 1, 4)]
+# (persistent NT launches [mnr_gemm_nt_set_persistent], weights-resident kernel, LDS-DMA landing late, fiber order): the
+# default as shipped, and the same step under the adversarial modes with few persistent workgroups / without the switches
+VARIANTS = [(1, 1, 0, 0), (-8, 2, 1, 5), (0, 0, 1, 2)]
 
 
 @pytest.mark.parametrize('name,extra,B', CASES)
@@ -73,16 +72,15 @@ def test_forward_and_train_step_on_the_simulator(name, extra, B):
 
 
 @pytest.mark.parametrize('variant', VARIANTS[1:])
-def test_360_step_with_the_prepared_gemm_configurations(variant):
+def test_360_step_under_adversarial_schedules(variant):
   _run(*CASES[0], variant)
 
 
 def _run(name, extra, B, variant):
-  nt_cfg, dma_late, order = variant
+  persist, wres, dma_late, order = variant
   with S.simulated_device() as sim:
-    assert sim.lib.mnr_gemm_nt_set_config(abs(nt_cfg) % 1000, 0) == 0
-    assert sim.lib.mnr_gemm_tn_set_split(1 if nt_cfg < 0 else 0) == 0
-    assert sim.lib.mnr_gemm_nt_set_wres(2 if nt_cfg >= 1000 else 0) == 0
+    assert sim.lib.mnr_gemm_nt_set_persistent(persist) == 0
+    assert sim.lib.mnr_gemm_nt_set_wres(wres) == 0
     sim.lib.hipsim_reset(dma_late, order)
     cfg, model, (om, on, op), params, flat, batch = _setup(name, extra, B)
     noise = helpers.make_noise(model, B)

@@ -73,7 +73,12 @@ def main():
     state, stats, gen = train_pstep(gen, state, batch, cameras, train_frac, 1.0)
     stats_buffer.append(stats)
     if step % config.print_every == 0 or step == num_steps:                              # train.py:141-216
-      s = stats_buffer[-1].materialize()
+      # train.py:150-186: the logged numbers are AVERAGES over the steps since the last print
+      mats = [b.materialize() for b in stats_buffer]
+      s = dict(mats[-1])
+      s['loss'] = float(np.mean([m['loss'] for m in mats]))
+      s['psnr'] = float(np.mean([m['psnr'] for m in mats]))
+      s['losses'] = {k: float(np.mean([m['losses'][k] for m in mats])) for k in mats[-1]['losses']}
       torch.cuda.synchronize()
       elapsed = time.time() - train_start
       steps_done = len(stats_buffer)
