@@ -331,6 +331,30 @@ int mnr_composite_bwd(const mnr_composite_cfg* cfg, int64_t B, const float* raw_
                       float* g_raw_density, uint16_t* g_raw_density_bf16, int ld_bf16,
                       float* g_raw_rgb, float* g_exposure_scale /* [B,3] +=, may be NULL */, void* stream);
 
+/* One level's backward pass in one launch: the training losses acting on this level's rendering with their gradients
+ * (train_utils.py:72-159: compute_data_loss on the composited colour; interlevel_loss of a proposal level against the
+ * final level's histogram, stepfun.py:64-86; distortion_loss of the final level, stepfun.py:266-276) fused with the
+ * compositing VJP (render.py:130-213).  d loss / d weights and d loss / d rgb never touch HBM.  Replaces one
+ * mnr_data_loss + mnr_interlevel_loss | mnr_distortion_loss + mnr_composite_bwd sequence; mnr_composite_bwd is this
+ * entry with both losses off. */
+typedef struct {
+  mnr_composite_cfg cfg;
+  int64_t B, B_valid;           /* rays (padded), rays that take part in the losses */
+  /* compositing VJP: as mnr_composite_bwd */
+  const float* raw_density; const float* density_noise; const float* raw_rgb; const float* tdist; const float* dirs;
+  const float* bg; const float* exposure_scale; const float* weights;
+  const float* g_rgb_out;       /* optional upstream [B,3], added to the fused data-loss gradient */
+  const float* g_weights;       /* optional upstream [B,n] (Ref-NeRF normal losses), added to the fused weight loss's */
+  float* g_raw_density; uint16_t* g_raw_density_bf16; int ld_bf16; float* g_raw_rgb; float* g_exposure_scale;
+  /* data loss; data_loss_type < 0: off.  data_stats[0] += weighted mse, [1] += data_loss_mult * loss (both / *denom) */
+  int data_loss_type; float charb_padding; float data_loss_mult;
+  const float* rgb_out; const float* gt; const float* lossmult; int lm_c; const float* denom; float* data_stats;
+  /* loss on the weights: 0 none; 1 interlevel, this level = envelope of (t_ref [B,n_ref+1], w_ref [B,n_ref]);
+   * 2 distortion on this level's own histogram.  sdist [B,n+1]: this level's normalised distances.  *wloss_stat += loss */
+  int wloss_mode; float wloss_mult; const float* sdist; int n_ref; const float* t_ref; const float* w_ref; float* wloss_stat;
+} mnr_level_bwd_args;
+int mnr_level_bwd(const mnr_level_bwd_args* args, void* stream);
+
 /* RawNeRF exposure (replaces models.py:257-267).  out[b,c] = exposure_values[b] *
  * (1 + [idx[b] > 0] * offsets[idx[b], c]); offsets = the 'exposure_scaling_offsets' embedding
  * [num_embeddings,3] or NULL when Model.learned_exposure_scaling is off.  The backward scatters

@@ -92,6 +92,18 @@ class CompositeCfg(C.Structure):
               ('rgb_padding', C.c_float), ('bg_mode', C.c_int), ('bg_value', C.c_float)]
 
 
+class LevelBwdArgs(C.Structure):
+  _fields_ = [('cfg', CompositeCfg), ('B', C.c_int64), ('B_valid', C.c_int64),
+              ('raw_density', vp), ('density_noise', vp), ('raw_rgb', vp), ('tdist', vp), ('dirs', vp),
+              ('bg', vp), ('exposure_scale', vp), ('weights', vp), ('g_rgb_out', vp), ('g_weights', vp),
+              ('g_raw_density', vp), ('g_raw_density_bf16', vp), ('ld_bf16', C.c_int), ('g_raw_rgb', vp),
+              ('g_exposure_scale', vp),
+              ('data_loss_type', C.c_int), ('charb_padding', C.c_float), ('data_loss_mult', C.c_float),
+              ('rgb_out', vp), ('gt', vp), ('lossmult', vp), ('lm_c', C.c_int), ('denom', vp), ('data_stats', vp),
+              ('wloss_mode', C.c_int), ('wloss_mult', C.c_float), ('sdist', vp), ('n_ref', C.c_int), ('t_ref', vp),
+              ('w_ref', vp), ('wloss_stat', vp)]
+
+
 class IdeTables(C.Structure):
   _fields_ = [('T', C.c_int), ('lmax', C.c_int), ('m', vp), ('l', vp), ('sigma', vp), ('mat', vp)]
 
@@ -133,6 +145,7 @@ _PROTOS = {
     'mnr_composite_fwd': ([C.POINTER(CompositeCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_composite_bwd': ([C.POINTER(CompositeCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32,
                            vp, vp, vp], i32),
+    'mnr_level_bwd': ([C.POINTER(LevelBwdArgs), vp], i32),
     'mnr_exposure_scale': ([i64, vp, vp, vp, vp, vp], i32),
     'mnr_exposure_scale_bwd': ([i64, vp, vp, vp, vp, vp], i32),
     'mnr_render_extras': ([i64, i32, vp, vp, vp, vp, vp], i32),

@@ -10,13 +10,7 @@
 // atomically to a small fp32 stats array.
 #include "common.h"
 
-#define LS_THREADS 64
-
-__device__ __forceinline__ float ls_wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
+#include "ray_losses.h"
 
 __global__ void lossmult_sum_kernel(int64_t B, const float* __restrict__ lm, int lm_c, float* out) {
   float s = 0.0f;
@@ -171,37 +165,6 @@ extern "C" int mnr_data_loss(int loss_type, float charb_padding, float loss_mult
 // ---------------------------------------------------------------------------
 // interlevel loss.  Per ray, in LDS [elem][ray]: lo[n+1], hi[n+1] (as floats), g[n].
 
-__device__ __forceinline__ void ls_outer_sweep(int n, const float* t, const float* w, int ne, const float* te,
-                                               const float* we, float* lo_f, float* hi_f, float* g_or_loss,
-                                               int S, float scale, bool want_grad, float& loss_sum) {
-  // searchsorted(t_env, t) (stepfun.py:49-53) with cursors:
-  //   lo = last idx with te[idx] <= v (0 if none), hi = first idx with te[idx] > v (ne if none).
-  // cy[idx] = sum_{j<idx} we[j] accumulated left to right as the cursors advance.
-  int lo = 0, hi = 0;
-  float cy_lo = 0.0f, cy_hi = 0.0f, cy_lo_prev = 0.0f;
-  const float eps = MNR_F32_EPS;
-  for (int k = 0; k <= n; ++k) {
-    const float v = t[k];
-    while (lo + 1 <= ne && te[lo + 1] <= v) { cy_lo += we[lo]; ++lo; }
-    const int lo_k = (te[0] <= v) ? lo : 0;                   // none true -> i[0]
-    const float cylo_k = (te[0] <= v) ? cy_lo : 0.0f;
-    while (hi <= ne && !(te[hi] > v)) { if (hi < ne) cy_hi += we[hi]; ++hi; }
-    const int hi_k = hi <= ne ? hi : ne;                      // none false... -> last index
-    // cy at hi_k: if hi ran past ne, cy_hi holds the full sum = cy[ne].
-    lo_f[k * S] = (float)lo_k;
-    hi_f[k * S] = (float)hi_k;
-    if (k >= 1) {
-      const float w_outer = cy_hi - cy_lo_prev;               // stepfun.py:74
-      const float wi = w[k - 1];
-      const float d = fmaxf(0.0f, wi - w_outer);
-      const float l = d * d / (wi + eps);                     // stepfun.py:86
-      loss_sum += l;
-      g_or_loss[(k - 1) * S] = want_grad ? (-2.0f * d / (wi + eps)) * scale : l;
-    }
-    cy_lo_prev = cylo_k;
-  }
-}
-
 __global__ __launch_bounds__(LS_THREADS) void interlevel_kernel(float mult, int64_t B, int64_t B_valid, int n,
                                                                 const float* __restrict__ t,
                                                                 const float* __restrict__ w, int ne,
@@ -217,7 +180,7 @@ __global__ __launch_bounds__(LS_THREADS) void interlevel_kernel(float mult, int6
   float loss_sum = 0.0f;
   if (b < B_valid) {
     const float scale = mult / ((float)B_valid * (float)n);   // jnp.mean over [B, n]
-    ls_outer_sweep(n, t + b * (n + 1), w + b * n, ne, te + b * (ne + 1), we + b * ne, lo_f, hi_f, gi, S, scale,
+    ls_outer_sweep(n, t + b * (n + 1), w + b * n, ne, te + b * (ne + 1), we + b * ne, 1, lo_f, hi_f, gi, S, scale,
                    per_elem == nullptr, loss_sum);
     if (per_elem) {
       for (int i = 0; i < n; ++i) per_elem[b * n + i] = gi[i * S];

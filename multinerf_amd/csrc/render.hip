@@ -9,6 +9,7 @@
 // A workgroup's rows are staged through LDS so that global loads/stores are
 // coalesced although each lane walks its own row.
 #include "common.h"
+#include "ray_losses.h"
 
 #define CP_THREADS 64
 
@@ -154,46 +155,119 @@ extern "C" int mnr_composite_fwd(const mnr_composite_cfg* cfg, int64_t B, const 
   return MNR_OK;
 }
 
-// VJP.  With x_i = sigma_i * delta_i, T_i = exp(-sum_{k<i} x_k), w_i = (1 - exp(-x_i)) T_i:
+// One level's backward pass up to the MLP heads: the training losses that act on this level's rendering and their
+// gradients (train_utils.py:72-159: data loss on the composited colour; interlevel loss of a proposal level, whose
+// histogram is the envelope of the final level's; distortion loss of the final level), then the compositing VJP.
+// One launch per level instead of data_loss + interlevel / distortion + composite_bwd: d loss / d weights lives in LDS
+// and d loss / d rgb in registers, never in HBM.
+//
+// Compositing VJP.  With x_i = sigma_i * delta_i, T_i = exp(-sum_{k<i} x_k), w_i = (1 - exp(-x_i)) T_i:
 //   g^_i = g_w[i] + g_rgb . c_i - [acc < 1] (g_rgb . bg)
 //   dL/dx_i = g^_i (T_i - w_i) - sum_{k>i} g^_k w_k ;  dL/dsigma_i = delta_i dL/dx_i ; dL/dc_i = w_i g_rgb.
-__global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
-    mnr_composite_cfg c, int64_t B, int S, const float* __restrict__ raw_density, const float* __restrict__ noise,
-    const float* __restrict__ raw_rgb, const float* __restrict__ tdist, const float* __restrict__ dirs,
-    const float* __restrict__ bg, const float* __restrict__ expo, const float* __restrict__ weights,
-    const float* __restrict__ g_rgb_out, const float* __restrict__ g_weights, float* __restrict__ g_raw_density,
-    bf16* __restrict__ g_den_bf16, int ld_bf16, float* __restrict__ g_raw_rgb, float* __restrict__ g_expo) {
+// LDS per ray (floats): raw density n | tdist n+1 | weights n | raw rgb 3n | g_w n | [sdist n+1 | lo n_ref+1 | hi n_ref+1 | gi n_ref]
+__global__ __launch_bounds__(CP_THREADS) void level_bwd_kernel(mnr_level_bwd_args a, int S) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const mnr_composite_cfg c = a.cfg;
   const int n = c.n;
   float* l_den = lds;                       // n   raw density in, g_raw_density out
   float* l_t = l_den + n * S;               // n+1
-  float* l_w = l_t + (n + 1) * S;           // n   weights in (g_weights added on the fly from HBM)
+  float* l_w = l_t + (n + 1) * S;           // n   weights
   float* l_rgb = l_w + n * S;               // 3n  raw rgb in, g_raw_rgb out
+  float* l_gw = l_rgb + 3 * n * S;          // n   d loss / d weights
+  float* l_s = l_gw + n * S;                // n+1 sdist (weight losses only)
+  float* l_lo = l_s + (n + 1) * S;          // n_ref+1, n_ref+1, n_ref (interlevel only)
+  float* l_hi = l_lo + (a.n_ref + 1) * S;
+  float* l_gi = l_hi + (a.n_ref + 1) * S;
+  const int64_t B = a.B;
   const int64_t ray0 = (int64_t)blockIdx.x * S;
   const int rows = (int)min((int64_t)S, B - ray0);
-  cp_load_rows(l_den, raw_density + ray0 * n, rows, n, S);
-  cp_load_rows(l_t, tdist + ray0 * (n + 1), rows, n + 1, S);
-  cp_load_rows(l_w, weights + ray0 * n, rows, n, S);
-  if (c.has_rgb) cp_load_rows(l_rgb, raw_rgb + ray0 * n * 3, rows, 3 * n, S);
-  if (noise && c.density_noise_std > 0.0f) {
+  cp_load_rows(l_den, a.raw_density + ray0 * n, rows, n, S);
+  cp_load_rows(l_t, a.tdist + ray0 * (n + 1), rows, n + 1, S);
+  cp_load_rows(l_w, a.weights + ray0 * n, rows, n, S);
+  if (c.has_rgb) cp_load_rows(l_rgb, a.raw_rgb + ray0 * n * 3, rows, 3 * n, S);
+  if (a.g_weights) {
+    cp_load_rows(l_gw, a.g_weights + ray0 * n, rows, n, S);
+  } else {
+    for (int e = threadIdx.x; e < S * n; e += CP_THREADS) l_gw[e] = 0.0f;
+  }
+  if (a.wloss_mode != 0) cp_load_rows(l_s, a.sdist + ray0 * (n + 1), rows, n + 1, S);
+  if (a.density_noise && c.density_noise_std > 0.0f) {
     __syncthreads();
     for (int e = threadIdx.x; e < rows * n; e += CP_THREADS) {
       const int r = e / n, i = e % n;
-      l_den[i * S + r] += c.density_noise_std * noise[ray0 * n + e];
+      l_den[i * S + r] += c.density_noise_std * a.density_noise[ray0 * n + e];
     }
   }
   __syncthreads();
   const int r = threadIdx.x;
+  float s_mse = 0.0f, s_dloss = 0.0f, s_wloss = 0.0f;
   if (r < rows) {
     const int64_t ray = ray0 + r;
-    const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+    const bool valid = ray < a.B_valid;      // padding rays take part in no loss
+    float go[3] = {0.0f, 0.0f, 0.0f};
+    if (a.g_rgb_out) { go[0] = a.g_rgb_out[ray * 3]; go[1] = a.g_rgb_out[ray * 3 + 1]; go[2] = a.g_rgb_out[ray * 3 + 2]; }
+    // ---- data loss on the composited colour (train_utils.py:85-111)
+    if (a.data_loss_type >= 0 && valid) {
+      const float denom = *a.denom;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float y = a.rgb_out[ray * 3 + ch], t = a.gt[ray * 3 + ch];
+        const float w = a.lm_c == 1 ? a.lossmult[ray] : a.lossmult[ray * 3 + ch];
+        const float rs = y - t;
+        s_mse += w * rs * rs;                                 // train_utils.py:86-88
+        float dl, dd;
+        if (a.data_loss_type == MNR_LOSS_MSE) {               // :90-92
+          dl = rs * rs;
+          dd = 2.0f * rs;
+        } else if (a.data_loss_type == MNR_LOSS_CHARB) {      // :93-95
+          dl = sqrtf(rs * rs + a.charb_padding * a.charb_padding);
+          dd = rs / dl;
+        } else {                                              // :96-103 rawnerf
+          const float yc = fminf(1.0f, y);
+          const float rc = yc - t;
+          const float sg = 1.0f / (1e-3f + yc);
+          dl = rc * rc * sg * sg;
+          dd = y < 1.0f ? 2.0f * rc * sg * sg : 0.0f;
+        }
+        s_dloss += w * dl;
+        go[ch] += a.data_loss_mult * w * dd / denom;
+      }
+    }
+    // ---- losses on the weights: d loss / d w_i accumulates in l_gw
+    if (a.wloss_mode == 1 && valid) {
+      // interlevel (train_utils.py:139-150, stepfun.py:64-86): this level (l_s, l_w) is the envelope of the final
+      // level's histogram (t_ref, w_ref), whose values carry no gradient
+      const int nr = a.n_ref;
+      const float scale = a.wloss_mult / ((float)a.B_valid * (float)nr);       // jnp.mean over [B, n_ref]
+      ls_outer_sweep(nr, a.t_ref + ray * (nr + 1), a.w_ref + ray * nr, n, l_s + r, l_w + r, S, l_lo + r, l_hi + r, l_gi + r, S,
+                     scale, true, s_wloss);
+      // d w_outer[i] / d we[j] = [lo[i] <= j < hi[i+1]]; starts and ends both ascend with i.
+      int is = 0, ie = 0;
+      float active = 0.0f;
+      for (int j = 0; j < n; ++j) {
+        while (is < nr && (int)l_lo[is * S + r] <= j) active += l_gi[(is++) * S + r];
+        while (ie < nr && (int)l_hi[(ie + 1) * S + r] <= j) active -= l_gi[(ie++) * S + r];
+        l_gw[j * S + r] += active;
+      }
+    } else if (a.wloss_mode == 2 && valid) {
+      // distortion (train_utils.py:153-159, stepfun.py:266-276) on this level's own (sdist, weights)
+      const float scale = a.wloss_mult / (float)a.B_valid;                     // jnp.mean over rays
+      for (int i = 0; i < n; ++i) {
+        const float ui = (l_s[(i + 1) * S + r] + l_s[i * S + r]) / 2.0f, wi = l_w[i * S + r];
+        float inner = 0.0f;
+        for (int j = 0; j < n; ++j) inner += l_w[j * S + r] * fabsf(ui - (l_s[(j + 1) * S + r] + l_s[j * S + r]) / 2.0f);
+        const float dt = l_s[(i + 1) * S + r] - l_s[i * S + r];
+        s_wloss += wi * inner + wi * wi * dt / 3.0f;
+        l_gw[i * S + r] += scale * (2.0f * inner + (2.0f / 3.0f) * wi * dt);
+      }
+    }
+    // ---- compositing VJP
+    const float dx = a.dirs[ray * 3], dy = a.dirs[ray * 3 + 1], dz = a.dirs[ray * 3 + 2];
     const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
     float ex[3] = {1.0f, 1.0f, 1.0f};
-    if (expo) { ex[0] = expo[ray * 3]; ex[1] = expo[ray * 3 + 1]; ex[2] = expo[ray * 3 + 2]; }
-    float go[3] = {0.0f, 0.0f, 0.0f};
-    if (g_rgb_out) { go[0] = g_rgb_out[ray * 3]; go[1] = g_rgb_out[ray * 3 + 1]; go[2] = g_rgb_out[ray * 3 + 2]; }
+    if (a.exposure_scale) { ex[0] = a.exposure_scale[ray * 3]; ex[1] = a.exposure_scale[ray * 3 + 1]; ex[2] = a.exposure_scale[ray * 3 + 2]; }
     float b[3] = {c.bg_value, c.bg_value, c.bg_value};
-    if (c.bg_mode == 1) { b[0] = bg[ray * 3]; b[1] = bg[ray * 3 + 1]; b[2] = bg[ray * 3 + 2]; }
+    if (c.bg_mode == 1) { b[0] = a.bg[ray * 3]; b[1] = a.bg[ray * 3 + 1]; b[2] = a.bg[ray * 3 + 2]; }
     float acc = 0.0f;
     for (int i = 0; i < n; ++i) acc += l_w[i * S + r];
     const float g_bgw = (1.0f - acc > 0.0f) ? (go[0] * b[0] + go[1] * b[1] + go[2] * b[2]) : 0.0f;
@@ -214,8 +288,7 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
       const bool opaque_last = c.opaque_background && i == n - 1;
       const float x = opaque_last ? INFINITY : sigma * delta;
       const float t_next = expf(-(run + x));              // T_{i+1} = T_i - w_i
-      float ghat = g_weights ? g_weights[ray * n + i] : 0.0f;
-      ghat -= g_bgw;
+      float ghat = l_gw[i * S + r] - g_bgw;
       float gc[3] = {0.0f, 0.0f, 0.0f};
       if (c.has_rgb) {
 #pragma unroll
@@ -242,45 +315,107 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
         run -= sp * (l_t[i * S + r] - l_t[(i - 1) * S + r]) * dnorm;
       }
     }
-    if (g_expo) {
+    if (a.g_exposure_scale) {
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) g_expo[ray * 3 + ch] += ges[ch];
+      for (int ch = 0; ch < 3; ++ch) a.g_exposure_scale[ray * 3 + ch] += ges[ch];
     }
+  }
+  // loss values: wave sums, one atomic each
+  if (a.data_loss_type >= 0 && a.data_stats) {
+    s_mse = ls_wave_sum(s_mse);
+    s_dloss = ls_wave_sum(s_dloss);
+    if (threadIdx.x == 0) {
+      const float denom = *a.denom;
+      unsafeAtomicAdd(a.data_stats + 0, s_mse / denom);
+      unsafeAtomicAdd(a.data_stats + 1, a.data_loss_mult * s_dloss / denom);
+    }
+  }
+  if (a.wloss_mode != 0 && a.wloss_stat) {
+    s_wloss = ls_wave_sum(s_wloss);
+    const float norm = a.wloss_mode == 1 ? (float)a.B_valid * (float)a.n_ref : (float)a.B_valid;
+    if (threadIdx.x == 0) unsafeAtomicAdd(a.wloss_stat, a.wloss_mult * s_wloss / norm);
   }
   __syncthreads();
-  if (g_raw_density) cp_store_rows(l_den, g_raw_density + ray0 * n, rows, n, S);
-  if (g_den_bf16) {
+  if (a.g_raw_density) cp_store_rows(l_den, a.g_raw_density + ray0 * n, rows, n, S);
+  if (a.g_raw_density_bf16) {
+    bf16* gb = (bf16*)a.g_raw_density_bf16;
     for (int e = threadIdx.x; e < rows * n; e += CP_THREADS) {
       const int rr = e / n, i = e % n;
-      g_den_bf16[(ray0 * n + e) * (int64_t)ld_bf16] = (bf16)l_den[i * S + rr];
+      gb[(ray0 * n + e) * (int64_t)a.ld_bf16] = (bf16)l_den[i * S + rr];
     }
   }
-  if (c.has_rgb && g_raw_rgb) cp_store_rows(l_rgb, g_raw_rgb + ray0 * n * 3, rows, 3 * n, S);
+  if (c.has_rgb && a.g_raw_rgb) cp_store_rows(l_rgb, a.g_raw_rgb + ray0 * n * 3, rows, 3 * n, S);
 }
 
+static size_t lb_floats_per_ray(const mnr_level_bwd_args* a) {
+  const int n = a->cfg.n;
+  size_t f = (size_t)(6 * n + 1) + n;                        // compositing VJP + d loss / d weights
+  if (a->wloss_mode != 0) f += n + 1;                        // sdist
+  if (a->wloss_mode == 1) f += 3 * (size_t)a->n_ref + 2;     // lo, hi, gi
+  return f;
+}
+
+extern "C" int mnr_level_bwd(const mnr_level_bwd_args* a, void* stream) {
+  MNR_CHECK_ARG(a != nullptr, "mnr_level_bwd: null args");
+  const mnr_composite_cfg* cfg = &a->cfg;
+  MNR_CHECK_ARG(a->B > 0 && a->B_valid > 0 && a->B_valid <= a->B && a->raw_density && a->tdist && a->dirs && a->weights,
+                "mnr_level_bwd: null argument");
+  MNR_CHECK_ARG(cfg->n >= 1 && cfg->n <= 1024, "mnr_level_bwd: n out of range");
+  MNR_CHECK_ARG(a->g_raw_density || a->g_raw_density_bf16, "mnr_level_bwd: no density-gradient output");
+  MNR_CHECK_ARG(!cfg->has_rgb || a->raw_rgb, "mnr_level_bwd: has_rgb needs raw_rgb");
+  MNR_CHECK_ARG(cfg->bg_mode == 0 || a->bg, "mnr_level_bwd: bg_mode 1 needs bg");
+  MNR_CHECK_ARG(a->data_loss_type < 0 || (a->data_loss_type <= MNR_LOSS_RAWNERF && a->rgb_out && a->gt && a->lossmult &&
+                                          a->denom && (a->lm_c == 1 || a->lm_c == 3)),
+                "mnr_level_bwd: the fused data loss needs rgb_out, gt, lossmult [B,1|3] and denom");
+  MNR_CHECK_ARG(a->wloss_mode >= 0 && a->wloss_mode <= 2, "mnr_level_bwd: wloss_mode must be 0, 1 or 2");
+  MNR_CHECK_ARG(a->wloss_mode == 0 || a->sdist, "mnr_level_bwd: weight losses need this level's sdist");
+  MNR_CHECK_ARG(a->wloss_mode != 1 || (a->n_ref >= 1 && a->n_ref <= 1024 && a->t_ref && a->w_ref),
+                "mnr_level_bwd: the interlevel loss needs the final level's (t_ref, w_ref)");
+  const size_t fpr = lb_floats_per_ray(a);
+  int S = CP_THREADS;
+  while (S > 1 && fpr * S * 4 > 150 * 1024) S >>= 1;
+  // lane per ray is latency-bound: spread small batches over >= 1024 workgroups (one wave each)
+  while (S > 8 && a->B / S < 1024) S >>= 1;
+  const size_t lds = fpr * S * 4;
+  MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_level_bwd: n=%d too long for LDS staging", cfg->n);
+  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if (mnr_attr_needed(&attr_set)) {
+    (void)hipFuncSetAttribute((const void*)level_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  hipLaunchKernelGGL(level_bwd_kernel, dim3(mnr_cdiv(a->B, S)), dim3(CP_THREADS), lds, (hipStream_t)stream, *a, S);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// The compositing VJP alone (no fused loss): the same kernel.
 extern "C" int mnr_composite_bwd(const mnr_composite_cfg* cfg, int64_t B, const float* raw_density,
                                  const float* density_noise, const float* raw_rgb, const float* tdist,
                                  const float* dirs, const float* bg, const float* exposure_scale,
                                  const float* weights, const float* g_rgb_out, const float* g_weights,
                                  float* g_raw_density, uint16_t* g_raw_density_bf16, int ld_bf16,
                                  float* g_raw_rgb, float* g_exposure_scale, void* stream) {
-  MNR_CHECK_ARG(cfg && B > 0 && raw_density && tdist && dirs && weights, "mnr_composite_bwd: null argument");
-  MNR_CHECK_ARG(g_raw_density || g_raw_density_bf16, "mnr_composite_bwd: no density-gradient output");
-  MNR_CHECK_ARG(!cfg->has_rgb || raw_rgb, "mnr_composite_bwd: has_rgb needs raw_rgb");
-  MNR_CHECK_ARG(cfg->bg_mode == 0 || bg, "mnr_composite_bwd: bg_mode 1 needs bg");
-  const int S = cp_rays_per_block(cfg->n, B);
-  const size_t lds = cp_lds_bytes(cfg->n, S);
-  MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_composite_bwd: n=%d too long for LDS staging", cfg->n);
-  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
-  if (mnr_attr_needed(&attr_set)) {
-    (void)hipFuncSetAttribute((const void*)composite_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3(mnr_cdiv(B, S)), dim3(CP_THREADS), lds, (hipStream_t)stream,
-                     *cfg, B, S, raw_density, density_noise, raw_rgb, tdist, dirs, bg, exposure_scale, weights,
-                     g_rgb_out, g_weights, g_raw_density, (bf16*)g_raw_density_bf16, ld_bf16, g_raw_rgb,
-                     g_exposure_scale);
-  MNR_CHECK_LAUNCH();
-  return MNR_OK;
+  MNR_CHECK_ARG(cfg != nullptr, "mnr_composite_bwd: null cfg");
+  mnr_level_bwd_args a = {};
+  a.cfg = *cfg;
+  a.B = a.B_valid = B;
+  a.raw_density = raw_density;
+  a.density_noise = density_noise;
+  a.raw_rgb = raw_rgb;
+  a.tdist = tdist;
+  a.dirs = dirs;
+  a.bg = bg;
+  a.exposure_scale = exposure_scale;
+  a.weights = weights;
+  a.g_rgb_out = g_rgb_out;
+  a.g_weights = g_weights;
+  a.g_raw_density = g_raw_density;
+  a.g_raw_density_bf16 = g_raw_density_bf16;
+  a.ld_bf16 = ld_bf16;
+  a.g_raw_rgb = g_raw_rgb;
+  a.g_exposure_scale = g_exposure_scale;
+  a.data_loss_type = -1;
+  a.wloss_mode = 0;
+  return mnr_level_bwd(&a, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -865,10 +865,11 @@ class Model:
     G = self.num_glo_features
     return flat[self.glo_off:self.glo_off + self.num_glo_embeddings * G].view(self.num_glo_embeddings, G)
 
-  def backward_level(self, lv, flat, grads, g_rgb_out, g_weights, g_expo=None, g_normals=None, g_npred=None):
+  def backward_level(self, lv, flat, grads, g_rgb_out, g_weights, g_expo=None, g_normals=None, g_npred=None, losses=None):
     """VJP of one level w.r.t. the parameters: compositing -> heads -> trunk.
     grads: flat fp32 gradient vector (accumulated into).  g_normals / g_npred [M,3]: from the Ref-NeRF
-    normal losses (train_utils.py:162-197)."""
+    normal losses (train_utils.py:162-197).  losses: this level's data / interlevel / distortion losses, evaluated
+    and differentiated inside the compositing VJP's launch (ops.composite_bwd)."""
     plan: MLPPlan = lv['plan']
     hp = plan.hp
     M, n, tag = lv['M'], lv['n'], lv['tag']
@@ -900,7 +901,7 @@ class Model:
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], raw_rgb=lv['raw_rgb'],
           density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights,
           g_den_bf16=dHB.view(-1)[bw:], ld_bf16=nh, want_f32=False, exposure_scale=lv['expo'],
-          g_exposure_scale=g_expo if lv['expo'] is not None else None)
+          g_exposure_scale=g_expo if lv['expo'] is not None else None, losses=losses)
       g_raw_rgb = g_rgb.view(M, 3)
       if plan.ref:
         # colour combine VJP: -> d raw specular rgb, and the diffuse / tint columns of the head gradient
@@ -987,7 +988,7 @@ class Model:
     else:
       g_raw_density, _ = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], density_noise=lv['dnoise'],
-          bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights, want_f32=True)
+          bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights, want_f32=True, losses=losses)
       d = plan.density
       if mlp.get('chain'):
         # fused dX chain: head dW / db from the last activation, then every dY_i in one launch; dW_i = x_{i-1}^T dY_i below

@@ -450,7 +450,10 @@ def composite_fwd(cfg, raw_density, tdist, dirs, *, raw_rgb=None, density_noise=
 
 def composite_bwd(cfg, raw_density, tdist, dirs, weights, *, raw_rgb=None, density_noise=None, bg=None,
                   exposure_scale=None, g_rgb_out=None, g_weights=None, g_den_bf16=None, ld_bf16=0,
-                  want_f32=True, g_exposure_scale=None):
+                  want_f32=True, g_exposure_scale=None, losses=None):
+  """Compositing VJP; with `losses` the level's training losses are fused in front of it (mnr_level_bwd):
+  losses = dict(B_valid=..., data=dict(type, charb_padding, mult, rgb_out, gt, lossmult, denom, stats) | None,
+                weights=dict(mode='interlevel'|'distortion', mult, sdist, t_ref, w_ref, stat) | None)."""
   B, n = raw_density.shape
   dev = raw_density.device
   for x, nm in ((raw_density, 'raw_density'), (tdist, 'tdist'), (dirs, 'dirs'), (weights, 'weights')):
@@ -460,11 +463,46 @@ def composite_bwd(cfg, raw_density, tdist, dirs, weights, *, raw_rgb=None, densi
   _chk(g_den_bf16, bf16, 'g_den_bf16', allow_none=True)
   g_raw_density = torch.empty((B, n), dtype=f32, device=dev) if want_f32 else None
   g_raw_rgb = torch.empty((B, n, 3), dtype=f32, device=dev) if cfg.has_rgb else None
+  a = L.LevelBwdArgs()
+  a.cfg = cfg
+  a.B = B
+  a.B_valid = B if losses is None else int(losses['B_valid'])
+  p = lambda t: None if t is None else t.data_ptr()
+  a.raw_density, a.density_noise, a.raw_rgb, a.tdist, a.dirs = p(raw_density), p(density_noise), p(raw_rgb), p(tdist), p(dirs)
+  a.bg, a.exposure_scale, a.weights, a.g_rgb_out, a.g_weights = p(bg), p(exposure_scale), p(weights), p(g_rgb_out), p(g_weights)
+  a.g_raw_density, a.g_raw_density_bf16, a.ld_bf16 = p(g_raw_density), p(g_den_bf16), ld_bf16
+  a.g_raw_rgb, a.g_exposure_scale = p(g_raw_rgb), p(g_exposure_scale)
+  a.data_loss_type, a.wloss_mode = -1, 0
+  keep = []
+  if losses is not None and losses.get('data') is not None:
+    d = losses['data']
+    if d['type'] not in L.DATA_LOSS:
+      raise ValueError(f"unsupported data_loss_type {d['type']!r}")
+    for k in ('rgb_out', 'gt', 'lossmult', 'denom', 'stats'):
+      _chk(d[k], f32, 'data.' + k)
+    assert d['rgb_out'].shape[0] == B and d['gt'].shape[0] == B and d['lossmult'].shape[0] == B
+    a.data_loss_type, a.charb_padding, a.data_loss_mult = L.DATA_LOSS[d['type']], float(d['charb_padding']), float(d['mult'])
+    a.rgb_out, a.gt, a.lossmult, a.lm_c = p(d['rgb_out']), p(d['gt']), p(d['lossmult']), d['lossmult'].shape[-1]
+    a.denom, a.data_stats = p(d['denom']), p(d['stats'])
+    keep.append(d)
+  if losses is not None and losses.get('weights') is not None:
+    w = losses['weights']
+    _chk(w['sdist'], f32, 'weights.sdist')
+    _chk(w['stat'], f32, 'weights.stat')
+    assert w['sdist'].shape == (B, n + 1)
+    a.wloss_mult, a.sdist, a.wloss_stat = float(w['mult']), p(w['sdist']), p(w['stat'])
+    if w['mode'] == 'interlevel':
+      _chk(w['t_ref'], f32, 'weights.t_ref')
+      _chk(w['w_ref'], f32, 'weights.w_ref')
+      assert w['t_ref'].shape[0] == B and w['t_ref'].shape[1] == w['w_ref'].shape[1] + 1
+      a.wloss_mode, a.n_ref, a.t_ref, a.w_ref = 1, w['w_ref'].shape[1], p(w['t_ref']), p(w['w_ref'])
+    elif w['mode'] == 'distortion':
+      a.wloss_mode = 2
+    else:
+      raise ValueError(f"weights.mode {w['mode']!r}")
+    keep.append(w)
   _e = PROFILE.start()
-  L.check(lib().mnr_composite_bwd(C.byref(cfg), B, _ptr(raw_density), _ptr(density_noise), _ptr(raw_rgb),
-                                  _ptr(tdist), _ptr(dirs), _ptr(bg), _ptr(exposure_scale), _ptr(weights),
-                                  _ptr(g_rgb_out), _ptr(g_weights), _ptr(g_raw_density), _ptr(g_den_bf16),
-                                  ld_bf16, _ptr(g_raw_rgb), _ptr(g_exposure_scale), _stream()))
+  L.check(lib().mnr_level_bwd(C.byref(a), _stream()))
   PROFILE.stop(_e, 'composite_bwd', 4 * (raw_density.numel() * (3 + (3 if raw_rgb is not None else 0))) + (2 + (12 if raw_rgb is not None else 0)) * raw_density.numel())
   return g_raw_density, g_raw_rgb
 

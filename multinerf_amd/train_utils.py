@@ -107,12 +107,21 @@ def create_train_step(model: models.Model, config, dataset=None):
     grads = model._buf(('train', 'grads'), (model.num_params,), f32)
     grads.zero_()
 
-    g_rgb, g_w = [None] * nlev, [None] * nlev
-    for li, lv in enumerate(levels):                                   # train_utils.py:85-111, 131-134
+    # Data, interlevel and distortion losses (train_utils.py:85-111, 131-159) are evaluated AND differentiated inside
+    # each level's backward launch (ops.composite_bwd(losses=...) -> mnr_level_bwd): only their specs are built here.
+    g_w = [None] * nlev                                               # upstream d loss / d weights (Ref-NeRF normal losses only)
+    data_spec, w_spec = [None] * nlev, [None] * nlev
+    last = levels[-1]
+    for li, lv in enumerate(levels):
       mult = config.data_loss_mult if li == nlev - 1 else config.data_coarse_loss_mult
-      g = ops.data_loss(config.data_loss_type, config.charb_padding, mult, lv['rgb_out'], gt, lossmult, denom,
-                        stats[2 * li:2 * li + 2], B_valid=B0, want_grad=mult > 0)
-      g_rgb[li] = g if mult > 0 else None
+      data_spec[li] = dict(type=config.data_loss_type, charb_padding=config.charb_padding, mult=mult, rgb_out=lv['rgb_out'],
+                           gt=gt, lossmult=lossmult, denom=denom, stats=stats[2 * li:2 * li + 2])
+      if li < nlev - 1 and config.interlevel_loss_mult > 0:           # train_utils.py:139-150
+        w_spec[li] = dict(mode='interlevel', mult=config.interlevel_loss_mult, sdist=lv['sdist'], t_ref=last['sdist'],
+                          w_ref=last['weights'], stat=stats[2 * nlev:2 * nlev + 1])
+      elif li == nlev - 1 and config.distortion_loss_mult > 0:        # train_utils.py:153-159
+        w_spec[li] = dict(mode='distortion', mult=config.distortion_loss_mult, sdist=lv['sdist'],
+                          stat=stats[2 * nlev + 1:2 * nlev + 2])
       rd = saved['renderings'][li]
       k0 = 2 * nlev + 5
       if config.compute_disp_metrics:                                  # train_utils.py:113-115
@@ -125,24 +134,12 @@ def create_train_step(model: models.Model, config, dataset=None):
           if batch.alphas is None or batch.normals is None:
             raise ValueError('compute_normal_metrics needs batch.alphas and batch.normals')
           ops.render_metrics(B0, acc=rd['acc'].reshape(-1).contiguous(),
-                             alphas=batch.alphas.reshape(-1).contiguous().float(),
+                             alphas=batch.alphas.reshape(-1).contiguous(),
                              normals=rd['normals'].reshape(-1, 3).contiguous(),
                              normals_gt=batch.normals.reshape(-1, 3).contiguous().float(),
                              out_normal=stats[k0 + nlev + li:k0 + nlev + li + 1])
         else:
           stats[k0 + nlev + li] = float('nan')
-    last = levels[-1]
-    if config.interlevel_loss_mult > 0:                                # train_utils.py:139-150
-      for li, lv in enumerate(levels[:-1]):
-        g_w[li] = model._buf(('train', 'g_w', li), (Bp, lv['n']), f32)
-        g_w[li].zero_()
-        ops.interlevel_loss(config.interlevel_loss_mult, last['sdist'], last['weights'], lv['sdist'],
-                            lv['weights'], stats[2 * nlev:2 * nlev + 1], g_w[li], B_valid=B0)
-    if config.distortion_loss_mult > 0:                                # train_utils.py:153-159
-      g_w[-1] = model._buf(('train', 'g_w', nlev - 1), (Bp, last['n']), f32)
-      g_w[-1].zero_()
-      ops.distortion_loss(config.distortion_loss_mult, last['sdist'], last['weights'],
-                          stats[2 * nlev + 1:2 * nlev + 2], g_w[-1], B_valid=B0)
 
     g_nrm, g_npr = [None] * nlev, [None] * nlev
     if use_orient or use_prednorm:                                     # train_utils.py:162-197
@@ -174,8 +171,13 @@ def create_train_step(model: models.Model, config, dataset=None):
       order = [nlev - 1] + order[:-1]
     for li in order:
       lv = levels[li]
-      if g_rgb[li] is not None or g_w[li] is not None:                 # (else this level receives no gradient)
-        model.backward_level(lv, flat, grads, g_rgb[li], g_w[li], g_expo, g_nrm[li], g_npr[li])
+      if data_spec[li]['mult'] > 0 or w_spec[li] is not None or g_w[li] is not None:
+        model.backward_level(lv, flat, grads, None, g_w[li], g_expo, g_nrm[li], g_npr[li],
+                             losses=dict(B_valid=B0, data=data_spec[li], weights=w_spec[li]))
+      else:                                                            # no gradient reaches this level: its mse for the log
+        d = data_spec[li]
+        ops.data_loss(d['type'], d['charb_padding'], d['mult'], d['rgb_out'], gt, lossmult, denom, d['stats'], B_valid=B0,
+                      want_grad=False)
       if overlap and li == nlev - 1:
         for name, b, e in model.modules:
           if name in ('NerfMLP_0', 'Embed_0'):

@@ -536,6 +536,79 @@ def test_losses(ops):
     np.testing.assert_allclose(g.cpu().numpy(), rgb.grad.numpy(), rtol=1e-4, atol=1e-9)
 
 
+@pytest.mark.parametrize('mode,loss_type,lm_c,has_rgb', [('interlevel', 'charb', 1, False), ('distortion', 'charb', 1, True),
+                                                         ('distortion', 'rawnerf', 3, True), (None, 'mse', 1, True)])
+def test_level_bwd_fuses_losses_and_compositing_vjp(ops, mode, loss_type, lm_c, has_rgb):
+  """mnr_level_bwd: data loss + interlevel | distortion loss + compositing VJP in ONE launch, against torch autograd of
+  the oracle's composed objective (train_utils.py:72-159 on render.py:130-213), B_valid < B, with an upstream d / d weights
+  (the Ref-NeRF normal losses' path) on top."""
+  gen = torch.Generator().manual_seed(21)
+  B, Bv, n, n_ref = 137, 130, 64 if mode == 'interlevel' else 32, 32
+  raw_d = torch.randn((B, n), generator=gen) * 2
+  raw_rgb = torch.randn((B, n, 3), generator=gen)
+  sdist, _ = rand_stepfun(gen, B, n)
+  tdist = 0.2 + 5.8 * sdist
+  t_ref, w_ref = rand_stepfun(gen, B, n_ref)
+  w_ref = w_ref * 0.9
+  dirs = torch.randn((B, 3), generator=gen)
+  bg = torch.rand((B, 3), generator=gen)
+  gt = torch.rand((B, 3), generator=gen)
+  lm = torch.rand((B, lm_c), generator=gen)
+  g_w_up = torch.randn((B, n), generator=gen) * 0.01
+  g_w_up[Bv:] = 0                                         # (upstream gradients of padded rays are zero by construction)
+  dbias, pad, dmult, wmult = -1.0, 0.001, 1.0, (1.0 if mode == 'interlevel' else 0.01)
+
+  rd = raw_d.clone().requires_grad_(True)
+  rr = raw_rgb.clone().requires_grad_(True)
+  density = torch.nn.functional.softplus(rd + dbias)
+  w, _, _ = orender.compute_alpha_weights(density, tdist, dirs, opaque_background=True)
+  rgb = torch.sigmoid(rr) * (1 + 2 * pad) - pad if has_rgb else torch.zeros((B, n, 3))
+  rend = orender.volumetric_rendering(rgb, w, tdist, bg, tdist[:, -1:], False)
+
+  class Cfg:
+    disable_multiscale_loss = False
+    charb_padding = 0.001
+    data_coarse_loss_mult = 0.0
+    data_loss_mult = dmult
+    compute_disp_metrics = False
+    compute_normal_metrics = False
+    data_loss_type = loss_type
+
+  class Obj:
+    pass
+
+  batch, rays = Obj(), Obj()
+  batch.rgb, rays.lossmult = gt[:Bv], lm[:Bv]
+  dloss, st = otrain.compute_data_loss(batch, [{'rgb': rend['rgb'][:Bv]}], rays, Cfg)
+  if mode == 'interlevel':
+    wloss = wmult * torch.mean(ostepfun.lossfun_outer(t_ref[:Bv], w_ref[:Bv], sdist[:Bv], w[:Bv]))
+  elif mode == 'distortion':
+    wloss = wmult * torch.mean(ostepfun.lossfun_distortion(sdist[:Bv], w[:Bv]))
+  else:
+    wloss = torch.zeros(())
+  (dloss + wloss + (w * g_w_up).sum()).backward()
+
+  cfg = ops.composite_cfg(n, opaque_background=True, density_act='softplus', density_bias=dbias, density_noise_std=0.0,
+                          has_rgb=has_rgb, rgb_act='sigmoid', rgb_premultiplier=1.0, rgb_bias=0.0, rgb_padding=pad, bg_mode=1,
+                          bg_value=0.0)
+  kw = dict(raw_rgb=dev(raw_rgb) if has_rgb else None, bg=dev(bg))
+  _, _, w_k, rgb_out, _ = ops.composite_fwd(cfg, dev(raw_d), dev(tdist), dev(dirs), **kw)
+  denom = torch.zeros(1).cuda()
+  ops.lossmult_sum(dev(lm), Bv, denom)
+  stats = torch.zeros(3).cuda()
+  wspec = None if mode is None else dict(mode=mode, mult=wmult, sdist=dev(sdist), t_ref=dev(t_ref), w_ref=dev(w_ref), stat=stats[2:3])
+  g_rd, g_rr = ops.composite_bwd(cfg, dev(raw_d), dev(tdist), dev(dirs), w_k, g_weights=dev(g_w_up), **kw,
+                                 losses=dict(B_valid=Bv, data=dict(type=loss_type, charb_padding=0.001, mult=dmult, rgb_out=rgb_out,
+                                                                  gt=dev(gt), lossmult=dev(lm), denom=denom, stats=stats[0:2]),
+                                             weights=wspec))
+  np.testing.assert_allclose(stats.cpu().numpy(), [st['mses'][0].item(), dloss.item(), wloss.item()], rtol=2e-4, atol=1e-9)
+  sc = rd.grad.abs().max().item()
+  np.testing.assert_allclose(g_rd.cpu().numpy(), rd.grad.numpy(), rtol=1e-3, atol=2e-4 * sc)
+  if has_rgb:
+    np.testing.assert_allclose(g_rr.cpu().numpy(), rr.grad.numpy(), rtol=1e-3, atol=2e-4 * rr.grad.abs().max().item())
+  assert (g_rd.cpu()[Bv:] == 0).all()                     # padded rays: no loss, no gradient
+
+
 def test_clip_adam(ops):
   gen = torch.Generator().manual_seed(12)
   P = 100003
