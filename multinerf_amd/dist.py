@@ -75,6 +75,24 @@ def all_gather_cat(t):
   return torch.cat(out, 0)
 
 
+def all_gather_packed(tensors):
+  """all_gather_cat of several per-ray tensors ([n_local, ...] each, same n_local, same dtype) with ONE collective: the
+  tensors are packed side by side into an [n_local, sum of widths] buffer, gathered, and split again.  (Image rendering
+  gathers ~8 pixel buffers per level and chunk: one RCCL call instead of 24.)"""
+  if world_size() == 1 or not tensors:
+    return list(tensors)
+  n = tensors[0].shape[0]
+  flat = [t.reshape(n, -1) for t in tensors]
+  assert all(f.shape[0] == n and f.dtype == flat[0].dtype for f in flat)
+  widths = [f.shape[1] for f in flat]
+  packed = all_gather_cat(torch.cat(flat, 1))
+  outs, c = [], 0
+  for t, w in zip(tensors, widths):
+    outs.append(packed[:, c:c + w].reshape((packed.shape[0],) + tuple(t.shape[1:])).contiguous())
+    c += w
+  return outs
+
+
 def barrier():
   if world_size() > 1:
     td.barrier()

@@ -272,8 +272,12 @@ def create_render_fn(model: models.Model):
   def render_eval_fn(variables, train_frac, _, rays):
     renderings, ray_history = model._forward(variables['flat'], None, rays, train_frac, True)
     if mdist.world_size() > 1:
-      renderings = [{k: (mdist.all_gather_cat(v) if not k.startswith('ray_') else v) for k, v in r.items()}
-                    for r in renderings]
+      # the pixel buffers of every level travel in ONE all-gather per chunk (the ray_* visualisation samples stay local)
+      keys = [(li, k) for li, r in enumerate(renderings) for k in r if not k.startswith('ray_')]
+      gathered = mdist.all_gather_packed([renderings[li][k].float() for li, k in keys])
+      renderings = [dict(r) for r in renderings]
+      for (li, k), g in zip(keys, gathered):
+        renderings[li][k] = g
     return renderings, ray_history
 
   return render_eval_fn

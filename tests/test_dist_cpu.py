@@ -39,6 +39,11 @@ def _worker(rank, world, port, q):
   ok2 = torch.equal(local.origins, glob[rank * 3:(rank + 1) * 3])
   back = mdist.all_gather_cat(local.origins * 2)
   ok3 = torch.equal(back, glob * 2)
+  # 2b. several pixel buffers in one collective: packed all-gather = per-tensor all-gathers
+  a, b3, c = local.origins[:, 0] + 100 * rank, local.origins.repeat(1, 2)[:, :3] * 3, local.origins.reshape(3, 2, 1) + 0.5
+  pa, pb, pc = mdist.all_gather_packed([a, b3, c])
+  ok3 = ok3 and torch.equal(pa, mdist.all_gather_cat(a)) and torch.equal(pb, mdist.all_gather_cat(b3)) and \
+      torch.equal(pc, mdist.all_gather_cat(c)) and pc.shape == (6, 2, 1)
   # 3. render_image: chunking, edge padding to a multiple of the world size, per-rank slice, unpad
   cfg = configs.Config()
   cfg.render_chunk_size = 7          # 5x3 = 15 rays -> chunks 7,7,1 -> each padded to an even count
@@ -83,3 +88,4 @@ def test_single_process_is_identity():
   assert mdist.world_size() == 1 and mdist.rank() == 0
   assert torch.equal(mdist.all_reduce_mean_(t.clone()), t)
   assert torch.equal(mdist.all_gather_cat(t), t)
+  assert torch.equal(mdist.all_gather_packed([t, t * 2])[1], t * 2)
