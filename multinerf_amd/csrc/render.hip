@@ -126,8 +126,8 @@ __global__ __launch_bounds__(CP_THREADS) void composite_fwd_kernel(
 static int cp_rays_per_block(int n, int64_t B) {
   int s = CP_THREADS;
   while (s > 1 && (size_t)(6 * n + 1) * s * 4 > 150 * 1024) s >>= 1;
-  // lane per ray is latency-bound: spread small batches over >= 1024 workgroups (one wave each)
-  while (s > 8 && B / s < 1024) s >>= 1;
+  // one wave per SIMD of the chip (common.h: mnr_ray_wave_target)
+  while (s > 8 && B / s < mnr_ray_wave_target()) s >>= 1;
   return s;
 }
 static size_t cp_lds_bytes(int n, int s) { return (size_t)(6 * n + 1) * s * 4; }
@@ -374,8 +374,8 @@ extern "C" int mnr_level_bwd(const mnr_level_bwd_args* a, void* stream) {
   const size_t fpr = lb_floats_per_ray(a);
   int S = CP_THREADS;
   while (S > 1 && fpr * S * 4 > 150 * 1024) S >>= 1;
-  // lane per ray is latency-bound: spread small batches over >= 1024 workgroups (one wave each)
-  while (S > 8 && a->B / S < 1024) S >>= 1;
+  // one wave per SIMD of the chip (common.h: mnr_ray_wave_target)
+  while (S > 8 && a->B / S < mnr_ray_wave_target()) S >>= 1;
   const size_t lds = fpr * S * 4;
   MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_level_bwd: n=%d too long for LDS staging", cfg->n);
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)

@@ -256,7 +256,7 @@ extern "C" int mnr_resample_level(const mnr_resample_cfg* cfg, int64_t B, const 
   RsLayout lay = rs_layout(cfg);
   // One lane per ray is latency-bound; with 64 rays per wave a 16384-ray batch is only 256 waves for 1024
   // SIMDs.  Fewer rays per (64-thread) workgroup spreads the same serial work over more SIMDs.
-  while (lay.rpb > 8 && B / lay.rpb < 1024) lay.rpb >>= 1;
+  while (lay.rpb > 8 && B / lay.rpb < mnr_ray_wave_target()) lay.rpb >>= 1;
   const size_t lds_bytes = (size_t)(lay.a_len + lay.b_len) * lay.rpb * 4;
   MNR_CHECK_ARG(lds_bytes <= 160 * 1024, "mnr_resample_level: step function too long for LDS");
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)

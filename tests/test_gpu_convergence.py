@@ -80,3 +80,59 @@ def test_equal_step_psnr_matches_oracle():
   # dW accumulates with fp32 atomics (order varies run to run) on top of the bf16 / fp32 difference: the
   # trajectories are not bit-reproducible; observed |diff| 0.05 - 0.3 dB at this size.
   assert abs(psnr_hip - psnr_or) <= 0.5
+
+
+def test_equal_step_psnr_360_full_width():
+  """The headline configuration itself: configs/360.gin as is (1024-wide NeRF MLP, 9.0 M parameters, levels 64/64/32) on
+  the procedural UNBOUNDED scene (multinerf_amd.synthetic.unbounded_scene_rays: content inside the unit ball, a ground
+  plane running through the contracted region to the horizon, sky at infinity behind the opaque last interval), 600
+  steps of 256 rays from the oracle's initialisation with the oracle's batches and jitter at every step.  The oracle's
+  side ran on the CPU ahead of time (tests/golden/make_golden_psnr.py -> tests/golden/psnr360.json); here the HIP path
+  replays the protocol and must land within 0.1 dB of the oracle's held-out PSNR at equal step count (north_star)."""
+  import importlib.util
+  import json
+  import os
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  here = os.path.dirname(os.path.abspath(__file__))
+  spec = importlib.util.spec_from_file_location('make_golden_psnr', os.path.join(here, 'golden', 'make_golden_psnr.py'))
+  G = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(G)
+  ref = json.load(open(os.path.join(here, 'golden', 'psnr360.json')))
+  assert ref['steps'] == G.STEPS and ref['rays'] == G.RAYS and ref['seed'] == G.SEED and ref['bindings'] == G.BINDINGS
+  cfg = configs.load_preset('360', G.BINDINGS)
+  model = models.Model(config=cfg)
+  model.build('cuda')
+  assert model.nerf_plan.W == 1024 and model.num_params == 9007493
+  om, on, op = helpers.oracle_hparams(model)
+  flat = model.flat_from_tree(omodels.init_params(om, on, op, seed=G.SEED))
+  ev = G.eval_rays()
+  ev_rays = ev.rays.map(lambda t: t.cuda())
+  state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+  step_fn = train_utils.create_train_step(model, cfg)
+  want = {c['step']: c for c in ref['curve']}
+  rows = []
+  for step in range(1, G.STEPS + 1):
+    batch, noise, tf = G.protocol(model, cfg, step)
+    state, stats, _ = step_fn(0, state, batch.map(lambda t: t.cuda()), None, tf, 0.0, noise=noise)
+    if step in want:
+      rend, _ = model.apply({'flat': state.params['flat']}, None, ev_rays, 1.0, False)
+      e = G.psnr(rend[-1]['rgb'].cpu().numpy(), ev.rgb.numpy())
+      s = stats.materialize()
+      rows.append(dict(step=step, hip_eval_psnr=e, oracle_eval_psnr=want[step]['eval_psnr'], hip_train_loss=s['loss'],
+                       oracle_train_loss=want[step]['train_loss']))
+      print(f'step {step:4d}: eval PSNR hip {e:.3f} oracle {want[step]["eval_psnr"]:.3f} ({e - want[step]["eval_psnr"]:+.3f} dB); '
+            f'train loss hip {s["loss"]:.5f} oracle {want[step]["train_loss"]:.5f}')
+  out = os.environ.get('MNR_PSNR_LOG')
+  if out:
+    with open(out, 'w') as f:
+      for r in rows:
+        f.write(json.dumps(r) + '\n')
+  first, last = rows[0], rows[-1]
+  assert abs(first['hip_eval_psnr'] - first['oracle_eval_psnr']) < 0.05                  # same start
+  assert last['oracle_eval_psnr'] > first['oracle_eval_psnr'] + 5.0, 'the reference run did not learn the scene'
+  diff = last['hip_eval_psnr'] - last['oracle_eval_psnr']
+  # the mean over the last three checkpoints averages out the step-to-step wobble of either trajectory
+  tail = float(np.mean([r['hip_eval_psnr'] - r['oracle_eval_psnr'] for r in rows[-3:]]))
+  print(f'equal-step PSNR, 360.gin full width: final diff {diff:+.3f} dB, mean of the last three checkpoints {tail:+.3f} dB')
+  assert abs(diff) <= 0.1 and abs(tail) <= 0.1

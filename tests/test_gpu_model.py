@@ -3,9 +3,12 @@ through the C ABI vs the CPU oracle on identical rays, weights and jitter.  -m g
 
 Tolerance model.  The Dense stack runs bf16 x bf16 -> fp32 on the MFMA units.  The
 oracle is evaluated twice: (a) emulating that rounding (dense_dtype=bfloat16): the
-kernels must agree with it up to accumulation-order noise + rare 1-ulp bf16 flips;
-(b) plain fp32: the distance (a)-(b) is the bf16 precision cost and is REPORTED,
-with the kernel held to 3x that distance.
+kernels must agree with it up to accumulation-order noise + rare 1-ulp bf16 flips,
+within the STATED tolerances of TOL below (one number per output and preset: max abs
+error of sdist in [0, 1], of the weights, of the final rgb; relative L2 error of each
+top-level module's gradient; DESIGN.md section 2 has the same table with the
+round-2 measurements they were set from, about 2x headroom); (b) plain fp32: the
+distance (a)-(b) is the bf16 precision cost and is REPORTED next to the error.
 """
 
 import numpy as np
@@ -54,6 +57,17 @@ def _setup(name, extra, B, seed=3):
   return cfg, model, (om, on, op), params, flat, batch
 
 
+# max |kernel - oracle_bf16| per output (sdist: levels >= 1; level 0 depends on no MLP output and is held to 2e-6),
+# relative L2 error of a module's gradient.  Measured in round 2 (gpurun_out/r2_gpu_tests1.log): 360 (widths 256 / 128)
+# sdist 2.2e-3, weights 4.4e-3, rgb 3.5e-3, grad 6.9e-2; blender_256 1.5e-4 / 4.3e-4 / 6.5e-4 / 2.6e-2;
+# llff_raw 6.7e-5 / 4.3e-5 / 1.0e-5 / 7.5e-3; blender_refnerf 2.7e-5 / 9.5e-5 / 1.8e-4 / 8.1e-3.
+TOL = {
+    '360': dict(sdist=5e-3, weights=1e-2, rgb=8e-3, grad=0.15),
+    'blender_256': dict(sdist=5e-4, weights=1.5e-3, rgb=2e-3, grad=0.06),
+    'llff_raw': dict(sdist=3e-4, weights=2e-4, rgb=5e-5, grad=0.03),
+    'blender_refnerf': dict(sdist=1e-4, weights=4e-4, rgb=6e-4, grad=0.03),
+}
+
 CASES = [
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128'], 40),
     ('blender_256', [], 24),
@@ -87,22 +101,22 @@ def test_forward_parity(name, extra, B, randomized):
   for lv in range(model.num_levels):
     s_k, s_o = hist[lv]['sdist'].cpu(), h_bf[lv]['sdist']
     # level 0 depends on no MLP output: fp32-exact up to transcendental ulps.
-    tol_s = 2e-6 if lv == 0 else 2e-3
+    tol_s = 2e-6 if lv == 0 else TOL[name]['sdist']
     err_s = (s_k - s_o).abs().max().item()
     cost_s = (h_bf[lv]['sdist'] - h_32[lv]['sdist']).abs().max().item()
     print(f'{name} rand={randomized} level {lv}: |sdist - oracle_bf16| = {err_s:.2e} (bf16 cost {cost_s:.2e})')
-    assert err_s <= max(tol_s, 3 * cost_s)
+    assert err_s <= tol_s, (lv, err_s, tol_s)
     w_k, w_o = hist[lv]['weights'].cpu(), h_bf[lv]['weights']
     err_w = (w_k - w_o).abs().max().item()
     cost_w = (h_bf[lv]['weights'] - h_32[lv]['weights']).abs().max().item()
     print(f'    weights err {err_w:.2e} (bf16 cost {cost_w:.2e})')
-    assert err_w <= max(5e-3, 3 * cost_w)
+    assert err_w <= TOL[name]['weights'], (lv, err_w)
   rgb_k, rgb_o, rgb_32 = rend[-1]['rgb'].cpu(), r_bf[-1]['rgb'], r_32[-1]['rgb']
   err = (rgb_k - rgb_o).abs().max().item()
   cost = (rgb_o - rgb_32).abs().max().item()
   print(f'{name} rand={randomized}: rgb |kernel - oracle_bf16| = {err:.2e}; bf16 cost |oracle_bf16 - oracle_fp32| = {cost:.2e}; '
         f'|kernel - oracle_fp32| = {(rgb_k - rgb_32).abs().max().item():.2e}')
-  assert err <= max(5e-3, 3 * cost)
+  assert err <= TOL[name]['rgb'], err
   for k in ('acc', 'distance_mean', 'distance_median', 'distance_percentile_5', 'distance_percentile_95'):
     a, b = rend[-1][k].cpu(), r_bf[-1][k]
     rel = ((a - b).abs() / b.abs().clamp_min(1e-3)).max().item()
@@ -149,7 +163,7 @@ def test_train_step_parity(name, extra, B):
     rel = ((a - r).norm() / (r.norm() + 1e-30)).item()
     cost = ((r - r32).norm() / (r32.norm() + 1e-30)).item()
     print(f'{name} {mod}: grad cos {cos:.6f} rel err {rel:.3e} (bf16 cost {cost:.3e}) |g| {r.norm().item():.3e}')
-    assert cos > 0.995 and rel < max(0.05, 3 * cost)
+    assert cos > 0.995 and rel < TOL[name]['grad'], (mod, cos, rel)
   # per-Dense check (catches a layer whose gradient lands at the wrong offset); the hinge in the
   # interlevel loss makes proposal gradients sensitive to bf16-level weight changes, so each layer is
   # judged against its own bf16 cost.
