@@ -11,8 +11,8 @@ per-module clip, Adam) on one batch of synthetic rays already resident in HBM
 owns `batch_size` rays (weak scaling), one RCCL all-reduce of the flat fp32 gradient
 per step.  Rank 0 prints ONE JSON line.
 
-roofline: the dominant kernels are the bf16 MFMA GEMMs (gemm_nt_kernel forward/dX,
-gemm_tn_kernel dW).  achieved = algorithmic training FLOPs of one step (SURVEY.md 8d:
+roofline: the dominant kernels are the bf16 MFMA kernels (gemm_nt_kernel forward/dX,
+gemm_tn_kernel dW, the fused per-level chain kernels of the proposal MLP).  achieved = algorithmic training FLOPs of one step (SURVEY.md 8d:
 1815.994 MFLOP/ray at 360.gin x rays per launch-set) / summed duration of those
 kernels within the step, measured with HIP events on the launch stream during the
 timed region (a second, identical, instrumented pass so the events do not perturb
@@ -243,7 +243,7 @@ def main():
         },
         'roofline': {
             'bound': 'mfma',
-            'kernel': 'gemm_nt_kernel + gemm_tn_kernel (bf16 MFMA 32x32x16)',
+            'kernel': 'gemm_nt_kernel + gemm_nt_wres_kernel + gemm_tn_kernel + mlp_chain_fwd/bwd_kernel (bf16 MFMA 32x32x16)',
             'achieved': achieved_tflops,
             'peak': 2500.0,
             'unit': 'TFLOP/s',
