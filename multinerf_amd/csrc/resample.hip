@@ -25,20 +25,6 @@
 
 #define RS_THREADS 64
 
-// LDS layout per ray (floats), element i of an array at [i * rpb + ray]:
-//   region A: T[np+1] | spare | W[np]                       (a_len >= 2np+2)
-//   region B: dilation:    TD[3np+1] | WD[3np]              (b_len = 6np+1)
-//             no dilation: centers[n] .. | sdist[n+1]       (b_len = 2n+2)
-// With dilation, region A is dead after the dilation and hosts centers/sdist.
-// The CDF (nb+1 fence-posts for nb bins) is built in place one slot BEFORE the
-// array of bin weights it integrates: WD[0] (the trimmed-away first weight) with
-// dilation, the spare slot without.
-struct RsLayout {
-  int rpb;     // rays per block (<= 64)
-  int a_len;
-  int b_len;
-};
-
 __device__ __forceinline__ float rs_s_to_t(int fn, float s, float near, float far) {
   // coord.py:96-98: fn_inv(s * fn(far) + (1 - s) * fn(near)).
   float fn_near, fn_far;
@@ -66,51 +52,6 @@ __device__ __forceinline__ float rs_s_to_t(int fn, float s, float near, float fa
   }
 }
 
-// stepfun.max_dilate_weights(renormalize=True): (t[0..n], w[0..n-1]) -> (td[0..3n], wd[0..3n-1]).
-// `p` holds w on entry and is overwritten by the pdf.  All arrays indexed [i * stride].
-__device__ __forceinline__ void rs_max_dilate(int n, const float* t, float* p, float* td, float* wd,
-                                              int stride, float dilation, float lo, float hi) {
-  const float eps2 = MNR_F32_EPS * MNR_F32_EPS;
-  // stepfun.py:89-91: pdf = w / max(eps^2, dt).
-  for (int j = 0; j < n; ++j) {
-    const float dt = t[(j + 1) * stride] - t[j * stride];
-    p[j * stride] = p[j * stride] / fmaxf(eps2, dt);
-  }
-  // stepfun.py:101-104: sort(concat[t, t[:-1]-d, t[1:]+d]) = 3-way merge of sorted lists; clip.
-  int ia = 0, ib = 0, ic = 0;
-  const int m = 3 * n + 1;
-  for (int k = 0; k < m; ++k) {
-    const float va = ia <= n ? t[ia * stride] : INFINITY;
-    const float vb = ib < n ? t[ib * stride] - dilation : INFINITY;
-    const float vc = ic < n ? t[(ic + 1) * stride] + dilation : INFINITY;
-    float v;
-    if (vb <= va && vb <= vc) { v = vb; ++ib; }
-    else if (va <= vc) { v = va; ++ia; }
-    else { v = vc; ++ic; }
-    td[k * stride] = fminf(fmaxf(v, lo), hi);
-  }
-  // stepfun.py:105-112: wd[k] = max_j { p[j] : t0[j] <= td[k] < t1[j] } for k < 3n.
-  // t0 and t1 ascend, so the admissible j form a window [jlo, jhi] that only moves right.
-  int jlo = 0, jhi = -1;
-  for (int k = 0; k < m - 1; ++k) {
-    const float x = td[k * stride];
-    while (jhi + 1 < n && t[(jhi + 1) * stride] - dilation <= x) ++jhi;
-    while (jlo < n && !(t[(jlo + 1) * stride] + dilation > x)) ++jlo;
-    float best = 0.0f;
-    for (int j = jlo; j <= jhi; ++j) best = fmaxf(best, p[j * stride]);
-    wd[k * stride] = best;
-  }
-  // stepfun.py:125-127: back to weights, renormalise by max(eps^2, sum).
-  float sum = 0.0f;
-  for (int k = 0; k < m - 1; ++k) {
-    const float w = wd[k * stride] * (td[(k + 1) * stride] - td[k * stride]);
-    wd[k * stride] = w;
-    sum += w;
-  }
-  const float denom = fmaxf(eps2, sum);
-  for (int k = 0; k < m - 1; ++k) wd[k * stride] = wd[k * stride] / denom;
-}
-
 // One query of math.sorted_interp (math.py:108-127).  `i` is a cursor holding the last
 // index with xp[i] <= x (or -1); since the queries ascend it moves O(1) amortised.
 __device__ __forceinline__ float rs_interp_one(float x, const float* xp, const float* fp, int stride, int nc,
@@ -125,121 +66,257 @@ __device__ __forceinline__ float rs_interp_one(float x, const float* xp, const f
   return f0 + off * (f1 - f0);
 }
 
+// ---------------------------------------------------------------------------
+// The level kernel: RSP_LPR = 16 lanes per ray, 4 rays per 64-lane workgroup.
+//
+// One lane per ray (round 1) is a ~35 k-instruction dependent stream per wave whatever the number of rays: 0.23 ms per
+// level.  Here the 16 lanes of a ray split every pass:
+//   * the 3-way merge of max_dilate is a RANKING: the position of an element in the sorted union is its own index plus
+//     the number of elements of the other two lists in front of it (two binary searches; ties ordered b < a < c as the
+//     sequential merge takes them, so the ranks are a permutation);
+//   * the sliding-window max and the inverse CDF keep their monotone cursors, but every lane owns a contiguous chunk of
+//     the queries and finds its first cursor position with a binary search;
+//   * the three sums (renormalisation of the dilated weights, softmax denominator, CDF) are BLOCKED: a lane sums its
+//     contiguous chunk of ceil(len / 16) elements left to right, the 16 chunk sums are then added left to right, and the
+//     running value at element k is (sum of the chunks before k's) + (k's prefix inside its chunk).  That association
+//     order is part of the contract for bit-exact sample indices and is restated in oracle/stepfun.py
+//     (blocked_cumsum / blocked_sum): given the same inputs the oracle and the kernel produce the same CDF bit for bit
+//     (up to the device's expf / logf), hence the same indices.
+#define RSP_LPR 16
+#define RSP_RPW 4
+
+struct RspLay {
+  int T, P, TD, WD, CW, CEN, SO, RED, per_ray;      // offsets (floats) inside one ray's LDS block
+};
+
+// number of i in [0, n) with a[i] + shift <= x (le) or < x; a ascending.  (t[j] - d is computed as t[j] + (-d): the same
+// IEEE operation, so the searched values are exactly the merged ones.)
+__device__ __forceinline__ int rsp_count(const float* a, int n, float shift, float x, bool le) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const float v = a[mid] + shift;
+    if (le ? (v <= x) : (v < x)) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// Exclusive prefix of the 16 lanes' chunk sums, added left to right (identical on every lane); `total` = all 16.
+__device__ __forceinline__ float rsp_chunk_offset(float chunk_sum, float* red, int l, float& total) {
+  __syncthreads();
+  red[l] = chunk_sum;
+  __syncthreads();
+  float off = 0.0f, tot = 0.0f;
+#pragma unroll
+  for (int i = 0; i < RSP_LPR; ++i) {
+    if (i == l) off = tot;
+    tot += red[i];
+  }
+  total = tot;
+  return off;
+}
+
+// stepfun.max_dilate_weights(renormalize=True) by the 16 lanes of one ray: t[0..n], p[0..n-1] (weights on entry, pdf
+// after) -> td[0..3n], wd[0..3n-1].  Every thread of the workgroup must call it (barriers inside).
+__device__ __forceinline__ void rsp_max_dilate(int n, const float* t, float* p, float* td, float* wd, float* red, int l,
+                                               float dilation, float lo, float hi) {
+  const float eps2 = MNR_F32_EPS * MNR_F32_EPS;
+  const int m = 3 * n + 1;
+  // stepfun.py:89-91: pdf = w / max(eps^2, dt).
+  for (int j = l; j < n; j += RSP_LPR) p[j] = p[j] / fmaxf(eps2, t[j + 1] - t[j]);
+  // stepfun.py:101-104: sort(concat[a = t, b = t[:-1] - d, c = t[1:] + d]) by ranking; clip.
+  for (int e = l; e < m; e += RSP_LPR) {
+    float v;
+    int rank;
+    if (e <= n) {                                        // a[i]: b's equal to it go first, c's equal to it after
+      v = t[e];
+      rank = e + rsp_count(t, n, -dilation, v, true) + rsp_count(t + 1, n, dilation, v, false);
+    } else if (e <= 2 * n) {                             // b[j]
+      const int j = e - (n + 1);
+      v = t[j] - dilation;
+      rank = j + rsp_count(t, n + 1, 0.0f, v, false) + rsp_count(t + 1, n, dilation, v, false);
+    } else {                                             // c[k]
+      const int k = e - (2 * n + 1);
+      v = t[k + 1] + dilation;
+      rank = k + rsp_count(t, n + 1, 0.0f, v, true) + rsp_count(t, n, -dilation, v, true);
+    }
+    td[rank] = fminf(fmaxf(v, lo), hi);
+  }
+  __syncthreads();
+  // stepfun.py:105-112: wd[k] = max_j { p[j] : t[j] - d <= td[k] < t[j+1] + d } for k < 3n; the admissible j are a
+  // window [jlo, jhi] that only moves right with k: chunked queries, first window by binary search.
+  const int nw = m - 1;
+  const int ch = (nw + RSP_LPR - 1) / RSP_LPR;
+  const int k0 = min(nw, l * ch), k1 = min(nw, k0 + ch);
+  float csum = 0.0f;
+  if (k0 < k1) {
+    int jhi = rsp_count(t, n, -dilation, td[k0], true) - 1;
+    int jlo = rsp_count(t + 1, n, dilation, td[k0], true);
+    for (int k = k0; k < k1; ++k) {
+      const float x = td[k];
+      while (jhi + 1 < n && t[jhi + 1] - dilation <= x) ++jhi;
+      while (jlo < n && !(t[jlo + 1] + dilation > x)) ++jlo;
+      float best = 0.0f;
+      for (int j = jlo; j <= jhi; ++j) best = fmaxf(best, p[j]);
+      // stepfun.py:125-127: back to weights; the sum runs over the lane's chunk left to right
+      const float w = best * (td[k + 1] - x);
+      wd[k] = w;
+      csum += w;
+    }
+  }
+  float total;
+  (void)rsp_chunk_offset(csum, red, l, total);
+  const float denom = fmaxf(eps2, total);
+  for (int k = k0; k < k1; ++k) wd[k] = wd[k] / denom;
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(RS_THREADS) void resample_level_kernel(
-    mnr_resample_cfg c, int64_t B, RsLayout lay, const float* __restrict__ sdist_prev,
+    mnr_resample_cfg c, int64_t B, RspLay lay, const float* __restrict__ sdist_prev,
     const float* __restrict__ w_prev, const float* __restrict__ u_base, const float* __restrict__ jitter,
     const float* __restrict__ near, const float* __restrict__ far, float* __restrict__ sdist_out,
     float* __restrict__ tdist_out, int32_t* __restrict__ idx_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int rpb = lay.rpb;
-  float* regA = lds;
-  float* regB = lds + lay.a_len * rpb;
-  const int64_t ray0 = (int64_t)blockIdx.x * rpb;
-  const int nrays = (int)min((int64_t)rpb, B - ray0);
   const int np = c.n_prev, n = c.n_samples;
-  const int w_off = np + 2;                      // T[np+1] | spare | W
-
-  // Coalesced load of the block's rows into [elem][ray] order.
-  for (int e = threadIdx.x; e < nrays * (np + 1); e += RS_THREADS) {
+  const int64_t ray0 = (int64_t)blockIdx.x * RSP_RPW;
+  const int nrays = (int)min((int64_t)RSP_RPW, B - ray0);
+  // coalesced load of the workgroup's rows (contiguous in HBM) into the per-ray blocks; a short last workgroup loads its
+  // last ray again into the unused slots (every lane runs every phase: barriers inside; nothing of those slots is stored)
+  for (int e = threadIdx.x; e < RSP_RPW * (np + 1); e += RS_THREADS) {
     const int r = e / (np + 1), i = e % (np + 1);
-    regA[i * rpb + r] = sdist_prev[ray0 * (np + 1) + e];
+    lds[r * lay.per_ray + lay.T + i] = sdist_prev[(ray0 + min(r, nrays - 1)) * (np + 1) + i];
   }
-  for (int e = threadIdx.x; e < nrays * np; e += RS_THREADS) {
+  for (int e = threadIdx.x; e < RSP_RPW * np; e += RS_THREADS) {
     const int r = e / np, i = e % np;
-    regA[(w_off + i) * rpb + r] = w_prev[ray0 * np + e];
+    lds[r * lay.per_ray + lay.P + i] = w_prev[(ray0 + min(r, nrays - 1)) * np + i];
+  }
+  const int g = threadIdx.x / RSP_LPR, l = threadIdx.x % RSP_LPR;
+  const int gr = min(g, nrays - 1);
+  __syncthreads();
+  float* base = lds + g * lay.per_ray;
+  float* t = base + lay.T;
+  float* w = base + lay.P;
+  float* red = base + lay.RED;
+  const float* td;
+  float* wd;
+  int nb;                                              // bins of the histogram being sampled
+  if (c.use_dilation) {
+    rsp_max_dilate(np, t, w, base + lay.TD, base + lay.WD, red, l, c.dilation, c.domain_lo, c.domain_hi);
+    td = base + lay.TD + 1;                            // models.py:170-171: drop first/last fence-post
+    wd = base + lay.WD + 1;                            //                    and first/last weight
+    nb = 3 * np - 2;
+  } else {
+    td = t;
+    wd = w;
+    nb = np;
+  }
+  // models.py:183-185 logits; jax.nn.softmax (stepfun.py:156).  Chunked ownership: lane l holds bins [k0, k1).
+  const int ch = (nb + RSP_LPR - 1) / RSP_LPR;
+  const int k0 = min(nb, l * ch), k1 = min(nb, k0 + ch);
+  float mx = -INFINITY;
+  for (int k = k0; k < k1; ++k) {
+    const bool open = td[k + 1] > td[k];
+    const float lg = open ? c.anneal * logf(wd[k] + c.resample_padding) : -INFINITY;
+    wd[k] = lg;
+    mx = (lg != lg || mx != mx) ? NAN : fmaxf(mx, lg);          // jnp.max propagates NaN (0 * log 0 at train_frac 0)
+  }
+  __syncthreads();
+  red[l] = mx;
+  __syncthreads();
+  mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < RSP_LPR; ++i) {
+    const float v = red[i];
+    mx = (v != v || mx != mx) ? NAN : fmaxf(mx, v);
+  }
+  float csum = 0.0f;
+  for (int k = k0; k < k1; ++k) {
+    const float e = expf(wd[k] - mx);
+    wd[k] = e;
+    csum += e;
+  }
+  float denom;
+  (void)rsp_chunk_offset(csum, red, l, denom);
+  // stepfun.py:146-149: cw = [0, min(1, cumsum(w[:-1])), 1], blocked cumulative sum.
+  float* cw = base + lay.CW;
+  csum = 0.0f;
+  for (int k = k0; k < k1; ++k) {
+    const float wk = wd[k] / denom;
+    wd[k] = wk;
+    if (k < nb - 1) csum += wk;
+  }
+  float unused;
+  const float off = rsp_chunk_offset(csum, red, l, unused);
+  float run = 0.0f;
+  for (int k = k0; k < k1 && k < nb - 1; ++k) {
+    run += wd[k];
+    const float cs = off + run;
+    cw[k + 1] = (cs != cs) ? cs : fminf(1.0f, cs);              // jnp.minimum propagates NaN
+  }
+  if (l == 0) {
+    cw[0] = 0.0f;
+    cw[nb] = 1.0f;
   }
   __syncthreads();
 
-  float* out_reg = c.use_dilation ? regA : regB;  // centers[n] | sdist[n+1]
-  const int r = threadIdx.x;
-  if (r < nrays) {
-    float* t = regA + r;
-    float* w = regA + w_off * rpb + r;
-    float* td;
-    float* wd;
-    int nb;                                      // bins of the histogram being sampled
-    if (c.use_dilation) {
-      float* TD = regB + r;
-      float* WD = regB + (3 * np + 1) * rpb + r;
-      rs_max_dilate(np, t, w, TD, WD, rpb, c.dilation, c.domain_lo, c.domain_hi);
-      td = TD + rpb;                             // models.py:170-171: drop first/last fence-post
-      wd = WD + rpb;                             //                    and first/last weight
-      nb = 3 * np - 2;
-    } else {
-      td = t;
-      wd = w;
-      nb = np;
+  // Inverse CDF (stepfun.py:153-161 -> math.py:108-127): lane l owns samples [j0, j1); the queries ascend, so after a
+  // binary search for the first one the cursor (last index with cw[i] <= u, or -1) only moves up.
+  float* centers = base + lay.CEN;
+  const int64_t ray = ray0 + gr;
+  const int chs = (n + RSP_LPR - 1) / RSP_LPR;
+  const int j0 = min(n, l * chs), j1 = min(n, j0 + chs);
+  const float jit1 = (jitter && c.single_jitter) ? jitter[ray] * c.max_jitter : 0.0f;
+  int cur = -2;
+  for (int j = j0; j < j1; ++j) {
+    float u = u_base[j];
+    if (jitter) u = u + (c.single_jitter ? jit1 : jitter[ray * n + j] * c.max_jitter);
+    if (cur == -2) {
+      // largest i with cw[i] <= u over the sorted CDF (a NaN CDF compares false everywhere: i stays at the start)
+      int lo_i = -1, hi_i = nb + 1;
+      while (hi_i - lo_i > 1) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (cw[mid] <= u) lo_i = mid;
+        else hi_i = mid;
+      }
+      cur = lo_i;
     }
-    // models.py:183-185 logits; jax.nn.softmax (stepfun.py:156) with a sequential denominator.
-    float mx = -INFINITY;
-    for (int k = 0; k < nb; ++k) {
-      const bool open = td[(k + 1) * rpb] > td[k * rpb];
-      const float lg = open ? c.anneal * logf(wd[k * rpb] + c.resample_padding) : -INFINITY;
-      wd[k * rpb] = lg;
-      mx = (lg != lg || mx != mx) ? NAN : fmaxf(mx, lg);      // jnp.max propagates NaN (0 * log 0 at train_frac 0)
-    }
-    float denom = 0.0f;
-    for (int k = 0; k < nb; ++k) {
-      const float e = expf(wd[k * rpb] - mx);
-      wd[k * rpb] = e;
-      denom += e;
-    }
-    // stepfun.py:146-149: cw = [0, min(1, cumsum(w[:-1])), 1] built one slot before wd:
-    // iteration k reads wd[k] (slot k+1 of cw's storage) and writes cw[k] (slot k).
-    float* cw = wd - rpb;
-    float run = 0.0f, prev = 0.0f;
-    for (int k = 0; k < nb; ++k) {
-      const float wk = wd[k * rpb] / denom;
-      cw[k * rpb] = prev;
-      run += wk;
-      prev = (run != run) ? run : fminf(1.0f, run);           // jnp.minimum propagates NaN
-    }
-    cw[0] = 0.0f;
-    cw[nb * rpb] = 1.0f;
-
-    // Inverse CDF (stepfun.py:153-161 -> math.py:108-127).
-    float* centers = out_reg + r;
-    int cur = 0;
-    const float jit1 = (jitter && c.single_jitter) ? jitter[ray0 + r] * c.max_jitter : 0.0f;
-    for (int j = 0; j < n; ++j) {
-      float u = u_base[j];
-      if (jitter) u = u + (c.single_jitter ? jit1 : jitter[(ray0 + r) * n + j] * c.max_jitter);
-      centers[j * rpb] = rs_interp_one(u, cw, td, rpb, nb + 1, cur);
-      if (idx_out) idx_out[(ray0 + r) * n + j] = cur;
-    }
-    // stepfun.py:252-262: fence-posts at midpoints; reflected + clamped ends.
-    float* so = out_reg + n * rpb + r;
-    const float c0 = centers[0], c1 = centers[rpb];
-    const float cl = centers[(n - 1) * rpb], cl1 = centers[(n - 2) * rpb];
-    so[0] = fmaxf(c.domain_lo, 2.0f * c0 - (c1 + c0) / 2.0f);
-    for (int j = 1; j < n; ++j) so[j * rpb] = (centers[j * rpb] + centers[(j - 1) * rpb]) / 2.0f;
-    so[n * rpb] = fminf(c.domain_hi, 2.0f * cl - (cl + cl1) / 2.0f);
+    centers[j] = rs_interp_one(u, cw, td, 1, nb + 1, cur);
+    if (idx_out && g < nrays) idx_out[ray * n + j] = cur;
+  }
+  __syncthreads();
+  // stepfun.py:252-262: fence-posts at midpoints; reflected + clamped ends.
+  float* so = base + lay.SO;
+  for (int j = l; j <= n; j += RSP_LPR) {
+    float v;
+    if (j == 0) v = fmaxf(c.domain_lo, 2.0f * centers[0] - (centers[1] + centers[0]) / 2.0f);
+    else if (j == n) v = fminf(c.domain_hi, 2.0f * centers[n - 1] - (centers[n - 1] + centers[n - 2]) / 2.0f);
+    else v = (centers[j] + centers[j - 1]) / 2.0f;
+    so[j] = v;
   }
   __syncthreads();
   // Coalesced write-out of sdist and tdist = s_to_t(sdist).
-  const float* so_base = out_reg + n * rpb;
   for (int e = threadIdx.x; e < nrays * (n + 1); e += RS_THREADS) {
     const int rr = e / (n + 1), i = e % (n + 1);
-    const float s = so_base[i * rpb + rr];
-    sdist_out[ray0 * (n + 1) + e] = s;
-    tdist_out[ray0 * (n + 1) + e] = rs_s_to_t(c.raydist_fn, s, near[ray0 + rr], far[ray0 + rr]);
+    const float sv = lds[rr * lay.per_ray + lay.SO + i];
+    sdist_out[ray0 * (n + 1) + e] = sv;
+    tdist_out[ray0 * (n + 1) + e] = rs_s_to_t(c.raydist_fn, sv, near[ray0 + rr], far[ray0 + rr]);
   }
 }
 
-static RsLayout rs_layout(const mnr_resample_cfg* c) {
-  RsLayout l;
-  const int np = c->n_prev, n = c->n_samples;
-  const int out_need = 2 * n + 1;                // centers[n] + sdist[n+1]
-  if (c->use_dilation) {
-    l.a_len = max(2 * np + 2, out_need);
-    l.b_len = 6 * np + 1;
-  } else {
-    l.a_len = 2 * np + 2;
-    l.b_len = out_need;
-  }
-  int rpb = 64;
-  while (rpb > 1 && (size_t)(l.a_len + l.b_len) * rpb * 4 > 150 * 1024) rpb >>= 1;
-  l.rpb = rpb;
+static RspLay rsp_layout(int np, int n) {
+  RspLay l;
+  const int m = 3 * np + 1;
+  int o = 0;
+  l.T = o; o += np + 1;
+  l.P = o; o += np;
+  l.TD = o; o += m;
+  l.WD = o; o += m;
+  l.CW = o; o += m;
+  l.CEN = o; o += n;
+  l.SO = o; o += n + 1;
+  l.RED = o; o += RSP_LPR;
+  l.per_ray = (o + 3) & ~3;
   return l;
 }
 
@@ -253,18 +330,15 @@ extern "C" int mnr_resample_level(const mnr_resample_cfg* cfg, int64_t B, const 
   MNR_CHECK_ARG(cfg->n_prev >= 1 && cfg->n_prev <= 1024 && cfg->n_samples <= 1024,
                 "mnr_resample_level: n_prev=%d / n_samples=%d out of range", cfg->n_prev, cfg->n_samples);
   MNR_CHECK_ARG(cfg->raydist_fn >= 0 && cfg->raydist_fn <= MNR_RAYDIST_SQUARE, "mnr_resample_level: bad raydist_fn");
-  RsLayout lay = rs_layout(cfg);
-  // One lane per ray is latency-bound; with 64 rays per wave a 16384-ray batch is only 256 waves for 1024
-  // SIMDs.  Fewer rays per (64-thread) workgroup spreads the same serial work over more SIMDs.
-  while (lay.rpb > 8 && B / lay.rpb < mnr_ray_wave_target()) lay.rpb >>= 1;
-  const size_t lds_bytes = (size_t)(lay.a_len + lay.b_len) * lay.rpb * 4;
+  const RspLay lay = rsp_layout(cfg->n_prev, cfg->n_samples);
+  const size_t lds_bytes = (size_t)lay.per_ray * RSP_RPW * 4;
   MNR_CHECK_ARG(lds_bytes <= 160 * 1024, "mnr_resample_level: step function too long for LDS");
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
   if (mnr_attr_needed(&attr_set)) {
     (void)hipFuncSetAttribute((const void*)resample_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
   }
-  const int grid = mnr_cdiv(B, lay.rpb);
+  const int grid = mnr_cdiv(B, RSP_RPW);
   hipLaunchKernelGGL(resample_level_kernel, dim3(grid), dim3(RS_THREADS), lds_bytes, (hipStream_t)stream, *cfg,
                      B, lay, sdist_prev, w_prev, u_base, jitter, near, far, sdist_out, tdist_out, idx_out);
   MNR_CHECK_LAUNCH();
@@ -294,21 +368,42 @@ extern "C" int mnr_sorted_interp(int64_t B, int nc, int nu, const float* u, cons
   return MNR_OK;
 }
 
-__global__ void max_dilate_kernel(int64_t B, int n, const float* t, const float* w, float dilation, float lo,
-                                  float hi, float* t_out, float* w_out, float* scratch) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  float* p = scratch + b * n;
-  for (int j = 0; j < n; ++j) p[j] = w[b * n + j];
-  rs_max_dilate(n, t + b * (n + 1), p, t_out + b * (3 * n + 1), w_out + b * 3 * n, 1, dilation, lo, hi);
+// Leaf: the dilation phase of the level kernel alone (same device function, 16 lanes per ray).
+__global__ __launch_bounds__(RS_THREADS) void max_dilate_kernel(int64_t B, int n, const float* t, const float* w, float dilation,
+                                                                float lo, float hi, float* t_out, float* w_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int m = 3 * n + 1;
+  const int per_ray = (n + 1) + n + 2 * m + RSP_LPR;
+  const int g = threadIdx.x / RSP_LPR, l = threadIdx.x % RSP_LPR;
+  const int64_t ray = min(B - 1, (int64_t)blockIdx.x * RSP_RPW + g);
+  float* tt = lds + g * per_ray;
+  float* p = tt + n + 1;
+  float* td = p + n;
+  float* wd = td + m;
+  float* red = wd + m;
+  for (int i = l; i <= n; i += RSP_LPR) tt[i] = t[ray * (n + 1) + i];
+  for (int i = l; i < n; i += RSP_LPR) p[i] = w[ray * n + i];
+  __syncthreads();
+  rsp_max_dilate(n, tt, p, td, wd, red, l, dilation, lo, hi);
+  if ((int64_t)blockIdx.x * RSP_RPW + g < B) {
+    for (int i = l; i < m; i += RSP_LPR) t_out[ray * m + i] = td[i];
+    for (int i = l; i < m - 1; i += RSP_LPR) w_out[ray * (m - 1) + i] = wd[i];
+  }
 }
 
 extern "C" int mnr_max_dilate_weights(int64_t B, int n, const float* t, const float* w, float dilation,
                                       float domain_lo, float domain_hi, float* t_out, float* w_out,
                                       float* scratch, void* stream) {
-  MNR_CHECK_ARG(B > 0 && n > 0 && t && w && t_out && w_out && scratch, "mnr_max_dilate_weights: bad arguments");
-  hipLaunchKernelGGL(max_dilate_kernel, dim3(mnr_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, B, n, t, w,
-                     dilation, domain_lo, domain_hi, t_out, w_out, scratch);
+  (void)scratch;                                           // (kept in the signature: callers of the round-1 ABI pass one)
+  MNR_CHECK_ARG(B > 0 && n > 0 && n <= 1024 && t && w && t_out && w_out, "mnr_max_dilate_weights: bad arguments");
+  const size_t lds_bytes = (size_t)((n + 1) + n + 2 * (3 * n + 1) + RSP_LPR) * RSP_RPW * 4;
+  MNR_CHECK_ARG(lds_bytes <= 160 * 1024, "mnr_max_dilate_weights: step function too long for LDS");
+  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if (mnr_attr_needed(&attr_set)) {
+    (void)hipFuncSetAttribute((const void*)max_dilate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  hipLaunchKernelGGL(max_dilate_kernel, dim3(mnr_cdiv(B, RSP_RPW)), dim3(RS_THREADS), lds_bytes, (hipStream_t)stream, B, n, t, w,
+                     dilation, domain_lo, domain_hi, t_out, w_out);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }

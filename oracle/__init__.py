@@ -24,7 +24,10 @@ Pinning status:
   * PARITY UNPINNED: optax.adam (restated from its published algorithm) and
     jax's PRNG bit streams (every draw is an explicit input here).
 
-Summation-order contract (bit-exact sample indices): `integrate_weights` and
-the softmax denominator inside `invert_cdf` accumulate strictly left-to-right
-in the working dtype, which is the order the HIP resampling kernel uses.
+Summation-order contract (bit-exact sample indices): the renormalisation sum of
+`max_dilate_weights`, the softmax denominator and the CDF inside `invert_cdf`
+accumulate in the BLOCKED order of the HIP level kernel (csrc/resample.hip: 16
+lanes per ray; each lane its contiguous chunk of ceil(len/16) elements left to
+right, then the 16 chunk sums left to right; `stepfun.blocked_cumsum`), in the
+working dtype.
 """

@@ -26,6 +26,43 @@ def seq_cumsum(x):
   return torch.from_numpy(np.cumsum(x.detach().numpy(), axis=-1, dtype=x.detach().numpy().dtype))
 
 
+LANES = 16   # lanes that share one ray in csrc/resample.hip (RSP_LPR)
+
+
+def blocked_cumsum(x, chunk=None):
+  """Cumulative sum in the association order of the HIP level kernel (csrc/resample.hip), in x's own dtype (no grad).
+
+  The 16 lanes of a ray each own a contiguous chunk of `chunk` = ceil(len / 16) elements: a lane sums its chunk left to
+  right (starting from 0), the 16 chunk sums are added left to right (starting from 0) into exclusive chunk offsets, and
+  the running sum at element k is offset[chunk of k] + (prefix of k inside its chunk).  This, not a strict left-to-right
+  sum, is the documented order behind bit-exact sample indices; `chunk` overrides the chunk length when the summed array
+  is a slice of the array the chunking is defined on (the CDF sums w[:-1] with the chunking of w)."""
+  a = x.detach().numpy()
+  n = a.shape[-1]
+  ch = int(chunk) if chunk is not None else -(-n // LANES)
+  pad = LANES * ch - n
+  assert pad >= 0
+  ap = np.concatenate([a, np.zeros(a.shape[:-1] + (pad,), dtype=a.dtype)], axis=-1).reshape(a.shape[:-1] + (LANES, ch))
+  local = np.zeros_like(ap)
+  run = np.zeros(ap.shape[:-1], dtype=a.dtype)
+  for i in range(ch):                                   # inside a chunk: left to right
+    run = run + ap[..., i]
+    local[..., i] = run
+  sums = local[..., -1]                                 # (adding the zero padding changes nothing)
+  offs = np.zeros_like(sums)
+  tot = np.zeros(sums.shape[:-1], dtype=a.dtype)
+  for l in range(LANES):                                # chunk sums: left to right
+    offs[..., l] = tot
+    tot = tot + sums[..., l]
+  out = (offs[..., None] + local).reshape(a.shape[:-1] + (LANES * ch,))[..., :n]
+  return torch.from_numpy(np.ascontiguousarray(out)), torch.from_numpy(np.ascontiguousarray(tot))
+
+
+def blocked_sum(x, chunk=None):
+  """Sum over the last axis in the kernel's blocked order (see blocked_cumsum); keeps the axis."""
+  return blocked_cumsum(x, chunk)[1][..., None]
+
+
 def searchsorted(a, v):
   """stepfun.py:30-53 -- (idx_lo, idx_hi) with a[idx_lo] <= v < a[idx_hi]."""
   i = torch.arange(a.shape[-1])
@@ -94,17 +131,27 @@ def max_dilate_weights(t, w, dilation, domain=(-np.inf, np.inf),
   t_dilate, p_dilate = max_dilate(t, p, dilation, domain=domain)
   w_dilate = pdf_to_weight(t_dilate, p_dilate)
   if renormalize:
-    w_dilate = w_dilate / torch.clamp(w_dilate.sum(dim=-1, keepdim=True), min=eps)
+    # (float32 without grad: the kernel's blocked order, so that the sampled indices downstream are reproducible bit
+    # for bit; anything else, e.g. the float64 goldens or a differentiated call: torch's sum)
+    if w_dilate.dtype == torch.float32 and not w_dilate.requires_grad:
+      total = blocked_sum(w_dilate)
+    else:
+      total = w_dilate.sum(dim=-1, keepdim=True)
+    w_dilate = w_dilate / torch.clamp(total, min=eps)
   return t_dilate, w_dilate
 
 
-def integrate_weights(w, sequential=True):
+def integrate_weights(w, sequential=True, blocked=False):
   """stepfun.py:131-150 -- [0, min(1, cumsum(w[:-1])), 1].
 
-  `sequential` picks the documented left-to-right accumulation (no grad);
-  otherwise torch.cumsum (differentiable; used by weighted_percentile tests).
+  `blocked` picks the level kernel's documented accumulation order (blocked_cumsum with the chunking of the
+  whole of w; no grad), `sequential` a strict left-to-right one (the order of the render_extras kernel's
+  percentiles; no grad); otherwise torch.cumsum (differentiable).
   """
-  cs = seq_cumsum(w[..., :-1]) if sequential else torch.cumsum(w[..., :-1], dim=-1)
+  if blocked:
+    cs = blocked_cumsum(w[..., :-1], chunk=-(-w.shape[-1] // LANES))[0]
+  else:
+    cs = seq_cumsum(w[..., :-1]) if sequential else torch.cumsum(w[..., :-1], dim=-1)
   cw = torch.clamp(cs, max=1)
   shape = cw.shape[:-1] + (1,)
   return torch.cat([torch.zeros(shape, dtype=w.dtype), cw,
@@ -112,17 +159,17 @@ def integrate_weights(w, sequential=True):
 
 
 def softmax_seq(logits):
-  """jax.nn.softmax (stepfun.py:156) with a left-to-right denominator."""
+  """jax.nn.softmax (stepfun.py:156) with the level kernel's blocked denominator (blocked_cumsum)."""
   m = logits.max(dim=-1, keepdim=True).values
   e = torch.exp(logits - m)
-  denom = seq_cumsum(e)[..., -1:]
+  denom = blocked_sum(e)
   return e / denom
 
 
 def invert_cdf(u, t, w_logits, use_gpu_resampling=False, return_index=False):
   """stepfun.py:153-161."""
   w = softmax_seq(w_logits)
-  cw = integrate_weights(w)
+  cw = integrate_weights(w, blocked=True)
   if use_gpu_resampling:
     return rmath.interp(u, cw, t)
   return rmath.sorted_interp(u, cw, t, return_index=return_index)
