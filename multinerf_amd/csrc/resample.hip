@@ -52,6 +52,73 @@ __device__ __forceinline__ float rs_s_to_t(int fn, float s, float near, float fa
   }
 }
 
+// exp / log of the sampling path, written out (Cephes' single-precision expf / logf: Cody-Waite reduction + polynomial,
+// every operation a separately rounded IEEE fp32 +, -, * under `fp contract(off)`) instead of the device library's, whose
+// last bit differs from the host library's.  oracle/math.py restates them operation for operation in NumPy float32
+// (kexp / klog), so the logits, the softmax and with them the CDF are the SAME BITS on the host and on the device, and
+// the sample indices are bit-exact by construction, not by luck of the libm.  Accuracy ~1 ulp like the libraries'.
+__device__ __forceinline__ float rs_pow2i(int n) { return __int_as_float((n + 127) << 23); }   // 2^n, -126 <= n <= 127
+
+__device__ __forceinline__ float rs_exp(float x) {
+  if (x != x) return x;
+  if (x < -103.9720840454f) return 0.0f;               // < log(2^-150): rounds to zero
+  if (x > 88.7228317261f) return INFINITY;
+  const float fn = floorf(x * 1.44269504088896341f + 0.5f);
+  float r = x - fn * 0.693359375f;
+  r = r - fn * -2.12194440e-4f;
+  const float z = r * r;
+  float p = 1.9875691500E-4f;
+  p = p * r + 1.3981999507E-3f;
+  p = p * r + 8.3334519073E-3f;
+  p = p * r + 4.1665795894E-2f;
+  p = p * r + 1.6666665459E-1f;
+  p = p * r + 5.0000001201E-1f;
+  p = p * z + r;
+  p = p + 1.0f;
+  const int n = (int)fn;
+  if (n >= -126) return p * rs_pow2i(n);               // exact scaling
+  return (p * rs_pow2i(n + 64)) * rs_pow2i(-64);        // subnormal result: one rounding, in the second product
+}
+
+__device__ __forceinline__ float rs_log(float x) {
+  if (x != x) return x;
+  if (x < 0.0f) return NAN;
+  if (x == 0.0f) return -INFINITY;
+  if (x == INFINITY) return x;
+  int e = 0;
+  if (x < 1.17549435e-38f) {                            // subnormal: scale by 2^23 (exact)
+    x = x * 8388608.0f;
+    e = -23;
+  }
+  const unsigned bits = __float_as_uint(x);
+  e += (int)((bits >> 23) & 0xffu) - 126;
+  float m = __uint_as_float((bits & 0x007fffffu) | 0x3f000000u);     // mantissa in [0.5, 1)
+  if (m < 0.707106781186547524f) {
+    e -= 1;
+    m = m + m - 1.0f;
+  } else {
+    m = m - 1.0f;
+  }
+  const float z = m * m;
+  float y = 7.0376836292E-2f;
+  y = y * m - 1.1514610310E-1f;
+  y = y * m + 1.1676998740E-1f;
+  y = y * m - 1.2420140846E-1f;
+  y = y * m + 1.4249322787E-1f;
+  y = y * m - 1.6668057665E-1f;
+  y = y * m + 2.0000714765E-1f;
+  y = y * m - 2.4999993993E-1f;
+  y = y * m + 3.3333331174E-1f;
+  y = y * m;
+  y = y * z;
+  const float fe = (float)e;
+  y = y + -2.12194440e-4f * fe;
+  y = y + -0.5f * z;
+  float r = m + y;
+  r = r + 0.693359375f * fe;
+  return r;
+}
+
 // One query of math.sorted_interp (math.py:108-127).  `i` is a cursor holding the last
 // index with xp[i] <= x (or -1); since the queries ascend it moves O(1) amortised.
 __device__ __forceinline__ float rs_interp_one(float x, const float* xp, const float* fp, int stride, int nc,
@@ -217,7 +284,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_level_kernel(
   float mx = -INFINITY;
   for (int k = k0; k < k1; ++k) {
     const bool open = td[k + 1] > td[k];
-    const float lg = open ? c.anneal * logf(wd[k] + c.resample_padding) : -INFINITY;
+    const float lg = open ? c.anneal * rs_log(wd[k] + c.resample_padding) : -INFINITY;
     wd[k] = lg;
     mx = (lg != lg || mx != mx) ? NAN : fmaxf(mx, lg);          // jnp.max propagates NaN (0 * log 0 at train_frac 0)
   }
@@ -232,7 +299,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_level_kernel(
   }
   float csum = 0.0f;
   for (int k = k0; k < k1; ++k) {
-    const float e = expf(wd[k] - mx);
+    const float e = rs_exp(wd[k] - mx);
     wd[k] = e;
     csum += e;
   }

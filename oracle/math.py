@@ -100,3 +100,75 @@ def sorted_interp(x, xp, fp, return_index=False):
     idx = mask.sum(dim=-2).to(torch.int32) - 1
     return ret, idx
   return ret
+
+
+# ----------------------------------------------------------------------------- the sampling path's exp / log
+#
+# csrc/resample.hip does not call the device library's expf / logf (their last bit differs from the host library's):
+# it spells both out (Cephes' single-precision algorithms), every operation a separately rounded fp32 +, -, *.  These
+# are the same operations in the same order in NumPy float32, so logits, softmax and CDF are the same bits on both
+# sides: the precondition of bit-exact sample indices.  (float32 only; ~1 ulp, like the libraries'.)
+
+_F = np.float32
+
+
+def kexp(x):
+  """rs_exp of csrc/resample.hip on a float32 array / tensor (returns the same type)."""
+  is_t = isinstance(x, torch.Tensor)
+  a = (x.detach().numpy() if is_t else np.asarray(x)).astype(np.float32)
+  with np.errstate(all='ignore'):
+    xs = np.where(np.isfinite(a), a, _F(0))
+    fn = np.floor(xs * _F(1.44269504088896341) + _F(0.5)).astype(np.float32)
+    r = xs - fn * _F(0.693359375)
+    r = r - fn * _F(-2.12194440e-4)
+    z = r * r
+    p = np.full_like(r, _F(1.9875691500E-4))
+    for c in (1.3981999507E-3, 8.3334519073E-3, 4.1665795894E-2, 1.6666665459E-1, 5.0000001201E-1):
+      p = p * r + _F(c)
+    p = p * z + r
+    p = p + _F(1.0)
+    n = np.clip(fn, -190, 127).astype(np.int32)
+    pow2 = lambda k: ((k + 127).astype(np.int32) << 23).view(np.float32)
+    normal = p * pow2(np.maximum(n, -126))
+    sub = (p * pow2(np.minimum(n, -127) + 64)) * _F(2.0 ** -64)
+    out = np.where(n >= -126, normal, sub).astype(np.float32)
+    out = np.where(a < _F(-103.9720840454), _F(0), out)
+    out = np.where(a > _F(88.7228317261), _F(np.inf), out)
+    out = np.where(np.isnan(a), a, out).astype(np.float32)
+  return torch.from_numpy(out) if is_t else out
+
+
+def klog(x):
+  """rs_log of csrc/resample.hip on a float32 array / tensor (returns the same type)."""
+  is_t = isinstance(x, torch.Tensor)
+  a = (x.detach().numpy() if is_t else np.asarray(x)).astype(np.float32)
+  with np.errstate(all='ignore'):
+    ok = np.isfinite(a) & (a > 0)
+    xs = np.where(ok, a, _F(1))
+    tiny = xs < _F(1.17549435e-38)
+    xs = np.where(tiny, xs * _F(8388608.0), xs).astype(np.float32)
+    e = np.where(tiny, -23, 0).astype(np.int32)
+    bits = xs.view(np.uint32)
+    e = e + ((bits >> 23) & 0xff).astype(np.int32) - 126
+    m = ((bits & np.uint32(0x007fffff)) | np.uint32(0x3f000000)).view(np.float32)
+    small = m < _F(0.707106781186547524)
+    e = np.where(small, e - 1, e)
+    m = np.where(small, m + m - _F(1.0), m - _F(1.0)).astype(np.float32)
+    z = m * m
+    y = np.full_like(m, _F(7.0376836292E-2))
+    for sign, c in ((-1, 1.1514610310E-1), (1, 1.1676998740E-1), (-1, 1.2420140846E-1), (1, 1.4249322787E-1),
+                    (-1, 1.6668057665E-1), (1, 2.0000714765E-1), (-1, 2.4999993993E-1), (1, 3.3333331174E-1)):
+      y = y * m + _F(c) if sign > 0 else y * m - _F(c)
+    y = y * m
+    y = y * z
+    fe = e.astype(np.float32)
+    y = y + _F(-2.12194440e-4) * fe
+    y = y + _F(-0.5) * z
+    r = m + y
+    r = r + _F(0.693359375) * fe
+    out = r.astype(np.float32)
+    out = np.where(a == 0, _F(-np.inf), out)
+    out = np.where(a < 0, _F(np.nan), out)
+    out = np.where(a == np.inf, a, out)
+    out = np.where(np.isnan(a), a, out).astype(np.float32)
+  return torch.from_numpy(out) if is_t else out

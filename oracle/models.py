@@ -448,10 +448,7 @@ def model_apply(model: Model, nerf_mlp: MLP, prop_mlp: Optional[MLP], params, ra
     else:
       anneal = 1.
 
-    logits_resample = torch.where(
-        sdist[..., 1:] > sdist[..., :-1],
-        anneal * torch.log(weights + model.resample_padding),
-        torch.full_like(weights, -float('inf')))
+    logits_resample = stepfun.resample_logits(sdist, weights, anneal, model.resample_padding)
 
     u_jit = None if noise is None else noise['u_jitter'][i_level]
     sdist = stepfun.sample_intervals(

@@ -55,7 +55,8 @@ def blocked_cumsum(x, chunk=None):
     offs[..., l] = tot
     tot = tot + sums[..., l]
   out = (offs[..., None] + local).reshape(a.shape[:-1] + (LANES * ch,))[..., :n]
-  return torch.from_numpy(np.ascontiguousarray(out)), torch.from_numpy(np.ascontiguousarray(tot))
+  return (torch.from_numpy(np.ascontiguousarray(out).reshape(a.shape)),
+          torch.from_numpy(np.ascontiguousarray(tot).reshape(a.shape[:-1])))
 
 
 def blocked_sum(x, chunk=None):
@@ -158,10 +159,19 @@ def integrate_weights(w, sequential=True, blocked=False):
                     torch.ones(shape, dtype=w.dtype)], dim=-1)
 
 
+def resample_logits(sdist, weights, anneal, resample_padding):
+  """models.py:183-185: where(sdist[1:] > sdist[:-1], anneal * log(weights + padding), -inf), with the sampling path's
+  own log in float32 (math.klog: the kernel's, bit for bit)."""
+  w = weights.detach() + resample_padding
+  lg = rmath.klog(w) if w.dtype == torch.float32 else torch.log(w)
+  return torch.where(sdist[..., 1:] > sdist[..., :-1], anneal * lg, torch.full_like(w, -float('inf')))
+
+
 def softmax_seq(logits):
-  """jax.nn.softmax (stepfun.py:156) with the level kernel's blocked denominator (blocked_cumsum)."""
+  """jax.nn.softmax (stepfun.py:156) with the level kernel's blocked denominator (blocked_cumsum) and, in float32, its
+  exp (math.kexp)."""
   m = logits.max(dim=-1, keepdim=True).values
-  e = torch.exp(logits - m)
+  e = rmath.kexp(logits - m) if logits.dtype == torch.float32 else torch.exp(logits - m)
   denom = blocked_sum(e)
   return e / denom
 

@@ -84,8 +84,7 @@ def _resample_ref(sd, w, u_jit, near, far, *, n, use_dil, dil, anneal, pad, sing
   if use_dil:
     sd, w = ostepfun.max_dilate_weights(sd, w, dil, domain=(0., 1.), renormalize=True)
     sd, w = sd[..., 1:-1], w[..., 1:-1]
-  logits = torch.where(sd[..., 1:] > sd[..., :-1], anneal * torch.log(w + pad),
-                       torch.full_like(w, -float('inf')))
+  logits = ostepfun.resample_logits(sd, w, anneal, pad)
   s, idx = ostepfun.sample_intervals(u_jit, sd, logits, n, single_jitter=single, domain=(0., 1.),
                                      return_index=True)
   _, s_to_t = ocoord.construct_ray_warps(raydist, near, far)
@@ -133,9 +132,9 @@ def test_resample_level(ops, case):
                                  single_jitter=c['single'], max_jitter=max_jitter, raydist_fn=c['raydist'],
                                  want_idx=True)
   mismatch = (idx.cpu() != idx_ref).float().mean().item()
-  # Sample indices are bit-exact (north_star): the kernel and the oracle sum the softmax denominator and the CDF in
-  # the same documented order, so an index can only differ where device expf/logf and the host's differ by an ulp AND
-  # u lands on that ulp of a CDF fence-post: 0 of 12800..25600 indices on these seeded cases.
+  # Sample indices are bit-exact (north_star) BY CONSTRUCTION: every operation between the inputs and the index is an
+  # individually rounded IEEE fp32 +, -, *, / or comparison in a documented order (blocked sums; the path's own exp / log,
+  # csrc/resample.hip rs_exp / rs_log = oracle/math.py kexp / klog), restated operation for operation in the oracle.
   print(f'{case}: index mismatch rate {mismatch:.2e} ({int((idx.cpu() != idx_ref).sum())} of {idx_ref.numel()})')
   assert mismatch == 0
   same = (idx.cpu() == idx_ref).all(-1)
