@@ -192,6 +192,9 @@ int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* args, void* stream);
 int mnr_debug_gemm_timeline(unsigned long long* device_buffer);
 /* A/B switch: 0 = one workgroup per output tile; n > 0 (default 1) = persistent launches, n workgroups per CU walk the
  * tiles; n < 0 = at most -n workgroups in total. */
+/* A/B switch: 1 (default) = the 256x256 tiles use the hand-pipelined K loop (BK = 32 x 4 stages, LDS-DMA issued between the
+   MFMAs), 0 = the two-stage BK = 64 loop.  Bitwise equal results. */
+int mnr_gemm_nt_set_pipelined(int on);
 int mnr_gemm_nt_set_persistent(int wgs_per_cu);
 /* A/B switch: 1 (default) = eligible short-K launches (N = 256, K1 <= 256, K2 = 0, full-width bf16 output, no fp32 side
  * output, no bf16 mask) go to the weights-resident persistent kernel (weights in registers, one workgroup per CU walking

@@ -51,14 +51,17 @@
 
 #define NT_CPAD 16                                   // epilogue staging: 16 B pad per row
 
-template <int MI_, int NJ_, int WM_, int WN_, int EPI_BATCH_ = 0, int BIAS_LDS_ = 0>
+template <int MI_, int NJ_, int WM_, int WN_, int EPI_BATCH_ = 0, int BIAS_LDS_ = 0, int PIPE_ = 0, int DBG_ = 0, int BK_ = 64, int STAGES_ = 2>
 struct NtCfg {
+  static constexpr int DBG = DBG_;                    // probe builds: 1 no DMA, 2 no MFMA, 3 no fragment reads, 4 MFMA only
+  // 1: K loop with explicitly double-buffered fragments (gemm_nt_body.inc), for the one-wave-per-SIMD configuration
+  static constexpr bool PIPE = PIPE_ != 0;
   // n > 0: the epilogue's store loop reads its staged chunks from LDS n at a time (n ds_read_b128 in flight per thread)
   // instead of one read per iteration waited for on the spot, and the fp32 side outputs (which read the accumulators)
   // are written before the store loop instead of after it, so that the accumulators' 128 registers are free for the
   // batch (with them alive, 16 reads at once spilled 85 registers).
   static constexpr int EPI_BATCH = EPI_BATCH_;
-  static constexpr int MI = MI_, NJ = NJ_, WM = WM_, WN = WN_, BK = 64, STAGES = 2;
+  static constexpr int MI = MI_, NJ = NJ_, WM = WM_, WN = WN_, BK = BK_, STAGES = STAGES_;
   static constexpr int MINW = 1;                      // __launch_bounds__ min waves per SIMD
   static constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   static constexpr int THREADS = 64 * WM * WN;
@@ -113,6 +116,29 @@ __device__ __forceinline__ bf16x8 nt_read_frag(const char* lds_tile, int row, in
   return *(const bf16x8*)(lds_tile + off);
 }
 
+__device__ __forceinline__ void nt_wait_lgkmcnt0() { MNR_GPU_ONLY(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")); }
+
+// A value the optimiser cannot see through: address arithmetic derived from it is recomputed where it is used instead of
+// being hoisted out of the tile loop and kept (or spilled) across it.
+__device__ __forceinline__ int mnr_opaque(int v) {
+  MNR_GPU_ONLY(asm volatile("" : "+v"(v)));
+  return v;
+}
+
+// lane index 0..63 from the exec-mask prefix count over an opaque zero (not derived from threadIdx.x, not hoistable)
+__device__ __forceinline__ int mnr_lane_id() {
+#ifdef MNR_HIPSIM
+  return (int)threadIdx.x & 63;
+#else
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)mnr_opaque(0)));
+#endif
+}
+__device__ __forceinline__ int mnr_opaque_s(int v) {
+  MNR_GPU_ONLY(asm volatile("" : "+s"(v)));
+  return v;
+}
+__device__ __forceinline__ void nt_launder(bf16x8& f) { MNR_GPU_ONLY(asm volatile("" : "+v"(f))); }
+
 template <int N>
 __device__ __forceinline__ void nt_wait_vmcnt() {
   MNR_GPU_ONLY(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"));
@@ -138,6 +164,10 @@ extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
 
 template <class CFG, bool BITS_IN>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
+  // the wave index lives in an SGPR across the tile loop and the lane index is re-derived per tile (mbcnt): with
+  // threadIdx.x itself kept alive across the loop, hipcc spills it and reloads it (behind a vmcnt(0)) at every tile
+  const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  unsigned long long* const tl = g_nt_timeline;          // read once: a load per tile is a vmcnt(0) behind the previous tile's stores
   for (int64_t vbid = blockIdx.x; vbid < vtotal; vbid += gridDim.x) {
 #include "gemm_nt_body.inc"
     if (vbid + gridDim.x < vtotal) __syncthreads();      // (persistent launch) this tile's LDS is free for the next one
@@ -149,6 +179,12 @@ static int g_nt_persist = 1;                             // workgroups per CU of
 
 // A/B switch: 0 = one workgroup per output tile; n > 0 = persistent launches of n workgroups per CU for the
 // single-resident-workgroup (> 80 KiB LDS) configurations; n < 0 = at most -n workgroups in total (tests).
+static int g_nt_pipe = 1;                                // round-2 A/B (profiles/r2_nt_pipe_probe.txt): K loop 3.7k -> 3.1k cycles per 64 k
+extern "C" int mnr_gemm_nt_set_pipelined(int on) {
+  g_nt_pipe = on;
+  return MNR_OK;
+}
+
 extern "C" int mnr_gemm_nt_set_persistent(int wgs_per_cu) {
   g_nt_persist = wgs_per_cu;
   return MNR_OK;
@@ -191,6 +227,8 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
 //            MI NJ WM WN EPI_BATCH BIAS_LDS
 typedef NtCfg<2, 2, 2, 2> NtSmall;                  // 128x128, 4 waves, 64 KiB: N not a multiple of 256 (heads, view MLP)
 typedef NtCfg<4, 2, 2, 4, 16, 1> NtBig;             // 256x256, 8 waves (2 x 4, 128x64 per wave), 128 KiB + bias row: the trunk layers
+typedef NtCfg<4, 4, 2, 2, 16, 1, 1, 0, 32, 4> NtWide;
+typedef NtCfg<4, 2, 2, 4, 8, 1, 1, 0, 32, 4> NtBigP;           // EXPERIMENT: NtBig with the hand-pipelined K loop, BK = 32 x 4 stages            // EXPERIMENT: 256x256, 4 waves (2 x 2, 128x128 per wave, accumulators in AGPRs)
 
 // ---------------------------------------------------------------------------
 // Weights-resident NT kernel for the short-K layers (N = 256, K <= 256: the proposal MLP's hidden layers and their dX).
@@ -445,6 +483,15 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   const int fast_epi = (!a->Cb || (a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0)) &&
                        (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));
   if (g_nt_wres > 0 && nt_wres_eligible(a, fast_epi)) return nt_wres_launch(a, g_nt_wres, stream);
+#ifdef MNR_NT_DEBUG_VARIANTS      // probe build (tools/nt_pipe_probe.py): the pipelined loop with one ingredient removed
+  if (a->M % 256 == 0 && a->N % 256 == 0) {
+    if (g_nt_pipe == 11) return nt_launch<NtCfg<4, 2, 2, 4, 8, 1, 1, 1, 32, 4>>(a, fast_epi, stream);      // no DMA
+    if (g_nt_pipe == 12) return nt_launch<NtCfg<4, 2, 2, 4, 8, 1, 1, 2, 32, 4>>(a, fast_epi, stream);      // no MFMA
+    if (g_nt_pipe == 13) return nt_launch<NtCfg<4, 2, 2, 4, 8, 1, 1, 3, 32, 4>>(a, fast_epi, stream);      // no fragment reads
+    if (g_nt_pipe == 14) return nt_launch<NtCfg<4, 2, 2, 4, 8, 1, 1, 4, 32, 4>>(a, fast_epi, stream);      // MFMA only
+  }
+#endif
+  if (g_nt_pipe && a->M % 256 == 0 && a->N % 256 == 0) return nt_launch<NtBigP>(a, fast_epi, stream);
   if (a->M % 256 == 0 && a->N % 256 == 0) return nt_launch<NtBig>(a, fast_epi, stream);
   return nt_launch<NtSmall>(a, fast_epi, stream);
 }

@@ -38,11 +38,11 @@ def _mfma_span(body):
 def test_the_shipped_mfma_kernels_are_all_there(report):
   _, bodies = report
   names = sorted(bodies)
-  assert sum('gemm_nt_kernel' in n for n in names) == 4          # NtBig / NtSmall, with / without bit-mask input
+  assert sum('gemm_nt_kernel' in n for n in names) == 6          # NtBigP (pipelined) / NtBig / NtSmall, with / without bit-mask input
   assert sum('gemm_nt_wres_kernel' in n for n in names) == 2
   assert sum('gemm_tn_kernel' in n for n in names) == 2          # TnBig / TnSmall
   assert sum('mlp_chain_fwd_kernel' in n for n in names) == 2 and sum('mlp_chain_bwd_kernel' in n for n in names) == 2   # W = 128 / 256
-  assert len(names) == 12, names
+  assert len(names) == 14, names
 
 
 def test_tiled_gemm_k_loops_carry_only_the_hand_counted_vmcnt_waits(report):
@@ -54,6 +54,35 @@ def test_tiled_gemm_k_loops_carry_only_the_hand_counted_vmcnt_waits(report):
       span = _mfma_span(body)
       assert sum('v_mfma' in l for l in span) >= 16, name
       assert mod.compiler_vmcnt_waits(span) == [], (name, mod.compiler_vmcnt_waits(span))
+
+
+def test_pipelined_nt_loop_spreads_its_dma_between_the_mfmas(report):
+  """NtBigP's steady-state K-tile (the loop block with the counted vmcnt(6) wait): 16 MFMAs, the tile's 4 LDS-DMA pieces
+  issued between them (as one burst behind the barrier, every wave waits in the address unit's queue instead of in its MFMAs:
+  K-tile time = MFMA time + DMA time, profiles/r2_nt_pipe_probe.txt), and no lgkmcnt wait between the barrier and the
+  first MFMA after it (the fragments of that k-step were waited for in front of the barrier; a wait there is for the NEXT
+  tile's reads)."""
+  _, bodies = report
+  pipe = {n: b for n, b in bodies.items() if 'gemm_nt_kernel' in n and 'Li32ELi4EE' in n}
+  assert len(pipe) == 2
+  for name, body in pipe.items():
+    code = [l.split(';')[0].rstrip() for l in body]
+    w = next(k for k, l in enumerate(code) if 's_waitcnt vmcnt(6)' in l)
+    start = max(k for k in range(w) if code[k].startswith('.LBB'))
+    end = next(k for k in range(w, len(code)) if code[k].startswith('\ts_cbranch'))
+    blk = code[start:end]
+    assert sum('v_mfma' in l for l in blk) == 16, name
+    assert sum('global_load_lds' in l for l in blk) == 4, name
+    assert not any('scratch_' in l for l in blk), name
+    ops = [l for l in blk if 'v_mfma' in l or 'global_load_lds' in l]
+    run = longest = 0
+    for l in ops:
+      run = run + 1 if 'global_load_lds' in l else 0
+      longest = max(longest, run)
+    assert longest <= 2, (name, longest)
+    b = next(k for k, l in enumerate(blk) if 's_barrier' in l)
+    m = next(k for k in range(b, len(blk)) if 'v_mfma' in blk[k])
+    assert not any('lgkmcnt' in l for l in blk[b:m]), (name, blk[b:m])
 
 
 def test_no_spills_inside_the_mfma_loops(report):

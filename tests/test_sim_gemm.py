@@ -63,6 +63,36 @@ def test_nt_forward_layer(sim, persist, mode):
   assert torch.equal(bits, _packbits(Cb.float()))
 
 
+@pytest.mark.parametrize('mode', [MODES[1], MODES[3]])
+@pytest.mark.parametrize('K1,K2', [(64, 0), (128, 0), (64, 64), (128, 192)])
+def test_nt_pipelined_loop_short_k_and_two_stage_loop(sim, K1, K2, mode):
+  """The hand-pipelined K loop (BK = 32, 4 stages; default) with fewer K-tiles than stages / in every tail flavour, against the
+  reference and bitwise against the two-stage BK = 64 loop it replaced (mnr_gemm_nt_set_pipelined(0))."""
+  g = torch.Generator().manual_seed(5)
+  M, N = 512, 256
+  A1 = torch.randn((M, K1), generator=g).bfloat16()
+  A2 = torch.randn((M, K2), generator=g).bfloat16() if K2 else None
+  Bt = (torch.randn((N, K1 + K2), generator=g) * 0.1).bfloat16()
+  bias = torch.randn(N, generator=g)
+  sim.mnr_gemm_nt_set_wres(0)
+  sim.mnr_gemm_nt_set_persistent(-8)
+  try:
+    sim.hipsim_reset(*mode)
+    Cb, _, bits = S.sim_gemm_nt(sim, A1, Bt, A2=A2, bias=bias, relu=True, bits_out=True)
+    sim.mnr_gemm_nt_set_pipelined(0)
+    sim.hipsim_reset(*mode)
+    Cb0, _, bits0 = S.sim_gemm_nt(sim, A1, Bt, A2=A2, bias=bias, relu=True, bits_out=True)
+    assert torch.equal(Cb.view(torch.int16), Cb0.view(torch.int16)) and torch.equal(bits, bits0)
+  finally:
+    sim.mnr_gemm_nt_set_pipelined(1)
+    sim.mnr_gemm_nt_set_persistent(1)
+    sim.mnr_gemm_nt_set_wres(1)
+  A = torch.cat([A1, A2], 1) if K2 else A1
+  ref = torch.relu(A.float() @ Bt.float().T + bias)
+  np.testing.assert_allclose(Cb.float().numpy(), ref.numpy(), atol=2e-2, rtol=1e-2)
+  assert torch.equal(bits, _packbits(Cb.float()))
+
+
 @pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('persist', [0, -8])
 def test_nt_dx_layer_with_bit_masks(sim, persist, mode):
