@@ -9,7 +9,8 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libmnerf_hip.so')
+# MNR_LIB_PATH: load another build of the same ABI (same-box A/B of two kernel versions; never a different implementation)
+LIB_PATH = os.environ.get('MNR_LIB_PATH') or os.path.join(HERE, 'libmnerf_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(HERE), 'include', 'mnerf.h')
 
 MNR_OK = 0

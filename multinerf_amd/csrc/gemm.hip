@@ -517,31 +517,15 @@ struct TnCfg {
   static constexpr int BKO = 32 * KI * WK;            // output rows (columns of A)
   static constexpr int BNO = 32 * NJ * WN;            // output cols (columns of B)
   static constexpr int THREADS = 64 * WK * WN;
-  static constexpr int A_BYTES = TN_BM * BKO * 2, B_BYTES = TN_BM * BNO * 2;
+  static constexpr int SBM = 32, STAGES = 4;          // reduction rows per stage buffer, stage buffers
+  static constexpr int A_BYTES = SBM * BKO * 2, B_BYTES = SBM * BNO * 2;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+  static constexpr int LOADS_PER_STAGE = STAGE_BYTES / 16 / THREADS;
 };
 typedef TnCfg<2, 2, 2, 2> TnSmall;   // 128x128 output tile, 4 waves,  64 KiB
 typedef TnCfg<4, 2, 2, 4> TnBig;     // 256x256 output tile, 8 waves, 128 KiB
 
-// Stage a [64 m][COLS] tile; 64-B block b of row r is stored at block position b ^ (r & 3).
-template <int COLS, int THREADS>
-__device__ __forceinline__ void tn_stage_tile(const bf16* __restrict__ g, int ld, int64_t row0,
-                                              int col0, char* lds_tile, int wave, int lane) {
-  constexpr int CPR = COLS / 8;                      // 16-B chunks per row
-  constexpr int NWAVES = THREADS / 64;
-  constexpr int ITERS = TN_BM * CPR / THREADS;
-#pragma unroll
-  for (int i = 0; i < ITERS; ++i) {
-    const int cbase = (i * NWAVES + wave) * 64;
-    const int c = cbase + lane;
-    const int r = c / CPR;
-    const int pos = c % CPR;
-    const int blk = (pos >> 2) ^ (r & 3);
-    const bf16* src = g + (row0 + r) * (int64_t)ld + col0 + blk * 32 + (pos & 3) * 8;
-    __builtin_amdgcn_global_load_lds(MNR_GLOBAL_PTR(src), MNR_LDS_PTR(lds_tile + cbase * 16), 16, 0, 0);
-  }
-}
 
 template <class CFG>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {

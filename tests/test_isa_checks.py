@@ -83,6 +83,17 @@ def test_pipelined_nt_loop_spreads_its_dma_between_the_mfmas(report):
     b = next(k for k, l in enumerate(blk) if 's_barrier' in l)
     m = next(k for k in range(b, len(blk)) if 'v_mfma' in blk[k])
     assert not any('lgkmcnt' in l for l in blk[b:m]), (name, blk[b:m])
+  # the TN kernels' loop has the same structure (its bias MFMAs sit in a branch, so the check is over the whole MFMA span)
+  for name, body in bodies.items():
+    if 'gemm_tn_kernel' not in name:
+      continue
+    ops = [l for l in _mfma_span(body) if 'v_mfma' in l or 'global_load_lds' in l]
+    assert sum('global_load_lds' in l for l in ops) >= 4, name
+    run = longest = 0
+    for l in ops:
+      run = run + 1 if 'global_load_lds' in l else 0
+      longest = max(longest, run)
+    assert longest <= 1, (name, longest)
 
 
 def test_no_spills_inside_the_mfma_loops(report):
