@@ -476,6 +476,8 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   MNR_CHECK_ARG(a->Cb || a->Cf, "mnr_gemm_nt_bf16: no output");
   MNR_CHECK_ARG(!(a->mask_bits_out && a->mask), "mnr_gemm_nt_bf16: mask_bits_out cannot be combined with a bf16 mask");
   MNR_CHECK_ARG(!a->bias || a->n_bias >= 1, "mnr_gemm_nt_bf16: bias needs n_bias >= 1");
+  MNR_CHECK_ARG(!a->mask_bits_in || (!a->bias && !a->relu), "mnr_gemm_nt_bf16: mask_bits_in (a dX layer) takes no bias and no ReLU");
+  MNR_CHECK_ARG(!a->mask_bits_in || a->bits_row_mod == 0 || a->bits_row_mod >= 256, "mnr_gemm_nt_bf16: bits_row_mod must be 0 or >= 256");
   MNR_CHECK_ARG(!a->mask_bits_out || (a->Cb && a->nb == a->N && a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0 &&
                                       a->ld_bits_out % 4 == 0 && ((uintptr_t)a->mask_bits_out % 4) == 0),
                 "mnr_gemm_nt_bf16: mask_bits_out needs a full-width, 16-byte-aligned bf16 output and a 4-byte-aligned bit matrix");
