@@ -84,7 +84,7 @@ int mnr_sorted_interp(int64_t B, int nc, int nu, const float* u, const float* cw
 
 /* Leaf: stepfun.max_dilate_weights(t, w, dilation, domain, renormalize=True)
  * (stepfun.py:116-128). t [B,n+1], w [B,n] -> t_out [B,3n+1], w_out [B,3n];
- * scratch [B,n] floats. */
+ * scratch: unused since round 2 (the kernel works in LDS); kept in the signature, may be NULL. */
 int mnr_max_dilate_weights(int64_t B, int n, const float* t, const float* w, float dilation,
                            float domain_lo, float domain_hi, float* t_out, float* w_out,
                            float* scratch, void* stream);
