@@ -18,6 +18,11 @@
 //   phase 3: all threads: coalesced copy of the [SPB, ld] bf16 rows to HBM
 #include "common.h"
 
+// No floating-point contraction in this file: the instantiations of cast_rays_ipe_kernel (bf16 rows, f32 rows for the parity
+// tests, tangent rows) must evaluate the same separately rounded operations, whatever hipcc would fuse in each of them (the
+// explicit fmaf calls are fused in all).
+#pragma clang fp contract(off)
+
 #define FE_THREADS 256
 #define FE_PI_2 1.57079632679489661923f
 #define FE_100PI 314.159265358979323846f
@@ -31,6 +36,28 @@ __device__ __forceinline__ float fe_safe_sin(float x) {
     x = m;
   }
   return sinf(x);
+}
+
+// sin and cos of y for |y| <= 100 pi (the argument after math.safe_sin's wrap): Cody-Waite reduction by pi/2 in three parts
+// (k <= 200: k * FE_PIO2_A is exact), Cephes single-precision kernels on [-pi/4, pi/4] (|error| ~1e-7, the features then go to
+// bf16).  ~20 VALU operations without a branch; the library sincosf carries its large-argument reduction along.
+#define FE_PIO2_A 1.5703125f
+#define FE_PIO2_B 4.837512969970703125e-4f
+#define FE_PIO2_C 7.54978995489188216e-8f
+__device__ __forceinline__ void fe_sincos_wrapped(float y, float* sn, float* cs) {
+  const float kf = rintf(y * 0.63661977236758134308f);
+  const int q = (int)kf;
+  float r = fmaf(-kf, FE_PIO2_A, y);
+  r = fmaf(-kf, FE_PIO2_B, r);
+  r = fmaf(-kf, FE_PIO2_C, r);
+  const float z = r * r;
+  const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  const float s = fmaf(r * z, ps, r);
+  const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  const float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  const float a = (q & 1) ? c : s, b = (q & 1) ? s : c;
+  *sn = (q & 2) ? -a : a;
+  *cs = ((q + 1) & 2) ? -b : b;
 }
 
 struct FeSample {
@@ -126,7 +153,7 @@ __device__ __forceinline__ void fe_gaussian(const mnr_ipe_cfg& c, float t0, floa
 
 template <bool OUT_F32, bool TANGENT>
 __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
-    mnr_ipe_cfg c, int64_t total, int n, int spb, const float* __restrict__ tdist,
+    mnr_ipe_cfg c, int64_t total, int n, int spb, int pitch, const float* __restrict__ tdist,
     const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ radii,
     const float* __restrict__ basis, void* __restrict__ feat_out, int ld_feat, float* __restrict__ means_out,
     float* __restrict__ covs_out) {
@@ -170,9 +197,20 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
   __syncthreads();
 
   const int row_elems = OUT_F32 ? nfeat : ld_feat;
+  // `pitch`: bytes between staged rows in LDS (row bytes + padding: with 1-KiB rows every sample of a wave hits the same banks).
+  // The kernel streams its feature rows out at ≈3.9 TB/s (1 GB per 64-sample proposal level in 0.27 ms), the write rate HBM
+  // sustains: the arithmetic only has to stay under that (round 2 cut it from ≈470 to ≈340 instructions per (sample,
+  // direction) without changing the time), so the inner loop is short rather than clever:
+  // an anchor every 4th degree = one sin / cos of the wrapped argument (math.safe_sin's wrap at float32(100 pi),
+  // math.py:26-28; fe_sincos_wrapped) and one hardware exp2 for the attenuation; the 3 degrees behind it by the double-angle
+  // recurrence (sin 2x = 2 sin x cos x, cos 2x = 1 - 2 sin^2 x; cf. stable_pos_enc in the reference's tests/coord_test.py:34-43)
+  // and by att(l+1) = att(l)^4 (exp(-v 4^l / 2): two squarings): at most 3 steps of a ~1e-7 error, each at most x4.
+  // cos is the reference's sin(x + pi/2).  sin and cos feature of a (degree, direction) leave as one packed bf16 pair.
   // TANGENT: three rows per sample (d/d mean_x, d/d mean_y, d/d mean_z), staged as [c][sample][ld].
+  const float inv_k = 1.0f / (float)K;
   for (int pair = threadIdx.x; pair < ns * K; pair += FE_THREADS) {
-    const int si = pair / K, k = pair % K;
+    const int si = (int)(((float)pair + 0.5f) * inv_k);       // pair / K, exact for pair < 2^20
+    const int k = pair - si * K;
     const FeSample g = gs[si];
     const float px = bs[k * 3 + 0], py = bs[k * 3 + 1], pz = bs[k * 3 + 2];
     // coord.py:131-132: mean . p_k ; p_k^T cov p_k.
@@ -181,16 +219,13 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
     const float cy = g.cov[1] * px + g.cov[3] * py + g.cov[4] * pz;
     const float cz = g.cov[2] * px + g.cov[4] * py + g.cov[5] * pz;
     const float lv = px * cx + py * cy + pz * cz;
-    // sin/cos of lm * 2^deg: an accurate sincosf every 4th degree ("anchor", with math.safe_sin's
-    // wrap at float32(100 pi), math.py:26-28, applied to its argument) and the double-angle
-    // recurrence (sin 2x = 2 sin x cos x, cos 2x = 1 - 2 sin^2 x; cf. stable_pos_enc in the
-    // reference's tests/coord_test.py:34-43) for the 3 degrees in between: at most 3 doublings of
-    // a ~1e-7 error, and 6x fewer transcendental expansions than one sinf per feature.
-    // cos is the reference's sin(x + pi/2).  The attenuation uses the hardware exp2.
     const float vscale = -0.5f * 1.44269504088896340736f * lv;       // exp(-v/2) = exp2(vscale * 4^deg)
-    float sn = 0.0f, cs = 1.0f;
+    char* rowp = rows + (size_t)si * pitch + (size_t)k * (OUT_F32 ? 4 : 2);       // column k of the sample's row (row 0 of 3 if TANGENT)
+    const int half = K * L * (OUT_F32 ? 4 : 2);                      // byte offset of the cos half of the row
+    const int lstep = K * (OUT_F32 ? 4 : 2);
+    float sc = ldexpf(1.0f, c.min_deg);                              // 2^deg, exact
+    float sn = 0.0f, cs = 1.0f, att = 1.0f;
     for (int l = 0; l < L; ++l) {
-      const float sc = ldexpf(1.0f, c.min_deg + l);       // 2^deg, exact
       if ((l & 3) == 0) {
         float y = lm * sc;
         if (!(fabsf(y) < FE_100PI)) {
@@ -198,34 +233,37 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
           if (m != 0.0f && (m < 0.0f)) m += FE_100PI;
           y = m;
         }
-        sincosf(y, &sn, &cs);
+        fe_sincos_wrapped(y, &sn, &cs);
+        att = exp2f(vscale * sc * sc);
       }
-      const float att = exp2f(vscale * sc * sc);
       const float fs = att * sn;
       const float fc = att * cs;
-      const int col = l * K + k;
       if (TANGENT) {
         // d/d mean_c of att sin(lm 2^l) = att 2^l cos(.) p_k[c];  of att cos(.) = -att 2^l sin(.) p_k[c]
         // (no warp: the variance does not depend on the mean).
         const float pc[3] = {px, py, pz};
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
-          bf16* rowp = (bf16*)rows + ((size_t)cc * spb + si) * row_elems;
-          rowp[col] = (bf16)(fc * sc * pc[cc]);
-          rowp[K * L + col] = (bf16)(-fs * sc * pc[cc]);
+          char* rp = rowp + (size_t)cc * spb * pitch;
+          *(bf16*)rp = (bf16)(fc * sc * pc[cc]);
+          *(bf16*)(rp + half) = (bf16)(-fs * sc * pc[cc]);
         }
       } else if (OUT_F32) {
-        float* rowp = (float*)rows + (size_t)si * row_elems;
-        rowp[col] = fs;
-        rowp[K * L + col] = fc;
+        *(float*)rowp = fs;
+        *(float*)(rowp + half) = fc;
       } else {
-        bf16* rowp = (bf16*)rows + (size_t)si * row_elems;
-        rowp[col] = (bf16)fs;
-        rowp[K * L + col] = (bf16)fc;
+        const f32x2 pr = {fs, fc};
+        const bf16x2 pb = __builtin_convertvector(pr, bf16x2);       // one v_cvt_pk_bf16_f32
+        *(bf16*)rowp = pb[0];
+        *(bf16*)(rowp + half) = pb[1];
       }
+      rowp += lstep;
       const float s2 = 2.0f * sn * cs;
       cs = 1.0f - 2.0f * sn * sn;
       sn = s2;
+      const float a2 = att * att;
+      att = a2 * a2;
+      sc *= 2.0f;
     }
   }
   if (!OUT_F32) {
@@ -234,27 +272,21 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
     const int nrows = TANGENT ? 3 * spb : ns;
     for (int e = threadIdx.x; e < nrows * pad; e += FE_THREADS) {
       const int si = e / pad, cidx = nfeat + e % pad;
-      ((bf16*)rows)[(size_t)si * ld_feat + cidx] = (bf16)0.0f;
+      ((bf16*)(rows + (size_t)si * pitch))[cidx] = (bf16)0.0f;
     }
   }
   __syncthreads();
-  if (TANGENT) {
-    const size_t row_bytes_t = (size_t)ld_feat * 2;
-    for (int cc = 0; cc < 3; ++cc) {
-      const size_t nbytes_t = (size_t)ns * row_bytes_t;
-      char* dst_t = (char*)feat_out + ((size_t)cc * total + s0) * row_bytes_t;
-      const char* src_t = rows + (size_t)cc * spb * row_bytes_t;
-      for (size_t off = (size_t)threadIdx.x * 16; off < nbytes_t; off += (size_t)FE_THREADS * 16)
-        *(uint4*)(dst_t + off) = *(const uint4*)(src_t + off);
+  // Coalesced write-out: the block's rows are contiguous in HBM (16 B per lane); in LDS they are `pitch` apart.
+  const int row_bytes = row_elems * (OUT_F32 ? 4 : 2);
+  const int cpr = row_bytes >> 4;                         // 16-B chunks per row (row_bytes is a multiple of 16)
+  for (int cc = 0; cc < (TANGENT ? 3 : 1); ++cc) {
+    char* dst = (char*)feat_out + ((size_t)cc * total + s0) * row_bytes;
+    const char* src = rows + (size_t)cc * spb * pitch;
+    for (int ch = threadIdx.x; ch < ns * cpr; ch += FE_THREADS) {
+      const int r = ch / cpr, o = (ch - r * cpr) << 4;
+      *(uint4*)(dst + (size_t)r * row_bytes + o) = *(const uint4*)(src + (size_t)r * pitch + o);
     }
-    return;
   }
-  // Coalesced write-out: the block's rows are contiguous in HBM (16 B per lane).
-  const size_t row_bytes = (size_t)row_elems * (OUT_F32 ? 4 : 2);
-  const size_t nbytes = (size_t)ns * row_bytes;
-  char* dst = (char*)feat_out + (size_t)s0 * row_bytes;
-  for (size_t off = (size_t)threadIdx.x * 16; off < nbytes; off += (size_t)FE_THREADS * 16)
-    *(uint4*)(dst + off) = *(const uint4*)(rows + off);
 }
 
 static int fe_launch(int mode /*0 bf16, 1 f32, 2 tangent*/, const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist, const float* origins,
@@ -277,18 +309,20 @@ static int fe_launch(int mode /*0 bf16, 1 f32, 2 tangent*/, const mnr_ipe_cfg* c
   if (spb > FE_THREADS) spb = FE_THREADS;
   spb &= ~3;                       // keeps the row buffer 16-byte aligned behind the FeSample array
   MNR_CHECK_ARG(spb >= 4, "mnr_cast_rays_ipe: feature row too long");
-  const size_t lds = (size_t)spb * sizeof(FeSample) + (size_t)((K * 3 + 3) & ~3) * 4 + (size_t)spb * row_bytes * (tangent ? 3 : 1);
+  // 48 B of padding per staged row: consecutive samples then sit 12 banks apart (a wave covers ~3 samples x 21 directions)
+  const int pitch = (int)row_bytes + 48;
+  const size_t lds = (size_t)spb * sizeof(FeSample) + (size_t)((K * 3 + 3) & ~3) * 4 + (size_t)spb * pitch * (tangent ? 3 : 1);
   const int64_t total = B * n;
   const int grid = mnr_cdiv(total, spb);
   if (tangent) {
     hipLaunchKernelGGL((cast_rays_ipe_kernel<false, true>), dim3(grid), dim3(FE_THREADS), lds, (hipStream_t)stream, *cfg,
-                       total, n, spb, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out, covs_out);
+                       total, n, spb, pitch, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out, covs_out);
   } else if (f32) {
     hipLaunchKernelGGL((cast_rays_ipe_kernel<true, false>), dim3(grid), dim3(FE_THREADS), lds, (hipStream_t)stream, *cfg,
-                       total, n, spb, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out, covs_out);
+                       total, n, spb, pitch, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out, covs_out);
   } else {
     hipLaunchKernelGGL((cast_rays_ipe_kernel<false, false>), dim3(grid), dim3(FE_THREADS), lds, (hipStream_t)stream, *cfg,
-                       total, n, spb, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out, covs_out);
+                       total, n, spb, pitch, tdist, origins, directions, radii, basis, feat_out, ld_feat, means_out, covs_out);
   }
   MNR_CHECK_LAUNCH();
   return MNR_OK;
