@@ -357,6 +357,9 @@ typedef struct {
   int wloss_mode; float wloss_mult; const float* sdist; int n_ref; const float* t_ref; const float* w_ref; float* wloss_stat;
 } mnr_level_bwd_args;
 int mnr_level_bwd(const mnr_level_bwd_args* args, void* stream);
+/* A/B switch: 1 (default) = four lanes per ray where a wave's 16 rays fit LDS, 0 = the lane-per-ray kernel everywhere.
+ * Sums are associated differently in the two; both are held to the oracle by the same tolerances. */
+int mnr_level_bwd_set_quad(int on);
 
 /* RawNeRF exposure (replaces models.py:257-267).  out[b,c] = exposure_values[b] *
  * (1 + [idx[b] > 0] * offsets[idx[b], c]); offsets = the 'exposure_scaling_offsets' embedding

@@ -132,6 +132,7 @@ _PROTOS = {
     'mnr_gemm_nt_bf16': ([C.POINTER(GemmNTArgs), vp], i32),
     'mnr_debug_gemm_timeline': ([vp], i32),
     'mnr_gemm_nt_set_persistent': ([i32], i32),
+    'mnr_level_bwd_set_quad': ([i32], i32),
     'mnr_gemm_nt_set_pipelined': ([i32], i32),
     'mnr_gemm_nt_set_wres': ([i32], i32),
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),

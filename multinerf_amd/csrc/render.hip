@@ -347,12 +347,362 @@ __global__ __launch_bounds__(CP_THREADS) void level_bwd_kernel(mnr_level_bwd_arg
   if (c.has_rgb && a.g_raw_rgb) cp_store_rows(l_rgb, a.g_raw_rgb + ray0 * n * 3, rows, 3 * n, S);
 }
 
+// ---------------------------------------------------------------------------
+// The same backward pass on FOUR lanes per ray (one DPP quad), 16 rays per wave.  The lane-per-ray kernel above is bound by the
+// instruction stream of its wave (one wave per SIMD, 16 of 64 lanes active: more lanes per wave were slower, there are
+// only 16384 rays for 1024 SIMDs); here lane q of a ray's quad owns the samples i = 4j + q and
+//   * prefix / suffix sums (cumulative envelope weights, optical depth, the reverse sum of g^_k w_k) are quad scans (two
+//     DPP steps) with a carry over j,
+//   * the searchsorted cursors of the interlevel loss become binary searches: with ub(v) = #{idx : te[idx] <= v},
+//     lo = max(ub - 1, 0), hi = min(ub, ne), w_outer[i] = CW[hi[i+1]] - CW[lo[i]] (CW = exclusive cumsum of the envelope
+//     weights), and d loss / d we[j] = PG[#{i : lo[i] <= j}] - PG[#{i : hi[i+1] <= j}] (PG = exclusive cumsum of the
+//     per-interval gradient factors; both index sequences ascend),
+//   * the distortion loss splits its outer index over the quad.
+// Sums are associated differently from the lane-per-ray kernel (blocked instead of sequential); both are held to the oracle
+// by the same tolerances.  LDS per ray, contiguous: den n | t n+1 | w n | [rgb 3n] | gw n | scratch, with a ray stride of
+// 4 x odd floats: the 32 lanes of a ds_read group (8 rays x 4 lanes, addresses r * stride + 4j + q) then hit 32 banks.
+#define LB_LPR 4
+#define LB_RPW (CP_THREADS / LB_LPR)
+
+template <int CTRL>
+__device__ __forceinline__ float lb_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lb_quad_sum(float v) {
+  v += lb_dpp<0xB1>(v);                      // quad_perm [1,0,3,2]
+  v += lb_dpp<0x4E>(v);                      // quad_perm [2,3,0,1]
+  return v;
+}
+// inclusive sum over the quad's lanes 0..q
+__device__ __forceinline__ float lb_quad_prefix(float v, int q) {
+  const float a = lb_dpp<0x90>(v);           // [0,0,1,2]: lane q-1
+  if (q >= 1) v += a;
+  const float b = lb_dpp<0x40>(v);           // [0,0,0,1]: lane q-2
+  if (q >= 2) v += b;
+  return v;
+}
+// inclusive sum over the quad's lanes q..3
+__device__ __forceinline__ float lb_quad_suffix(float v, int q) {
+  const float a = lb_dpp<0xF9>(v);           // [1,2,3,3]: lane q+1
+  if (q <= 2) v += a;
+  const float b = lb_dpp<0xFE>(v);           // [2,3,3,3]: lane q+2
+  if (q <= 1) v += b;
+  return v;
+}
+
+struct LbLay {
+  int den, t, w, rgb, gw, scr, stride;       // float offsets inside a ray's LDS block, ray stride
+};
+__host__ __device__ inline LbLay lb_layout(int n, int has_rgb, int wloss_mode, int n_ref) {
+  LbLay L;
+  int o = 0;
+  L.den = o; o += n;
+  L.t = o; o += n + 1;
+  L.w = o; o += n;
+  L.rgb = o; o += has_rgb ? 3 * n : 0;
+  L.gw = o; o += n;
+  L.scr = o;
+  // scratch: [sdist n+1 | CW n+1 | lo n_ref+1 | hi n_ref+1 | PG n_ref+1] during the losses, then [TN n | DG n | GH n]
+  int loss = wloss_mode != 0 ? n + 1 : 0;
+  if (wloss_mode == 1) loss += (n + 1) + 3 * (n_ref + 1);
+  o += loss > 3 * n ? loss : 3 * n;
+  o = (o + 3) & ~3;
+  if (((o >> 2) & 1) == 0) o += 4;           // 4 x odd
+  L.stride = o;
+  return L;
+}
+
+__global__ __launch_bounds__(CP_THREADS) void level_bwd_quad_kernel(mnr_level_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const mnr_composite_cfg c = a.cfg;
+  const int n = c.n;
+  const LbLay L = lb_layout(n, c.has_rgb, a.wloss_mode, a.n_ref);
+  const int64_t B = a.B;
+  const int64_t ray0 = (int64_t)blockIdx.x * LB_RPW;
+  const int rows = (int)min((int64_t)LB_RPW, B - ray0);
+  auto load_rows = [&](int off, const float* src, int len) {      // rows of `len` floats, contiguous in HBM
+    for (int e = threadIdx.x; e < rows * len; e += CP_THREADS) {
+      const int rr = e / len, i = e - rr * len;
+      lds[rr * L.stride + off + i] = src[e];
+    }
+  };
+  load_rows(L.den, a.raw_density + ray0 * n, n);
+  load_rows(L.t, a.tdist + ray0 * (n + 1), n + 1);
+  load_rows(L.w, a.weights + ray0 * n, n);
+  if (c.has_rgb) load_rows(L.rgb, a.raw_rgb + ray0 * n * 3, 3 * n);
+  if (a.g_weights) {
+    load_rows(L.gw, a.g_weights + ray0 * n, n);
+  } else {
+    for (int e = threadIdx.x; e < LB_RPW * n; e += CP_THREADS) lds[(e / n) * L.stride + L.gw + e % n] = 0.0f;
+  }
+  if (a.wloss_mode != 0) load_rows(L.scr, a.sdist + ray0 * (n + 1), n + 1);
+  if (a.density_noise && c.density_noise_std > 0.0f) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * n; e += CP_THREADS) {
+      const int rr = e / n, i = e - rr * n;
+      lds[rr * L.stride + L.den + i] += c.density_noise_std * a.density_noise[ray0 * n + e];
+    }
+  }
+  __syncthreads();
+  // Every lane runs every phase (the barriers between phases are workgroup barriers); rays past the batch end compute on
+  // whatever their LDS block holds and write nothing.
+  const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const bool live = r < rows;
+  const int64_t ray = live ? ray0 + r : B - 1;
+  const bool valid = live && ray < a.B_valid;      // padding rays take part in no loss
+  float* X = lds + r * L.stride;
+  float* l_den = X + L.den;
+  float* l_t = X + L.t;
+  float* l_w = X + L.w;
+  float* l_rgb = X + L.rgb;
+  float* l_gw = X + L.gw;
+  float* l_s = X + L.scr;
+  const int J = (n + 3) >> 2;                      // samples per lane
+  float s_mse = 0.0f, s_dloss = 0.0f, s_wloss = 0.0f;
+  float go[3] = {0.0f, 0.0f, 0.0f};
+  if (a.g_rgb_out) { go[0] = a.g_rgb_out[ray * 3]; go[1] = a.g_rgb_out[ray * 3 + 1]; go[2] = a.g_rgb_out[ray * 3 + 2]; }
+  // ---- data loss on the composited colour (train_utils.py:85-111): every lane of the quad needs go[], lane 0 keeps the sums
+  if (a.data_loss_type >= 0 && valid) {
+    const float denom = *a.denom;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float y = a.rgb_out[ray * 3 + ch], t = a.gt[ray * 3 + ch];
+      const float w = a.lm_c == 1 ? a.lossmult[ray] : a.lossmult[ray * 3 + ch];
+      const float rs = y - t;
+      float dl, dd;
+      if (a.data_loss_type == MNR_LOSS_MSE) {               // :90-92
+        dl = rs * rs;
+        dd = 2.0f * rs;
+      } else if (a.data_loss_type == MNR_LOSS_CHARB) {      // :93-95
+        dl = sqrtf(rs * rs + a.charb_padding * a.charb_padding);
+        dd = rs / dl;
+      } else {                                              // :96-103 rawnerf
+        const float yc = fminf(1.0f, y);
+        const float rc = yc - t;
+        const float sg = 1.0f / (1e-3f + yc);
+        dl = rc * rc * sg * sg;
+        dd = y < 1.0f ? 2.0f * rc * sg * sg : 0.0f;
+      }
+      if (q == 0) {
+        s_mse += w * rs * rs;                               // train_utils.py:86-88
+        s_dloss += w * dl;
+      }
+      go[ch] += a.data_loss_mult * w * dd / denom;
+    }
+  }
+  // ---- losses on the weights: d loss / d w_i accumulates in l_gw
+  if (a.wloss_mode == 1) {
+    // interlevel (train_utils.py:139-150, stepfun.py:64-86): this level (l_s, l_w) is the envelope of the final level's
+    // histogram (t_ref, w_ref), whose values carry no gradient
+    const int nr = a.n_ref;
+    const float scale = a.wloss_mult / ((float)a.B_valid * (float)nr);       // jnp.mean over [B, n_ref]
+    const float* tr = a.t_ref + ray * (nr + 1);
+    const float* wr = a.w_ref + ray * nr;
+    float* l_cw = l_s + (n + 1);                   // CW[idx] = sum_{j<idx} we[j], idx = 0..n
+    int* l_lo = (int*)(l_cw + (n + 1));            // per fence-post k of t_ref
+    int* l_hi = l_lo + (nr + 1);
+    float* l_pg = (float*)(l_hi + (nr + 1));       // gradient factors, then their exclusive cumsum (nr + 1)
+    {
+      float carry = 0.0f;
+      if (q == 0) l_cw[0] = 0.0f;
+      for (int j = 0; j < J; ++j) {
+        const int i = 4 * j + q;
+        const float inc = lb_quad_prefix(i < n ? l_w[i] : 0.0f, q) + carry;
+        if (i < n) l_cw[i + 1] = inc;
+        carry = lb_dpp<0xFF>(inc);
+      }
+    }
+    // searchsorted of the fence-posts (stepfun.py:49-53): ub = #{idx in [0, n] : te[idx] <= v}
+    for (int k = q; k <= nr; k += LB_LPR) {
+      const float v = tr[k];
+      int lo_b = 0, hi_b = n + 1;                  // ub in [lo_b, hi_b]
+      while (lo_b < hi_b) {
+        const int mid = (lo_b + hi_b) >> 1;
+        if (l_s[mid] <= v) lo_b = mid + 1; else hi_b = mid;
+      }
+      l_lo[k] = max(lo_b - 1, 0);
+      l_hi[k] = min(lo_b, n);
+    }
+    __syncthreads();
+    const float eps = MNR_F32_EPS;
+    for (int i = q; i < nr; i += LB_LPR) {
+      const float w_outer = l_cw[l_hi[i + 1]] - l_cw[l_lo[i]];             // stepfun.py:74
+      const float wi = wr[i];
+      const float d = fmaxf(0.0f, wi - w_outer);
+      if (valid) s_wloss += d * d / (wi + eps);                             // stepfun.py:86
+      l_pg[i + 1] = (-2.0f * d / (wi + eps)) * scale;
+    }
+    __syncthreads();
+    {
+      // exclusive cumsum in place: PG[0] = 0, PG[i+1] = sum_{i' <= i} g[i']
+      float carry = 0.0f;
+      if (q == 0) l_pg[0] = 0.0f;
+      const int JR = (nr + 3) >> 2;
+      for (int j = 0; j < JR; ++j) {
+        const int i = 4 * j + q;
+        const float inc = lb_quad_prefix(i < nr ? l_pg[i + 1] : 0.0f, q) + carry;
+        if (i < nr) l_pg[i + 1] = inc;
+        carry = lb_dpp<0xFF>(inc);
+      }
+    }
+    __syncthreads();
+    if (valid) {
+      // d w_outer[i] / d we[j] = [lo[i] <= j < hi[i+1]]; starts and ends both ascend with i
+      for (int j = q; j < n; j += LB_LPR) {
+        int lb = 0, hb = nr;                       // #{i < nr : lo[i] <= j}
+        while (lb < hb) {
+          const int mid = (lb + hb) >> 1;
+          if (l_lo[mid] <= j) lb = mid + 1; else hb = mid;
+        }
+        int le = 0, he = nr;                       // #{i < nr : hi[i+1] <= j}
+        while (le < he) {
+          const int mid = (le + he) >> 1;
+          if (l_hi[mid + 1] <= j) le = mid + 1; else he = mid;
+        }
+        l_gw[j] += l_pg[lb] - l_pg[le];
+      }
+    }
+  } else if (a.wloss_mode == 2) {
+    // distortion (train_utils.py:153-159, stepfun.py:266-276) on this level's own (sdist, weights)
+    const float scale = a.wloss_mult / (float)a.B_valid;                     // jnp.mean over rays
+    if (valid) {
+      for (int i = q; i < n; i += LB_LPR) {
+        const float ui = (l_s[i + 1] + l_s[i]) / 2.0f, wi = l_w[i];
+        float inner = 0.0f;
+        for (int j = 0; j < n; ++j) inner += l_w[j] * fabsf(ui - (l_s[j + 1] + l_s[j]) / 2.0f);
+        const float dt = l_s[i + 1] - l_s[i];
+        s_wloss += wi * inner + wi * wi * dt / 3.0f;
+        l_gw[i] += scale * (2.0f * inner + (2.0f / 3.0f) * wi * dt);
+      }
+    }
+  }
+  __syncthreads();                                 // l_gw complete; the loss scratch is free
+  // ---- compositing VJP
+  float* l_tn = X + L.scr;                         // T_{i+1}
+  float* l_dg = l_tn + n;                          // delta_i * act'(raw_i)
+  float* l_gh = l_dg + n;                          // g^_i
+  const float dx = a.dirs[ray * 3], dy = a.dirs[ray * 3 + 1], dz = a.dirs[ray * 3 + 2];
+  const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+  float ex[3] = {1.0f, 1.0f, 1.0f};
+  if (a.exposure_scale) { ex[0] = a.exposure_scale[ray * 3]; ex[1] = a.exposure_scale[ray * 3 + 1]; ex[2] = a.exposure_scale[ray * 3 + 2]; }
+  float b[3] = {c.bg_value, c.bg_value, c.bg_value};
+  if (c.bg_mode == 1) { b[0] = a.bg[ray * 3]; b[1] = a.bg[ray * 3 + 1]; b[2] = a.bg[ray * 3 + 2]; }
+  float acc = 0.0f;
+  for (int j = 0; j < J; ++j) {
+    const int i = 4 * j + q;
+    acc += i < n ? l_w[i] : 0.0f;
+  }
+  acc = lb_quad_sum(acc);
+  const float g_bgw = (1.0f - acc > 0.0f) ? (go[0] * b[0] + go[1] * b[1] + go[2] * b[2]) : 0.0f;
+  float ges[3] = {0.0f, 0.0f, 0.0f};               // d L / d exposure_scale[ray]
+  {
+    // forward over the samples: run_i = sum_{k<i} x_k (exclusive), T_{i+1} = exp(-(run_i + x_i)), g^_i, colour gradients
+    float carry = 0.0f;
+    for (int j = 0; j < J; ++j) {
+      const int i = 4 * j + q;
+      const bool in = i < n;
+      const float raw = (in ? l_den[i] : 0.0f) + c.density_bias;
+      const float sigma = cp_act(c.density_act, raw);
+      const float delta = in ? (l_t[i + 1] - l_t[i]) * dnorm : 0.0f;
+      const bool opaque_last = c.opaque_background && i == n - 1;
+      const float x = opaque_last ? INFINITY : (in ? sigma * delta : 0.0f);
+      const float inc = lb_quad_prefix(x, q);
+      const float below = lb_dpp<0x90>(inc);       // (DPP outside any lane-dependent branch: a disabled source lane reads as 0)
+      const float before = (q == 0 ? 0.0f : below) + carry;      // exclusive: the lanes below, no subtraction (x may be inf)
+      carry += lb_dpp<0xFF>(inc);
+      if (in) {
+        const float w = l_w[i];
+        l_tn[i] = expf(-(before + x));             // T_{i+1} = T_i - w_i
+        l_dg[i] = delta * cp_act_grad(c.density_act, raw, sigma);
+        float ghat = l_gw[i] - g_bgw;
+        if (c.has_rgb) {
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float z = c.rgb_premultiplier * l_rgb[3 * i + ch] + c.rgb_bias;
+            const float y = cp_act(c.rgb_act, z);
+            const float col_pre = y * (1.0f + 2.0f * c.rgb_padding) - c.rgb_padding;
+            const float col = col_pre * ex[ch];
+            ghat += go[ch] * col;
+            ges[ch] += w * go[ch] * col_pre;
+            // d col / d raw = ex * (1+2pad) * act'(z) * premult
+            l_rgb[3 * i + ch] = w * go[ch] * ex[ch] * (1.0f + 2.0f * c.rgb_padding) * cp_act_grad(c.rgb_act, z, y) *
+                                c.rgb_premultiplier;
+          }
+        }
+        l_gh[i] = ghat;
+      }
+    }
+  }
+  {
+    // backward: suffix_i = sum_{k>i} g^_k w_k (exclusive), dL/dx_i = g^_i T_{i+1} - suffix_i
+    float carry = 0.0f;
+    for (int j = J - 1; j >= 0; --j) {
+      const int i = 4 * j + q;
+      const bool in = i < n;
+      const float ghat = in ? l_gh[i] : 0.0f;
+      const float inc = lb_quad_suffix(in ? ghat * l_w[i] : 0.0f, q);
+      const float above = lb_dpp<0xF9>(inc);
+      const float after = (q == 3 ? 0.0f : above) + carry;
+      carry += lb_dpp<0x00>(inc);
+      if (in) {
+        float gx = ghat * l_tn[i] - after;
+        if (c.opaque_background && i == n - 1) gx = 0.0f;      // x = +inf is a constant
+        l_den[i] = gx * l_dg[i];
+      }
+    }
+  }
+  if (a.g_exposure_scale) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float g = lb_quad_sum(ges[ch]);
+      if (live && q == 0) a.g_exposure_scale[ray * 3 + ch] += g;
+    }
+  }
+  // loss values: wave sums, one atomic each
+  if (a.data_loss_type >= 0 && a.data_stats) {
+    s_mse = ls_wave_sum(s_mse);
+    s_dloss = ls_wave_sum(s_dloss);
+    if (threadIdx.x == 0) {
+      const float denom = *a.denom;
+      unsafeAtomicAdd(a.data_stats + 0, s_mse / denom);
+      unsafeAtomicAdd(a.data_stats + 1, a.data_loss_mult * s_dloss / denom);
+    }
+  }
+  if (a.wloss_mode != 0 && a.wloss_stat) {
+    s_wloss = ls_wave_sum(s_wloss);
+    const float norm = a.wloss_mode == 1 ? (float)a.B_valid * (float)a.n_ref : (float)a.B_valid;
+    if (threadIdx.x == 0) unsafeAtomicAdd(a.wloss_stat, a.wloss_mult * s_wloss / norm);
+  }
+  __syncthreads();
+  auto store_rows = [&](int off, float* dst, int len) {
+    for (int e = threadIdx.x; e < rows * len; e += CP_THREADS) {
+      const int rr = e / len, i = e - rr * len;
+      dst[e] = lds[rr * L.stride + off + i];
+    }
+  };
+  if (a.g_raw_density) store_rows(L.den, a.g_raw_density + ray0 * n, n);
+  if (a.g_raw_density_bf16) {
+    bf16* gb = (bf16*)a.g_raw_density_bf16;
+    for (int e = threadIdx.x; e < rows * n; e += CP_THREADS) {
+      const int rr = e / n, i = e - rr * n;
+      gb[(ray0 * n + e) * (int64_t)a.ld_bf16] = (bf16)lds[rr * L.stride + L.den + i];
+    }
+  }
+  if (c.has_rgb && a.g_raw_rgb) store_rows(L.rgb, a.g_raw_rgb + ray0 * n * 3, 3 * n);
+}
+
 static size_t lb_floats_per_ray(const mnr_level_bwd_args* a) {
   const int n = a->cfg.n;
   size_t f = (size_t)(6 * n + 1) + n;                        // compositing VJP + d loss / d weights
   if (a->wloss_mode != 0) f += n + 1;                        // sdist
   if (a->wloss_mode == 1) f += 3 * (size_t)a->n_ref + 2;     // lo, hi, gi
   return f;
+}
+
+static int g_level_bwd_quad = 1;                         // A/B switch: 0 = the lane-per-ray kernel for every shape
+extern "C" int mnr_level_bwd_set_quad(int on) {
+  g_level_bwd_quad = on;
+  return MNR_OK;
 }
 
 extern "C" int mnr_level_bwd(const mnr_level_bwd_args* a, void* stream) {
@@ -371,6 +721,14 @@ extern "C" int mnr_level_bwd(const mnr_level_bwd_args* a, void* stream) {
   MNR_CHECK_ARG(a->wloss_mode == 0 || a->sdist, "mnr_level_bwd: weight losses need this level's sdist");
   MNR_CHECK_ARG(a->wloss_mode != 1 || (a->n_ref >= 1 && a->n_ref <= 1024 && a->t_ref && a->w_ref),
                 "mnr_level_bwd: the interlevel loss needs the final level's (t_ref, w_ref)");
+  // four lanes per ray whenever a wave's 16 rays fit LDS four workgroups per CU (n <= ~128); else lane per ray
+  const LbLay lay = lb_layout(cfg->n, cfg->has_rgb, a->wloss_mode, a->n_ref);
+  const size_t quad_lds = (size_t)lay.stride * LB_RPW * 4;
+  if (g_level_bwd_quad && quad_lds <= 40 * 1024) {
+    hipLaunchKernelGGL(level_bwd_quad_kernel, dim3(mnr_cdiv(a->B, LB_RPW)), dim3(CP_THREADS), quad_lds, (hipStream_t)stream, *a);
+    MNR_CHECK_LAUNCH();
+    return MNR_OK;
+  }
   const size_t fpr = lb_floats_per_ray(a);
   int S = CP_THREADS;
   while (S > 1 && fpr * S * 4 > 150 * 1024) S >>= 1;

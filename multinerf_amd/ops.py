@@ -52,6 +52,8 @@ def lib():
       L.check(L.load().mnr_gemm_nt_set_persistent(int(os.environ['MNR_NT_PERSIST'])))
     if os.environ.get('MNR_NT_PIPE'):           # A/B switch: hand-pipelined K loop of the 256x256 NT tiles (0: off)
       L.check(L.load().mnr_gemm_nt_set_pipelined(int(os.environ['MNR_NT_PIPE'])))
+    if os.environ.get('MNR_LEVEL_BWD_QUAD'):    # A/B switch: four-lanes-per-ray level backward (0: lane per ray)
+      L.check(L.load().mnr_level_bwd_set_quad(int(os.environ['MNR_LEVEL_BWD_QUAD'])))
     if os.environ.get('MNR_NT_WRES'):           # A/B switch: weights-resident kernel for the short-K layers (0: off)
       L.check(L.load().mnr_gemm_nt_set_wres(int(os.environ['MNR_NT_WRES'])))
   return L.load()

@@ -29,6 +29,14 @@ def ops():
   return _ops
 
 
+@pytest.fixture(params=[1, 0], ids=['quad', 'lane'])
+def level_bwd_kernel(request, ops):
+  """Both level-backward kernels: four lanes per ray (default where 16 rays fit LDS) and lane per ray (long rays, A/B)."""
+  ops.L.check(ops.lib().mnr_level_bwd_set_quad(request.param))
+  yield request.param
+  ops.L.check(ops.lib().mnr_level_bwd_set_quad(1))
+
+
 def dev(x):
   return x.contiguous().cuda()
 
@@ -325,12 +333,51 @@ def test_gemm_nt_bit_masks(ops):
   assert torch.equal(got3, (act3.cpu().float() > 0).reshape(M, 16, 8))
 
 
+@pytest.mark.parametrize('K1,K2', [(64, 0), (128, 0), (1024, 0), (1024, 512)])
+def test_gemm_nt_pipelined_loop_is_bitwise_the_two_stage_loop(ops, K1, K2):
+  """The hand-pipelined K loop of the 256x256 tiles (default) against the two-stage loop it replaced
+  (mnr_gemm_nt_set_pipelined(0)): forward layer (bias, ReLU, bit masks, [A1|A2]) and the dX layer reading those masks, on
+  enough tiles for every workgroup of the persistent launch to walk several (64 M-tiles x 4 N-tiles over 256 CUs), with
+  fewer K-tiles than pipeline stages (K = 64), every tail flavour (K = 128) and the trunk's shapes."""
+  gen = torch.Generator().manual_seed(67)
+  M, N = 16384, 1024
+  A1 = dev(_bf(torch.relu(torch.randn((M, K1), generator=gen))))
+  A2 = dev(_bf(torch.randn((M, K2), generator=gen))) if K2 else None
+  Bt = dev(_bf(torch.randn((N, K1 + K2), generator=gen) / math.sqrt(K1 + K2)))
+  bias = dev(0.1 * torch.randn((N,), generator=gen))
+  G = dev(_bf(torch.randn((M, N), generator=gen)))
+  W2 = dev(_bf(torch.randn((N, N), generator=gen) / math.sqrt(N)))
+  outs = []
+  try:
+    for pipe in (1, 0):
+      ops.L.check(ops.lib().mnr_gemm_nt_set_pipelined(pipe))
+      act = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
+      bits = torch.zeros((M, N // 8), dtype=torch.uint8).cuda()
+      dx = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
+      ops.gemm_nt(A1, Bt, M=M, N=N, K1=K1, A2=A2, K2=K2, bias=bias, n_bias=N, relu=True, Cb=act, ldcb=N, nb=N, bits_out=bits)
+      ops.gemm_nt(G, W2, M=M, N=N, K1=N, bits_in=bits, Cb=dx, ldcb=N, nb=N)
+      torch.cuda.synchronize()
+      outs.append((act.cpu().view(torch.int16), bits.cpu(), dx.cpu().view(torch.int16)))
+  finally:
+    ops.L.check(ops.lib().mnr_gemm_nt_set_pipelined(1))
+  for a, b in zip(*outs):
+    assert torch.equal(a, b)
+  A = A1.cpu().float() if A2 is None else torch.cat([A1.cpu().float(), A2.cpu().float()], -1)
+  want = torch.relu(A[:512].double() @ Bt.cpu().double().T + bias.cpu().double())
+  np.testing.assert_allclose(outs[0][0].view(torch.bfloat16)[:512].double().numpy(), want.numpy(), rtol=2**-7, atol=1e-2)
+
+
 def test_gemm_nt_rejects_bad_shapes(ops):
   a = torch.zeros((128, 64), dtype=torch.bfloat16).cuda()
   with pytest.raises(ValueError, match='multiple of 128'):
     ops.gemm_nt(a, a, M=100, N=128, K1=64, Cb=a, ldcb=64, nb=64)
   with pytest.raises(ValueError, match='multiples of 64'):
     ops.gemm_nt(a, a, M=128, N=128, K1=48, Cb=a, ldcb=64, nb=64)
+  bits = torch.zeros((128, 16), dtype=torch.uint8).cuda()
+  with pytest.raises(ValueError, match='no bias and no ReLU'):
+    ops.gemm_nt(a, a, M=128, N=128, K1=64, Cb=a, ldcb=64, nb=64, bits_in=bits, relu=True)
+  with pytest.raises(ValueError, match='bits_row_mod'):
+    ops.gemm_nt(a, a, M=128, N=128, K1=64, Cb=a, ldcb=64, nb=64, bits_in=bits, bits_row_mod=64)
 
 
 @pytest.mark.parametrize('M,K,N', [(64, 128, 128), (4096, 256, 128), (8192, 512, 256), (2048 + 64, 128, 384)])
@@ -409,7 +456,7 @@ def test_colsum_pack_scatter_cast_smallhead(ops):
 @pytest.mark.parametrize('n,opaque,has_rgb,rgb_act,pad,noise', [(32, True, True, 'sigmoid', 0.001, False),
                                                                 (64, True, False, 'sigmoid', 0.001, False),
                                                                 (128, False, True, 'safe_exp', 0.0, True)])
-def test_composite_fwd_bwd(ops, n, opaque, has_rgb, rgb_act, pad, noise):
+def test_composite_fwd_bwd(ops, level_bwd_kernel, n, opaque, has_rgb, rgb_act, pad, noise):
   gen = torch.Generator().manual_seed(9)
   B = 150
   raw_d = torch.randn((B, n), generator=gen) * 2
@@ -537,7 +584,7 @@ def test_losses(ops):
 
 @pytest.mark.parametrize('mode,loss_type,lm_c,has_rgb', [('interlevel', 'charb', 1, False), ('distortion', 'charb', 1, True),
                                                          ('distortion', 'rawnerf', 3, True), (None, 'mse', 1, True)])
-def test_level_bwd_fuses_losses_and_compositing_vjp(ops, mode, loss_type, lm_c, has_rgb):
+def test_level_bwd_fuses_losses_and_compositing_vjp(ops, level_bwd_kernel, mode, loss_type, lm_c, has_rgb):
   """mnr_level_bwd: data loss + interlevel | distortion loss + compositing VJP in ONE launch, against torch autograd of
   the oracle's composed objective (train_utils.py:72-159 on render.py:130-213), B_valid < B, with an upstream d / d weights
   (the Ref-NeRF normal losses' path) on top."""
