@@ -369,11 +369,46 @@ __global__ void viewdir_enc_fill_kernel(int64_t total_rows, int n, const float* 
   for (int k = col0 + nenc; k < col_end; ++k) dst[row * ld + k] = (bf16)0.0f;
 }
 
+// The same with 16-byte stores: a lane owns 8 consecutive columns of a row (the encoding is evaluated per column; the
+// element-wise kernel above writes 2 bytes at a time, 0.16 ms per step for 28 MB at 360.gin).
+__global__ __launch_bounds__(256) void viewdir_enc_fill_vec_kernel(int64_t total_rows, int n, const float* __restrict__ viewdirs,
+                                                                   int deg_view, bf16* __restrict__ dst, int ld, int col0, int chunks) {
+  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = item / chunks;
+  const int ch = (int)(item - row * chunks);
+  if (row >= total_rows) return;
+  const int64_t ray = row / n;
+  const float x[3] = {viewdirs[ray * 3 + 0], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2]};
+  const int nenc = 3 + 6 * deg_view, half = 3 + 3 * deg_view;
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = ch * 8 + i;              // coord.py:136-147: [x, sin(2^l x) (l-major), sin(2^l x + pi/2)], plain sin
+    float val = 0.0f;
+    if (e < 3) {
+      val = x[e];
+    } else if (e < nenc) {
+      const int k = e < half ? e - 3 : e - half;
+      const float arg = x[k % 3] * ldexpf(1.0f, k / 3);
+      val = sinf(e < half ? arg : arg + FE_PI_2);
+    }
+    v[i] = (bf16)val;
+  }
+  *(bf16x8*)(dst + row * ld + col0 + ch * 8) = v;
+}
+
 extern "C" int mnr_viewdir_enc_fill(int64_t B, int n, const float* viewdirs, int deg_view, uint16_t* dst, int ld,
                                     int col0, int col_end, void* stream) {
   MNR_CHECK_ARG(B > 0 && n > 0 && viewdirs && dst && deg_view >= 0 && deg_view <= 16, "mnr_viewdir_enc_fill: bad arguments");
   MNR_CHECK_ARG(col0 + 3 + 6 * deg_view <= col_end && col_end <= ld, "mnr_viewdir_enc_fill: columns out of range");
   const int64_t rows = B * n;
+  if (col0 % 8 == 0 && (col_end - col0) % 8 == 0 && ld % 8 == 0 && ((uintptr_t)dst % 16) == 0) {
+    const int chunks = (col_end - col0) / 8;
+    hipLaunchKernelGGL(viewdir_enc_fill_vec_kernel, dim3(mnr_cdiv(rows * chunks, 256)), dim3(256), 0, (hipStream_t)stream, rows,
+                       n, viewdirs, deg_view, (bf16*)dst, ld, col0, chunks);
+    MNR_CHECK_LAUNCH();
+    return MNR_OK;
+  }
   hipLaunchKernelGGL(viewdir_enc_fill_kernel, dim3(mnr_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, rows, n,
                      viewdirs, deg_view, (bf16*)dst, ld, col0, col_end);
   MNR_CHECK_LAUNCH();
