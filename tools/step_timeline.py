@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-workgroup timeline (mnr_debug_gemm_timeline) of selected NT GEMM launches INSIDE a real 360.gin train step:
-real (ReLU-sparse) operands, real clocks.  Complements tools/gemm_probe.py --timeline (dense random operands)."""
+real (ReLU-sparse) operands, real clocks.  Complements tools/nt_pipe_probe.py (dense random operands, one launch)."""
 import os
 import sys
 
