@@ -80,7 +80,11 @@ struct NtCfg {
   static constexpr bool BIAS_LDS = BIAS_LDS_ != 0;
   static constexpr int LDS_MAIN = LDS_OPERANDS > EPI_ROWS * CPITCH ? LDS_OPERANDS : EPI_ROWS * CPITCH;
   static constexpr int BIAS_OFF = (LDS_MAIN + 15) / 16 * 16;
-  static constexpr int LDS_BYTES = BIAS_LDS ? BIAS_OFF + BN * 4 : LDS_MAIN;
+  // Pipelined dX layers park the tile's ReLU-mask bits ([BM][BN / 8] bytes) in LDS: one 16-byte load per thread behind the
+  // K loop instead of 16 byte loads held in registers across the epilogue (the 256-register kernel spilled them).
+  static constexpr bool BITS_LDS = PIPE && BM * BN / 8 == THREADS * 16;
+  static constexpr int BITS_OFF = BIAS_LDS ? BIAS_OFF + BN * 4 : LDS_MAIN;
+  static constexpr int LDS_BYTES = BITS_OFF + (BITS_LDS ? BM * BN / 8 : 0);
   static_assert(EPI_ROWS * CPITCH <= LDS_BYTES, "epilogue staging must fit in the operand buffers");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   static_assert(BM % EPI_ROWS == 0 && (32 * MI) <= EPI_ROWS && EPI_ROWS % (32 * MI) == 0, "epilogue pass shape");
@@ -493,7 +497,9 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
     if (g_nt_pipe == 14) return nt_launch<NtCfg<4, 2, 2, 4, 8, 1, 1, 4, 32, 4>>(a, fast_epi, stream);      // MFMA only
   }
 #endif
-  if (g_nt_pipe && a->M % 256 == 0 && a->N % 256 == 0) return nt_launch<NtBigP>(a, fast_epi, stream);
+  // (the pipelined dX flavour loads 16-byte rows of the bit tile)
+  const bool bits16 = !a->mask_bits_in || (a->ld_bits_in % 16 == 0 && ((uintptr_t)a->mask_bits_in % 16) == 0);
+  if (g_nt_pipe && a->M % 256 == 0 && a->N % 256 == 0 && bits16) return nt_launch<NtBigP>(a, fast_epi, stream);
   if (a->M % 256 == 0 && a->N % 256 == 0) return nt_launch<NtBig>(a, fast_epi, stream);
   return nt_launch<NtSmall>(a, fast_epi, stream);
 }
