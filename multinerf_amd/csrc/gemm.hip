@@ -231,8 +231,9 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
 //            MI NJ WM WN EPI_BATCH BIAS_LDS
 typedef NtCfg<2, 2, 2, 2> NtSmall;                  // 128x128, 4 waves, 64 KiB: N not a multiple of 256 (heads, view MLP)
 typedef NtCfg<4, 2, 2, 4, 16, 1> NtBig;             // 256x256, 8 waves (2 x 4, 128x64 per wave), 128 KiB + bias row: the trunk layers
-typedef NtCfg<4, 4, 2, 2, 16, 1, 1, 0, 32, 4> NtWide;
-typedef NtCfg<4, 2, 2, 4, 8, 1, 1, 0, 32, 4> NtBigP;           // EXPERIMENT: NtBig with the hand-pipelined K loop, BK = 32 x 4 stages            // EXPERIMENT: 256x256, 4 waves (2 x 2, 128x128 per wave, accumulators in AGPRs)
+// the same tile with the hand-pipelined K loop (gemm_nt_body.inc): BK = 32 x 4 stages, register double-buffered fragments,
+// the LDS-DMA pieces of a K-tile issued BETWEEN the MFMAs (default; bitwise equal to NtBig)
+typedef NtCfg<4, 2, 2, 4, 8, 1, 1, 0, 32, 4> NtBigP;
 
 // ---------------------------------------------------------------------------
 // Weights-resident NT kernel for the short-K layers (N = 256, K <= 256: the proposal MLP's hidden layers and their dX).
