@@ -98,6 +98,24 @@ __device__ __forceinline__ float mnr_nan0_clip01(float x) {
   return fminf(fmaxf(x, 0.0f), 1.0f);
 }
 
+// (element > 0) flags of 8 bf16 values held as 4 dwords -> one byte, bit e = element e.  Clamp the halves at 0 as signed
+// 16-bit (a no-op after a ReLU), then "> 0" is "bits != 0" = min(half, 1) as unsigned 16-bit: a flag in bit 0 and bit 16 of
+// each dword (the packed min as inline asm: hipcc turns min(max(x, 0), 1) into a compare + select per half).
+__device__ __forceinline__ unsigned mnr_relu_mask_byte(unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+  typedef short mnr_s16x2 __attribute__((ext_vector_type(2)));
+  const unsigned w[4] = {w0, w1, w2, w3};
+  unsigned m[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const mnr_s16x2 z = {0, 0};
+    const unsigned pos = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(mnr_s16x2, w[d]), z));
+    MNR_GPU_ONLY(asm("v_pk_min_u16 %0, %1, %2" : "=v"(m[d]) : "v"(pos), "v"(0x00010001u)));
+    MNR_SIM_HOOK(m[d] = ((pos & 0xffffu) ? 1u : 0u) | ((pos >> 16) ? 0x10000u : 0u));
+  }
+  const unsigned t = (((m[3] << 2) | m[2]) << 4) | ((m[1] << 2) | m[0]);      // element 2d at bit 2d, 2d+1 at bit 16+2d
+  return ((t >> 15) & 0xaau) | (t & 0x55u);
+}
+
 __device__ __forceinline__ float mnr_softplus(float x) {
   // jax.nn.softplus = logaddexp(x, 0) = max(x,0) + log1p(exp(-|x|)).
   return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));

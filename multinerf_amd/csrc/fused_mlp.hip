@@ -247,15 +247,7 @@ __device__ __forceinline__ void fm_copy_out(const char* X, int tid_, int64_t m0,
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       if constexpr (BITS) {
-        unsigned f = 0;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const unsigned wd = w[u][d];
-          const s16x2 z = {0, 0};
-          const unsigned pos = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, wd), z));
-          f |= ((pos + 0x7fff7fffu) & 0x80008000u) >> (15 - 2 * d);
-        }
-        unsigned mb = (f | (f >> 15)) & 0xffu;
+        unsigned mb = mnr_relu_mask_byte(w[u][0], w[u][1], w[u][2], w[u][3]);
         mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xF5, 0xf, 0xf, false) << 8;     // quad_perm [1,1,3,3]
         mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xAA, 0xf, 0xf, false) << 16;    // quad_perm [2,2,2,2]
         if ((ch & 3) == 0) *(unsigned*)(bits + bo + (int64_t)u * C::ROW_STEP * (W / 8)) = mb;

@@ -414,16 +414,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wres_kernel(mnr_gemm_nt_args p) {
           }
         }
         if (bptr) {                                        // kernel-uniform
-          typedef short s16x2b __attribute__((ext_vector_type(2)));
-          unsigned f = 0;
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            const unsigned wd = w[d];
-            const s16x2b z = {0, 0};
-            const unsigned pos = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2b, wd), z));
-            f |= ((pos + 0x7fff7fffu) & 0x80008000u) >> (15 - 2 * d);
-          }
-          unsigned mb = (f | (f >> 15)) & 0xffu;
+          unsigned mb = mnr_relu_mask_byte(w[0], w[1], w[2], w[3]);
           mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xF5, 0xf, 0xf, false) << 8;
           mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xAA, 0xf, 0xf, false) << 16;
           if ((ch & 3) == 0) *(unsigned*)(bptr + (int64_t)it * 16 * p.ld_bits_out) = mb;
