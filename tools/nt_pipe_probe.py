@@ -64,7 +64,7 @@ def case(M, N, K1, K2=0, fwd=True, sparse=True):
       t = full[:, :4]
       med = lambda x: float(np.median(x))
       tl_text = (f'      cycles/tile: prologue {med(t[:, 1] - t[:, 0]):.0f}  K-loop {med(t[:, 2] - t[:, 1]):.0f} ({med(t[:, 2] - t[:, 1]) / ((K1 + K2) / 64):.0f}/K-tile)  '
-            f'epilogue {med(t[:, 3] - t[:, 2]):.0f}' + (f'  (pipeline fill {med(full[:, 12] - full[:, 1]):.0f}; first tiles {med((full[:, 12] - full[:, 1])[first]):.0f}, later {med((full[:, 12] - full[:, 1])[~first]):.0f})' if full[:, 12].any() else ''))
+            f'epilogue {med(t[:, 3] - t[:, 2]):.0f}' + (f'  (staging {med(full[:, 8] - full[:, 2]):.0f} + store loop {med(full[:, 9] - full[:, 8]):.0f})' if full[:, 8].any() else '') + (f'  (pipeline fill {med(full[:, 12] - full[:, 1]):.0f}; first tiles {med((full[:, 12] - full[:, 1])[first]):.0f}, later {med((full[:, 12] - full[:, 1])[~first]):.0f})' if full[:, 12].any() else ''))
     outs.setdefault(wide, (C.view(torch.int16).clone(), bo.clone()))
     print(f'M={M} N={N} K={K1}+{K2} {"fwd" if fwd else "dX "} pipe={wide}: {us:8.1f} us  {2.0 * M * N * (K1 + K2) / us / 1e6:7.1f} TF/s', flush=True)
     if tl_text:
