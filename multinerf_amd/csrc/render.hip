@@ -132,6 +132,21 @@ static int cp_rays_per_block(int n, int64_t B) {
 }
 static size_t cp_lds_bytes(int n, int s) { return (size_t)(6 * n + 1) * s * 4; }
 
+// A/B switch of the per-ray kernels: 1 = four lanes per ray (composite_fwd_quad_kernel, level_bwd_quad_kernel) where a
+// wave's 16 rays fit LDS, 0 = lane per ray for every shape
+static int g_level_bwd_quad = 1;
+extern "C" int mnr_level_bwd_set_quad(int on) {
+  g_level_bwd_quad = on;
+  return MNR_OK;
+}
+
+__global__ void composite_fwd_quad_kernel(mnr_composite_cfg c, int64_t B, int stride, const float* __restrict__ raw_density,
+                                          const float* __restrict__ noise, const float* __restrict__ raw_rgb,
+                                          const float* __restrict__ tdist, const float* __restrict__ dirs,
+                                          const float* __restrict__ bg, const float* __restrict__ expo,
+                                          float* __restrict__ density, float* __restrict__ rgb, float* __restrict__ weights,
+                                          float* __restrict__ rgb_out, float* __restrict__ acc_out);
+
 extern "C" int mnr_composite_fwd(const mnr_composite_cfg* cfg, int64_t B, const float* raw_density,
                                  const float* density_noise, const float* raw_rgb, const float* tdist,
                                  const float* dirs, const float* bg, const float* exposure_scale, float* density,
@@ -141,6 +156,20 @@ extern "C" int mnr_composite_fwd(const mnr_composite_cfg* cfg, int64_t B, const 
   MNR_CHECK_ARG(cfg->n >= 1 && cfg->n <= 1024, "mnr_composite_fwd: n out of range");
   MNR_CHECK_ARG(!cfg->has_rgb || raw_rgb, "mnr_composite_fwd: has_rgb needs raw_rgb");
   MNR_CHECK_ARG(cfg->bg_mode == 0 || bg, "mnr_composite_fwd: bg_mode 1 needs bg");
+  {
+    // four lanes per ray: den n | t n+1 | w n | [rgb 3n], ray stride 4 x odd floats (conflict-free quads)
+    int o = 3 * cfg->n + 1 + (cfg->has_rgb ? 3 * cfg->n : 0);
+    o = (o + 3) & ~3;
+    if (((o >> 2) & 1) == 0) o += 4;
+    const size_t quad_lds = (size_t)o * (CP_THREADS / 4) * 4;
+    if (g_level_bwd_quad && quad_lds <= 40 * 1024) {
+      hipLaunchKernelGGL(composite_fwd_quad_kernel, dim3(mnr_cdiv(B, CP_THREADS / 4)), dim3(CP_THREADS), quad_lds,
+                         (hipStream_t)stream, *cfg, B, o, raw_density, density_noise, raw_rgb, tdist, dirs, bg, exposure_scale,
+                         density, rgb, weights, rgb_out, acc);
+      MNR_CHECK_LAUNCH();
+      return MNR_OK;
+    }
+  }
   const int S = cp_rays_per_block(cfg->n, B);
   const size_t lds = cp_lds_bytes(cfg->n, S);
   MNR_CHECK_ARG(lds <= 160 * 1024, "mnr_composite_fwd: n=%d too long for LDS staging", cfg->n);
@@ -691,18 +720,107 @@ __global__ __launch_bounds__(CP_THREADS) void level_bwd_quad_kernel(mnr_level_bw
   if (c.has_rgb && a.g_raw_rgb) store_rows(L.rgb, a.g_raw_rgb + ray0 * n * 3, 3 * n);
 }
 
+// The forward compositing on four lanes per ray (the same quad helpers and LDS plan as level_bwd_quad_kernel): lane q owns the
+// samples 4j + q, the optical depth in front of a sample is a quad scan with a carry (summed in blocked instead of sequential
+// order: weights differ from the lane-per-ray kernel in the last bits, both are held to the oracle by the same tolerances).
+// LDS per ray: den n | t n+1 | w n | [rgb 3n], ray stride 4 x odd floats.
+__global__ __launch_bounds__(CP_THREADS) void composite_fwd_quad_kernel(
+    mnr_composite_cfg c, int64_t B, int stride, const float* __restrict__ raw_density, const float* __restrict__ noise,
+    const float* __restrict__ raw_rgb, const float* __restrict__ tdist, const float* __restrict__ dirs,
+    const float* __restrict__ bg, const float* __restrict__ expo, float* __restrict__ density,
+    float* __restrict__ rgb, float* __restrict__ weights, float* __restrict__ rgb_out, float* __restrict__ acc_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n = c.n;
+  const int o_den = 0, o_t = n, o_w = 2 * n + 1, o_rgb = 3 * n + 1;
+  const int64_t ray0 = (int64_t)blockIdx.x * LB_RPW;
+  const int rows = (int)min((int64_t)LB_RPW, B - ray0);
+  auto load_rows = [&](int off, const float* src, int len) {
+    for (int e = threadIdx.x; e < rows * len; e += CP_THREADS) {
+      const int rr = e / len, i = e - rr * len;
+      lds[rr * stride + off + i] = src[e];
+    }
+  };
+  auto store_rows = [&](int off, float* dst, int len) {
+    for (int e = threadIdx.x; e < rows * len; e += CP_THREADS) {
+      const int rr = e / len, i = e - rr * len;
+      dst[e] = lds[rr * stride + off + i];
+    }
+  };
+  load_rows(o_den, raw_density + ray0 * n, n);
+  load_rows(o_t, tdist + ray0 * (n + 1), n + 1);
+  if (c.has_rgb) load_rows(o_rgb, raw_rgb + ray0 * n * 3, 3 * n);
+  if (noise && c.density_noise_std > 0.0f) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * n; e += CP_THREADS) {
+      const int rr = e / n, i = e - rr * n;
+      lds[rr * stride + o_den + i] += c.density_noise_std * noise[ray0 * n + e];     // models.py:462-464
+    }
+  }
+  __syncthreads();
+  const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const bool live = r < rows;
+  const int64_t ray = live ? ray0 + r : B - 1;
+  float* X = lds + r * stride;
+  const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+  const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+  float ex[3] = {1.0f, 1.0f, 1.0f};
+  if (expo) { ex[0] = expo[ray * 3]; ex[1] = expo[ray * 3 + 1]; ex[2] = expo[ray * 3 + 2]; }
+  float carry = 0.0f, acc = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+  const int J = (n + 3) >> 2;
+  for (int j = 0; j < J; ++j) {
+    const int i = 4 * j + q;
+    const bool in = i < n;
+    const float sigma = cp_act(c.density_act, (in ? X[o_den + i] : 0.0f) + c.density_bias);   // models.py:506
+    const float delta = in ? (X[o_t + i + 1] - X[o_t + i]) * dnorm : 0.0f;                    // render.py:132-133
+    float x = in ? sigma * delta : 0.0f;
+    if (c.opaque_background && i == n - 1) x = INFINITY;                                      // render.py:136-142
+    const float inc = lb_quad_prefix(x, q);
+    const float below = lb_dpp<0x90>(inc);
+    const float before = (q == 0 ? 0.0f : below) + carry;       // sum_{k<i} x_k (never contains the opaque last sample)
+    carry += lb_dpp<0xFF>(inc);
+    if (in) {
+      const float w = (1.0f - expf(-x)) * expf(-before);
+      X[o_den + i] = sigma;
+      X[o_w + i] = w;
+      acc += w;
+      if (c.has_rgb) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          // models.py:584-586, 602, then exposure scaling :257-267.
+          float v = cp_act(c.rgb_act, c.rgb_premultiplier * X[o_rgb + 3 * i + ch] + c.rgb_bias);
+          v = v * (1.0f + 2.0f * c.rgb_padding) - c.rgb_padding;
+          v *= ex[ch];
+          X[o_rgb + 3 * i + ch] = v;
+          if (ch == 0) cr += w * v; else if (ch == 1) cg += w * v; else cb += w * v;
+        }
+      }
+    }
+  }
+  acc = lb_quad_sum(acc);
+  cr = lb_quad_sum(cr);
+  cg = lb_quad_sum(cg);
+  cb = lb_quad_sum(cb);
+  if (live && q == 0) {
+    const float bgw = fmaxf(0.0f, 1.0f - acc);                                         // render.py:180
+    float b0 = c.bg_value, b1 = c.bg_value, b2 = c.bg_value;
+    if (c.bg_mode == 1) { b0 = bg[ray * 3]; b1 = bg[ray * 3 + 1]; b2 = bg[ray * 3 + 2]; }
+    rgb_out[ray * 3 + 0] = cr + bgw * b0;                                              // render.py:181
+    rgb_out[ray * 3 + 1] = cg + bgw * b1;
+    rgb_out[ray * 3 + 2] = cb + bgw * b2;
+    if (acc_out) acc_out[ray] = acc;
+  }
+  __syncthreads();
+  store_rows(o_den, density + ray0 * n, n);
+  store_rows(o_w, weights + ray0 * n, n);
+  if (c.has_rgb && rgb) store_rows(o_rgb, rgb + ray0 * n * 3, 3 * n);
+}
+
 static size_t lb_floats_per_ray(const mnr_level_bwd_args* a) {
   const int n = a->cfg.n;
   size_t f = (size_t)(6 * n + 1) + n;                        // compositing VJP + d loss / d weights
   if (a->wloss_mode != 0) f += n + 1;                        // sdist
   if (a->wloss_mode == 1) f += 3 * (size_t)a->n_ref + 2;     // lo, hi, gi
   return f;
-}
-
-static int g_level_bwd_quad = 1;                         // A/B switch: 0 = the lane-per-ray kernel for every shape
-extern "C" int mnr_level_bwd_set_quad(int on) {
-  g_level_bwd_quad = on;
-  return MNR_OK;
 }
 
 extern "C" int mnr_level_bwd(const mnr_level_bwd_args* a, void* stream) {
