@@ -457,6 +457,7 @@ def test_colsum_pack_scatter_cast_smallhead(ops):
 
 @pytest.mark.parametrize('n,opaque,has_rgb,rgb_act,pad,noise', [(32, True, True, 'sigmoid', 0.001, False),
                                                                 (64, True, False, 'sigmoid', 0.001, False),
+                                                                (30, True, True, 'sigmoid', 0.001, False),     # not a multiple of the 4 lanes per ray
                                                                 (128, False, True, 'safe_exp', 0.0, True)])
 def test_composite_fwd_bwd(ops, level_bwd_kernel, n, opaque, has_rgb, rgb_act, pad, noise):
   gen = torch.Generator().manual_seed(9)
