@@ -86,7 +86,10 @@ def main():
   ap.add_argument('--preset', default='360')
   ap.add_argument('--gin_bindings', action='append', default=[])
   ap.add_argument('--no_cpu_baseline', action='store_true')
-  ap.add_argument('--cpu_rays', type=int, default=128)
+  ap.add_argument('--cpu_rays', type=int, default=256, help='rays of the CPU-baseline sample (SURVEY 8d: B = 256)')
+  ap.add_argument('--check_collectives', action='store_true',
+                  help='before the benchmark: all-reduce / all-gather known patterns over the process group, assert the results '
+                       'and time a 36 MB fp32 all-reduce (first contact with RCCL must not be the first bug)')
   ap.add_argument('--no_aux', action='store_true', help='skip the secondary measurements (4096x192 north-star shape, render)')
   args = ap.parse_args()
 
@@ -97,8 +100,22 @@ def main():
   if world != args.gpus:
     raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run')
   local = int(os.environ.get('LOCAL_RANK', '0'))
+  ndev = torch.cuda.device_count()
+  if ndev < 1:
+    raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+  if local >= ndev:
+    raise SystemExit(f'LOCAL_RANK {local} but only {ndev} visible GPU(s): one process per GPU on ONE node')
   torch.cuda.set_device(local)
   dev = torch.device('cuda', local)
+  dist_info = mdist.describe(dev)
+  if world > 1:
+    # every rank must sit on its own device: gather (hostname, device index, PCI bus id) and fail loudly on a clash
+    ids = mdist.all_gather_objects((os.uname().nodename, local, dist_info['device_uuid']))
+    if len(set(ids)) != world:
+      raise SystemExit(f'rank / device mismatch: {ids}')
+    dist_info['rank_devices'] = [list(i) for i in ids]
+  if args.check_collectives or (world > 1 and os.environ.get('MNR_SKIP_COLLECTIVE_CHECK') != '1'):
+    dist_info['collective_check'] = mdist.check_collectives(dev)
 
   cfg = configs.load_preset(args.preset, args.gin_bindings)
   if args.global_batch:
@@ -131,13 +148,20 @@ def main():
   torch.cuda.synchronize()
   mdist.barrier()
   torch.cuda.synchronize()
+  # per-step HIP events on the launch stream (median of per-step hipEvent times); `value` stays the wall clock
+  # over exactly K steps between the two barrier + synchronize brackets
+  evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
   t0 = time.perf_counter()
-  for _ in range(args.steps):
+  evs[0].record()
+  for i in range(args.steps):
     stats = step()
+    evs[i + 1].record()
   torch.cuda.synchronize()
   mdist.barrier()
   torch.cuda.synchronize()
   elapsed = time.perf_counter() - t0
+  step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+  median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
   if world > 1:
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -204,11 +228,18 @@ def main():
 
   # HBM bytes of the GEMM kernels per train step from the PMC passes of the last profiled build (same command,
   # same workload); null for any other workload.  tools/profile_round.sh regenerates the inputs.
-  traffic = None
+  traffic, traffic_note = None, 'no PMC pass for this workload'
   tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic.json')
+  from multinerf_amd import _lib as mlib
+  lib_info = mlib.describe()
   if args.preset == '360' and not args.gin_bindings and B == 16384 and os.path.exists(tpath):
     with open(tpath) as f:
-      traffic = json.load(f).get('gemm_hbm_bytes_per_step')
+      tj = json.load(f)
+    if tj.get('lib_digest') and tj.get('lib_digest') == lib_info.get('source_digest') and not lib_info['overridden']:
+      traffic, traffic_note = tj.get('gemm_hbm_bytes_per_step'), tj.get('source')
+    else:
+      traffic_note = (f"profiles/traffic.json was measured on build {str(tj.get('lib_digest'))[:12]}, the loaded library is "
+                      f"{str(lib_info.get('source_digest'))[:12]}: not reported")
 
   out = None
   if rank == 0:
@@ -222,6 +253,8 @@ def main():
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': ms_per_step,
+        'ms_per_step_median_hip_event': median_ms,
+        'ms_per_step_min_max_hip_event': [step_ms[0], step_ms[-1]],
         'higher_is_better': True,
         'scaling': 'strong' if args.global_batch else 'weak',
         'vs_baseline': None,
@@ -254,6 +287,7 @@ def main():
             'whole_step_achieved': train_flops * B / (ms_per_step * 1e-3) / 1e12,
             'whole_step_frac': train_flops * B / (ms_per_step * 1e-3) / 2.5e15,
             'traffic': traffic,
+            'traffic_source': traffic_note,
             'gemm_ms_per_step': gemm_ms_per_step,
             'gemm_launches_per_step': gemm_launches / nprof,
             'gemm_share_of_step': gemm_ms_per_step / ms_per_step,
@@ -262,8 +296,11 @@ def main():
     }
     if aux:
       out['aux'] = aux
+    out['library'] = lib_info
+    out['distributed'] = dist_info
 
-  # ---- CPU baseline (rank 0, N=1 only): the oracle's train_step on a bounded sample
+  # ---- CPU baseline (rank 0, N=1 only): the oracle on a bounded sample of the same workload (SURVEY 8d protocol:
+  # B = 256 rays, forward and train_step separately, 1 warm-up + 3 timed runs each, medians)
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     from oracle import bridge as obridge
     from oracle import models as omodels
@@ -272,22 +309,38 @@ def main():
     params = omodels.init_params(om, on, op, seed=0)
     nb = args.cpu_rays
     cb = synthetic.synthetic_rays(nb, near=cfg.near, far=cfg.far)
+    if cfg.rawnerf_mode:
+      g0 = torch.Generator().manual_seed(5)
+      cb.rays.exposure_idx = torch.randint(0, 5, (nb, 1), generator=g0).to(torch.int32)
+      cb.rays.exposure_values = 0.5 + torch.rand((nb, 1), generator=g0)
+      cb.rays.lossmult = (torch.rand((nb, 3), generator=g0) > 0.4).float()
+    if cfg.compute_normal_metrics:
+      g0 = torch.Generator().manual_seed(6)
+      cb.alphas = torch.rand((nb,), generator=g0)
+      cb.normals = torch.randn((nb, 3), generator=g0)
     noise = obridge.make_noise(model, nb)
     st = otrain.init_opt_state(params)
     cores = torch.get_num_threads()
-    t0 = time.perf_counter()
-    otrain.train_step(params, st, om, on, op, cfg, cb, train_frac, noise=noise)     # warm-up (allocator, threads)
-    t_warm = time.perf_counter() - t0
-    reps = max(1, min(4, int(20.0 / max(t_warm, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-      otrain.train_step(params, st, om, on, op, cfg, cb, train_frac, noise=noise)
-    dt = (time.perf_counter() - t0) / reps
+
+    def med3(fn):
+      fn()                                                             # warm-up (allocator, thread pool)
+      ts = []
+      for _ in range(3):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+      return sorted(ts)[1]
+
+    with torch.no_grad():
+      dt_fwd = med3(lambda: omodels.model_apply(om, on, op, params, cb.rays, train_frac, False))
+    dt = med3(lambda: otrain.train_step(params, st, om, on, op, cfg, cb, train_frac, noise=noise))
     out['cpu_baseline'] = {
         'value': nb / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-        'sample': f'{reps} x oracle train_step (fp32 torch-CPU restatement of the reference; NOT the reference\'s JAX, which '
-                  f'cannot be installed here) on {nb} rays of the same workload; '
-                  f'host has {os.cpu_count()} logical CPUs, torch used {cores} threads',
+        'forward_rays_per_sec': nb / dt_fwd,
+        'sample': f'oracle train_step (value) and deterministic Model forward (forward_rays_per_sec) on {nb} rays of the same '
+                  f'workload, 1 warm-up + 3 runs each, medians; fp32 torch-CPU restatement of the reference (NOT the '
+                  f'reference\'s JAX, which cannot be installed here); host has {os.cpu_count()} logical CPUs, torch used '
+                  f'{cores} threads',
     }
   if rank == 0:
     print(json.dumps(out))

@@ -13,6 +13,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MNR_LIB_PATH') or os.path.join(HERE, 'libmnerf_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(HERE), 'include', 'mnerf.h')
 
+
+def describe():
+  """Which build is loaded: bench.py records it next to its numbers (an A/B library loaded through MNR_LIB_PATH or a
+  build with extra hipcc flags must not pass for the shipped kernels)."""
+  stamp = LIB_PATH + '.stamp'
+  digest = None
+  if os.path.exists(stamp):
+    with open(stamp) as f:
+      digest = f.read().strip()
+  return {'path': os.path.relpath(LIB_PATH, os.path.dirname(HERE)), 'overridden': bool(os.environ.get('MNR_LIB_PATH')),
+          'source_digest': digest, 'extra_hipcc_flags': os.environ.get('MNR_EXTRA_HIPCC_FLAGS', '')}
+
 MNR_OK = 0
 MNR_ERR_INVALID_ARGUMENT = -1
 

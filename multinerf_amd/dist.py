@@ -112,3 +112,69 @@ def shard_batch(batch, ws=None, rk=None):
     return x[rk * per:(rk + 1) * per].contiguous()
 
   return batch.map(fn)
+
+
+def describe(device=None):
+  """What the bench line records about the process group: backend, world size, the RCCL version torch was built
+  against, this rank's device."""
+  info = {'world_size': world_size(), 'rank': rank(), 'backend': td.get_backend() if is_initialized() else None}
+  try:
+    info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+  except Exception as e:                                 # CPU-only build / no RCCL
+    info['rccl_version'] = f'unavailable ({type(e).__name__})'
+  if device is not None and torch.cuda.is_available() and torch.device(device).type == 'cuda':
+    p = torch.cuda.get_device_properties(device)
+    info['device'] = f'{torch.device(device)}: {p.name}, {p.multi_processor_count} CUs, {p.total_memory >> 30} GiB'
+    info['device_uuid'] = str(getattr(p, 'uuid', '')) or f'index {torch.device(device).index}'
+  else:
+    info['device'], info['device_uuid'] = str(device), f'host pid {os.getpid()}'
+  return info
+
+
+def all_gather_objects(obj):
+  """Every rank's picklable `obj`, in rank order."""
+  if world_size() == 1:
+    return [obj]
+  out = [None] * world_size()
+  td.all_gather_object(out, obj)
+  return out
+
+
+def check_collectives(device, nbytes=36 * 1024 * 1024):
+  """All-reduce / all-gather known patterns and assert the results; time an all-reduce of `nbytes` of fp32 (the flat
+  gradient of 360.gin is 36 MB).  Raises on a wrong result: a mis-wired group must not reach the timed region."""
+  import time
+  ws, rk = world_size(), rank()
+  n = 1 << 16
+  i = torch.arange(n, device=device, dtype=torch.float32)
+  t = (i % 251) * (rk + 1)                               # rank r holds (r + 1) * pattern
+  all_reduce_mean_(t)
+  want = (i % 251) * (ws + 1) / 2
+  if not torch.allclose(t, want, rtol=1e-6, atol=1e-6):
+    raise RuntimeError(f'all-reduce check failed on rank {rk}: max |diff| {(t - want).abs().max().item():.3e}')
+  g = all_gather_cat(torch.full((3, 2), float(rk), device=device))
+  want_g = torch.arange(ws, device=device, dtype=torch.float32).repeat_interleave(3)[:, None].expand(3 * ws, 2)
+  if not torch.equal(g, want_g):
+    raise RuntimeError(f'all-gather check failed on rank {rk}')
+  parts = all_gather_packed([torch.full((2, 3), float(rk), device=device), torch.full((2,), float(10 + rk), device=device)])
+  if not (torch.equal(parts[0][:, 0], torch.arange(ws, device=device, dtype=torch.float32).repeat_interleave(2)) and
+          torch.equal(parts[1], 10 + torch.arange(ws, device=device, dtype=torch.float32).repeat_interleave(2))):
+    raise RuntimeError(f'packed all-gather check failed on rank {rk}')
+  buf = torch.ones(nbytes // 4, device=device, dtype=torch.float32)
+  sync = torch.cuda.synchronize if torch.device(device).type == 'cuda' else (lambda: None)
+  for _ in range(2):
+    all_reduce_mean_(buf)
+  sync()
+  barrier()
+  reps = 5
+  t0 = time.perf_counter()
+  for _ in range(reps):
+    h = all_reduce_sum_async(buf)
+    finish_mean_(buf, h)
+  sync()
+  barrier()
+  dt = (time.perf_counter() - t0) / reps
+  if not torch.allclose(buf, torch.ones_like(buf)):
+    raise RuntimeError(f'timed all-reduce corrupted its buffer on rank {rk}')
+  return {'ok': True, 'allreduce_bytes': nbytes, 'allreduce_ms': 1e3 * dt,
+          'allreduce_busbw_GBps': (2 * (ws - 1) / ws * nbytes / dt / 1e9) if ws > 1 else None}

@@ -729,8 +729,14 @@ class Model:
   @staticmethod
   def _chain_ok(plan: MLPPlan):
     """The fused per-level kernel (csrc/fused_mlp.hip) covers density-only MLPs without a skip concat: PropMLP."""
-    return (_USE_CHAIN and not plan.has_rgb and not plan.ref and plan.W in (128, 256) and
-            1 <= len(plan.trunk) <= L.CHAIN_MAX_DEPTH and not any(c for _, c in plan.trunk))
+    if not (_USE_CHAIN and not plan.has_rgb and not plan.ref and plan.W in (128, 256) and
+            1 <= len(plan.trunk) <= L.CHAIN_MAX_DEPTH and not any(c for _, c in plan.trunk)):
+      return False
+    # the kernels read every bias row and the fp32 head kernel as 16-byte vectors straight out of the flat parameter
+    # vector: a module base that is not a multiple of 4 floats (e.g. PropMLP_0 behind a Ref-NeRF NerfMLP_0 of 713,230
+    # parameters) takes the per-layer path, which has no such requirement
+    offs = [d.bias_off for d, _ in plan.trunk] + [plan.density.kernel_off]
+    return all(o % 4 == 0 for o in offs)
 
   def _chain_forward(self, plan: MLPPlan, flat, feat, M, tag, keep):
     """models.py:441-465 for a density-only MLP as ONE launch: every Dense + ReLU layer and the density head."""

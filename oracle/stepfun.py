@@ -26,7 +26,29 @@ def seq_cumsum(x):
   return torch.from_numpy(np.cumsum(x.detach().numpy(), axis=-1, dtype=x.detach().numpy().dtype))
 
 
-LANES = 16   # lanes that share one ray in csrc/resample.hip (RSP_LPR)
+LANES = 16   # lanes that share one ray in csrc/resample.hip (RSP_LPR; tests/test_oracle_leaves.py holds the two together)
+
+# Association order and transcendental functions of the fp32 sampling path.
+#   'kernel'    : the HIP level kernel's documented order (blocked sums, its own exp / log): the oracle the kernel's
+#                 sample INDICES are bit-exact against, by construction;
+#   'reference' : the reference's (stepfun.py:146,156 as NumPy executes them): strict left-to-right sums and
+#                 cumulative sums, libm exp / log.  The kernel's index mismatch rate against THIS order is measured and
+#                 reported (tests/test_gpu_kernels.py::test_resample_level, tests/test_oracle_leaves.py), not assumed zero.
+_ORDER = 'kernel'
+
+
+class reference_order:
+  """Context manager: evaluate the fp32 sampling path in the reference's association order (see _ORDER)."""
+
+  def __enter__(self):
+    global _ORDER
+    self._prev, _ORDER = _ORDER, 'reference'
+    return self
+
+  def __exit__(self, *exc):
+    global _ORDER
+    _ORDER = self._prev
+    return False
 
 
 def blocked_cumsum(x, chunk=None):
@@ -39,6 +61,10 @@ def blocked_cumsum(x, chunk=None):
   is a slice of the array the chunking is defined on (the CDF sums w[:-1] with the chunking of w)."""
   a = x.detach().numpy()
   n = a.shape[-1]
+  if _ORDER == 'reference':                              # strict left to right
+    cs = np.cumsum(a, axis=-1, dtype=a.dtype)
+    tot = cs[..., -1] if n else np.zeros(a.shape[:-1], dtype=a.dtype)
+    return torch.from_numpy(np.ascontiguousarray(cs)), torch.from_numpy(np.ascontiguousarray(tot))
   ch = int(chunk) if chunk is not None else -(-n // LANES)
   pad = LANES * ch - n
   assert pad >= 0
@@ -163,7 +189,7 @@ def resample_logits(sdist, weights, anneal, resample_padding):
   """models.py:183-185: where(sdist[1:] > sdist[:-1], anneal * log(weights + padding), -inf), with the sampling path's
   own log in float32 (math.klog: the kernel's, bit for bit)."""
   w = weights.detach() + resample_padding
-  lg = rmath.klog(w) if w.dtype == torch.float32 else torch.log(w)
+  lg = rmath.klog(w) if (w.dtype == torch.float32 and _ORDER == 'kernel') else torch.log(w)
   return torch.where(sdist[..., 1:] > sdist[..., :-1], anneal * lg, torch.full_like(w, -float('inf')))
 
 
@@ -171,7 +197,7 @@ def softmax_seq(logits):
   """jax.nn.softmax (stepfun.py:156) with the level kernel's blocked denominator (blocked_cumsum) and, in float32, its
   exp (math.kexp)."""
   m = logits.max(dim=-1, keepdim=True).values
-  e = rmath.kexp(logits - m) if logits.dtype == torch.float32 else torch.exp(logits - m)
+  e = rmath.kexp(logits - m) if (logits.dtype == torch.float32 and _ORDER == 'kernel') else torch.exp(logits - m)
   denom = blocked_sum(e)
   return e / denom
 

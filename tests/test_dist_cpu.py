@@ -61,6 +61,13 @@ def _worker(rank, world, port, q):
   out = models.render_image(render_fn, img_rays, None, cfg, verbose=False, world_size=world, rank=rank)
   ok4 = out['rgb'].shape == (H, W, 3) and torch.equal(out['acc'], base[..., 0])
   ok5 = len(out['ray_sdist']) == 2
+  # 4. the bench's first-contact check (bench.py --check_collectives): known patterns through every collective the
+  # product uses, a timed all-reduce, and the rank / device roll call
+  chk = mdist.check_collectives('cpu', nbytes=1 << 20)
+  info = mdist.describe('cpu')
+  ids = mdist.all_gather_objects((rank, info['device_uuid']))
+  ok5 = ok5 and chk['ok'] and chk['allreduce_ms'] > 0 and info['world_size'] == world and info['backend'] == 'gloo' \
+      and [i[0] for i in ids] == list(range(world)) and len(set(ids)) == world
   mdist.barrier()
   q.put((rank, ok1, ok2, ok3, ok4, ok5))
   td.destroy_process_group()

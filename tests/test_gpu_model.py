@@ -83,6 +83,14 @@ CASES = [
     ('blender_256', ["Config.weight_decay_mults = {'NerfMLP_0': 3e-5, 'PropMLP_0': 1e-5}"], 16),
     # the north-star's synthetic shape: 192 samples per ray = levels (64, 64, 64)
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_nerf_samples = 64'], 16),
+    # a chain-eligible PropMLP behind a Ref-NeRF NerfMLP: PropMLP_0 starts at parameter 713,230 (2 mod 4), so its bias
+    # rows are not 16-byte aligned and Model._chain_ok must hand it to the per-layer path (round-2 advisor finding)
+    ('blender_refnerf', ['Model.single_mlp = False', 'PropMLP.net_depth = 4', 'PropMLP.net_width = 256',
+                         'PropMLP.disable_rgb = True', 'PropMLP.disable_density_normals = True',
+                         "PropMLP.basis_shape = 'octahedron'", 'PropMLP.basis_subdivisions = 1',
+                         'PropMLP.max_deg_point = 16', 'Config.interlevel_loss_mult = 1.0',
+                         'Config.orientation_loss_mult = 0.0', 'Config.orientation_coarse_loss_mult = 0.0',
+                         'Config.predicted_normal_loss_mult = 0.0', 'Config.predicted_normal_coarse_loss_mult = 0.0'], 12),
 ]
 
 
@@ -153,8 +161,12 @@ def test_train_step_parity(name, extra, B):
   assert abs(s['loss'] - float(stats_o['loss'])) <= 0.02 * abs(float(stats_o['loss'])) + 1e-5
   np.testing.assert_allclose(s['mses'], stats_o['mses'].detach().numpy(), rtol=0.03, atol=1e-5)
   if cfg.compute_normal_metrics:
-    print(f'{name}: normal_maes kernel {s["normal_maes"]} oracle {stats_o["normal_maes"].detach().numpy()}')
-    np.testing.assert_allclose(s['normal_maes'], stats_o['normal_maes'].detach().numpy(), rtol=0.02)
+    mae_o, mae_32 = stats_o['normal_maes'].detach().numpy(), stats_32['normal_maes'].detach().numpy()
+    print(f'{name}: normal_maes kernel {s["normal_maes"]} oracle_bf16 {mae_o} oracle_fp32 {mae_32}')
+    # (an angle between RENDERED normals: at random init those are sums of nearly cancelling unit vectors, so the metric
+    # is judged against its own bf16 cost where that is larger than 2 %)
+    cost = np.nanmax(np.abs(mae_o - mae_32) / np.abs(mae_32))
+    np.testing.assert_allclose(s['normal_maes'], mae_o, rtol=max(0.02, 1.5 * cost))
     for k in ('orientation', 'predicted_normals'):
       assert abs(s['losses'][k] - float(stats_o['losses'][k])) <= 0.03 * abs(float(stats_o['losses'][k])) + 1e-7, k
   for mod, b, e in model.modules:

@@ -26,6 +26,7 @@ pytestmark = pytest.mark.gpu
 
 from multinerf_amd import configs, models, train_utils
 from oracle import models as omodels
+from oracle import train_utils as otrain
 from tests import helpers
 
 B_FULL = int(os.environ.get('MNR_FULLSIZE_RAYS', '16384'))
@@ -86,6 +87,64 @@ def test_full_batch_rows_are_the_small_batch_and_the_small_batch_is_the_oracle(s
   err = (rs[-1]['rgb'].cpu() - r_bf[-1]['rgb']).abs().max().item()
   print(f'rgb: |kernel - oracle_bf16| = {err:.2e} (bf16 cost {cost:.2e})')
   assert err <= max(5e-3, 3 * cost)
+
+
+N_TRAIN = int(os.environ.get('MNR_FULLSIZE_TRAIN_RAYS', '32'))
+# Stated tolerances of the full-width gradient (relative L2 per top-level module / per Dense kernel), against the
+# bf16-emulating oracle and against the plain fp32 oracle; measured values are printed next to them (round 3, first
+# GPU call: see DESIGN.md section 2).
+GRAD_TOL = dict(module_bf16=0.10, module_fp32=0.30, dense_bf16=0.15, dense_fp32=0.40)
+
+
+def test_full_width_train_step_gradient_is_the_oracles(setup):
+  """configs/360.gin AS IS (1024-wide NeRF trunk incl. its 1536-wide skip layer, 256-wide fused proposal chain, 9.0 M
+  parameters): one train_step on N_TRAIN rays against oracle.train_utils.train_step, both with the Dense layers' bf16
+  rounding emulated and in plain fp32.  This is where the pipelined dX path at K = 1024 / 1536, the 256-wide weight-gradient
+  tiles at 1024 x 1024 outputs and mlp_chain_bwd_kernel<256> meet the oracle directly (the reduced-width cases of
+  tests/test_gpu_model.py cover the same code at 256 / 128)."""
+  cfg, model, (om, on, op), params, flat, batch = setup
+  n = N_TRAIN
+  sub = batch.map(lambda t: t[:n])
+  noise = helpers.make_noise(model, n)
+  tf = 0.3
+  st = otrain.init_opt_state(params)
+  _, _, stats_bf, grads_bf = otrain.train_step(params, st, om, on, op, cfg, sub, tf, noise=noise, dense_dtype=torch.bfloat16)
+  _, _, stats_32, grads_32 = otrain.train_step(params, st, om, on, op, cfg, sub, tf, noise=noise)
+  g_bf = model.flat_from_tree(grads_bf, device='cpu').double()
+  g_32 = model.flat_from_tree(grads_32, device='cpu').double()
+  step = train_utils.create_train_step(model, cfg)
+  state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})
+  state2, stats, _ = step(0, state, _dev(sub), None, tf, 0.0, noise={k: {lv: t.cuda() for lv, t in d.items()} for k, d in noise.items()},
+                          return_grads=True)
+  torch.cuda.synchronize()
+  g = stats['_grads'].double().cpu()
+  s = stats.materialize()
+  print(f'full width, {n} rays: loss kernel {s["loss"]:.6f} oracle_bf16 {float(stats_bf["loss"]):.6f} oracle_fp32 {float(stats_32["loss"]):.6f}')
+  assert abs(s['loss'] - float(stats_bf['loss'])) <= 0.02 * abs(float(stats_bf['loss'])) + 1e-5
+  assert abs(s['loss'] - float(stats_32['loss'])) <= 0.05 * abs(float(stats_32['loss'])) + 1e-5
+  rel = lambda a, r: ((a - r).norm() / (r.norm() + 1e-30)).item()
+  for name, b, e in model.modules:
+    r_bf, r_32, cost = rel(g[b:e], g_bf[b:e]), rel(g[b:e], g_32[b:e]), rel(g_bf[b:e], g_32[b:e])
+    cos = (g[b:e] @ g_bf[b:e] / (g[b:e].norm() * g_bf[b:e].norm() + 1e-30)).item()
+    print(f'FULLWIDTH {name}: |g - oracle_bf16| / |g| = {r_bf:.3e}, |g - oracle_fp32| / |g| = {r_32:.3e} '
+          f'(bf16 cost {cost:.3e}), cos {cos:.6f}, |g| = {g_bf[b:e].norm().item():.3e}')
+    assert cos > 0.995 and r_bf <= GRAD_TOL['module_bf16'] and r_32 <= GRAD_TOL['module_fp32'], (name, cos, r_bf, r_32)
+  worst_bf = worst_32 = 0.0
+  for p in model._plans:
+    for d in p.dense:
+      o, nelem = d.kernel_off, d.fan_in * d.fan_out
+      if nelem < 8 or g_bf[o:o + nelem].norm() < 1e-12:
+        continue
+      r_bf, r_32, cost = rel(g[o:o + nelem], g_bf[o:o + nelem]), rel(g[o:o + nelem], g_32[o:o + nelem]), rel(g_bf[o:o + nelem], g_32[o:o + nelem])
+      print(f'FULLWIDTH LAYER {p.module_name}/{d.name}/kernel [{d.fan_in}x{d.fan_out}]: bf16 {r_bf:.3e} fp32 {r_32:.3e} (bf16 cost {cost:.3e})')
+      worst_bf, worst_32 = max(worst_bf, r_bf), max(worst_32, r_32)
+      ob, nb_ = d.bias_off, d.fan_out
+      if nb_ >= 8:
+        worst_bf = max(worst_bf, rel(g[ob:ob + nb_], g_bf[ob:ob + nb_]))
+  print(f'FULLWIDTH worst Dense: bf16 {worst_bf:.3e} fp32 {worst_32:.3e}')
+  assert worst_bf <= GRAD_TOL['dense_bf16'] and worst_32 <= GRAD_TOL['dense_fp32'], (worst_bf, worst_32)
+  # one numeric Adam step at 9.0 M parameters on the kernel's own gradient
+  helpers.assert_adam_matches_oracle(model, cfg, flat.float().cpu(), g.float(), None, state2, what='full width: ')
 
 
 def test_invariants_hold_on_every_ray_of_the_full_batch(setup):

@@ -217,3 +217,57 @@ def test_ide_vs_scipy():
   phi = np.arctan2(xyz[:, 1], xyz[:, 0])
   sh = np.stack([scipy.special.sph_harm(m, l, phi, theta) for m, l in ml.T], -1)
   np.testing.assert_allclose(de, np.concatenate([sh.real, sh.imag], -1), atol=0.02)
+
+
+# ----------------------------------------------------------------------------- summation-order contract of the sampling path
+
+
+def test_oracle_lanes_match_the_kernel_source():
+  """oracle.stepfun.blocked_cumsum restates the level kernel's chunking by hand: the chunk count must be the kernel's
+  lanes per ray (csrc/resample.hip RSP_LPR), or 'bit-exact by construction' silently stops being about the kernel."""
+  import os
+  import re
+  src = open(os.path.join(os.path.dirname(__file__), '..', 'multinerf_amd', 'csrc', 'resample.hip')).read()
+  m = re.search(r'^#define\s+RSP_LPR\s+(\d+)', src, re.M)
+  assert m and int(m.group(1)) == stepfun.LANES
+
+
+def _rand_stepfun(gen, B, n):
+  d = torch.rand((B, n + 1), generator=gen) + 0.02
+  t = torch.cumsum(d, -1)
+  t = (t - t[:, :1]) / (t[:, -1:] - t[:, :1])
+  w = torch.rand((B, n), generator=gen) ** 3
+  return t.float(), (w / w.sum(-1, keepdim=True)).float()
+
+
+@pytest.mark.parametrize('n_prev,n,dil', [(64, 64, 0.0103125), (64, 32, 0.00262207), (128, 128, 0.0)])
+def test_kernel_order_vs_reference_order(n_prev, n, dil):
+  """The fp32 oracle evaluates the sampling path in the HIP kernel's association order (blocked sums, the kernel's own
+  exp / log); the reference sums left to right with the host library's exp / log (stepfun.py:146,156).  Both are held to
+  the float64 goldens by tolerance above; here the two are compared with each other on the resample inputs of the GPU
+  tests: the sample positions agree to a few ulps of the CDF and the INDEX mismatch rate between the two orders is
+  reported and bounded (it is what 'bit-exact sample indices' costs when the order is not pinned)."""
+  gen = torch.Generator().manual_seed(3)
+  B = 400
+  sd, w = _rand_stepfun(gen, B, n_prev)
+  w = w * 0.98
+  u_jit = torch.rand((B, 1), generator=gen)
+
+  def run():
+    s_, w_ = sd, w
+    if dil > 0:
+      s_, w_ = stepfun.max_dilate_weights(s_, w_, dil, domain=(0., 1.), renormalize=True)
+      s_, w_ = s_[..., 1:-1], w_[..., 1:-1]
+    logits = stepfun.resample_logits(s_, w_, 0.9090909, 0.0)
+    return stepfun.sample_intervals(u_jit, s_, logits, n, single_jitter=True, domain=(0., 1.), return_index=True)
+
+  s_k, i_k = run()
+  with stepfun.reference_order():
+    s_r, i_r = run()
+  mism = int((i_k != i_r).sum())
+  rate = mism / i_k.numel()
+  print(f'n_prev={n_prev} n={n} dilation={dil}: kernel-order vs reference-order index mismatches {mism} of {i_k.numel()} '
+        f'({rate:.2e}); max |s| difference {(s_k - s_r).abs().max().item():.2e}')
+  assert rate < 5e-3
+  # a flipped index moves a sample across a CDF knot it was within an ulp of: the position itself barely moves
+  np.testing.assert_allclose(s_k.numpy(), s_r.numpy(), atol=5e-5, rtol=0)

@@ -31,7 +31,11 @@ def main():
   w = sum(v[1] for k, v in write.items() if any(n in k for n in MFMA))
   total_f = sum(v[1] for v in fetch.values())
   total_w = sum(v[1] for v in write.values())
+  import os
+  stamp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'multinerf_amd', 'libmnerf_hip.so.stamp')
   out = {
+      # the build these counters were read on (bench.py reports the figure only for that build)
+      'lib_digest': open(stamp).read().strip() if os.path.exists(stamp) else None,
       'source': f'{sys.argv[1]} + {sys.argv[2]} (separate rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1; tools/profile_round.sh)',
       'train_steps_in_profile': steps,
       'mfma_kernels': list(MFMA),
