@@ -475,7 +475,7 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd_kernel(mnr_mlp_chain_bwd_ar
 }
 
 static int fm_grid(int64_t tiles) {
-  const int cus = mnr_cu_count();
+  const int cus = mnr_cu_budget();
   return (int)(tiles < cus ? tiles : cus);
 }
 

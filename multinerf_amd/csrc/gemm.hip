@@ -209,7 +209,7 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   // tile's K loop instead of in front of the workgroup's retirement, and the per-workgroup launch gap goes away.
   int64_t grid = vtotal;
   if (g_nt_persist != 0 && CFG::LDS_BYTES > 80 * 1024) {
-    const int64_t cap = g_nt_persist > 0 ? (int64_t)g_nt_persist * mnr_cu_count() : -(int64_t)g_nt_persist;
+    const int64_t cap = g_nt_persist > 0 ? (int64_t)g_nt_persist * mnr_cu_budget() : -(int64_t)g_nt_persist;
     if (grid > cap && cap >= 8) grid = cap / 8 * 8;
   }
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
@@ -443,7 +443,7 @@ static bool nt_wres_eligible(const mnr_gemm_nt_args* a, int fast_epi) {
 }
 
 static int nt_wres_launch(const mnr_gemm_nt_args* a, int max_wgs, void* stream) {
-  const int cus = mnr_cu_count();
+  const int cus = mnr_cu_budget();
   const int64_t mt = a->M / 256;
   const int cap = max_wgs > 1 ? max_wgs : cus;            // MNR_NT_WRES = 1: one workgroup per CU; n > 1: at most n workgroups
   const int grid = (int)(mt < cap ? mt : cap);
@@ -527,6 +527,15 @@ typedef TnCfg<2, 2, 2, 2> TnSmall;   // 128x128 output tile, 4 waves,  64 KiB
 typedef TnCfg<4, 2, 2, 4> TnBig;     // 256x256 output tile, 8 waves, 128 KiB
 
 
+static inline int mnr_gcd(int a, int b) {
+  while (b) {
+    const int t = a % b;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
 template <class CFG>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
 #include "gemm_tn_body.inc"
@@ -536,10 +545,22 @@ template <class CFG>
 static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   const int tiles = (a->K / CFG::BKO) * (a->N / CFG::BNO);
   const int total_steps = (int)(a->M / TN_BM);
-  // Enough M-splits for >= target_wgs workgroups, in multiples of 8 (one group of tiles per XCD).
-  int splits = ((target_wgs + tiles - 1) / tiles + 7) / 8 * 8;
-  if (splits < 8) splits = 8;
-  while (splits > 8 && (total_steps + splits - 1) / splits < 4) splits -= 8;
+  // Enough M-splits for ~target_wgs workgroups.  The grid (splits x tiles) is a multiple of 8 and workgroup b belongs to
+  // XCD b % 8: the kernel hands XCD x the (split, tile) pairs [x * grid / 8, (x + 1) * grid / 8) in split-major order, so
+  // the tiles of one split (which share its operand rows) run on one XCD (two when a split straddles a boundary).
+  // With the whole chip as the budget that is the round-1 rule (a multiple of 8 splits, >= target); under a CU budget
+  // (mnr_set_cu_budget: two streams side by side) the grid must not EXCEED the budget, or the surplus workgroups run as a
+  // second round behind the first.
+  const int unit = 8 / mnr_gcd(tiles, 8);                  // splits come in multiples of this
+  int splits;
+  if (g_mnr_cu_budget > 0 && target_wgs <= mnr_cu_count()) {
+    const int budget = target_wgs < mnr_cu_budget() ? target_wgs : mnr_cu_budget();
+    splits = budget / tiles / unit * unit;
+  } else {
+    splits = ((target_wgs + tiles - 1) / tiles + 7) / 8 * 8;
+  }
+  if (splits < unit) splits = unit;
+  while (splits > unit && (total_steps + splits - 1) / splits < 4) splits -= unit;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   const int64_t grid = (int64_t)splits * tiles;
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
@@ -582,7 +603,9 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
     const char* e = getenv("MNR_TN_SMALL_TARGET_WGS");
     tn_small_target = e ? atoi(e) : 768;
   }
-  return tn_launch<TnSmall>(a, tn_small_target, stream);
+  // (the 64-KiB small tile runs two or three workgroups per CU: its target scales with the CU budget)
+  const int small_target = g_mnr_cu_budget > 0 ? (int)((long long)tn_small_target * mnr_cu_budget() / mnr_cu_count()) : tn_small_target;
+  return tn_launch<TnSmall>(a, small_target, stream);
 }
 
 // ---------------------------------------------------------------------------

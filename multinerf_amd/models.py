@@ -38,6 +38,37 @@ def _rup(x, m):
 import os as _os
 _USE_BITS = _os.environ.get('MNR_RELU_BITS', '1') != '0'   # A/B switch: 1-bit ReLU masks vs re-reading activations
 _USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused per-level Dense chain vs one GEMM per layer
+# A/B switch: the weight-gradient GEMMs (dW_l = x_{l-1}^T dY_l) on a second HIP stream behind the dX chain.  dW_l and the
+# dX GEMM that turns dY_l into dY_{l-1} are independent, so with one dY buffer per layer (instead of two ping-pong
+# buffers) the dX chain runs ahead and the dW launches fill the CUs each dX launch's tail leaves idle (and the other way
+# round); both are full-size launches, nothing is partitioned.
+_DW_STREAM = _os.environ.get('MNR_DW_STREAM', '0') != '0'
+
+
+class _SideLaunch:
+  """`with model._dw():` the launches inside go to the weight-gradient stream, ordered after everything enqueued on the
+  current stream so far; a no-op context when the switch is off (or on the kernel-source simulator's host tensors)."""
+
+  def __init__(self, model):
+    self.model = model
+
+  def __enter__(self):
+    s2 = self.model._dw_stream
+    if s2 is None:
+      return self
+    cur = torch.cuda.current_stream(self.model.device)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    s2.wait_event(ev)
+    self.ctx = torch.cuda.stream(s2)
+    self.ctx.__enter__()
+    self.model._dw_pending = True
+    return self
+
+  def __exit__(self, *exc):
+    if self.model._dw_stream is not None:
+      self.ctx.__exit__(*exc)
+    return False
 
 
 # =============================================================================
@@ -338,6 +369,8 @@ class Model:
       p.basis_dev = torch.as_tensor(p.basis, dtype=f32, device=self.device).contiguous()
       self._layout_packed(p)
     self._ws: Dict[Any, torch.Tensor] = {}
+    self._dw_stream = torch.cuda.Stream(device=self.device) if (_DW_STREAM and self.device.type == 'cuda') else None
+    self._dw_pending = False
     self._built = True
     return self
 
@@ -867,6 +900,18 @@ class Model:
     res['raw_density'] = raw_density
     return res
 
+  def _dw(self):
+    return _SideLaunch(self)
+
+  def _dw_join(self):
+    """The current stream waits for the weight-gradient launches enqueued so far (end of a level's backward pass: the
+    gradient vector is complete, the per-level buffers they read may be overwritten)."""
+    if self._dw_stream is not None and self._dw_pending:
+      ev = torch.cuda.Event()
+      ev.record(self._dw_stream)
+      torch.cuda.current_stream(self.device).wait_event(ev)
+      self._dw_pending = False
+
   def _glo_table(self, flat):
     G = self.num_glo_features
     return flat[self.glo_off:self.glo_off + self.num_glo_embeddings * G].view(self.num_glo_embeddings, G)
@@ -884,9 +929,22 @@ class Model:
     acts = mlp['acts']
     x_last = acts[-1]
     W = plan.W
+    D = len(plan.trunk)
+    per_layer = self._dw_stream is not None                # one dY buffer per layer: the dX chain may run ahead of the dW launches
+
+    def dy_buf(i):
+      """dY of trunk layer i's output: two ping-pong buffers shared across levels, or one per layer (dW stream)."""
+      if per_layer:
+        return self._buf(('bwd', 'dY', W, i), (M, W), bf16)
+      return self._buf(('bwd', 'dA' if (D - 1 - i) % 2 == 0 else 'dB', W), (M, W), bf16)
+
+    def dv_buf(i, nv):
+      if per_layer:
+        return self._buf(('bwd', 'dV', WV, i), (M, WV), bf16)
+      return self._buf(('bwd', 'dV0' if (nv - 1 - i) % 2 == 0 else 'dV1', WV), (M, WV), bf16)
+
     if not mlp.get('chain'):
-      dA = self._buf(('bwd', 'dA', W), (M, W), bf16)     # ping-pong dY buffers (shared across levels)
-      dB = self._buf(('bwd', 'dB', W), (M, W), bf16)
+      dA = dy_buf(D - 1)
 
     def gslice(off, size):
       return grads[off:off + size]
@@ -917,13 +975,13 @@ class Model:
       WV = hp.net_width_viewdirs
       vacts = mlp['vacts']
       d = plan.rgb
-      dV0 = self._buf(('bwd', 'dV0', WV), (M, WV), bf16)
-      dV1 = self._buf(('bwd', 'dV1', WV), (M, WV), bf16)
+      NV = len(plan.view)
+      dV0 = dv_buf(NV - 1, NV)
       h_last = vacts[-1]
       ops.small_head_bwd(h_last, WV, g_raw_rgb, flat[d.kernel_off:d.kernel_off + d.fan_in * 3].view(d.fan_in, 3),
                          M=M, K=WV, Cn=3, dX=dV0, lddx=WV, relu_mask=True,
                          dW=gslice(d.kernel_off, d.fan_in * 3), db=gslice(d.bias_off, 3))
-      dy, other = dV0, dV1
+      dy = dV0
       VI = mlp['VI']
       dVIa = dVIb = None
       want_glo = plan.glo > 0 and self._glo_cam is not None
@@ -936,14 +994,16 @@ class Model:
         inp = VI if i == 0 else vacts[i - 1]
         in_w = plan.ldVI if i == 0 else WV
         # dW (rows of the first input segment; then the skip-concat rows), db
-        ops.gemm_tn(inp, dy, gslice(d.kernel_off, d.fan_in * d.fan_out), M=M, K=in_w, N=WV,
-                    lda=inp.stride(0), ldb=WV, ldc=d.fan_out,
-                    k_valid=(plan.vi_width if i == 0 else WV), n_valid=d.fan_out,
-                    bias_out=gslice(d.bias_off, d.fan_out), bias_n_valid=d.fan_out)
+        with self._dw():
+          ops.gemm_tn(inp, dy, gslice(d.kernel_off, d.fan_in * d.fan_out), M=M, K=in_w, N=WV,
+                      lda=inp.stride(0), ldb=WV, ldc=d.fan_out,
+                      k_valid=(plan.vi_width if i == 0 else WV), n_valid=d.fan_out,
+                      bias_out=gslice(d.bias_off, d.fan_out), bias_n_valid=d.fan_out)
+          if concat:
+            ops.gemm_tn(VI, dy, gslice(d.kernel_off + WV * d.fan_out, plan.vi_width * d.fan_out), M=M,
+                        K=plan.ldVI, N=WV, lda=plan.ldVI, ldb=WV, ldc=d.fan_out, k_valid=plan.vi_width,
+                        n_valid=d.fan_out)
         if concat:
-          ops.gemm_tn(VI, dy, gslice(d.kernel_off + WV * d.fan_out, plan.vi_width * d.fan_out), M=M,
-                      K=plan.ldVI, N=WV, lda=plan.ldVI, ldb=WV, ldc=d.fan_out, k_valid=plan.vi_width,
-                      n_valid=d.fan_out)
           # the view input also receives gradient through the skip concat (bottleneck, IDE / n.v / GLO columns)
           first_skip = dVIb is None
           tVI = self._buf(('bwd', 'dVIb', 0 if first_skip else 1), (M, plan.ldVI), bf16)
@@ -964,8 +1024,9 @@ class Model:
           else:
             ops.gemm_nt(dy, Bw, M=M, N=e['b_rows'], K1=e['b_ld'], Cb=dHB, ldcb=nh, nb=bw, **glo_kw(gGa))
         else:
+          other = dv_buf(i - 1, NV)
           ops.gemm_nt(dy, Bw, M=M, N=WV, K1=e['b_ld'], mask=vacts[i - 1], ldmask=WV, Cb=other, ldcb=WV, nb=WV)
-          dy, other = other, dy
+          dy = other
       if want_glo:
         G = plan.glo
         ops.glo_bwd(gGa, gGb, self._glo_cam, M // n, n, grads[self.glo_off:self.glo_off + self.num_glo_embeddings * G],
@@ -980,15 +1041,16 @@ class Model:
                                       dVIa, dVIb, bw, g_npred, g_normals, dHB, bw + 1, bw + 10)
       # merged head: dW, db, dX_last
       e = plan.packed['head']
-      tmpW = self._buf(('bwd', 'tmpW', W, nh), (W, nh), f32)
-      tmpW.zero_()
-      tmpb = self._buf(('bwd', 'tmpb', nh), (nh,), f32)
-      tmpb.zero_()
-      ops.gemm_tn(x_last, dHB, tmpW, M=M, K=W, N=nh, lda=W, ldb=nh, ldc=nh, bias_out=tmpb,
-                  bias_n_valid=plan.head_cols)
-      for (d, c0) in plan.head_segs:
-        ops.scatter_add(tmpW, nh, 0, c0, W, d.fan_out, gslice(d.kernel_off, W * d.fan_out), d.fan_out)
-        ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
+      with self._dw():
+        tmpW = self._buf(('bwd', 'tmpW', W, nh), (W, nh), f32)
+        tmpW.zero_()
+        tmpb = self._buf(('bwd', 'tmpb', nh), (nh,), f32)
+        tmpb.zero_()
+        ops.gemm_tn(x_last, dHB, tmpW, M=M, K=W, N=nh, lda=W, ldb=nh, ldc=nh, bias_out=tmpb,
+                    bias_n_valid=plan.head_cols)
+        for (d, c0) in plan.head_segs:
+          ops.scatter_add(tmpW, nh, 0, c0, W, d.fan_out, gslice(d.kernel_off, W * d.fan_out), d.fan_out)
+          ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
       Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
       ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=nh, Cb=dA, ldcb=W, nb=W, **mask_kw(len(acts) - 1))
     else:
@@ -1007,10 +1069,12 @@ class Model:
                         for i in range(1, D)]
         ops.mlp_chain_bwd(g_raw_density.view(M), w_head, mlp['bits'], Bws, dYs, M=M, W=W)
         feat = lv['feat']
-        for i, (dl, _) in enumerate(plan.trunk):
-          inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
-          ops.gemm_tn(inp, dYs[i], gslice(dl.kernel_off, kv * W), M=M, K=in_w, N=W, lda=in_w, ldb=W, ldc=W,
-                      k_valid=kv, n_valid=W, bias_out=gslice(dl.bias_off, W), bias_n_valid=W)
+        with self._dw():
+          for i, (dl, _) in enumerate(plan.trunk):
+            inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
+            ops.gemm_tn(inp, dYs[i], gslice(dl.kernel_off, kv * W), M=M, K=in_w, N=W, lda=in_w, ldb=W, ldc=W,
+                        k_valid=kv, n_valid=W, bias_out=gslice(dl.bias_off, W), bias_n_valid=W)
+        self._dw_join()
         return
       ops.small_head_bwd(x_last, W, g_raw_density.view(M, 1), flat[d.kernel_off:d.kernel_off + W].view(W, 1),
                          M=M, K=W, Cn=1, dX=dA, lddx=W, relu_mask=True,
@@ -1018,24 +1082,28 @@ class Model:
     feat = lv['feat']
     if g_raw_grad is not None:
       self._tangent_backward(plan, flat, grads, mlp, feat, M, g_raw_grad)
-    # trunk
-    dy, other = dA, dB
+    # trunk: per layer its dW (independent of the dX chain: on the dW stream when that switch is on), then the dX GEMM the
+    # next layer waits for
+    dy = dA
     for i in reversed(range(len(plan.trunk))):
       d, concat = plan.trunk[i]
       e = plan.packed[('trunk', i)]
-      if i == 0:
-        ops.gemm_tn(feat, dy, gslice(d.kernel_off, plan.F * W), M=M, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
-                    ldc=W, k_valid=plan.F, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W)
-      else:
-        ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W,
-                    bias_out=gslice(d.bias_off, W), bias_n_valid=W)
-        if concat:
-          ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
-                      lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
+      with self._dw():
+        if i == 0:
+          ops.gemm_tn(feat, dy, gslice(d.kernel_off, plan.F * W), M=M, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
+                      ldc=W, k_valid=plan.F, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W)
+        else:
+          ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W,
+                      bias_out=gslice(d.bias_off, W), bias_n_valid=W)
+          if concat:
+            ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
+                        lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
       if i > 0:
         Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
+        other = dy_buf(i - 1)
         ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, **mask_kw(i - 1))
-        dy, other = other, dy
+        dy = other
+    self._dw_join()
 
   def _tangent_backward(self, plan, flat, grads, mlp, feat, M, g_raw_grad):
     """Backward pass through the tangent network T_l = bits_l * (T_{l-1} W_l), raw_grad = T_last w_density

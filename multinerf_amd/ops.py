@@ -69,6 +69,8 @@ class _GemmProfile:
 
   def enable(self):
     self.on, self.events = True, []
+    self.base = torch.cuda.Event(enable_timing=True)     # time origin for the busy-time union across streams
+    self.base.record(torch.cuda.current_stream())
 
   def disable(self):
     self.on = False
@@ -95,12 +97,26 @@ class _GemmProfile:
 
   def collect_by_tag(self):
     """-> {tag: {'ms', 'launches', 'bytes'}}; empties the event list."""
-    out = {}
+    out, spans = {}, {}
     for a, b, tag, nbytes in self.events:
       d = out.setdefault(tag, dict(ms=0.0, launches=0, bytes=0))
       d['ms'] += a.elapsed_time(b)
       d['launches'] += 1
       d['bytes'] += nbytes
+      spans.setdefault(tag, []).append((self.base.elapsed_time(a), self.base.elapsed_time(b)))
+    # 'busy_ms': length of the UNION of the tag's launch intervals (= 'ms' when the launches are serial on one stream;
+    # less when two streams run kernels of the tag side by side, multinerf_amd/streams.py)
+    for tag, iv in spans.items():
+      iv.sort()
+      busy, end = 0.0, None
+      for a0, b0 in iv:
+        if end is None or a0 > end:
+          busy += b0 - a0
+          end = b0
+        elif b0 > end:
+          busy += b0 - end
+          end = b0
+      out[tag]['busy_ms'] = busy
     self.events = []
     return out
 
@@ -398,10 +414,12 @@ _HEAD_SCRATCH = {}
 
 
 def _head_scratch(device):
-  """Workspace for the per-workgroup dW / db partials of mnr_small_head_bwd (4 MiB per device, allocated once)."""
-  t = _HEAD_SCRATCH.get(device)
+  """Workspace for the per-workgroup dW / db partials of mnr_small_head_bwd (4 MiB per device AND stream, allocated
+  once: two levels' backward passes may run side by side on different streams, multinerf_amd/streams.py)."""
+  key = (device, getattr(_stream(), 'value', None))
+  t = _HEAD_SCRATCH.get(key)
   if t is None:
-    t = _HEAD_SCRATCH[device] = torch.empty(1 << 20, dtype=f32, device=device)
+    t = _HEAD_SCRATCH[key] = torch.empty(1 << 20, dtype=f32, device=device)
   return t
 
 

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from multinerf_amd import camera_utils, dist as mdist
+from multinerf_amd import streams as mstreams
 from multinerf_amd import models
 from multinerf_amd import ops
 from multinerf_amd import utils
@@ -73,6 +74,15 @@ def create_train_step(model: models.Model, config, dataset=None):
     raise ValueError(f'orientation_loss_target {config.orientation_loss_target!r} is not a ray_history field')
   lr_fn = lambda step: learning_rate_decay(step, config.lr_init, config.lr_final, config.max_steps,
                                            config.lr_delay_steps, config.lr_delay_mult)
+  side_cache = {}
+
+  def backward_streams(dev):
+    """The proposal levels' backward on its own stream next to the NeRF level's (multinerf_amd/streams.py); None = off."""
+    if dev.type != 'cuda' or model.single_mlp or model.num_levels < 2:
+      return None
+    if 'v' not in side_cache:
+      side_cache['v'] = mstreams.BackwardStreams.from_env(dev)
+    return side_cache['v']
 
   def train_step(rng, state: TrainState, batch, cameras, train_frac, loss_threshold, noise=None,
                  return_grads=False):
@@ -169,7 +179,8 @@ def create_train_step(model: models.Model, config, dataset=None):
     overlap = mdist.world_size() > 1 and nlev > 1 and not model.single_mlp
     if overlap:
       order = [nlev - 1] + order[:-1]
-    for li in order:
+
+    def level_backward(li):
       lv = levels[li]
       if data_spec[li]['mult'] > 0 or w_spec[li] is not None or g_w[li] is not None:
         model.backward_level(lv, flat, grads, None, g_w[li], g_expo, g_nrm[li], g_npr[li],
@@ -184,6 +195,34 @@ def create_train_step(model: models.Model, config, dataset=None):
             if config.weight_decay_mults and name in config.weight_decay_mults:
               ops.weight_decay(flat, b, e, config.weight_decay_mults[name], grads, stats[4 * nlev + 5:4 * nlev + 6])
             early.append((b, e, mdist.all_reduce_sum_async(grads[b:e])))
+
+    bs = backward_streams(dev)
+    if bs is None:
+      for li in order:
+        level_backward(li)
+    else:
+      # Two streams side by side: the proposal levels (HBM-bound) on `bs.prop`, the NeRF level (MFMA-bound) on `bs.nerf`
+      # (or the caller's stream), each sized for its CU share; the caller's stream waits for both.
+      cur = torch.cuda.current_stream(dev)
+      ready = torch.cuda.Event()
+      ready.record(cur)
+      nerf_stream = bs.nerf if bs.nerf is not None else cur
+      if bs.nerf is not None:
+        bs.nerf.wait_event(ready)
+      bs.prop.wait_event(ready)
+      with torch.cuda.stream(bs.prop), mstreams.budget(bs.prop_budget):
+        for li in order:
+          if li != nlev - 1:
+            level_backward(li)
+        done_prop = torch.cuda.Event()
+        done_prop.record(bs.prop)
+      with torch.cuda.stream(nerf_stream), mstreams.budget(bs.nerf_budget):
+        level_backward(nlev - 1)
+        if bs.nerf is not None:
+          done_nerf = torch.cuda.Event()
+          done_nerf.record(bs.nerf)
+          cur.wait_event(done_nerf)
+      cur.wait_event(done_prop)
     if g_expo is not None:
       n_off = model.num_glo_embeddings * 3
       ops.exposure_scale_bwd(R.exposure_values.reshape(-1).contiguous().float(),

@@ -74,6 +74,12 @@ struct hipDeviceProp_t {
 inline const char* hipGetErrorString(hipError_t) { return "hipsim"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+// (streams: the simulator runs every launch to completion at the call; a "CU-masked stream" is just another null handle)
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) {
+  *s = nullptr;
+  return hipSuccess;
+}
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) {
   *d = 0;
   return hipSuccess;
