@@ -51,7 +51,9 @@ def algorithmic_flops_per_ray(model):
       elif concat:
         no_dx += plan.F * d.fan_out
     macs += plan.density.fan_in
-    if plan.has_rgb:
+    if plan.has_rgb and plan.bottleneck is None:       # use_viewdirs = False: rgb straight off the trunk
+      macs += plan.rgb.fan_in * plan.rgb.fan_out
+    elif plan.has_rgb:
       macs += plan.bottleneck.fan_in * plan.bottleneck.fan_out
       for li, (d, concat) in enumerate(plan.view):
         macs += d.fan_in * d.fan_out

@@ -207,6 +207,8 @@ int mnr_debug_gemm_timeline(unsigned long long* device_buffer);
    MFMAs), 0 = the two-stage BK = 64 loop.  Bitwise equal results. */
 int mnr_gemm_nt_set_pipelined(int on);
 int mnr_gemm_nt_set_persistent(int wgs_per_cu);
+/* A/B switch: 1 = the bf16 output tile (and its 1-bit masks) leaves with streaming (non-temporal) stores; 0 (default) = plain. */
+int mnr_gemm_nt_set_nt_stores(int on);
 /* A/B switch: 1 (default) = eligible short-K launches (N = 256, K1 <= 256, K2 = 0, full-width bf16 output, no fp32 side
  * output, no bf16 mask) go to the weights-resident persistent kernel (weights in registers, one workgroup per CU walking
  * the M tiles); n > 1 = the same with at most n workgroups; 0 = off. */
@@ -288,6 +290,11 @@ int mnr_scatter_add_f32(const float* src, int ld_src, int row0, int col0, int ro
 /* fp32 -> bf16 cast of a strided matrix [M, n] (ld_src) into dst [M, ld_dst] at col0. */
 int mnr_cast_f32_to_bf16(const float* src, int ld_src, int64_t M, int n, uint16_t* dst, int ld_dst,
                          int col0, void* stream);
+
+/* X[m, c] += scale * noise[m, c] (fp32 add, one bf16 rounding) for the first `cols` columns of the bf16 matrix X [M, ld]:
+ * the bottleneck noise of models.py:530-533 (`bottleneck += bottleneck_noise * random.normal(...)`) on the
+ * bottleneck columns of the view-MLP input.  noise fp32 [M, cols], cols %% 8 == 0. */
+int mnr_add_noise_bf16(int64_t M, int cols, uint16_t* X, int ld, const float* noise, float scale, void* stream);
 
 /* Small-N dense VJP pieces (heads with 1..4 outputs, e.g. the rgb Dense(3)):
  *  dX[m,k] = relu'(H[m,k]) * sum_c g[m,c] W[k,c]          (bf16 out)

@@ -155,9 +155,11 @@ _PROTOS = {
     'mnr_mlp_chain_bwd': ([C.POINTER(MlpChainBwdArgs), vp], i32),
     'mnr_debug_chain_timeline': ([vp], i32),
     'mnr_gemm_tn_set_config': ([i32], i32),
+    'mnr_gemm_nt_set_nt_stores': ([i32], i32),
     'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),
     'mnr_pack_weights_bf16': ([vp, vp, i32, i32, vp, vp], i32),
     'mnr_scatter_add_f32': ([vp, i32, i32, i32, i32, i32, vp, i32, vp], i32),
+    'mnr_add_noise_bf16': ([i64, i32, vp, i32, vp, f32, vp], i32),
     'mnr_cast_f32_to_bf16': ([vp, i32, i64, i32, vp, i32, i32, vp], i32),
     'mnr_small_head_bwd': ([i64, i32, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i64, vp, i64, vp], i32),
     'mnr_composite_fwd': ([C.POINTER(CompositeCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),

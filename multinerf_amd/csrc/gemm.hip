@@ -189,6 +189,12 @@ extern "C" int mnr_gemm_nt_set_pipelined(int on) {
   return MNR_OK;
 }
 
+static int g_nt_nt_stores = 0;
+extern "C" int mnr_gemm_nt_set_nt_stores(int on) {
+  g_nt_nt_stores = on;
+  return MNR_OK;
+}
+
 extern "C" int mnr_gemm_nt_set_persistent(int wgs_per_cu) {
   g_nt_persist = wgs_per_cu;
   return MNR_OK;
@@ -438,7 +444,7 @@ extern "C" int mnr_gemm_nt_set_wres(int max_wgs) {
 }
 
 static bool nt_wres_eligible(const mnr_gemm_nt_args* a, int fast_epi) {
-  return a->N == 256 && a->K2 == 0 && a->K1 <= 256 && a->M % 256 == 0 && !a->mask && !a->Cf && a->Cb && a->nb == a->N && fast_epi &&
+  return a->N == 256 && a->K2 == 0 && a->K1 <= 256 && a->M % 256 == 0 && !a->mask && !a->Cf && a->Cb && a->nb == a->N && (fast_epi & 1) &&
          (!a->mask_bits_out || (a->ld_bits_out % 4 == 0)) && (!a->mask_bits_in || ((a->bits_row_mod == 0 || a->bits_row_mod >= 256) && !a->bias && !a->relu && !a->mask_bits_out));
 }
 
@@ -478,8 +484,9 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
                                       a->ld_bits_out % 4 == 0 && ((uintptr_t)a->mask_bits_out % 4) == 0),
                 "mnr_gemm_nt_bf16: mask_bits_out needs a full-width, 16-byte-aligned bf16 output and a 4-byte-aligned bit matrix");
   // 16-byte row segments in the epilogue need 8-element-aligned output / mask pitches and bases.
-  const int fast_epi = (!a->Cb || (a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0)) &&
-                       (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0));
+  const int fast_epi = (int)((!a->Cb || (a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0)) &&
+                             (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0))) |
+                       (g_nt_nt_stores ? 2 : 0);     // bit 1: streaming stores of the bf16 output tile (A/B switch)
   if (g_nt_wres > 0 && nt_wres_eligible(a, fast_epi)) return nt_wres_launch(a, g_nt_wres, stream);
 #ifdef MNR_NT_DEBUG_VARIANTS      // probe build (tools/nt_pipe_probe.py): the pipelined loop with one ingredient removed
   if (a->M % 256 == 0 && a->N % 256 == 0) {
@@ -727,6 +734,37 @@ extern "C" int mnr_cast_f32_to_bf16(const float* src, int ld_src, int64_t M, int
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, ld_src, M, n,
                      (bf16*)dst, ld_dst, col0);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// X[m, c] = bf16(float(X[m, c]) + scale * noise[m, c]) for c < cols (a multiple of 8): the bottleneck noise of
+// reference internal/models.py:530-533, added to the bf16 bottleneck columns of the view-MLP input in fp32.
+__global__ __launch_bounds__(256) void add_noise_bf16_kernel(int64_t M, int cols, bf16* __restrict__ X, int ld,
+                                                             const float* __restrict__ noise, float scale) {
+  const int cpr = cols / 8;
+  const int64_t total = M * cpr;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cpr;
+    const int c = (int)(e % cpr) * 8;
+    bf16x8 v = *(const bf16x8*)(X + r * ld + c);
+    const f32x4 n0 = *(const f32x4*)(noise + r * cols + c), n1 = *(const f32x4*)(noise + r * cols + c + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = (bf16)((float)v[i] + scale * n0[i]);
+      v[4 + i] = (bf16)((float)v[4 + i] + scale * n1[i]);
+    }
+    *(bf16x8*)(X + r * ld + c) = v;
+  }
+}
+
+extern "C" int mnr_add_noise_bf16(int64_t M, int cols, uint16_t* X, int ld, const float* noise, float scale, void* stream) {
+  MNR_CHECK_ARG(X && noise && M > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols &&
+                    ((uintptr_t)X % 16) == 0 && ((uintptr_t)noise % 16) == 0,
+                "mnr_add_noise_bf16: cols and ld must be multiples of 8, pointers 16-byte aligned");
+  int64_t want = (M * (cols / 8) + 255) / 256;
+  const int grid = (int)(want > 8192 ? 8192 : want);
+  hipLaunchKernelGGL(add_noise_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, cols, (bf16*)X, ld, noise, scale);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }

@@ -140,8 +140,6 @@ class MLP:
       bad.append('density-gradient normals with a warp_fn')
     if self.is_ref() and self.roughness_activation != 'softplus':
       bad.append('roughness_activation != softplus')
-    if self.bottleneck_noise > 0:
-      bad.append('bottleneck_noise')
     if self.net_activation != 'relu':
       bad.append(f'net_activation={self.net_activation}')
     if self.warp_fn not in (None, 'contract'):
@@ -259,12 +257,17 @@ class MLPPlan:
       else:
         rgb_in = self.x_width
       self.rgb = add(rgb_in, hp.num_rgb_channels)                    # models.py:585
-      # merged head: (Dense, first column) -- bottleneck first, then the scalar / 3-vector heads
-      bw = hp.bottleneck_width
-      self.head_segs = [(self.bottleneck, 0), (self.density, bw)]
-      if self.ref:
-        self.head_segs += [(self.gradpred, bw + 1), (self.diffuse, bw + 4), (self.tint, bw + 7), (self.rough, bw + 10)]
-      self.head_cols = bw + (11 if self.ref else 1)
+      if self.use_viewdirs:
+        # merged head: (Dense, first column) -- bottleneck first, then the scalar / 3-vector heads
+        bw = hp.bottleneck_width
+        self.head_segs = [(self.bottleneck, 0), (self.density, bw)]
+        if self.ref:
+          self.head_segs += [(self.gradpred, bw + 1), (self.diffuse, bw + 4), (self.tint, bw + 7), (self.rough, bw + 10)]
+        self.head_cols = bw + (11 if self.ref else 1)
+      else:
+        # use_viewdirs = False (models.py:57,226,585): rgb = Dense(3)(trunk output); density and rgb share one 4-column head
+        self.head_segs = [(self.density, 0), (self.rgb, 1)]
+        self.head_cols = 4
     # flat parameter offsets: kernel then bias, Dense_k in creation order
     off = param_base
     for d in self.dense:
@@ -324,6 +327,8 @@ class Model:
       bad += [f'{name}: {b}' for b in hp.hip_supported()]
     if not self.stop_level_grad:
       bad.append('stop_level_grad=False')
+    if not self.use_viewdirs and (self.nerf_hp.is_ref() or self.prop_hp.is_ref()):
+      bad.append('the Ref-NeRF head without view directions')
     if self.ray_shape not in ('cone', 'cylinder'):
       raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')
     if self.num_glo_features > 0 and self.single_mlp:
@@ -458,7 +463,11 @@ class Model:
       assert not getattr(p, 'v_concat', False), 'view MLP ending on a skip layer is not supported on the HIP path'
       pack_layer('rgb', p.rgb, [(0, p.rgb.fan_in, 0, _rup(p.rgb.fan_in, 64))], 128)
     elif p.has_rgb:
-      raise NotImplementedError('use_viewdirs=False with rgb is not yet on the HIP path')
+      # use_viewdirs = False: [density | rgb] as one 4-column forward operand (rows 0..3 of a 128-row tile)
+      fo = alloc(128, p.W)
+      for (d, c0) in p.head_segs:
+        descs.append(L.PackDesc(d.kernel_off, p.W, d.fan_out, fo, p.W, c0, 0, 1))
+      p.packed['head4'] = dict(f_off=fo, f_ld=p.W, n_pad=128)
     else:
       pack_layer('density', p.density, [(0, p.W, 0, p.W)], 128)
     p.packed_elems = off
@@ -467,7 +476,7 @@ class Model:
     p.pack_descs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
     p.pack_max_elems = max(d.rows_in * d.cols_out for d in descs)
     p.wbf = torch.zeros(off, dtype=bf16, device=self.device)     # padding stays zero forever
-    if p.has_rgb and p.use_viewdirs:
+    if p.has_rgb:
       p.head_bias = torch.zeros(_rup(p.head_cols, 128), dtype=f32, device=self.device)
     if p.ref:
       p.ide = ops.IdeTablesDev(p.hp.deg_view, self.device)
@@ -476,7 +485,7 @@ class Model:
     """fp32 master parameters -> bf16 GEMM operands (one launch per MLP)."""
     for p in self._plans:
       ops.pack_weights(flat_params, p.pack_descs_dev, len(p.pack_descs), p.pack_max_elems, p.wbf)
-      if p.has_rgb and p.use_viewdirs:
+      if p.has_rgb:
         for (d, c0) in p.head_segs:
           p.head_bias[c0:c0 + d.fan_out].copy_(flat_params[d.bias_off:d.bias_off + d.fan_out])
 
@@ -671,7 +680,17 @@ class Model:
                         warp_contract=(hp.warp_fn == 'contract'), min_deg=hp.min_deg_point,
                         max_deg=hp.max_deg_point, ld_feat=plan.ldF, disable_integration=self.disable_integration,
                         out=feat)
-      mlp_out = self._mlp_forward(plan, flat, feat, M, n, R, tag, keep_for_backward, tdist=tdist)
+      bnoise = None
+      if randomized and plan.has_rgb and plan.use_viewdirs and hp.bottleneck_noise > 0:      # models.py:530-533
+        bw_ = hp.bottleneck_width
+        if noise is not None and 'bottleneck_noise' in noise:
+          bnoise = noise['bottleneck_noise'][i_level].to(dev).reshape(-1, n, bw_).float()
+          if bnoise.shape[0] != Bp:
+            bnoise = torch.cat([bnoise, bnoise[-1:].expand(Bp - bnoise.shape[0], n, bw_)], 0)
+          bnoise = bnoise.reshape(M, bw_).contiguous()
+        else:
+          bnoise = torch.randn((M, bw_), generator=gen, device=dev, dtype=f32)
+      mlp_out = self._mlp_forward(plan, flat, feat, M, n, R, tag, keep_for_backward, tdist=tdist, bnoise=bnoise)
 
       # --- density noise (models.py:462-464), background colour (:241-254)
       dnoise = None
@@ -787,7 +806,7 @@ class Model:
                       b_head=flat[d.bias_off:d.bias_off + 1], head_out=raw_density, acts=acts, bits=bits)
     return dict(acts=acts or [], bits=bits or [], raw_density=raw_density, chain=True)
 
-  def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep, tdist=None):
+  def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep, tdist=None, bnoise=None):
     """MLP.__call__ (models.py:402-612) for the M = B*n samples of one level."""
     hp = plan.hp
     if self._chain_ok(plan):
@@ -816,6 +835,17 @@ class Model:
       x = out
     res = dict(acts=acts, bits=bits)
     raw_density = self._buf((tag, 'raw_density'), (M,), f32)
+    if plan.has_rgb and not plan.use_viewdirs:
+      # models.py:585 with x = the trunk output: one 4-column head [raw_density | raw_rgb] as an fp32 side output
+      e = plan.packed['head4']
+      small4 = self._buf((tag, 'small4'), (M, 4), f32)
+      ops.gemm_nt(x, self._w(plan, e['f_off'], e['n_pad'], e['f_ld']), M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias,
+                  n_bias=4, relu=False, Cf=small4, ldcf=4, f0=0, nf=4)
+      raw_density.copy_(small4[:, 0])
+      raw_rgb = self._buf((tag, 'raw_rgb'), (M, 3), f32)
+      raw_rgb.copy_(small4[:, 1:4])
+      res.update(raw_rgb=raw_rgb, raw_density=raw_density)
+      return res
     if plan.has_rgb:
       bw = hp.bottleneck_width
       e = plan.packed['head']
@@ -862,6 +892,9 @@ class Model:
         ops.viewdir_enc_fill(R.viewdirs, n, hp.deg_view, VI, bw, plan.ldVI)
       if plan.glo > 0:
         ops.glo_fill(self._glo_table(flat), self._glo_cam, M // n, n, VI, plan.glo_col)
+      if bnoise is not None:
+        # bottleneck += bottleneck_noise * N(0, 1) (models.py:530-533): additive, so the backward pass is unchanged
+        ops.add_noise_bf16(VI, bw, bnoise, hp.bottleneck_noise)
       h = VI
       vacts, vbits = [], []
       WV = hp.net_width_viewdirs
@@ -956,7 +989,26 @@ class Model:
       return dict(mask=acts[i], ldmask=W)
 
     g_raw_grad = None
-    if plan.has_rgb:
+    if plan.has_rgb and not plan.use_viewdirs:
+      g_raw_density, g_rgb = ops.composite_bwd(
+          lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], raw_rgb=lv['raw_rgb'],
+          density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights, want_f32=True,
+          exposure_scale=lv['expo'], g_exposure_scale=g_expo if lv['expo'] is not None else None, losses=losses)
+      # the 4-column head [density | rgb]: dX into the trunk, dW / db scattered to the two Dense layers
+      g4 = self._buf(('bwd', 'g4'), (M, 4), f32)
+      g4[:, 0].copy_(g_raw_density.view(M))
+      g4[:, 1:4].copy_(g_rgb.view(M, 3))
+      dn, dr = plan.density, plan.rgb
+      w4 = self._buf(('bwd', 'w4', W), (W, 4), f32)
+      w4[:, 0].copy_(flat[dn.kernel_off:dn.kernel_off + W])
+      w4[:, 1:4].copy_(flat[dr.kernel_off:dr.kernel_off + 3 * W].view(W, 3))
+      t4 = self._buf(('bwd', 't4', W), (W + 1, 4), f32)
+      t4.zero_()
+      ops.small_head_bwd(x_last, W, g4, w4, M=M, K=W, Cn=4, dX=dA, lddx=W, relu_mask=True, dW=t4[:W].view(-1), db=t4[W])
+      for (d, c0) in plan.head_segs:
+        ops.scatter_add(t4, 4, 0, c0, W, d.fan_out, gslice(d.kernel_off, W * d.fan_out), d.fan_out)
+        ops.scatter_add(t4, 4, W, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
+    elif plan.has_rgb:
       bw = hp.bottleneck_width
       e = plan.packed['head']
       nh = e['nb_pad']

@@ -54,6 +54,8 @@ def lib():
       L.check(L.load().mnr_gemm_nt_set_pipelined(int(os.environ['MNR_NT_PIPE'])))
     if os.environ.get('MNR_LEVEL_BWD_QUAD'):    # A/B switch: four-lanes-per-ray level backward (0: lane per ray)
       L.check(L.load().mnr_level_bwd_set_quad(int(os.environ['MNR_LEVEL_BWD_QUAD'])))
+    if os.environ.get('MNR_NT_STORES'):         # A/B switch: streaming stores of the NT GEMM's output tile (1: on)
+      L.check(L.load().mnr_gemm_nt_set_nt_stores(int(os.environ['MNR_NT_STORES'])))
     if os.environ.get('MNR_NT_WRES'):           # A/B switch: weights-resident kernel for the short-K layers (0: off)
       L.check(L.load().mnr_gemm_nt_set_wres(int(os.environ['MNR_NT_WRES'])))
   return L.load()
@@ -408,6 +410,16 @@ def cast_f32_to_bf16(src, ld_src, M, n, dst, ld_dst, col0):
   _chk(src, f32, 'src')
   _chk(dst, bf16, 'dst')
   L.check(lib().mnr_cast_f32_to_bf16(_ptr(src), ld_src, M, n, _ptr(dst), ld_dst, col0, _stream()))
+
+
+def add_noise_bf16(X, cols, noise, scale):
+  """X[:, :cols] += scale * noise (fp32 add, one bf16 rounding); X bf16 [M, ld], noise fp32 [M, cols]."""
+  _chk(noise, f32, 'noise')
+  if X.dtype != bf16 or not _on_device(X):
+    raise ValueError('X must be a bf16 device tensor')
+  M = X.shape[0]
+  assert noise.shape == (M, cols)
+  L.check(lib().mnr_add_noise_bf16(M, cols, _ptr(X), X.stride(0), _ptr(noise), float(scale), _stream()))
 
 
 _HEAD_SCRATCH = {}

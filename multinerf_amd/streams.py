@@ -6,8 +6,9 @@ power-bound.  `BackwardStreams` runs the two on separate HIP streams; with a CU 
 mask (mnr_stream_create_cu_mask = hipExtStreamCreateWithCUMask) and the persistent kernels launched on it are sized for
 its share (mnr_set_cu_budget), so that neither side's workgroups queue behind the other's.
 
-Environment (A/B switches; the default is what measured best):
-  MNR_SIDE_STREAM = 0 | 1      proposal-level backward on its own stream
+Environment (A/B switches; the default is what measured best, DESIGN.md section 6: round 3, same box, 360.gin at
+16384 rays: one stream 487.6 k rays/s, plain side stream 500.5 k, CU-masked 32 / 64 CUs 466 k / 480 k):
+  MNR_SIDE_STREAM = 1 | 0      proposal-level backward on its own stream (default on)
   MNR_SIDE_CUS    = k          k > 0: CU-masked pair, the proposal side gets k CUs (a multiple of 8), the NeRF side the rest;
                                0: two plain streams, every launch sized for the whole chip
 """
@@ -63,7 +64,7 @@ class BackwardStreams:
 
   @staticmethod
   def from_env(device):
-    if os.environ.get('MNR_SIDE_STREAM', '0') == '0':
+    if os.environ.get('MNR_SIDE_STREAM', '1') == '0':
       return None
     return BackwardStreams(device, int(os.environ.get('MNR_SIDE_CUS', '0')))
 
@@ -73,7 +74,7 @@ class BackwardStreams:
 
 def describe_env():
   """What MNR_SIDE_STREAM / MNR_SIDE_CUS ask for (bench.py records it next to its numbers)."""
-  on = os.environ.get('MNR_SIDE_STREAM', '0') != '0'
+  on = os.environ.get('MNR_SIDE_STREAM', '1') != '0'
   return {'side_stream': on, 'side_cus': int(os.environ.get('MNR_SIDE_CUS', '0')) if on else 0}
 
 

@@ -29,4 +29,12 @@ def make_noise(model, B, seed=0):
     noise['u_jitter'][i] = torch.rand((B, 1 if model.single_jitter else n), generator=g)
     noise['density_noise'][i] = torch.randn((B, n), generator=g)
     noise['bg_rgbs'][i] = torch.rand((B, 3), generator=g)
+  # bottleneck noise (models.py:530-533) from its own generator: the draws above stay what they were without it
+  g2 = torch.Generator().manual_seed(seed + 1000)
+  for i in range(model.num_levels):
+    is_prop = i < model.num_levels - 1
+    hp = model.prop_hp if is_prop else model.nerf_hp
+    if hp.bottleneck_noise > 0 and not hp.disable_rgb and model.use_viewdirs:
+      n = model.num_prop_samples if is_prop else model.num_nerf_samples
+      noise.setdefault('bottleneck_noise', {})[i] = torch.randn((B, n, hp.bottleneck_width), generator=g2)
   return noise

@@ -62,10 +62,20 @@ def _setup(name, extra, B, seed=3):
 # sdist 2.2e-3, weights 4.4e-3, rgb 3.5e-3, grad 6.9e-2; blender_256 1.5e-4 / 4.3e-4 / 6.5e-4 / 2.6e-2;
 # llff_raw 6.7e-5 / 4.3e-5 / 1.0e-5 / 7.5e-3; blender_refnerf 2.7e-5 / 9.5e-5 / 1.8e-4 / 8.1e-3.
 TOL = {
-    '360': dict(sdist=5e-3, weights=1e-2, rgb=8e-3, grad=0.15),
-    'blender_256': dict(sdist=5e-4, weights=1.5e-3, rgb=2e-3, grad=0.06),
-    'llff_raw': dict(sdist=3e-4, weights=2e-4, rgb=5e-5, grad=0.03),
-    'blender_refnerf': dict(sdist=1e-4, weights=4e-4, rgb=6e-4, grad=0.03),
+    '360': dict(sdist=5e-3, weights=1e-2, rgb=8e-3, grad=0.10),
+    'blender_256': dict(sdist=5e-4, weights=1.5e-3, rgb=2e-3, grad=0.04),
+    'llff_raw': dict(sdist=3e-4, weights=2e-4, rgb=5e-5, grad=0.015),
+    'blender_refnerf': dict(sdist=1e-4, weights=4e-4, rgb=6e-4, grad=0.02),
+}
+# The same outputs against the PLAIN fp32 oracle (north_star: "within a stated fp32 tolerance"): |kernel - oracle_fp32|,
+# i.e. the kernels' own error plus the precision cost of bf16 Dense inputs, which dominates it (the reference's TPU default
+# precision pays the same cost: internal/math.py:21-23).  Measured in round 3 (gpurun_out/r3_gpu_tests*.log): rgb 360
+# <= 9.6e-3, blender_256 <= 1.7e-3, blender_refnerf <= 7.6e-4, llff_raw <= 1.9e-5.
+TOL32 = {
+    '360': dict(sdist=2e-2, weights=4e-2, rgb=1.5e-2, grad=0.30),
+    'blender_256': dict(sdist=2e-3, weights=6e-3, rgb=2.5e-3, grad=0.06),
+    'llff_raw': dict(sdist=1e-3, weights=8e-4, rgb=3e-5, grad=0.04),
+    'blender_refnerf': dict(sdist=4e-4, weights=1.6e-3, rgb=1.2e-3, grad=0.035),
 }
 
 CASES = [
@@ -83,6 +93,10 @@ CASES = [
     ('blender_256', ["Config.weight_decay_mults = {'NerfMLP_0': 3e-5, 'PropMLP_0': 1e-5}"], 16),
     # the north-star's synthetic shape: 192 samples per ray = levels (64, 64, 64)
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_nerf_samples = 64'], 16),
+    # bottleneck noise (models.py:530-533; the reference's 360 training default is 0, its goldens use 0.4)
+    ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'NerfMLP.bottleneck_noise = 0.4'], 24),
+    # no view directions (models.py:57,226): rgb = Dense(3) straight off the trunk, density + rgb as one 4-column head
+    ('blender_256', ['Model.use_viewdirs = False'], 16),
     # a chain-eligible PropMLP behind a Ref-NeRF NerfMLP: PropMLP_0 starts at parameter 713,230 (2 mod 4), so its bias
     # rows are not 16-byte aligned and Model._chain_ok must hand it to the per-layer path (round-2 advisor finding)
     ('blender_refnerf', ['Model.single_mlp = False', 'PropMLP.net_depth = 4', 'PropMLP.net_width = 256',
@@ -112,19 +126,24 @@ def test_forward_parity(name, extra, B, randomized):
     tol_s = 2e-6 if lv == 0 else TOL[name]['sdist']
     err_s = (s_k - s_o).abs().max().item()
     cost_s = (h_bf[lv]['sdist'] - h_32[lv]['sdist']).abs().max().item()
-    print(f'{name} rand={randomized} level {lv}: |sdist - oracle_bf16| = {err_s:.2e} (bf16 cost {cost_s:.2e})')
+    e32_s = (s_k - h_32[lv]['sdist']).abs().max().item()
+    print(f'{name} rand={randomized} level {lv}: |sdist - oracle_bf16| = {err_s:.2e} (bf16 cost {cost_s:.2e}) FP32DIST sdist {e32_s:.2e}')
     assert err_s <= tol_s, (lv, err_s, tol_s)
+    assert e32_s <= (2e-6 if lv == 0 else TOL32[name]['sdist']), (lv, e32_s)
     w_k, w_o = hist[lv]['weights'].cpu(), h_bf[lv]['weights']
     err_w = (w_k - w_o).abs().max().item()
     cost_w = (h_bf[lv]['weights'] - h_32[lv]['weights']).abs().max().item()
-    print(f'    weights err {err_w:.2e} (bf16 cost {cost_w:.2e})')
+    e32_w = (w_k - h_32[lv]['weights']).abs().max().item()
+    print(f'    weights err {err_w:.2e} (bf16 cost {cost_w:.2e}) FP32DIST weights {e32_w:.2e}')
     assert err_w <= TOL[name]['weights'], (lv, err_w)
+    assert e32_w <= TOL32[name]['weights'], (lv, e32_w)
   rgb_k, rgb_o, rgb_32 = rend[-1]['rgb'].cpu(), r_bf[-1]['rgb'], r_32[-1]['rgb']
   err = (rgb_k - rgb_o).abs().max().item()
   cost = (rgb_o - rgb_32).abs().max().item()
   print(f'{name} rand={randomized}: rgb |kernel - oracle_bf16| = {err:.2e}; bf16 cost |oracle_bf16 - oracle_fp32| = {cost:.2e}; '
         f'|kernel - oracle_fp32| = {(rgb_k - rgb_32).abs().max().item():.2e}')
   assert err <= TOL[name]['rgb'], err
+  assert (rgb_k - rgb_32).abs().max().item() <= TOL32[name]['rgb']
   for k in ('acc', 'distance_mean', 'distance_median', 'distance_percentile_5', 'distance_percentile_95'):
     a, b = rend[-1][k].cpu(), r_bf[-1][k]
     rel = ((a - b).abs() / b.abs().clamp_min(1e-3)).max().item()
@@ -177,8 +196,10 @@ def test_train_step_parity(name, extra, B):
     cos = (a @ r / (a.norm() * r.norm() + 1e-30)).item()
     rel = ((a - r).norm() / (r.norm() + 1e-30)).item()
     cost = ((r - r32).norm() / (r32.norm() + 1e-30)).item()
-    print(f'{name} {mod}: grad cos {cos:.6f} rel err {rel:.3e} (bf16 cost {cost:.3e}) |g| {r.norm().item():.3e}')
+    rel32 = ((a - r32).norm() / (r32.norm() + 1e-30)).item()
+    print(f'{name} {mod}: grad cos {cos:.6f} rel err {rel:.3e} (bf16 cost {cost:.3e}) FP32DIST grad {rel32:.3e} |g| {r.norm().item():.3e}')
     assert cos > 0.995 and rel < TOL[name]['grad'], (mod, cos, rel)
+    assert rel32 < TOL32[name]['grad'], (mod, rel32)
   # per-Dense check (catches a layer whose gradient lands at the wrong offset); the hinge in the
   # interlevel loss makes proposal gradients sensitive to bf16-level weight changes, so each layer is
   # judged against its own bf16 cost.
