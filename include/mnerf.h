@@ -214,10 +214,11 @@ int mnr_gemm_nt_set_nt_stores(int on);
  * the M tiles); n > 1 = the same with at most n workgroups; 0 = off. */
 int mnr_gemm_nt_set_wres(int max_wgs);
 
-/* ---- Fused Dense chain (csrc/fused_mlp.hip): the proposal MLP of internal/models.py:441-465 (net_depth <= skip_layer:
- * Dense + ReLU layers without a skip concat) and its Dense(1) density head (:460) as ONE persistent kernel per sampling
- * level; replaces depth + 1 mnr_gemm_nt_bf16 launches (forward) / the dX chain (backward).  The activation tile of a
- * 256-row block stays in LDS between layers; weights go global -> registers. */
+/* ---- Fused Dense chain (csrc/fused_mlp.hip): the trunk of internal/models.py:441-465 (Dense + ReLU layers, optionally
+ * one skip concat of the input features, :458-459) and, for a density-only MLP, its Dense(1) head (:460) as ONE
+ * persistent kernel per sampling level; replaces depth (+ 1) mnr_gemm_nt_bf16 launches (forward) / the dX chain
+ * (backward).  The activation tile of a 256-row block stays in LDS between layers; weights go global -> registers.
+ * Widths 128 / 256: the proposal MLP of every config and the 256-wide NeRF MLPs of blender_256 / llff_raw / blender_refnerf. */
 #define MNR_CHAIN_MAX_DEPTH 8
 typedef struct {
   int64_t M;                  /* rows (samples of the level): a multiple of 256 */
@@ -233,6 +234,8 @@ typedef struct {
   float* head_out;            /* [M] fp32: x_last . w_head + b_head */
   uint16_t* acts[MNR_CHAIN_MAX_DEPTH];       /* optional out: activation of layer i, [M, W] bf16 (training: dW inputs) */
   uint8_t* bits[MNR_CHAIN_MAX_DEPTH];        /* optional out: its ReLU mask, 1 bit per element, [M, W/8] */
+  int skip_layer;             /* > 0: layer `skip_layer` reads [x_{skip_layer-1} | feat] (the skip concat of models.py:458-459):
+                                 Bt[skip_layer] has W + K0 columns, the feature part behind the W activation columns; 0: none */
 } mnr_mlp_chain_fwd_args;
 int mnr_mlp_chain_fwd(const mnr_mlp_chain_fwd_args* args, void* stream);
 
@@ -245,6 +248,9 @@ typedef struct {
   int ldb[MNR_CHAIN_MAX_DEPTH];
   uint16_t* dY[MNR_CHAIN_MAX_DEPTH];         /* out: gradient w.r.t. layer i's pre-activation, [M, W] bf16
                                                 (dY[depth-1] = mask * (g_head (x) w_head) may be NULL: not stored) */
+  const uint16_t* dY_in;      /* optional: [M, W] bf16 gradient w.r.t. the LAST layer's pre-activation, already masked (an MLP
+                                 with heads: the merged head's dX GEMM wrote it); then g_head / w_head / bits[depth-1] are unused
+                                 and dY[depth-1] must be NULL */
 } mnr_mlp_chain_bwd_args;
 int mnr_mlp_chain_bwd(const mnr_mlp_chain_bwd_args* args, void* stream);
 /* Profiling hook: device buffer of 32 uint64 per workgroup, stamped (s_memtime per phase of the workgroup's second tile,
@@ -290,6 +296,13 @@ int mnr_scatter_add_f32(const float* src, int ld_src, int row0, int col0, int ro
 /* fp32 -> bf16 cast of a strided matrix [M, n] (ld_src) into dst [M, ld_dst] at col0. */
 int mnr_cast_f32_to_bf16(const float* src, int ld_src, int64_t M, int n, uint16_t* dst, int ld_dst,
                          int col0, void* stream);
+
+/* Non-ReLU MLP.net_activation (models.py:348,457,578; jax.nn.softplus / jax.nn.silu are the ones the reference registers,
+ * configs.py:29-31).  The Dense GEMM stores the bf16 pre-activation z [n elements, contiguous]:
+ *   mnr_act_fwd_bf16: a = act(z);   mnr_act_bwd_bf16: d *= act'(z) in place (d = gradient w.r.t. a -> w.r.t. z).
+ * kind: 1 = softplus, 2 = silu; arithmetic in fp32, one bf16 rounding. */
+int mnr_act_fwd_bf16(int kind, int64_t n, const uint16_t* z, uint16_t* a, void* stream);
+int mnr_act_bwd_bf16(int kind, int64_t n, const uint16_t* z, uint16_t* d, void* stream);
 
 /* X[m, c] += scale * noise[m, c] (fp32 add, one bf16 rounding) for the first `cols` columns of the bf16 matrix X [M, ld]:
  * the bottleneck noise of models.py:530-533 (`bottleneck += bottleneck_noise * random.normal(...)`) on the

@@ -33,6 +33,7 @@ RAYDIST = {None: 0, 'identity': 0, 'reciprocal': 1, 'piecewise': 2, 'log': 3, 'e
            'square': 6}
 ACT = {'sigmoid': 0, 'safe_exp': 1, 'softplus': 2, 'exp': 3, 'relu': 4, 'identity': 5}
 DATA_LOSS = {'mse': 0, 'charb': 1, 'rawnerf': 2}
+NET_ACT = {'softplus': 1, 'silu': 2}          # mnr_act_*_bf16 kinds ('relu' lives in the GEMM epilogues)
 
 c_f32p = C.POINTER(C.c_float)
 c_u16p = C.POINTER(C.c_uint16)
@@ -82,14 +83,14 @@ class MlpChainFwdArgs(C.Structure):
               ('feat', vp), ('ld_feat', C.c_int), ('K0', C.c_int),
               ('Bt', vp * CHAIN_MAX_DEPTH), ('ldb', C.c_int * CHAIN_MAX_DEPTH), ('bias', vp * CHAIN_MAX_DEPTH),
               ('w_head', vp), ('b_head', vp), ('head_out', vp),
-              ('acts', vp * CHAIN_MAX_DEPTH), ('bits', vp * CHAIN_MAX_DEPTH)]
+              ('acts', vp * CHAIN_MAX_DEPTH), ('bits', vp * CHAIN_MAX_DEPTH), ('skip_layer', C.c_int)]
 
 
 class MlpChainBwdArgs(C.Structure):
   _fields_ = [('M', C.c_int64), ('W', C.c_int), ('depth', C.c_int),
               ('g_head', vp), ('w_head', vp),
               ('bits', vp * CHAIN_MAX_DEPTH), ('Bw', vp * CHAIN_MAX_DEPTH), ('ldb', C.c_int * CHAIN_MAX_DEPTH),
-              ('dY', vp * CHAIN_MAX_DEPTH)]
+              ('dY', vp * CHAIN_MAX_DEPTH), ('dY_in', vp)]
 
 
 class PackDesc(C.Structure):
@@ -159,6 +160,8 @@ _PROTOS = {
     'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),
     'mnr_pack_weights_bf16': ([vp, vp, i32, i32, vp, vp], i32),
     'mnr_scatter_add_f32': ([vp, i32, i32, i32, i32, i32, vp, i32, vp], i32),
+    'mnr_act_fwd_bf16': ([i32, i64, vp, vp, vp], i32),
+    'mnr_act_bwd_bf16': ([i32, i64, vp, vp, vp], i32),
     'mnr_add_noise_bf16': ([i64, i32, vp, i32, vp, f32, vp], i32),
     'mnr_cast_f32_to_bf16': ([vp, i32, i64, i32, vp, i32, i32, vp], i32),
     'mnr_small_head_bwd': ([i64, i32, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i64, vp, i64, vp], i32),

@@ -88,7 +88,11 @@ struct FmCfg {
   static constexpr int STAGE_BYTES = FM_KT_BYTES + W * 128;       // layer 0: feature tile + weight tile [W][64]
   static constexpr int LDS_MAIN = X_BYTES > 2 * STAGE_BYTES ? X_BYTES : 2 * STAGE_BYTES;
   static constexpr int BIAS_OFF = LDS_MAIN;                        // [MNR_CHAIN_MAX_DEPTH][W] fp32 bias rows
-  static constexpr int LDS_BYTES = BIAS_OFF + MNR_CHAIN_MAX_DEPTH * W * 4;
+  // skip-concat layer (models.py:458-459): its feature segment streams through two [256 rows][16 k] stages = one MFMA
+  // k-step each (the activation tile occupies the main buffer at that point)
+  static constexpr int SKIP_STAGE_BYTES = FM_ROWS * 32;
+  static constexpr int SKIP_OFF = BIAS_OFF + MNR_CHAIN_MAX_DEPTH * W * 4;
+  static constexpr int LDS_BYTES = SKIP_OFF + 2 * SKIP_STAGE_BYTES;
   static constexpr int CPR = W / 8;                    // 16-byte chunks per activation row
   static constexpr int COPY_ITERS = FM_ROWS * CPR / 512;
   static constexpr int ROW_STEP = 512 / CPR;
@@ -163,6 +167,53 @@ __device__ __forceinline__ void fm_layer_mfma(const char* X, const bf16* __restr
     for (int i = 0; i < HB; ++i)
       acc[h * HB + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[c & 1][j], fa[step & 1][i], acc[h * HB + i], 0, 0, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, HB, 0);            // ... then its MFMAs
+  }
+}
+
+// The feature segment of a skip-concat layer: acc[rb] += feat[rows of this wave, 0..K0) * Bt[cols of this wave, kcol0..kcol0+K0)^T.
+// The [256][K0] feature tile streams HBM -> LDS one MFMA k-step ([256 rows][16 k] = 8 KiB = one 16-byte LDS-DMA piece per
+// thread) at a time through two stages; the wave's weight fragment of a k-step comes global -> registers one step ahead.
+// Stage image: row r at byte r * 32, its two 16-byte k-halves swapped when (r >> 3) & 1 (rows 8 apart would otherwise
+// share banks in a ds_read_b128 of 16 consecutive rows); the swizzle is applied to the SOURCE address, the DMA image is
+// lane-linear.
+template <int W>
+__device__ __forceinline__ void fm_skip_segment(char* stages, const bf16* __restrict__ feat_tile, int ld_feat, int K0,
+                                                const bf16* __restrict__ Bt, int ldb, int kcol0, int cw, int rg, int wave,
+                                                int lane_, f32x16 (&acc)[FmCfg<W>::RB]) {
+  typedef FmCfg<W> C;
+  static_assert(FM_ROWS * 2 == 512, "one 16-byte piece per thread and k-step");
+  const int lane = fm_opaque(lane_), frow = lane & 31, khalf = lane >> 5;
+  const int nks = K0 / 16;
+  const int c = wave * 64 + lane;                        // piece index: row c >> 1, position c & 1
+  const int prow = c >> 1;
+  const unsigned src_off = (unsigned)(prow * ld_feat + (((c & 1) ^ ((prow >> 3) & 1)) << 3));
+  auto stage = [&](int ks) {
+    __builtin_amdgcn_global_load_lds(MNR_GLOBAL_PTR(feat_tile + ks * 16 + src_off),
+                                     MNR_LDS_PTR(stages + (ks & 1) * C::SKIP_STAGE_BYTES + wave * 1024), 16, 0, 0);
+  };
+  const bf16* wsrc = Bt + (int64_t)(cw * 32) * ldb + kcol0 + (unsigned)(frow * ldb + khalf * 8);
+  bf16x8 wq[2];
+  stage(0);
+  wq[0] = *(const bf16x8*)wsrc;
+  for (int ks = 0; ks < nks; ++ks) {
+    MNR_GPU_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"));
+    MNR_SIM_HOOK(hipsim::wait_vmcnt(0));
+    __builtin_amdgcn_s_barrier();                        // k-step ks has landed everywhere; the other stage is free
+    asm volatile("" ::: "memory");
+    if (ks + 1 < nks) {
+      stage(ks + 1);
+      wq[(ks + 1) & 1] = *(const bf16x8*)(wsrc + (ks + 1) * 16);
+    }
+    const char* sb = stages + (ks & 1) * C::SKIP_STAGE_BYTES;
+    bf16x8 fa[C::RB];
+#pragma unroll
+    for (int rb = 0; rb < C::RB; ++rb) {
+      const int row = (rg * C::RB + rb) * 32 + frow;
+      fa[rb] = *(const bf16x8*)(sb + row * 32 + ((khalf ^ ((row >> 3) & 1)) << 4));
+    }
+#pragma unroll
+    for (int rb = 0; rb < C::RB; ++rb)
+      acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks & 1], fa[rb], acc[rb], 0, 0, 0);
   }
 }
 
@@ -371,6 +422,9 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(mnr_mlp_chain_fwd_ar
     for (int li = 0; li < p.depth; ++li) {
       if (li > 0) {
         fm_layer_mfma<W>(smem, (const bf16*)p.Bt[li], p.ldb[li], cw, rg, lane, w0, acc);
+        if (li == p.skip_layer)                             // input = [x_{li-1} | features] (models.py:458-459)
+          fm_skip_segment<W>(smem + C::SKIP_OFF, feat + m0 * (int64_t)p.ld_feat, p.ld_feat, p.K0, (const bf16*)p.Bt[li],
+                             p.ldb[li], W, cw, rg, wave, lane, acc);
         if (li + 1 < p.depth) {
           const int ln = fm_opaque(lane);
           fm_load_wchunk((const bf16*)p.Bt[li + 1], p.ldb[li + 1], cw, ln & 31, ln >> 5, 0, w0);
@@ -405,7 +459,15 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd_kernel(mnr_mlp_chain_bwd_ar
     FM_STAMP(0);
     if (tl_on) g_fm_timeline[32 * (int64_t)blockIdx.x + 30] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();                                    // the previous tile's copy-out is done reading the buffer
-    {
+    if (p.dY_in) {
+      // the chain starts from a dY_last the caller computed (an MLP with heads: the merged head's dX GEMM wrote it)
+      const bf16* src = (const bf16*)p.dY_in + m0 * (int64_t)W;
+      const int ln = fm_opaque(lane);
+#pragma unroll
+      for (int kt = 0; kt < C::NKT; ++kt) fm_stage_tile<FM_ROWS>(src + kt * 64, W, smem + kt * FM_KT_BYTES, wave, ln);
+      MNR_GPU_ONLY(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"));
+      MNR_SIM_HOOK(hipsim::wait_vmcnt(0));
+    } else {
       // rank-1 start: dY_last = mask_last * (g (x) w_head), this thread's 8 columns of its COPY_ITERS rows
       const int last = p.depth - 1;
       const int t_ = fm_opaque(tid);
@@ -501,6 +563,8 @@ extern "C" int mnr_mlp_chain_fwd(const mnr_mlp_chain_fwd_args* a, void* stream) 
   }
   MNR_CHECK_ARG(((uintptr_t)a->feat % 16) == 0, "mnr_mlp_chain_fwd: feat must be 16-byte aligned");
   MNR_CHECK_ARG(!a->w_head || (a->head_out && ((uintptr_t)a->w_head % 16) == 0), "mnr_mlp_chain_fwd: head needs head_out");
+  MNR_CHECK_ARG(a->skip_layer <= 0 || (a->skip_layer < a->depth && a->K0 % 16 == 0 && a->ldb[a->skip_layer] >= a->W + a->K0),
+                "mnr_mlp_chain_fwd: skip_layer %d needs 0 < skip_layer < depth and an operand of W + K0 columns", a->skip_layer);
   const int grid = fm_grid(a->M / FM_ROWS);
   if (a->W == 256) {
     (void)hipFuncSetAttribute((const void*)mlp_chain_fwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, FmCfg<256>::LDS_BYTES);
@@ -516,10 +580,12 @@ extern "C" int mnr_mlp_chain_fwd(const mnr_mlp_chain_fwd_args* a, void* stream) 
 extern "C" int mnr_mlp_chain_bwd(const mnr_mlp_chain_bwd_args* a, void* stream) {
   MNR_CHECK_ARG(a != nullptr, "mnr_mlp_chain_bwd: null args");
   if (int s = fm_check_common("mnr_mlp_chain_bwd", a->M, a->W, a->depth)) return s;
-  MNR_CHECK_ARG(a->g_head && a->w_head && ((uintptr_t)a->w_head % 16) == 0, "mnr_mlp_chain_bwd: head gradient / 16-byte-aligned head kernel missing");
+  MNR_CHECK_ARG(a->dY_in ? ((uintptr_t)a->dY_in % 16) == 0 : (a->g_head && a->w_head && ((uintptr_t)a->w_head % 16) == 0),
+                "mnr_mlp_chain_bwd: needs dY_in (16-byte aligned) or a head gradient with a 16-byte-aligned head kernel");
   for (int i = 0; i < a->depth; ++i) {
     MNR_CHECK_ARG(a->bits[i] && ((uintptr_t)a->bits[i] % 4) == 0, "mnr_mlp_chain_bwd: layer %d needs its ReLU mask bits", i);
     MNR_CHECK_ARG(a->dY[i] || i == a->depth - 1, "mnr_mlp_chain_bwd: dY[%d] missing", i);
+    MNR_CHECK_ARG(!(a->dY_in && i == a->depth - 1 && a->dY[i]), "mnr_mlp_chain_bwd: with dY_in the last dY is the input itself");
     MNR_CHECK_ARG(!a->dY[i] || ((uintptr_t)a->dY[i] % 16) == 0, "mnr_mlp_chain_bwd: dY[%d] must be 16-byte aligned", i);
     if (i >= 1)
       MNR_CHECK_ARG(a->Bw[i] && a->ldb[i] % 8 == 0 && a->ldb[i] >= a->W && ((uintptr_t)a->Bw[i] % 16) == 0,

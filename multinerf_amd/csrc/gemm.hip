@@ -738,6 +738,54 @@ extern "C" int mnr_cast_f32_to_bf16(const float* src, int ld_src, int64_t M, int
   return MNR_OK;
 }
 
+// Non-ReLU net_activation (reference internal/models.py:348,457,578; the reference registers jax.nn.softplus and jax.nn.silu,
+// internal/configs.py:29-31): the Dense GEMM stores the bf16 PRE-activation z, these two kernels apply the activation
+// (forward) and its derivative (backward, in place on the gradient) in fp32.  kind: 1 = softplus, 2 = silu.
+__device__ __forceinline__ float mnr_act_apply(int kind, float z) {
+  if (kind == 1) return mnr_softplus(z);
+  return z * mnr_sigmoid(z);
+}
+__device__ __forceinline__ float mnr_act_deriv(int kind, float z) {
+  const float sg = mnr_sigmoid(z);
+  if (kind == 1) return sg;
+  return sg + z * sg * (1.0f - sg);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void act_bf16_kernel(int kind, int64_t chunks, const bf16* __restrict__ z, bf16* __restrict__ io) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < chunks; e += (int64_t)gridDim.x * blockDim.x) {
+    const bf16x8 zv = *(const bf16x8*)(z + e * 8);
+    bf16x8 v;
+    if constexpr (BWD) v = *(const bf16x8*)(io + e * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (BWD) v[i] = (bf16)((float)v[i] * mnr_act_deriv(kind, (float)zv[i]));
+      else v[i] = (bf16)mnr_act_apply(kind, (float)zv[i]);
+    }
+    *(bf16x8*)(io + e * 8) = v;
+  }
+}
+
+static int act_launch(bool bwd, int kind, int64_t n, const uint16_t* z, uint16_t* io, void* stream) {
+  MNR_CHECK_ARG((kind == 1 || kind == 2) && z && io && n > 0 && n % 8 == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)io % 16) == 0,
+                "mnr_act_*_bf16: kind 1 (softplus) / 2 (silu), n a multiple of 8, 16-byte-aligned pointers");
+  const int64_t chunks = n / 8;
+  const int64_t want = (chunks + 255) / 256;
+  const int grid = (int)(want > 16384 ? 16384 : want);
+  if (bwd) hipLaunchKernelGGL(act_bf16_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, kind, chunks, (const bf16*)z, (bf16*)io);
+  else hipLaunchKernelGGL(act_bf16_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, kind, chunks, (const bf16*)z, (bf16*)io);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+extern "C" int mnr_act_fwd_bf16(int kind, int64_t n, const uint16_t* z, uint16_t* a, void* stream) {
+  return act_launch(false, kind, n, z, a, stream);
+}
+
+extern "C" int mnr_act_bwd_bf16(int kind, int64_t n, const uint16_t* z, uint16_t* d, void* stream) {
+  return act_launch(true, kind, n, z, d, stream);
+}
+
 // X[m, c] = bf16(float(X[m, c]) + scale * noise[m, c]) for c < cols (a multiple of 8): the bottleneck noise of
 // reference internal/models.py:530-533, added to the bf16 bottleneck columns of the view-MLP input in fp32.
 __global__ __launch_bounds__(256) void add_noise_bf16_kernel(int64_t M, int cols, bf16* __restrict__ X, int ld,

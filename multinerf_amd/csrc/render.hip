@@ -135,6 +135,20 @@ static size_t cp_lds_bytes(int n, int s) { return (size_t)(6 * n + 1) * s * 4; }
 // A/B switch of the per-ray kernels: 1 = four lanes per ray (composite_fwd_quad_kernel, level_bwd_quad_kernel) where a
 // wave's 16 rays fit LDS, 0 = lane per ray for every shape
 static int g_level_bwd_quad = 1;
+// Largest LDS footprint (bytes per single-wave workgroup) at which the four-lanes-per-ray kernels are used: 40 KiB keeps four
+// workgroups (one per SIMD) on a CU; rays of 128 samples need 49 KiB (forward) / 66 KiB (backward), i.e. three / two
+// workgroups per CU, and are still faster there than on the lane-per-ray kernels (round-3 A/B).
+// MNR_QUAD_LDS_MAX overrides (tuning).
+static size_t quad_lds_max() {
+  static size_t v = 0;
+  if (v == 0) {
+    const char* e = getenv("MNR_QUAD_LDS_MAX");
+    v = e ? (size_t)atoll(e) : 40 * 1024;
+    if (v < 1024) v = 1024;
+    if (v > 160 * 1024) v = 160 * 1024;
+  }
+  return v;
+}
 extern "C" int mnr_level_bwd_set_quad(int on) {
   g_level_bwd_quad = on;
   return MNR_OK;
@@ -162,7 +176,10 @@ extern "C" int mnr_composite_fwd(const mnr_composite_cfg* cfg, int64_t B, const 
     o = (o + 3) & ~3;
     if (((o >> 2) & 1) == 0) o += 4;
     const size_t quad_lds = (size_t)o * (CP_THREADS / 4) * 4;
-    if (g_level_bwd_quad && quad_lds <= 40 * 1024) {
+    if (g_level_bwd_quad && quad_lds <= quad_lds_max()) {
+      static unsigned long long attr_q = 0;
+      if (quad_lds > 64 * 1024 && mnr_attr_needed(&attr_q))
+        (void)hipFuncSetAttribute((const void*)composite_fwd_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(composite_fwd_quad_kernel, dim3(mnr_cdiv(B, CP_THREADS / 4)), dim3(CP_THREADS), quad_lds,
                          (hipStream_t)stream, *cfg, B, o, raw_density, density_noise, raw_rgb, tdist, dirs, bg, exposure_scale,
                          density, rgb, weights, rgb_out, acc);
@@ -842,7 +859,10 @@ extern "C" int mnr_level_bwd(const mnr_level_bwd_args* a, void* stream) {
   // four lanes per ray whenever a wave's 16 rays fit LDS four workgroups per CU (n <= ~128); else lane per ray
   const LbLay lay = lb_layout(cfg->n, cfg->has_rgb, a->wloss_mode, a->n_ref);
   const size_t quad_lds = (size_t)lay.stride * LB_RPW * 4;
-  if (g_level_bwd_quad && quad_lds <= 40 * 1024) {
+  if (g_level_bwd_quad && quad_lds <= quad_lds_max()) {
+    static unsigned long long attr_q = 0;
+    if (quad_lds > 64 * 1024 && mnr_attr_needed(&attr_q))
+      (void)hipFuncSetAttribute((const void*)level_bwd_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(level_bwd_quad_kernel, dim3(mnr_cdiv(a->B, LB_RPW)), dim3(CP_THREADS), quad_lds, (hipStream_t)stream, *a);
     MNR_CHECK_LAUNCH();
     return MNR_OK;

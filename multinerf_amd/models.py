@@ -140,8 +140,11 @@ class MLP:
       bad.append('density-gradient normals with a warp_fn')
     if self.is_ref() and self.roughness_activation != 'softplus':
       bad.append('roughness_activation != softplus')
-    if self.net_activation != 'relu':
+    if self.net_activation not in ('relu', 'softplus', 'silu'):   # what the reference registers (configs.py:29-31)
       bad.append(f'net_activation={self.net_activation}')
+    if self.net_activation != 'relu' and self.is_ref():
+      # the forward-mode tangent network of the density-gradient normals is built on ReLU's piecewise linearity
+      bad.append(f'net_activation={self.net_activation} with density-gradient normals')
     if self.warp_fn not in (None, 'contract'):
       bad.append(f'warp_fn={self.warp_fn}')
     if self.net_width % 128 != 0:
@@ -780,15 +783,34 @@ class Model:
 
   @staticmethod
   def _chain_ok(plan: MLPPlan):
-    """The fused per-level kernel (csrc/fused_mlp.hip) covers density-only MLPs without a skip concat: PropMLP."""
-    if not (_USE_CHAIN and not plan.has_rgb and not plan.ref and plan.W in (128, 256) and
-            1 <= len(plan.trunk) <= L.CHAIN_MAX_DEPTH and not any(c for _, c in plan.trunk)):
+    """The fused per-level kernels (csrc/fused_mlp.hip) cover a trunk of width 128 / 256, depth <= 8, with at most one
+    skip concat: the proposal MLP of every config (with its Dense(1) head inside the kernel) and the 256-wide NeRF
+    trunks of blender_256 / llff_raw / blender_refnerf (heads stay per-layer GEMMs on the trunk's output)."""
+    skips = [i for i, (_, c) in enumerate(plan.trunk) if c]
+    if not (_USE_CHAIN and _USE_BITS and plan.hp.net_activation == 'relu' and plan.W in (128, 256) and
+            1 <= len(plan.trunk) <= L.CHAIN_MAX_DEPTH and
+            len(skips) <= 1 and not plan.x_concat):
       return False
-    # the kernels read every bias row and the fp32 head kernel as 16-byte vectors straight out of the flat parameter
-    # vector: a module base that is not a multiple of 4 floats (e.g. PropMLP_0 behind a Ref-NeRF NerfMLP_0 of 713,230
-    # parameters) takes the per-layer path, which has no such requirement
-    offs = [d.bias_off for d, _ in plan.trunk] + [plan.density.kernel_off]
+    # the kernels read every bias row (and, for a density-only MLP, the fp32 head kernel) as 16-byte vectors straight out
+    # of the flat parameter vector: a module base that is not a multiple of 4 floats (e.g. PropMLP_0 behind a Ref-NeRF
+    # NerfMLP_0 of 713,230 parameters) takes the per-layer path, which has no such requirement
+    offs = [d.bias_off for d, _ in plan.trunk] + ([] if plan.has_rgb else [plan.density.kernel_off])
     return all(o % 4 == 0 for o in offs)
+
+  def _chain_trunk(self, plan: MLPPlan, flat, feat, M, tag, keep, need_bits):
+    """models.py:455-459 (the Dense + ReLU trunk incl. its skip concat) as ONE launch; -> (acts, bits) like the per-layer
+    loop: every layer's activation when `keep` (training: dW inputs), else only the last one (the heads' input)."""
+    W, D = plan.W, len(plan.trunk)
+    acts = [self._buf((tag, 'act', i if keep else i % 2), (M, W), bf16) if (keep or i == D - 1) else None for i in range(D)]
+    bits = [self._buf((tag, 'bits', i), (M, W // 8), torch.uint8) if need_bits else None for i in range(D)]
+    layers, skip = [], 0
+    for i, (d, concat) in enumerate(plan.trunk):
+      e = plan.packed[('trunk', i)]
+      layers.append((self._w(plan, e['f_off'], e['n_pad'], e['f_ld']), flat[d.bias_off:d.bias_off + d.fan_out]))
+      if concat:
+        skip = i
+    ops.mlp_chain_fwd(feat, plan.ldF, layers, M=M, W=W, acts=acts, bits=bits if need_bits else None, skip_layer=skip)
+    return acts, bits
 
   def _chain_forward(self, plan: MLPPlan, flat, feat, M, tag, keep):
     """models.py:441-465 for a density-only MLP as ONE launch: every Dense + ReLU layer and the density head."""
@@ -809,12 +831,24 @@ class Model:
   def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep, tdist=None, bnoise=None):
     """MLP.__call__ (models.py:402-612) for the M = B*n samples of one level."""
     hp = plan.hp
-    if self._chain_ok(plan):
+    chain = self._chain_ok(plan)
+    if chain and not plan.has_rgb:
       return self._chain_forward(plan, flat, feat, M, tag, keep)
-    need_bits = (keep and _USE_BITS) or plan.ref
-    acts, bits = [], []
+    relu = hp.net_activation == 'relu'
+    need_bits = ((keep and _USE_BITS) or plan.ref) and relu
+    acts, bits, zs, vzs = [], [], [], []
     x = None
-    for i, (d, concat) in enumerate(plan.trunk):
+
+    def activate(z_key, out, n_cols, zlist):
+      """Non-ReLU net_activation: the GEMM wrote the pre-activation into `out`'s twin buffer; apply act (models.py:457,578)."""
+      z = self._buf(z_key, (M, n_cols), bf16)
+      zlist.append(z)
+      return z
+
+    if chain:
+      acts, bits = self._chain_trunk(plan, flat, feat, M, tag, keep, need_bits)
+      x = acts[-1]
+    for i, (d, concat) in enumerate([] if chain else plan.trunk):
       e = plan.packed[('trunk', i)]
       out = self._buf((tag, 'act', i if keep else i % 2), (M, plan.W), bf16)
       # 1-bit ReLU mask: backward pass (training) and the tangent pass of the density-gradient normals
@@ -822,18 +856,22 @@ class Model:
       bits.append(bo)
       Bt = self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])
       bias = flat[d.bias_off:d.bias_off + d.fan_out]
+      # non-ReLU activations: the GEMM stores the pre-activation, a second kernel applies softplus / silu
+      dst = out if relu else activate((tag, 'z', i if keep else i % 2), out, plan.W, zs)
       if i == 0:
-        ops.gemm_nt(feat, Bt, M=M, N=e['n_pad'], K1=plan.ldF, bias=bias, n_bias=d.fan_out, relu=True,
-                    Cb=out, ldcb=plan.W, nb=plan.W, bits_out=bo)
+        ops.gemm_nt(feat, Bt, M=M, N=e['n_pad'], K1=plan.ldF, bias=bias, n_bias=d.fan_out, relu=relu,
+                    Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo)
       elif concat:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, A2=feat, K2=plan.ldF, bias=bias, n_bias=d.fan_out,
-                    relu=True, Cb=out, ldcb=plan.W, nb=plan.W, bits_out=bo)
+                    relu=relu, Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo)
       else:
-        ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=bias, n_bias=d.fan_out, relu=True,
-                    Cb=out, ldcb=plan.W, nb=plan.W, bits_out=bo)
+        ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=bias, n_bias=d.fan_out, relu=relu,
+                    Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo)
+      if not relu:
+        ops.act_fwd(hp.net_activation, dst, out)
       acts.append(out)
       x = out
-    res = dict(acts=acts, bits=bits)
+    res = dict(acts=acts, bits=bits, chain_trunk=chain, zs=zs, vzs=vzs)
     raw_density = self._buf((tag, 'raw_density'), (M,), f32)
     if plan.has_rgb and not plan.use_viewdirs:
       # models.py:585 with x = the trunk output: one 4-column head [raw_density | raw_rgb] as an fp32 side output
@@ -903,15 +941,18 @@ class Model:
         out = self._buf((tag, 'vact', i if keep else i % 2), (M, WV), bf16)
         Bt = self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])
         bias = flat[d.bias_off:d.bias_off + d.fan_out]
+        dst = out if relu else activate((tag, 'vz', i if keep else i % 2), out, WV, vzs)
         if i == 0:
-          ops.gemm_nt(VI, Bt, M=M, N=e['n_pad'], K1=plan.ldVI, bias=bias, n_bias=d.fan_out, relu=True,
-                      Cb=out, ldcb=WV, nb=WV)
+          ops.gemm_nt(VI, Bt, M=M, N=e['n_pad'], K1=plan.ldVI, bias=bias, n_bias=d.fan_out, relu=relu,
+                      Cb=dst, ldcb=WV, nb=WV)
         elif concat:
           ops.gemm_nt(h, Bt, M=M, N=e['n_pad'], K1=WV, A2=VI, K2=plan.ldVI, bias=bias, n_bias=d.fan_out,
-                      relu=True, Cb=out, ldcb=WV, nb=WV)
+                      relu=relu, Cb=dst, ldcb=WV, nb=WV)
         else:
-          ops.gemm_nt(h, Bt, M=M, N=e['n_pad'], K1=WV, bias=bias, n_bias=d.fan_out, relu=True,
-                      Cb=out, ldcb=WV, nb=WV)
+          ops.gemm_nt(h, Bt, M=M, N=e['n_pad'], K1=WV, bias=bias, n_bias=d.fan_out, relu=relu,
+                      Cb=dst, ldcb=WV, nb=WV)
+        if not relu:
+          ops.act_fwd(hp.net_activation, dst, out)
         vacts.append(out)
         h = out
       e = plan.packed['rgb']
@@ -982,8 +1023,17 @@ class Model:
     def gslice(off, size):
       return grads[off:off + size]
 
+    relu = hp.net_activation == 'relu'
+
+    def act_vjp(z, d):
+      """Non-ReLU activations: d (gradient w.r.t. a layer's activation, just written without a mask) *= act'(z)."""
+      if not relu:
+        ops.act_bwd(hp.net_activation, z, d)
+
     def mask_kw(i):
       """ReLU VJP of trunk layer i's output: 1-bit mask if available, else the saved activation."""
+      if not relu:
+        return {}
       if mlp['bits'][i] is not None:
         return dict(bits_in=mlp['bits'][i])
       return dict(mask=acts[i], ldmask=W)
@@ -1004,7 +1054,8 @@ class Model:
       w4[:, 1:4].copy_(flat[dr.kernel_off:dr.kernel_off + 3 * W].view(W, 3))
       t4 = self._buf(('bwd', 't4', W), (W + 1, 4), f32)
       t4.zero_()
-      ops.small_head_bwd(x_last, W, g4, w4, M=M, K=W, Cn=4, dX=dA, lddx=W, relu_mask=True, dW=t4[:W].view(-1), db=t4[W])
+      ops.small_head_bwd(x_last, W, g4, w4, M=M, K=W, Cn=4, dX=dA, lddx=W, relu_mask=relu, dW=t4[:W].view(-1), db=t4[W])
+      act_vjp(mlp['zs'][-1] if not relu else None, dA)
       for (d, c0) in plan.head_segs:
         ops.scatter_add(t4, 4, 0, c0, W, d.fan_out, gslice(d.kernel_off, W * d.fan_out), d.fan_out)
         ops.scatter_add(t4, 4, W, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
@@ -1031,8 +1082,9 @@ class Model:
       dV0 = dv_buf(NV - 1, NV)
       h_last = vacts[-1]
       ops.small_head_bwd(h_last, WV, g_raw_rgb, flat[d.kernel_off:d.kernel_off + d.fan_in * 3].view(d.fan_in, 3),
-                         M=M, K=WV, Cn=3, dX=dV0, lddx=WV, relu_mask=True,
+                         M=M, K=WV, Cn=3, dX=dV0, lddx=WV, relu_mask=relu,
                          dW=gslice(d.kernel_off, d.fan_in * 3), db=gslice(d.bias_off, 3))
+      act_vjp(mlp['vzs'][-1] if not relu else None, dV0)
       dy = dV0
       VI = mlp['VI']
       dVIa = dVIb = None
@@ -1077,7 +1129,11 @@ class Model:
             ops.gemm_nt(dy, Bw, M=M, N=e['b_rows'], K1=e['b_ld'], Cb=dHB, ldcb=nh, nb=bw, **glo_kw(gGa))
         else:
           other = dv_buf(i - 1, NV)
-          ops.gemm_nt(dy, Bw, M=M, N=WV, K1=e['b_ld'], mask=vacts[i - 1], ldmask=WV, Cb=other, ldcb=WV, nb=WV)
+          if relu:
+            ops.gemm_nt(dy, Bw, M=M, N=WV, K1=e['b_ld'], mask=vacts[i - 1], ldmask=WV, Cb=other, ldcb=WV, nb=WV)
+          else:
+            ops.gemm_nt(dy, Bw, M=M, N=WV, K1=e['b_ld'], Cb=other, ldcb=WV, nb=WV)
+            act_vjp(mlp['vzs'][i - 1], other)
           dy = other
       if want_glo:
         G = plan.glo
@@ -1105,6 +1161,7 @@ class Model:
           ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
       Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
       ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=nh, Cb=dA, ldcb=W, nb=W, **mask_kw(len(acts) - 1))
+      act_vjp(mlp['zs'][-1] if not relu else None, dA)
     else:
       g_raw_density, _ = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], density_noise=lv['dnoise'],
@@ -1129,11 +1186,29 @@ class Model:
         self._dw_join()
         return
       ops.small_head_bwd(x_last, W, g_raw_density.view(M, 1), flat[d.kernel_off:d.kernel_off + W].view(W, 1),
-                         M=M, K=W, Cn=1, dX=dA, lddx=W, relu_mask=True,
+                         M=M, K=W, Cn=1, dX=dA, lddx=W, relu_mask=relu,
                          dW=gslice(d.kernel_off, W), db=gslice(d.bias_off, 1))
+      act_vjp(mlp['zs'][-1] if not relu else None, dA)
     feat = lv['feat']
     if g_raw_grad is not None:
       self._tangent_backward(plan, flat, grads, mlp, feat, M, g_raw_grad)
+    if mlp.get('chain_trunk'):
+      # fused dX chain from the dY_last the head GEMMs left in dA; then dW_i = [x_{i-1} | feat]^T dY_i per layer
+      dYs = [self._buf(('bwd', 'dYc', W, i), (M, W), bf16) for i in range(D - 1)] + [None]
+      Bws = [None] + [self._w(plan, plan.packed[('trunk', i)]['b_off'], _rup(W, 128), plan.packed[('trunk', i)]['b_ld'])
+                      for i in range(1, D)]
+      ops.mlp_chain_bwd(None, None, mlp['bits'], Bws, dYs, M=M, W=W, dY_in=dA)
+      dYs[D - 1] = dA
+      with self._dw():
+        for i, (d, concat) in enumerate(plan.trunk):
+          inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
+          ops.gemm_tn(inp, dYs[i], gslice(d.kernel_off, kv * W), M=M, K=in_w, N=W, lda=in_w, ldb=W, ldc=W,
+                      k_valid=kv, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W)
+          if concat:
+            ops.gemm_tn(feat, dYs[i], gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
+                        lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
+      self._dw_join()
+      return
     # trunk: per layer its dW (independent of the dX chain: on the dW stream when that switch is on), then the dX GEMM the
     # next layer waits for
     dy = dA
@@ -1154,6 +1229,7 @@ class Model:
         Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
         other = dy_buf(i - 1)
         ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, **mask_kw(i - 1))
+        act_vjp(mlp['zs'][i - 1] if not relu else None, other)
         dy = other
     self._dw_join()
 

@@ -327,7 +327,7 @@ def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, 
   PROFILE.stop(_e)
 
 
-def mlp_chain_fwd(feat, K0, layers, *, M, W, w_head=None, b_head=None, head_out=None, acts=None, bits=None):
+def mlp_chain_fwd(feat, K0, layers, *, M, W, w_head=None, b_head=None, head_out=None, acts=None, bits=None, skip_layer=0):
   """Fused Dense + ReLU chain with a Dense(1) head (csrc/fused_mlp.hip): `layers` = [(Bt [W, ldb] bf16, bias [W] fp32)],
   layer 0 reading feat [M, ld_feat] over K0 columns.  acts / bits: optional per-layer outputs (training)."""
   depth = len(layers)
@@ -338,7 +338,7 @@ def mlp_chain_fwd(feat, K0, layers, *, M, W, w_head=None, b_head=None, head_out=
   _chk(b_head, f32, 'b_head', allow_none=True)
   _chk(head_out, f32, 'head_out', allow_none=True)
   a = L.MlpChainFwdArgs()
-  a.M, a.W, a.depth = M, W, depth
+  a.M, a.W, a.depth, a.skip_layer = M, W, depth, int(skip_layer)
   a.feat, a.ld_feat, a.K0 = feat.data_ptr(), feat.stride(0), K0
   for i, (Bt, bias) in enumerate(layers):
     _chk(Bt, bf16, f'Bt[{i}]')
@@ -362,16 +362,22 @@ def mlp_chain_fwd(feat, K0, layers, *, M, W, w_head=None, b_head=None, head_out=
   PROFILE.stop(_e)
 
 
-def mlp_chain_bwd(g_head, w_head, bits, Bws, dYs, *, M, W):
+def mlp_chain_bwd(g_head, w_head, bits, Bws, dYs, *, M, W, dY_in=None):
   """The dX chain of the fused Dense stack: dY[last] = mask * (g_head (x) w_head), dY[i-1] = mask_{i-1} * (dY[i] W_i^T).
   Bws[i] (i >= 1): [W, ldb] bf16 kernel as stored (rows = inputs); Bws[0] unused."""
   depth = len(bits)
-  _chk(g_head, f32, 'g_head')
-  _chk(w_head, f32, 'w_head')
-  assert g_head.numel() == M and w_head.numel() == W and len(dYs) == depth and len(Bws) == depth
+  assert len(dYs) == depth and len(Bws) == depth
   a = L.MlpChainBwdArgs()
   a.M, a.W, a.depth = M, W, depth
-  a.g_head, a.w_head = g_head.data_ptr(), w_head.data_ptr()
+  if dY_in is not None:
+    _chk(dY_in, bf16, 'dY_in')
+    assert dY_in.shape == (M, W) and dYs[depth - 1] is None
+    a.dY_in = dY_in.data_ptr()
+  else:
+    _chk(g_head, f32, 'g_head')
+    _chk(w_head, f32, 'w_head')
+    assert g_head.numel() == M and w_head.numel() == W
+    a.g_head, a.w_head = g_head.data_ptr(), w_head.data_ptr()
   for i in range(depth):
     _chk(bits[i], torch.uint8, f'bits[{i}]')
     assert bits[i].shape == (M, W // 8)
@@ -410,6 +416,22 @@ def cast_f32_to_bf16(src, ld_src, M, n, dst, ld_dst, col0):
   _chk(src, f32, 'src')
   _chk(dst, bf16, 'dst')
   L.check(lib().mnr_cast_f32_to_bf16(_ptr(src), ld_src, M, n, _ptr(dst), ld_dst, col0, _stream()))
+
+
+def act_fwd(kind, z, a):
+  """a = act(z) for a non-ReLU net_activation ('softplus' | 'silu'); z, a contiguous bf16 of the same shape."""
+  _chk(z, bf16, 'z')
+  _chk(a, bf16, 'a')
+  assert z.shape == a.shape
+  L.check(lib().mnr_act_fwd_bf16(L.NET_ACT[kind], z.numel(), _ptr(z), _ptr(a), _stream()))
+
+
+def act_bwd(kind, z, d):
+  """d *= act'(z) in place: gradient w.r.t. the activation -> w.r.t. the pre-activation."""
+  _chk(z, bf16, 'z')
+  _chk(d, bf16, 'd')
+  assert z.shape == d.shape
+  L.check(lib().mnr_act_bwd_bf16(L.NET_ACT[kind], z.numel(), _ptr(z), _ptr(d), _stream()))
 
 
 def add_noise_bf16(X, cols, noise, scale):

@@ -107,3 +107,85 @@ def test_fused_chain_equals_per_layer_path(W, bindings, B, monkeypatch):
     # (samples move with the head's last ulp: not bitwise.  The proposal MLP's own gradient stays within 1e-3; what is
     # downstream of the moved samples sees bf16 roundings flip, 3-7 % at these 8-24 ray batches)
     assert rel < (2e-2 if name == 'PropMLP_0' else 0.2), (name, rel)
+
+
+@pytest.mark.parametrize('preset,bindings,B', [
+    ('llff_raw', [], 8),                                   # 96 -> 256 x 8, skip concat into layer 5 (K = 256 + 128), heads + view MLP
+    ('blender_256', [], 8),                                # the same trunk behind a fused proposal level
+    ('llff_raw', ['NerfMLP.net_width = 128', 'NerfMLP.net_depth = 4', 'NerfMLP.skip_layer = 2'], 8),   # W = 128, skip into layer 3
+])
+def test_fused_trunk_with_skip_equals_per_layer_path(preset, bindings, B, monkeypatch):
+  """The 256-wide NeRF trunks (models.py:441-465 incl. the skip concat of :458-459) on the fused chain: activations and
+  masks of every layer bit for bit against the per-layer GEMMs on identical inputs, the dX chain from a given dY_last
+  bit for bit against one masked NT GEMM per layer, and the whole train step close to the per-layer path."""
+  cfg = configs.load_preset(preset, bindings)
+  m0 = models.Model(config=cfg).build('cuda')
+  plan = m0.nerf_plan
+  skips = [i for i, (_, c) in enumerate(plan.trunk) if c]
+  if len(skips) != 1:
+    pytest.skip(f'{len(skips)} skip layers')
+  assert models.Model._chain_ok(plan) and plan.has_rgb
+  om, on, op = helpers.oracle_hparams(m0)
+  params = omodels.init_params(om, on, op, seed=5)
+  g = torch.Generator().manual_seed(6)
+  for mname, mod in params.items():
+    if mname in ('exposure_scaling_offsets', 'Embed_0'):
+      continue
+    for d in mod.values():
+      d['bias'] = 0.05 * torch.randn(d['bias'].shape, generator=g)
+  flat = m0.flat_from_tree(params)
+  batch = helpers.synthetic_rays(B, near=cfg.near, far=cfg.far)
+  if cfg.rawnerf_mode:
+    batch.rays.exposure_idx = torch.randint(0, 5, (B, 1), generator=g).to(torch.int32)
+    batch.rays.exposure_values = 0.5 + torch.rand((B, 1), generator=g)
+    batch.rays.lossmult = (torch.rand((B, 3), generator=g) > 0.4).float()
+  noise = helpers.make_noise(m0, B)
+
+  def run(use_chain):
+    monkeypatch.setattr(models, '_USE_CHAIN', use_chain)
+    model = models.Model(config=cfg).build('cuda')
+    state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})
+    step = train_utils.create_train_step(model, cfg)
+    _, stats, _ = step(0, state, batch.map(lambda t: t.cuda()), None, 0.4, 0.0,
+                       noise={k: {lv: t.cuda() for lv, t in d.items()} for k, d in noise.items()}, return_grads=True)
+    torch.cuda.synchronize()
+    lvs = model._saved['levels']
+    lv = [l for l in lvs if l['plan'] is model.nerf_plan][0]          # first level that runs the NeRF MLP
+    assert bool(lv['mlp'].get('chain_trunk')) == use_chain
+    return dict(grads=stats['_grads'].cpu(), loss=stats.materialize()['loss'], model=model, lv=lv, first=lvs.index(lv),
+                acts=[a.cpu().clone() for a in lv['mlp']['acts']], bits=[b.cpu().clone() for b in lv['mlp']['bits']])
+
+  a, b = run(True), run(False)
+  if a['first'] == 0:
+    # level 0 sees identical inputs on both paths: every layer bit for bit (incl. the skip layer and what follows it)
+    for i, (x, y) in enumerate(zip(a['acts'], b['acts'])):
+      assert torch.equal(x.view(torch.int16), y.view(torch.int16)), f'activation {i}'
+    for i, (x, y) in enumerate(zip(a['bits'], b['bits'])):
+      assert torch.equal(x, y), f'mask bits {i}'
+  # the dX chain from a seeded dY_last on the chain run's own masks: bitwise against one masked NT GEMM per layer
+  model, lv = a['model'], a['lv']
+  W, M, D = plan.W, lv['M'], len(plan.trunk)
+  bits = lv['mlp']['bits']
+  ops = models.ops
+  gl = torch.Generator().manual_seed(7)
+  keep = ((bits[-1].cpu().int()[..., None] >> torch.arange(8)) & 1).reshape(M, W).bool()
+  dy_last = (torch.randn((M, W), generator=gl) * 0.01 * keep).to(torch.bfloat16).cuda()
+  dYs = [torch.empty((M, W), dtype=torch.bfloat16, device='cuda') for _ in range(D - 1)] + [None]
+  Bws = [None] + [model._w(model.nerf_plan, model.nerf_plan.packed[('trunk', i)]['b_off'], models._rup(W, 128),
+                           model.nerf_plan.packed[('trunk', i)]['b_ld']) for i in range(1, D)]
+  ops.mlp_chain_bwd(None, None, bits, Bws, dYs, M=M, W=W, dY_in=dy_last)
+  ref = dy_last
+  for i in reversed(range(1, D)):
+    nxt = torch.empty((M, W), dtype=torch.bfloat16, device='cuda')
+    ops.gemm_nt(ref, Bws[i], M=M, N=models._rup(W, 128), K1=model.nerf_plan.packed[('trunk', i)]['b_ld'], Cb=nxt, ldcb=W, nb=W,
+                bits_in=bits[i - 1])
+    torch.cuda.synchronize()
+    assert torch.equal(nxt.view(torch.int16), dYs[i - 1].view(torch.int16)), f'dY of layer {i - 1}'
+    ref = nxt
+  # end to end
+  assert abs(a['loss'] - b['loss']) <= 1e-3 * abs(b['loss'])
+  for name, lo, hi in model.modules:
+    x, y = a['grads'][lo:hi].double(), b['grads'][lo:hi].double()
+    rel = ((x - y).norm() / (y.norm() + 1e-30)).item()
+    print(f'{preset} {name}: |g(fused trunk) - g(per-layer)| / |g| = {rel:.2e}')
+    assert rel < (1e-4 if a['first'] == 0 and cfg.interlevel_loss_mult == 0 and model.single_mlp else 0.2), (name, rel)

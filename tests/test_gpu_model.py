@@ -78,6 +78,19 @@ TOL32 = {
     'blender_refnerf': dict(sdist=4e-4, weights=1.6e-3, rgb=1.2e-3, grad=0.035),
 }
 
+def _tols(name, extra):
+  """(TOL, TOL32) of a case.  Non-ReLU activations run as GEMM (bf16 pre-activation) + activation kernel: two bf16
+  roundings per layer where the ReLU epilogue has one, so those cases get twice the forward tolerances (measured on the
+  simulator: sdist 7.6e-4 against 5e-4 for blender_256 with softplus) and 1.5x the gradient tolerance."""
+  t, t32 = dict(TOL[name]), dict(TOL32[name])
+  if any('net_activation' in b for b in extra):
+    for d in (t, t32):
+      for k in ('sdist', 'weights', 'rgb'):
+        d[k] *= 2.0
+      d['grad'] *= 1.5
+  return t, t32
+
+
 CASES = [
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128'], 40),
     ('blender_256', [], 24),
@@ -97,6 +110,10 @@ CASES = [
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'NerfMLP.bottleneck_noise = 0.4'], 24),
     # no view directions (models.py:57,226): rgb = Dense(3) straight off the trunk, density + rgb as one 4-column head
     ('blender_256', ['Model.use_viewdirs = False'], 16),
+    # non-ReLU net_activation, bound the way the reference's gin files would (configs.py:29-31 registers softplus, silu):
+    # pre-activations stored, act / act' as separate fp32 kernels; per-layer GEMMs for that MLP, the fused chain for the other
+    ('blender_256', ['NerfMLP.net_activation = @jax.nn.softplus', 'PropMLP.net_activation = @jax.nn.softplus'], 16),
+    ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'NerfMLP.net_activation = @jax.nn.silu'], 16),
     # a chain-eligible PropMLP behind a Ref-NeRF NerfMLP: PropMLP_0 starts at parameter 713,230 (2 mod 4), so its bias
     # rows are not 16-byte aligned and Model._chain_ok must hand it to the per-layer path (round-2 advisor finding)
     ('blender_refnerf', ['Model.single_mlp = False', 'PropMLP.net_depth = 4', 'PropMLP.net_width = 256',
@@ -113,6 +130,7 @@ CASES = [
 def test_forward_parity(name, extra, B, randomized):
   cfg, model, (om, on, op), params, flat, batch = _setup(name, extra, B)
   noise = helpers.make_noise(model, B) if randomized else None
+  tol, tol32 = _tols(name, extra)
   tf = 0.5
   r_bf, h_bf = omodels.model_apply(om, on, op, params, batch.rays, tf, True, noise=noise,
                                    dense_dtype=torch.bfloat16)
@@ -123,27 +141,27 @@ def test_forward_parity(name, extra, B, randomized):
   for lv in range(model.num_levels):
     s_k, s_o = hist[lv]['sdist'].cpu(), h_bf[lv]['sdist']
     # level 0 depends on no MLP output: fp32-exact up to transcendental ulps.
-    tol_s = 2e-6 if lv == 0 else TOL[name]['sdist']
+    tol_s = 2e-6 if lv == 0 else tol['sdist']
     err_s = (s_k - s_o).abs().max().item()
     cost_s = (h_bf[lv]['sdist'] - h_32[lv]['sdist']).abs().max().item()
     e32_s = (s_k - h_32[lv]['sdist']).abs().max().item()
     print(f'{name} rand={randomized} level {lv}: |sdist - oracle_bf16| = {err_s:.2e} (bf16 cost {cost_s:.2e}) FP32DIST sdist {e32_s:.2e}')
     assert err_s <= tol_s, (lv, err_s, tol_s)
-    assert e32_s <= (2e-6 if lv == 0 else TOL32[name]['sdist']), (lv, e32_s)
+    assert e32_s <= (2e-6 if lv == 0 else tol32['sdist']), (lv, e32_s)
     w_k, w_o = hist[lv]['weights'].cpu(), h_bf[lv]['weights']
     err_w = (w_k - w_o).abs().max().item()
     cost_w = (h_bf[lv]['weights'] - h_32[lv]['weights']).abs().max().item()
     e32_w = (w_k - h_32[lv]['weights']).abs().max().item()
     print(f'    weights err {err_w:.2e} (bf16 cost {cost_w:.2e}) FP32DIST weights {e32_w:.2e}')
-    assert err_w <= TOL[name]['weights'], (lv, err_w)
-    assert e32_w <= TOL32[name]['weights'], (lv, e32_w)
+    assert err_w <= tol['weights'], (lv, err_w)
+    assert e32_w <= tol32['weights'], (lv, e32_w)
   rgb_k, rgb_o, rgb_32 = rend[-1]['rgb'].cpu(), r_bf[-1]['rgb'], r_32[-1]['rgb']
   err = (rgb_k - rgb_o).abs().max().item()
   cost = (rgb_o - rgb_32).abs().max().item()
   print(f'{name} rand={randomized}: rgb |kernel - oracle_bf16| = {err:.2e}; bf16 cost |oracle_bf16 - oracle_fp32| = {cost:.2e}; '
         f'|kernel - oracle_fp32| = {(rgb_k - rgb_32).abs().max().item():.2e}')
-  assert err <= TOL[name]['rgb'], err
-  assert (rgb_k - rgb_32).abs().max().item() <= TOL32[name]['rgb']
+  assert err <= tol['rgb'], err
+  assert (rgb_k - rgb_32).abs().max().item() <= tol32['rgb']
   for k in ('acc', 'distance_mean', 'distance_median', 'distance_percentile_5', 'distance_percentile_95'):
     a, b = rend[-1][k].cpu(), r_bf[-1][k]
     rel = ((a - b).abs() / b.abs().clamp_min(1e-3)).max().item()
@@ -160,6 +178,7 @@ def _flat_grads(model, grads_tree):
 def test_train_step_parity(name, extra, B):
   cfg, model, (om, on, op), params, flat, batch = _setup(name, extra, B)
   noise = helpers.make_noise(model, B)
+  tol, tol32 = _tols(name, extra)
   tf = 0.3
   st = otrain.init_opt_state(params)
   new_p, new_s, stats_o, grads_o = otrain.train_step(params, st, om, on, op, cfg, batch, tf, noise=noise,
@@ -198,8 +217,8 @@ def test_train_step_parity(name, extra, B):
     cost = ((r - r32).norm() / (r32.norm() + 1e-30)).item()
     rel32 = ((a - r32).norm() / (r32.norm() + 1e-30)).item()
     print(f'{name} {mod}: grad cos {cos:.6f} rel err {rel:.3e} (bf16 cost {cost:.3e}) FP32DIST grad {rel32:.3e} |g| {r.norm().item():.3e}')
-    assert cos > 0.995 and rel < TOL[name]['grad'], (mod, cos, rel)
-    assert rel32 < TOL32[name]['grad'], (mod, rel32)
+    assert cos > 0.995 and rel < tol['grad'], (mod, cos, rel)
+    assert rel32 < tol32['grad'], (mod, rel32)
   # per-Dense check (catches a layer whose gradient lands at the wrong offset); the hinge in the
   # interlevel loss makes proposal gradients sensitive to bf16-level weight changes, so each layer is
   # judged against its own bf16 cost.
@@ -207,6 +226,10 @@ def test_train_step_parity(name, extra, B):
   # (with the normal losses switched off the predicted-normal head only sees gradient through the reflection direction:
   # a weak, cancelling signal whose bf16 noise is judged at 2x its own bf16 cost instead of 1.5x)
   layer_factor = 2.0 if 'Config.predicted_normal_loss_mult = 0.0' in extra else 1.5
+  if any('net_activation' in b for b in extra):
+    # softplus / silu: pre-activation, activation and both gradients are each rounded to bf16 (GEMM + separate kernel);
+    # measured on the simulator up to 2.0x the layer's own bf16 cost (PropMLP_0/Dense_0, through the interlevel hinge)
+    layer_factor = 2.5
   for p in model._plans:
     for d in p.dense:
       for (o, nelem, what) in ((d.kernel_off, d.fan_in * d.fan_out, 'kernel'), (d.bias_off, d.fan_out, 'bias')):
@@ -247,8 +270,14 @@ def test_unsupported_features_fail_loudly():
                                             'NerfMLP.disable_density_normals = False'])
   with pytest.raises(NotImplementedError, match='HIP path'):
     models.Model(config=cfg).build('cuda')
-  cfg = configs.load_preset('360', ['NerfMLP.net_activation = "softplus"'])
+  cfg = configs.load_preset('360', ['NerfMLP.net_activation = "tanh"'])       # not an activation the reference registers
   with pytest.raises(NotImplementedError, match='net_activation'):
+    models.Model(config=cfg).build('cuda')
+  cfg = configs.load_preset('blender_refnerf', ['NerfMLP.net_activation = @jax.nn.softplus'])
+  with pytest.raises(NotImplementedError, match='density-gradient normals'):
+    models.Model(config=cfg).build('cuda')
+  cfg = configs.load_preset('360', ['Model.stop_level_grad = False'])
+  with pytest.raises(NotImplementedError, match='stop_level_grad'):
     models.Model(config=cfg).build('cuda')
 
 
