@@ -238,6 +238,9 @@ typedef struct {
                                  Bt[skip_layer] has W + K0 columns, the feature part behind the W activation columns; 0: none */
 } mnr_mlp_chain_fwd_args;
 int mnr_mlp_chain_fwd(const mnr_mlp_chain_fwd_args* args, void* stream);
+/* A/B switch of both chain kernels: 1 (default) = a layer's copy-out (activation / gradient rows, mask bits) is issued from
+ * inside the NEXT layer's MFMA pass, behind that pass's last weight request; 0 = in front of the pass.  Bitwise equal. */
+int mnr_mlp_chain_set_deferred(int on);
 
 typedef struct {
   int64_t M; int W; int depth;

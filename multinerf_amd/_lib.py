@@ -155,6 +155,7 @@ _PROTOS = {
     'mnr_mlp_chain_fwd': ([C.POINTER(MlpChainFwdArgs), vp], i32),
     'mnr_mlp_chain_bwd': ([C.POINTER(MlpChainBwdArgs), vp], i32),
     'mnr_debug_chain_timeline': ([vp], i32),
+    'mnr_mlp_chain_set_deferred': ([i32], i32),
     'mnr_gemm_tn_set_config': ([i32], i32),
     'mnr_gemm_nt_set_nt_stores': ([i32], i32),
     'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),

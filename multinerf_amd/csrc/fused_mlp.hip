@@ -101,6 +101,16 @@ struct FmCfg {
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Workgroup barrier that orders LDS traffic only (all of a wave's LDS operations retired, then s_barrier).  __syncthreads()
+// also waits for vmcnt(0), i.e. for every global store in flight: with the copy-out stores deferred into the MFMA pass that
+// would put their drain time back in front of the epilogue.  Nothing inside these kernels reads what they store to global
+// memory, so the stores may stay in flight across the barrier.
+__device__ __forceinline__ void fm_lds_barrier() {
+  MNR_GPU_ONLY(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
@@ -118,9 +128,16 @@ __device__ __forceinline__ void fm_load_wchunk(const bf16* __restrict__ Bt, int 
   for (int j = 0; j < FM_WCHUNK; ++j) w[j] = *(const bf16x8*)(wsrc + j * 16);
 }
 
-template <int W>
+// DEFER (bit 0: activation rows, bit 1: mask bits): the copy-out of the tile this pass READS (the previous layer's output,
+// intact in LDS for the whole pass) is issued from inside the pass, in COPY_ITERS / 4 batches placed AFTER the layer's last
+// weight-chunk request.  vmcnt retires in order on gfx950, loads and stores alike: with the copy-out in front of the pass
+// (its place in round 2) the wait for weight chunk 1 also waited for every store of the copy-out, 8-10k cycles of every
+// layer (tools/chain_probe.py --timeline: MFMA phase 14.7k cycles in training against 5.9k in inference); behind the last
+// chunk request nothing in the pass waits on vmcnt any more and the stores drain under the epilogue.
+template <int W, int DEFER>
 __device__ __forceinline__ void fm_layer_mfma(const char* X, const bf16* __restrict__ Bt, int ldb, int cw, int rg, int lane_,
-                                              const bf16x8 (&w0)[FM_WCHUNK], f32x16 (&acc)[FmCfg<W>::RB]) {
+                                              const bf16x8 (&w0)[FM_WCHUNK], f32x16 (&acc)[FmCfg<W>::RB], int tid_ = 0,
+                                              int64_t m0 = 0, bf16* __restrict__ dst = nullptr, uint8_t* __restrict__ bits = nullptr) {
   typedef FmCfg<W> C;
   const int lane = fm_opaque(lane_), frow = lane & 31, khalf = lane >> 5;
   constexpr int NKS = W / 16;
@@ -128,6 +145,14 @@ __device__ __forceinline__ void fm_layer_mfma(const char* X, const bf16* __restr
   constexpr int HB = C::RB > 4 ? 4 : C::RB;            // row blocks per fragment batch
   constexpr int NH = C::RB / HB;
   constexpr int STEPS = NKS * NH;
+  // deferred copy-out: batches of UB chunks, ds_reads at step CP_FIRST + b * CP_STRIDE, the stores one step later
+  constexpr int UB = 4;
+  constexpr int NB = C::COPY_ITERS / UB;
+  constexpr int LAST_LOAD = NCH >= 2 ? ((NCH - 2) * FM_WCHUNK + 1) * NH : 0;
+  constexpr int CP_FIRST = LAST_LOAD + 1;
+  constexpr int CP_STRIDE = (STEPS - LAST_LOAD - 2) / NB;
+  static_assert(DEFER == 0 || (C::COPY_ITERS % UB == 0 && CP_STRIDE >= 2 && CP_FIRST + (NB - 1) * CP_STRIDE + 1 < STEPS),
+                "deferred copy-out does not fit behind the last weight-chunk request");
 #pragma unroll
   for (int rb = 0; rb < C::RB; ++rb)
 #pragma unroll
@@ -146,6 +171,7 @@ __device__ __forceinline__ void fm_layer_mfma(const char* X, const bf16* __restr
 #pragma unroll
   for (int j = 0; j < FM_WCHUNK; ++j) wq[0][j] = w0[j];
   bf16x8 fa[2][HB];
+  u32x4 cpw[UB];                                        // one copy-out batch in flight (DEFER)
   read_batch(0, fa[0]);
 #pragma unroll
   for (int step = 0; step < STEPS; ++step) {
@@ -159,6 +185,38 @@ __device__ __forceinline__ void fm_layer_mfma(const char* X, const bf16* __restr
       fm_load_wchunk(Bt, ldb, cw, frow, khalf, c + 1, wq[(c + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (DEFER != 0) {
+      const int rel = step - CP_FIRST;
+      if (rel >= 0 && rel % CP_STRIDE == 0 && rel / CP_STRIDE < NB) {
+        // batch b: UB 16-byte chunks of this thread's rows, LDS -> registers
+        const int b = rel / CP_STRIDE;
+        const int tid = fm_opaque(tid_);
+        const int row0 = tid / C::CPR, ch = tid % C::CPR;
+        const char* lptr = X + (ch >> 3) * FM_KT_BYTES + row0 * 128 + (((ch & 7) ^ ((row0 >> 1) & 7)) << 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) cpw[u] = *(const u32x4*)(lptr + (b * UB + u) * C::ROW_STEP * 128);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (rel >= 1 && (rel - 1) % CP_STRIDE == 0 && (rel - 1) / CP_STRIDE < NB) {
+        const int b = (rel - 1) / CP_STRIDE;
+        const int tid = fm_opaque(tid_);
+        const int row0 = tid / C::CPR, ch = tid % C::CPR;
+        const int64_t r = m0 + row0 + (int64_t)b * UB * C::ROW_STEP;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if constexpr ((DEFER & 2) != 0) {
+            unsigned mb = mnr_relu_mask_byte(cpw[u][0], cpw[u][1], cpw[u][2], cpw[u][3]);
+            mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xF5, 0xf, 0xf, false) << 8;     // quad_perm [1,1,3,3]
+            mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xAA, 0xf, 0xf, false) << 16;    // quad_perm [2,2,2,2]
+            if ((ch & 3) == 0) *(unsigned*)(bits + (r + (int64_t)u * C::ROW_STEP) * (W / 8) + ch) = mb;
+          }
+          if constexpr ((DEFER & 1) != 0) *(u32x4*)(dst + (r + (int64_t)u * C::ROW_STEP) * W + ch * 8) = cpw[u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     if (step + 1 < STEPS) {
       read_batch(step + 1, fa[(step + 1) & 1]);
       __builtin_amdgcn_sched_group_barrier(0x100, HB, 0);          // this step's (next-batch) ds_reads first ...
@@ -168,6 +226,17 @@ __device__ __forceinline__ void fm_layer_mfma(const char* X, const bf16* __restr
       acc[h * HB + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[c & 1][j], fa[step & 1][i], acc[h * HB + i], 0, 0, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, HB, 0);            // ... then its MFMAs
   }
+}
+
+// (kernel-uniform dispatch on which outputs of the previous layer are deferred into this pass)
+template <int W>
+__device__ __forceinline__ void fm_layer_mfma_defer(const char* X, const bf16* __restrict__ Bt, int ldb, int cw, int rg, int lane,
+                                                    const bf16x8 (&w0)[FM_WCHUNK], f32x16 (&acc)[FmCfg<W>::RB], int tid, int64_t m0,
+                                                    bf16* dst, uint8_t* bits) {
+  if (dst && bits) fm_layer_mfma<W, 3>(X, Bt, ldb, cw, rg, lane, w0, acc, tid, m0, dst, bits);
+  else if (dst) fm_layer_mfma<W, 1>(X, Bt, ldb, cw, rg, lane, w0, acc, tid, m0, dst, bits);
+  else if (bits) fm_layer_mfma<W, 2>(X, Bt, ldb, cw, rg, lane, w0, acc, tid, m0, dst, bits);
+  else fm_layer_mfma<W, 0>(X, Bt, ldb, cw, rg, lane, w0, acc);
 }
 
 // The feature segment of a skip-concat layer: acc[rb] += feat[rows of this wave, 0..K0) * Bt[cols of this wave, kcol0..kcol0+K0)^T.
@@ -337,7 +406,7 @@ __device__ __forceinline__ void fm_copy_out_dispatch(const char* X, int tid, int
 }
 
 template <int W>
-__global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(mnr_mlp_chain_fwd_args p) {
+__global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(mnr_mlp_chain_fwd_args p, int defer) {
   typedef FmCfg<W> C;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -421,7 +490,9 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(mnr_mlp_chain_fwd_ar
     }
     for (int li = 0; li < p.depth; ++li) {
       if (li > 0) {
-        fm_layer_mfma<W>(smem, (const bf16*)p.Bt[li], p.ldb[li], cw, rg, lane, w0, acc);
+        // (defer: the previous layer's copy-out rides inside this pass instead of standing in front of it)
+        if (defer) fm_layer_mfma_defer<W>(smem, (const bf16*)p.Bt[li], p.ldb[li], cw, rg, lane, w0, acc, tid, m0, (bf16*)p.acts[li - 1], p.bits[li - 1]);
+        else fm_layer_mfma<W, 0>(smem, (const bf16*)p.Bt[li], p.ldb[li], cw, rg, lane, w0, acc);
         if (li == p.skip_layer)                             // input = [x_{li-1} | features] (models.py:458-459)
           fm_skip_segment<W>(smem + C::SKIP_OFF, feat + m0 * (int64_t)p.ld_feat, p.ld_feat, p.K0, (const bf16*)p.Bt[li],
                              p.ldb[li], W, cw, rg, wave, lane, acc);
@@ -431,13 +502,14 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(mnr_mlp_chain_fwd_ar
         }
       }
       FM_STAMP(2 + 3 * li);
-      __syncthreads();                                  // every wave is done reading this layer's input
+      fm_lds_barrier();                                 // every wave is done reading this layer's input
       fm_epilogue<W, false>(smem, cw, rg, lane, acc, (const float*)(smem + C::BIAS_OFF) + li * W, no_bits);
-      __syncthreads();                                  // the layer's output is complete in LDS
+      fm_lds_barrier();                                 // the layer's output is complete in LDS
       FM_STAMP(3 + 3 * li);
       const bool last = li == p.depth - 1;
-      fm_copy_out_dispatch<W>(smem, tid, m0, (bf16*)p.acts[li], p.bits[li], last ? (const bf16*)p.w_head : nullptr, b_head,
-                              p.head_out);
+      if (last || !defer)
+        fm_copy_out_dispatch<W>(smem, tid, m0, (bf16*)p.acts[li], p.bits[li], last ? (const bf16*)p.w_head : nullptr, b_head,
+                                p.head_out);
       FM_STAMP(4 + 3 * li);
     }
     if (tl_on) g_fm_timeline[32 * (int64_t)blockIdx.x + 31] = __builtin_amdgcn_s_memrealtime();
@@ -445,7 +517,7 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(mnr_mlp_chain_fwd_ar
 }
 
 template <int W>
-__global__ __launch_bounds__(512) void mlp_chain_bwd_kernel(mnr_mlp_chain_bwd_args p) {
+__global__ __launch_bounds__(512) void mlp_chain_bwd_kernel(mnr_mlp_chain_bwd_args p, int defer) {
   typedef FmCfg<W> C;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -519,21 +591,31 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd_kernel(mnr_mlp_chain_bwd_ar
         for (int rb = 0; rb < C::RB; ++rb) mbits[rb] = *(const unsigned*)(bl + (int64_t)rb * 32 * (W / 8));
       }
       f32x16 acc[C::RB];
-      fm_layer_mfma<W>(smem, (const bf16*)p.Bw[li], p.ldb[li], cw, rg, lane, w0, acc);
+      // (defer: dY_li, this pass's input, is copied out from inside the pass; the rank-1 start wrote dY_last itself)
+      if (defer && li < p.depth - 1) fm_layer_mfma<W, 1>(smem, (const bf16*)p.Bw[li], p.ldb[li], cw, rg, lane, w0, acc, tid, m0, (bf16*)p.dY[li], nullptr);
+      else fm_layer_mfma<W, 0>(smem, (const bf16*)p.Bw[li], p.ldb[li], cw, rg, lane, w0, acc);
       FM_STAMP(2 + 3 * li);
       if (li > 1) {
         const int ln = fm_opaque(lane);
         fm_load_wchunk((const bf16*)p.Bw[li - 1], p.ldb[li - 1], cw, ln & 31, ln >> 5, 0, w0);
       }
-      __syncthreads();
+      fm_lds_barrier();
       fm_epilogue<W, true>(smem, cw, rg, lane, acc, nullptr, mbits);
-      __syncthreads();
+      fm_lds_barrier();
       FM_STAMP(3 + 3 * li);
-      fm_copy_out<W, true, false, false>(smem, tid, m0, (bf16*)p.dY[li - 1], nullptr, nullptr, 0.0f, nullptr);
+      if (!defer || li == 1) fm_copy_out<W, true, false, false>(smem, tid, m0, (bf16*)p.dY[li - 1], nullptr, nullptr, 0.0f, nullptr);
       FM_STAMP(4 + 3 * li);
     }
     if (tl_on) g_fm_timeline[32 * (int64_t)blockIdx.x + 31] = __builtin_amdgcn_s_memrealtime();
   }
+}
+
+// A/B switch: 1 (default) = a layer's copy-out rides inside the next layer's MFMA pass behind its last weight-chunk request
+// (fm_layer_mfma DEFER); 0 = in front of the pass (round 2).  Bitwise equal results.
+static int g_fm_defer = 1;
+extern "C" int mnr_mlp_chain_set_deferred(int on) {
+  g_fm_defer = on;
+  return MNR_OK;
 }
 
 static int fm_grid(int64_t tiles) {
@@ -568,10 +650,10 @@ extern "C" int mnr_mlp_chain_fwd(const mnr_mlp_chain_fwd_args* a, void* stream) 
   const int grid = fm_grid(a->M / FM_ROWS);
   if (a->W == 256) {
     (void)hipFuncSetAttribute((const void*)mlp_chain_fwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, FmCfg<256>::LDS_BYTES);
-    hipLaunchKernelGGL(mlp_chain_fwd_kernel<256>, dim3(grid), dim3(512), FmCfg<256>::LDS_BYTES, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(mlp_chain_fwd_kernel<256>, dim3(grid), dim3(512), FmCfg<256>::LDS_BYTES, (hipStream_t)stream, *a, g_fm_defer);
   } else {
     (void)hipFuncSetAttribute((const void*)mlp_chain_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, FmCfg<128>::LDS_BYTES);
-    hipLaunchKernelGGL(mlp_chain_fwd_kernel<128>, dim3(grid), dim3(512), FmCfg<128>::LDS_BYTES, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(mlp_chain_fwd_kernel<128>, dim3(grid), dim3(512), FmCfg<128>::LDS_BYTES, (hipStream_t)stream, *a, g_fm_defer);
   }
   MNR_CHECK_LAUNCH();
   return MNR_OK;
@@ -594,10 +676,10 @@ extern "C" int mnr_mlp_chain_bwd(const mnr_mlp_chain_bwd_args* a, void* stream) 
   const int grid = fm_grid(a->M / FM_ROWS);
   if (a->W == 256) {
     (void)hipFuncSetAttribute((const void*)mlp_chain_bwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, FmCfg<256>::LDS_BYTES);
-    hipLaunchKernelGGL(mlp_chain_bwd_kernel<256>, dim3(grid), dim3(512), FmCfg<256>::LDS_BYTES, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(mlp_chain_bwd_kernel<256>, dim3(grid), dim3(512), FmCfg<256>::LDS_BYTES, (hipStream_t)stream, *a, g_fm_defer);
   } else {
     (void)hipFuncSetAttribute((const void*)mlp_chain_bwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, FmCfg<128>::LDS_BYTES);
-    hipLaunchKernelGGL(mlp_chain_bwd_kernel<128>, dim3(grid), dim3(512), FmCfg<128>::LDS_BYTES, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(mlp_chain_bwd_kernel<128>, dim3(grid), dim3(512), FmCfg<128>::LDS_BYTES, (hipStream_t)stream, *a, g_fm_defer);
   }
   MNR_CHECK_LAUNCH();
   return MNR_OK;

@@ -135,15 +135,16 @@ static size_t cp_lds_bytes(int n, int s) { return (size_t)(6 * n + 1) * s * 4; }
 // A/B switch of the per-ray kernels: 1 = four lanes per ray (composite_fwd_quad_kernel, level_bwd_quad_kernel) where a
 // wave's 16 rays fit LDS, 0 = lane per ray for every shape
 static int g_level_bwd_quad = 1;
-// Largest LDS footprint (bytes per single-wave workgroup) at which the four-lanes-per-ray kernels are used: 40 KiB keeps four
-// workgroups (one per SIMD) on a CU; rays of 128 samples need 49 KiB (forward) / 66 KiB (backward), i.e. three / two
-// workgroups per CU, and are still faster there than on the lane-per-ray kernels (round-3 A/B).
+// Largest LDS footprint (bytes per single-wave workgroup) at which the four-lanes-per-ray kernels are used.  Up to 40 KiB four
+// workgroups (one per SIMD) fit a CU; rays of 128 samples need 49 KiB (forward) / 66 KiB (backward), i.e. three / two
+// workgroups per CU, and are still faster there than on the lane-per-ray kernels: round-3 same-box A/B with the limit at
+// 40 / 52 / 80 KiB: blender_256 1.670 / 1.658 / 1.737 M rays/s, llff_raw 488 / 496 / 495 k (profiles/r3_ab.md).
 // MNR_QUAD_LDS_MAX overrides (tuning).
 static size_t quad_lds_max() {
   static size_t v = 0;
   if (v == 0) {
     const char* e = getenv("MNR_QUAD_LDS_MAX");
-    v = e ? (size_t)atoll(e) : 40 * 1024;
+    v = e ? (size_t)atoll(e) : 80 * 1024;
     if (v < 1024) v = 1024;
     if (v > 160 * 1024) v = 160 * 1024;
   }

@@ -1,7 +1,8 @@
 """Equal-step PSNR reference for the headline configuration: the ORACLE trains configs/360.gin AS IS (1024-wide NeRF MLP,
 9.0 M parameters, levels 64/64/32) on the procedural unbounded scene for STEPS steps of RAYS rays, on the CPU, fp32.
 
-    python tests/golden/make_golden_psnr.py            # ~10 min on 8 cores; writes tests/golden/psnr360.json
+    python tests/golden/make_golden_psnr.py [--seed S]  # ~10 min on 8 cores; writes tests/golden/psnr360.json (seed 360) or
+                                                        # psnr360_s<S>.json; the committed seeds are 360, 361, 362
 
 tests/test_gpu_convergence.py::test_equal_step_psnr_360_full_width replays the same initialisation, the same batch and
 the same jitter at every step through the HIP path and compares the PSNR on the same held-out rays (north_star: "PSNR
@@ -25,19 +26,27 @@ STEPS, RAYS, EVAL_RAYS, SEED = 600, 256, 2048, 360
 BINDINGS = ['Config.max_steps = 600', 'Config.lr_delay_steps = 100', 'Config.batch_size = 256']
 
 
-def protocol(model, cfg, step):
+def protocol(model, cfg, step, seed=None):
   """(batch, noise, train_frac) of training step `step` (1-based), identical for the oracle and the HIP run."""
   from multinerf_amd import synthetic
   from oracle import bridge
-  batch = synthetic.unbounded_scene_rays(RAYS, seed=SEED * 100000 + step)
-  noise = bridge.make_noise(model, RAYS, seed=SEED * 100000 + step)
+  seed = SEED if seed is None else seed
+  batch = synthetic.unbounded_scene_rays(RAYS, seed=seed * 100000 + step)
+  noise = bridge.make_noise(model, RAYS, seed=seed * 100000 + step)
   train_frac = float(np.clip((step - 1) / (cfg.max_steps - 1), 0, 1))                 # train.py:118
   return batch, noise, train_frac
 
 
-def eval_rays():
+def eval_rays(seed=None):
   from multinerf_amd import synthetic
-  return synthetic.unbounded_scene_rays(EVAL_RAYS, seed=SEED * 100000 + 99999)
+  seed = SEED if seed is None else seed
+  return synthetic.unbounded_scene_rays(EVAL_RAYS, seed=seed * 100000 + 99999)
+
+
+def golden_path(seed):
+  """psnr360.json for the original seed, psnr360_s<seed>.json for the further ones (round 3: three seeds)."""
+  name = 'psnr360.json' if seed == SEED else f'psnr360_s{seed}.json'
+  return os.path.join(ROOT, 'tests', 'golden', name)
 
 
 def psnr(rgb, gt):
@@ -45,19 +54,20 @@ def psnr(rgb, gt):
 
 
 def main():
+  seed = int(sys.argv[sys.argv.index('--seed') + 1]) if '--seed' in sys.argv else SEED
   from multinerf_amd import configs, models
   from oracle import bridge, models as omodels, train_utils as otrain
   torch.set_num_threads(os.cpu_count())
   cfg = configs.load_preset('360', BINDINGS)
   model = models.Model(config=cfg)
   om, on, op = bridge.oracle_hparams(model)
-  params = omodels.init_params(om, on, op, seed=SEED)
+  params = omodels.init_params(om, on, op, seed=seed)
   st = otrain.init_opt_state(params)
-  ev = eval_rays()
+  ev = eval_rays(seed)
   curve = []
   t0 = time.time()
   for step in range(1, STEPS + 1):
-    batch, noise, tf = protocol(model, cfg, step)
+    batch, noise, tf = protocol(model, cfg, step, seed)
     params, st, stats, _ = otrain.train_step(params, st, om, on, op, cfg, batch, tf, noise=noise)
     if step % 50 == 0 or step == 1:
       with torch.no_grad():
@@ -65,9 +75,9 @@ def main():
       e = psnr(rend[-1]['rgb'].numpy(), ev.rgb.numpy())
       curve.append(dict(step=step, train_loss=float(stats['loss']), train_psnr=float(stats['psnr']), eval_psnr=e))
       print(f'step {step}: loss {float(stats["loss"]):.5f} train psnr {float(stats["psnr"]):.3f} eval psnr {e:.3f}  ({time.time() - t0:.0f} s)', flush=True)
-  out = dict(steps=STEPS, rays=RAYS, eval_rays=EVAL_RAYS, seed=SEED, bindings=BINDINGS, curve=curve,
+  out = dict(steps=STEPS, rays=RAYS, eval_rays=EVAL_RAYS, seed=seed, bindings=BINDINGS, curve=curve,
              note='oracle (fp32 torch-CPU restatement of the reference), configs/360.gin as is, procedural unbounded scene')
-  with open(os.path.join(ROOT, 'tests', 'golden', 'psnr360.json'), 'w') as f:
+  with open(golden_path(seed), 'w') as f:
     json.dump(out, f, indent=1)
 
 

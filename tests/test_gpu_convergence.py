@@ -87,8 +87,11 @@ def test_equal_step_psnr_360_full_width():
   the procedural UNBOUNDED scene (multinerf_amd.synthetic.unbounded_scene_rays: content inside the unit ball, a ground
   plane running through the contracted region to the horizon, sky at infinity behind the opaque last interval), 600
   steps of 256 rays from the oracle's initialisation with the oracle's batches and jitter at every step.  The oracle's
-  side ran on the CPU ahead of time (tests/golden/make_golden_psnr.py -> tests/golden/psnr360.json); here the HIP path
-  replays the protocol and must land within 0.1 dB of the oracle's held-out PSNR at equal step count (north_star)."""
+  side ran on the CPU ahead of time (tests/golden/make_golden_psnr.py [--seed S] -> tests/golden/psnr360*.json); here the
+  HIP path replays the protocol and must land within 0.1 dB of the oracle's held-out PSNR at equal step count
+  (north_star).  Round 3: THREE seeds (initialisation, batches and jitter all differ); every seed's difference is
+  printed, the mean |difference| over the seeds is held to 0.1 dB and no single seed may be further than 0.25 dB off
+  (two fp32-vs-bf16 trajectories of a 600-step run wander up to ~0.4 dB apart mid-run and come back)."""
   import importlib.util
   import json
   import os
@@ -98,41 +101,53 @@ def test_equal_step_psnr_360_full_width():
   spec = importlib.util.spec_from_file_location('make_golden_psnr', os.path.join(here, 'golden', 'make_golden_psnr.py'))
   G = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(G)
-  ref = json.load(open(os.path.join(here, 'golden', 'psnr360.json')))
-  assert ref['steps'] == G.STEPS and ref['rays'] == G.RAYS and ref['seed'] == G.SEED and ref['bindings'] == G.BINDINGS
+  seeds = [sd for sd in (G.SEED, G.SEED + 1, G.SEED + 2) if os.path.exists(G.golden_path(sd))]
+  assert G.SEED in seeds
   cfg = configs.load_preset('360', G.BINDINGS)
   model = models.Model(config=cfg)
   model.build('cuda')
   assert model.nerf_plan.W == 1024 and model.num_params == 9007493
   om, on, op = helpers.oracle_hparams(model)
-  flat = model.flat_from_tree(omodels.init_params(om, on, op, seed=G.SEED))
-  ev = G.eval_rays()
-  ev_rays = ev.rays.map(lambda t: t.cuda())
-  state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
-  step_fn = train_utils.create_train_step(model, cfg)
-  want = {c['step']: c for c in ref['curve']}
-  rows = []
-  for step in range(1, G.STEPS + 1):
-    batch, noise, tf = G.protocol(model, cfg, step)
-    state, stats, _ = step_fn(0, state, batch.map(lambda t: t.cuda()), None, tf, 0.0, noise=noise)
-    if step in want:
-      rend, _ = model.apply({'flat': state.params['flat']}, None, ev_rays, 1.0, False)
-      e = G.psnr(rend[-1]['rgb'].cpu().numpy(), ev.rgb.numpy())
-      s = stats.materialize()
-      rows.append(dict(step=step, hip_eval_psnr=e, oracle_eval_psnr=want[step]['eval_psnr'], hip_train_loss=s['loss'],
-                       oracle_train_loss=want[step]['train_loss']))
-      print(f'step {step:4d}: eval PSNR hip {e:.3f} oracle {want[step]["eval_psnr"]:.3f} ({e - want[step]["eval_psnr"]:+.3f} dB); '
-            f'train loss hip {s["loss"]:.5f} oracle {want[step]["train_loss"]:.5f}')
   out = os.environ.get('MNR_PSNR_LOG')
+  all_rows, finals, tails = [], {}, {}
+  for seed in seeds:
+    ref = json.load(open(G.golden_path(seed)))
+    assert ref['steps'] == G.STEPS and ref['rays'] == G.RAYS and ref['seed'] == seed and ref['bindings'] == G.BINDINGS
+    flat = model.flat_from_tree(omodels.init_params(om, on, op, seed=seed))
+    ev = G.eval_rays(seed)
+    ev_rays = ev.rays.map(lambda t: t.cuda())
+    state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+    step_fn = train_utils.create_train_step(model, cfg)
+    want = {c['step']: c for c in ref['curve']}
+    rows = []
+    for step in range(1, G.STEPS + 1):
+      batch, noise, tf = G.protocol(model, cfg, step, seed)
+      state, stats, _ = step_fn(0, state, batch.map(lambda t: t.cuda()), None, tf, 0.0, noise=noise)
+      if step in want:
+        rend, _ = model.apply({'flat': state.params['flat']}, None, ev_rays, 1.0, False)
+        e = G.psnr(rend[-1]['rgb'].cpu().numpy(), ev.rgb.numpy())
+        s = stats.materialize()
+        rows.append(dict(seed=seed, step=step, hip_eval_psnr=e, oracle_eval_psnr=want[step]['eval_psnr'], hip_train_loss=s['loss'],
+                         oracle_train_loss=want[step]['train_loss']))
+        print(f'seed {seed} step {step:4d}: eval PSNR hip {e:.3f} oracle {want[step]["eval_psnr"]:.3f} ({e - want[step]["eval_psnr"]:+.3f} dB); '
+              f'train loss hip {s["loss"]:.5f} oracle {want[step]["train_loss"]:.5f}')
+    first, last = rows[0], rows[-1]
+    assert abs(first['hip_eval_psnr'] - first['oracle_eval_psnr']) < 0.05                  # same start
+    assert last['oracle_eval_psnr'] > first['oracle_eval_psnr'] + 5.0, 'the reference run did not learn the scene'
+    finals[seed] = last['hip_eval_psnr'] - last['oracle_eval_psnr']
+    # the mean over the last three checkpoints averages out the step-to-step wobble of either trajectory
+    tails[seed] = float(np.mean([r['hip_eval_psnr'] - r['oracle_eval_psnr'] for r in rows[-3:]]))
+    print(f'equal-step PSNR, 360.gin full width, seed {seed}: final diff {finals[seed]:+.3f} dB, mean of the last three checkpoints '
+          f'{tails[seed]:+.3f} dB')
+    all_rows += rows
   if out:
     with open(out, 'w') as f:
-      for r in rows:
+      for r in all_rows:
         f.write(json.dumps(r) + '\n')
-  first, last = rows[0], rows[-1]
-  assert abs(first['hip_eval_psnr'] - first['oracle_eval_psnr']) < 0.05                  # same start
-  assert last['oracle_eval_psnr'] > first['oracle_eval_psnr'] + 5.0, 'the reference run did not learn the scene'
-  diff = last['hip_eval_psnr'] - last['oracle_eval_psnr']
-  # the mean over the last three checkpoints averages out the step-to-step wobble of either trajectory
-  tail = float(np.mean([r['hip_eval_psnr'] - r['oracle_eval_psnr'] for r in rows[-3:]]))
-  print(f'equal-step PSNR, 360.gin full width: final diff {diff:+.3f} dB, mean of the last three checkpoints {tail:+.3f} dB')
-  assert abs(diff) <= 0.1 and abs(tail) <= 0.1
+  mean_abs = float(np.mean([abs(v) for v in finals.values()]))
+  mean_abs_tail = float(np.mean([abs(v) for v in tails.values()]))
+  print(f'equal-step PSNR over seeds {seeds}: final diffs {[round(v, 3) for v in finals.values()]} dB, mean |diff| {mean_abs:.3f} dB '
+        f'(last-three-checkpoint means: {[round(v, 3) for v in tails.values()]}, mean |.| {mean_abs_tail:.3f} dB)')
+  assert abs(finals[G.SEED]) <= 0.1 and abs(tails[G.SEED]) <= 0.1        # the round-2 seed keeps its own bound
+  assert mean_abs <= 0.1 and mean_abs_tail <= 0.1
+  assert max(abs(v) for v in finals.values()) <= 0.25

@@ -72,11 +72,15 @@ TOL = {
 # precision pays the same cost: internal/math.py:21-23).  Measured in round 3 (gpurun_out/r3_gpu_tests*.log): rgb 360
 # <= 9.6e-3, blender_256 <= 1.7e-3, blender_refnerf <= 7.6e-4, llff_raw <= 1.9e-5.
 TOL32 = {
-    '360': dict(sdist=2e-2, weights=4e-2, rgb=1.5e-2, grad=0.30),
-    'blender_256': dict(sdist=2e-3, weights=6e-3, rgb=2.5e-3, grad=0.06),
-    'llff_raw': dict(sdist=1e-3, weights=8e-4, rgb=3e-5, grad=0.04),
-    'blender_refnerf': dict(sdist=4e-4, weights=1.6e-3, rgb=1.2e-3, grad=0.035),
+    '360': dict(sdist=9e-3, weights=2.1e-2, rgb=1.5e-2, grad=0.27),
+    'blender_256': dict(sdist=1.3e-3, weights=1.6e-3, rgb=2.5e-3, grad=0.052),
+    'llff_raw': dict(sdist=8e-4, weights=4e-4, rgb=3e-5, grad=0.036),
+    'blender_refnerf': dict(sdist=4.7e-4, weights=6e-4, rgb=1.2e-3, grad=0.03),
 }
+# (measured, gpurun_out/r3_gpu_tests2.log, max over the cases of a preset: 360 sdist 5.7e-3, weights 1.4e-2, rgb 9.6e-3 (1.8e-2
+# with bottleneck noise), grad 0.18; blender_256 8.7e-4 / 1.0e-3 / 1.7e-3 / 0.034; llff_raw 5.4e-4 / 2.7e-4 / 1.9e-5 / 0.024;
+# blender_refnerf 3.1e-4 / 4.0e-4 / 7.6e-4 / 0.020)
+
 
 def _tols(name, extra):
   """(TOL, TOL32) of a case.  Non-ReLU activations run as GEMM (bf16 pre-activation) + activation kernel: two bf16
@@ -88,6 +92,8 @@ def _tols(name, extra):
       for k in ('sdist', 'weights', 'rgb'):
         d[k] *= 2.0
       d['grad'] *= 1.5
+  if any('bottleneck_noise' in b for b in extra):
+    t32['rgb'] *= 1.8        # bf16(bottleneck + 0.4 N(0,1)) rounds a larger number than bf16(bottleneck): measured 1.8e-2
   return t, t32
 
 
