@@ -109,7 +109,7 @@ __global__ __launch_bounds__(RF_THREADS) void ref_head_fwd_kernel(
     int64_t M, int n, const float* __restrict__ small, const float* __restrict__ raw_grad,
     const float* __restrict__ viewdirs, mnr_ide_tables tabs, float roughness_bias, bf16* __restrict__ vi, int ldvi,
     int col0, int col_end, float* __restrict__ normals_out, float* __restrict__ npred_out,
-    float* __restrict__ rough_out) {
+    float* __restrict__ rough_out, int vec8) {
   __shared__ IdeTab tab;
   rf_load_tab(tab, tabs);
   __syncthreads();
@@ -134,9 +134,22 @@ __global__ __launch_bounds__(RF_THREADS) void ref_head_fwd_kernel(
   rf_ide<false>(tab, u[0], u[1], u[2], rough, ide, nullptr, nullptr, nullptr);
   bf16* o = vi + s * ldvi + col0;
   const int T2 = 2 * tab.T;
-  for (int i = 0; i < T2; ++i) o[i] = (bf16)ide[i];
-  o[T2] = (bf16)ndv;                                            // models.py:560-563 (un-negated viewdirs)
-  for (int c = col0 + T2 + 1; c < col_end; ++c) vi[s * ldvi + c] = (bf16)0.0f;
+  if (vec8) {
+    // [IDE (2T) | n.v | zeros up to col_end] in 16-byte pieces (col0 and col_end are multiples of 8 here)
+    for (int c8 = 0; col0 + c8 * 8 < col_end; ++c8) {
+      bf16x8 w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = c8 * 8 + e;
+        w[e] = (bf16)(i < T2 ? ide[i] : (i == T2 ? ndv : 0.0f));      // models.py:560-563 (un-negated viewdirs)
+      }
+      *(bf16x8*)(o + c8 * 8) = w;
+    }
+  } else {
+    for (int i = 0; i < T2; ++i) o[i] = (bf16)ide[i];
+    o[T2] = (bf16)ndv;                                          // models.py:560-563 (un-negated viewdirs)
+    for (int c = col0 + T2 + 1; c < col_end; ++c) vi[s * ldvi + c] = (bf16)0.0f;
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     normals_out[s * 3 + i] = nrm[i];
@@ -155,7 +168,8 @@ extern "C" int mnr_ref_head_fwd(int64_t M, int n, const float* small, const floa
   MNR_CHECK_ARG(col0 + 2 * tabs->T + 1 <= col_end && col_end <= ldvi, "mnr_ref_head_fwd: columns out of range");
   hipLaunchKernelGGL(ref_head_fwd_kernel, dim3(mnr_cdiv(M, RF_THREADS)), dim3(RF_THREADS), 0, (hipStream_t)stream, M, n,
                      small, raw_grad, viewdirs, *tabs, roughness_bias, (bf16*)vi, ldvi, col0, col_end, normals_out,
-                     normals_pred_out, roughness_out);
+                     normals_pred_out, roughness_out,
+                     (col0 % 8 == 0 && col_end % 8 == 0 && ldvi % 8 == 0 && ((uintptr_t)vi % 16) == 0) ? 1 : 0);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(RF_THREADS) void ref_head_bwd_kernel(
     const float* __restrict__ viewdirs, mnr_ide_tables tabs, float roughness_bias, const bf16* __restrict__ dvi_a,
     const bf16* __restrict__ dvi_b, int lddvi, int col0, const float* __restrict__ g_npred_in,
     const float* __restrict__ g_n_in, bf16* __restrict__ dhb, int lddhb, int col_gp, int col_rough,
-    float* __restrict__ g_raw_grad) {
+    float* __restrict__ g_raw_grad, int vec8) {
   __shared__ IdeTab tab;
   rf_load_tab(tab, tabs);
   __syncthreads();
@@ -194,13 +208,34 @@ __global__ __launch_bounds__(RF_THREADS) void ref_head_bwd_kernel(
   for (int i = 0; i < 3; ++i) u[i] = v[i] - 2.0f * ndv * npred[i];
   const int T2 = 2 * tab.T;
   float g[2 * RF_MAX_T];
-  for (int i = 0; i < T2; ++i) {
-    float x = (float)dvi_a[s * lddvi + col0 + i];
-    if (dvi_b) x += (float)dvi_b[s * lddvi + col0 + i];
-    g[i] = x;
+  float g_ndv = 0.0f;
+  if (vec8) {
+    // the T2 + 1 gradient columns of this sample's row in 16-byte pieces (73 two-byte loads per matrix and thread before:
+    // the kernel was bound by their issue, 5.6 ms per level at 2^21 samples)
+    const bf16* pa = dvi_a + s * lddvi + col0;
+    const bf16* pb = dvi_b ? dvi_b + s * lddvi + col0 : nullptr;
+    for (int c8 = 0; c8 * 8 <= T2; ++c8) {
+      const bf16x8 a = *(const bf16x8*)(pa + c8 * 8);
+      bf16x8 b;
+      if (pb) b = *(const bf16x8*)(pb + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = c8 * 8 + e;
+        float x = (float)a[e];
+        if (pb) x += (float)b[e];
+        if (i < T2) g[i] = x;
+        else if (i == T2) g_ndv = x;
+      }
+    }
+  } else {
+    for (int i = 0; i < T2; ++i) {
+      float x = (float)dvi_a[s * lddvi + col0 + i];
+      if (dvi_b) x += (float)dvi_b[s * lddvi + col0 + i];
+      g[i] = x;
+    }
+    g_ndv = (float)dvi_a[s * lddvi + col0 + T2];
+    if (dvi_b) g_ndv += (float)dvi_b[s * lddvi + col0 + T2];
   }
-  float g_ndv = (float)dvi_a[s * lddvi + col0 + T2];
-  if (dvi_b) g_ndv += (float)dvi_b[s * lddvi + col0 + T2];
   float gu[3] = {0.0f, 0.0f, 0.0f}, gk = 0.0f;
   rf_ide<true>(tab, u[0], u[1], u[2], rough, nullptr, g, gu, &gk);
   // u = v - 2 (n.v) n  ->  d/dn
@@ -263,9 +298,13 @@ extern "C" int mnr_ref_head_bwd(int64_t M, int n, const float* small, const floa
   MNR_CHECK_ARG(M > 0 && n > 0 && small && raw_grad && viewdirs && tabs && dvi_a && dhb && g_raw_grad,
                 "mnr_ref_head_bwd: null argument");
   MNR_CHECK_ARG(tabs->T >= 1 && tabs->T <= RF_MAX_T && tabs->lmax <= RF_MAX_L, "Only deg_view of at most 5 is numerically stable.");
+  // 16-byte row pieces when the columns [col0, col0 + 8 ceil((2T + 1) / 8)) are aligned and inside the row
+  const int ncol8 = (2 * tabs->T + 1 + 7) / 8 * 8;
+  const int vec8 = (col0 % 8 == 0 && lddvi % 8 == 0 && col0 + ncol8 <= lddvi && ((uintptr_t)dvi_a % 16) == 0 &&
+                    (!dvi_b || ((uintptr_t)dvi_b % 16) == 0)) ? 1 : 0;
   hipLaunchKernelGGL(ref_head_bwd_kernel, dim3(mnr_cdiv(M, RF_THREADS)), dim3(RF_THREADS), 0, (hipStream_t)stream, M, n,
                      small, raw_grad, viewdirs, *tabs, roughness_bias, (const bf16*)dvi_a, (const bf16*)dvi_b, lddvi,
-                     col0, g_npred, g_n, (bf16*)dhb, lddhb, col_gp, col_rough, g_raw_grad);
+                     col0, g_npred, g_n, (bf16*)dhb, lddhb, col_gp, col_rough, g_raw_grad, vec8);
   MNR_CHECK_LAUNCH();
   if (col0 > 0) {
     MNR_CHECK_ARG(col0 % 8 == 0 && lddvi % 8 == 0 && lddhb % 8 == 0, "mnr_ref_head_bwd: bottleneck width / strides must be multiples of 8");

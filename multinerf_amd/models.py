@@ -1173,7 +1173,8 @@ class Model:
         ops.small_head_bwd(x_last, W, g_raw_density.view(M, 1), w_head.view(W, 1), M=M, K=W, Cn=1, dX=None,
                            relu_mask=False, dW=gslice(d.kernel_off, W), db=gslice(d.bias_off, 1))
         D = len(plan.trunk)
-        dYs = [self._buf(('bwd', 'dYc', W, i), (M, W), bf16) for i in range(D)]
+        # (keyed by level: the proposal levels' backward passes may run side by side on streams of their own)
+        dYs = [self._buf(('bwd', 'dYc', W, i, lv['level']), (M, W), bf16) for i in range(D)]
         Bws = [None] + [self._w(plan, plan.packed[('trunk', i)]['b_off'], _rup(W, 128), plan.packed[('trunk', i)]['b_ld'])
                         for i in range(1, D)]
         ops.mlp_chain_bwd(g_raw_density.view(M), w_head, mlp['bits'], Bws, dYs, M=M, W=W)

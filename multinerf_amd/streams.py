@@ -61,6 +61,9 @@ class BackwardStreams:
       self.prop = torch.cuda.Stream(device=self.device)
       self.nerf = None                                   # the NeRF level stays on the caller's stream
       self.prop_budget = self.nerf_budget = 0
+    # MNR_SIDE_STREAMS = 2: every proposal level on a stream of its own (A/B switch; plain streams only)
+    n = int(os.environ.get('MNR_SIDE_STREAMS', '1'))
+    self.props = [self.prop] + [torch.cuda.Stream(device=self.device) for _ in range(max(0, n - 1) if not self.side_cus else 0)]
 
   @staticmethod
   def from_env(device):

@@ -209,20 +209,24 @@ def create_train_step(model: models.Model, config, dataset=None):
       nerf_stream = bs.nerf if bs.nerf is not None else cur
       if bs.nerf is not None:
         bs.nerf.wait_event(ready)
-      bs.prop.wait_event(ready)
-      with torch.cuda.stream(bs.prop), mstreams.budget(bs.prop_budget):
-        for li in order:
-          if li != nlev - 1:
-            level_backward(li)
-        done_prop = torch.cuda.Event()
-        done_prop.record(bs.prop)
+      done_props = []
+      for si, ps in enumerate(bs.props):
+        ps.wait_event(ready)
+        with torch.cuda.stream(ps), mstreams.budget(bs.prop_budget):
+          for li in order:
+            if li != nlev - 1 and li % len(bs.props) == si:
+              level_backward(li)
+          ev = torch.cuda.Event()
+          ev.record(ps)
+          done_props.append(ev)
       with torch.cuda.stream(nerf_stream), mstreams.budget(bs.nerf_budget):
         level_backward(nlev - 1)
         if bs.nerf is not None:
           done_nerf = torch.cuda.Event()
           done_nerf.record(bs.nerf)
           cur.wait_event(done_nerf)
-      cur.wait_event(done_prop)
+      for ev in done_props:
+        cur.wait_event(ev)
     if g_expo is not None:
       n_off = model.num_glo_embeddings * 3
       ops.exposure_scale_bwd(R.exposure_values.reshape(-1).contiguous().float(),
