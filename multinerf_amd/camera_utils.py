@@ -169,7 +169,11 @@ def transform_poses_pca(poses):
 
   Principal axes from the SVD of the centred [N,3] centre matrix (its right singular vectors, already sorted by
   spread).  An axis is only defined up to sign; the sign is fixed here by making every axis' largest-magnitude
-  component positive before the handedness / up-vector rules below are applied.
+  component positive before the handedness / up-vector rules below are applied.  The reference takes its signs from
+  LAPACK's general eigen-solver instead, and its two fix-ups leave a 180-degree turn about z open: over the 12 captures of
+  tests/golden/pca_poses.npz (the reference's own outputs) this function's frame is identical to the reference's in 11
+  and differs by exactly diag(-1, -1, 1) in one (tests/test_oracle_camera.py).  Anything expressed in the normalised
+  frame (a checkpoint, a render path) is interchangeable with the reference's up to that turn only.
   """
   centres = poses[:, :3, 3]
   mean = centres.mean(0)
