@@ -290,6 +290,11 @@ def main():
             # two fractions of the same 2.5 PFLOP/s: `frac` / `gemm_frac` = algorithmic FLOPs / time spent INSIDE the MFMA
             # kernels (HIP events); `whole_step_frac` = SURVEY 8(d)'s definition, rays/s x FLOPs/ray / peak per GPU
             'gemm_frac': achieved_tflops / 2500.0,
+            # With the proposal levels' backward on its own stream (multinerf_amd/streams.py, the default) MFMA kernels of
+            # two streams overlap: `gemm_ms_per_step` is the UNION of their launch intervals (time during which at least one
+            # MFMA kernel runs), `gemm_ms_per_step_sum_of_launches` the plain sum (what a rocprofv3 --stats table adds up
+            # to: a launch that shares the chip takes longer).  MNR_SIDE_STREAM=0 makes the two equal.
+            'frac_definition': 'algorithmic training FLOPs per step / union of the MFMA kernels\' launch intervals / 2.5 PFLOP/s',
             'whole_step_achieved': train_flops * B / (ms_per_step * 1e-3) / 1e12,
             'whole_step_frac': train_flops * B / (ms_per_step * 1e-3) / 2.5e15,
             'traffic': traffic,
