@@ -39,10 +39,15 @@ def assert_adam_matches_oracle(model, cfg, flat0, raw_grad, opt0, state2, what='
   ref_nu = model.flat_from_tree(new_opt['nu'], device='cpu').double()
   got_p, got_mu, got_nu = (t.detach().double().cpu() for t in (state2.params['flat'], state2.mu, state2.nu))
   assert state2.step == new_opt['count'], (state2.step, new_opt['count'])
+  # mu = b1 mu + (1 - b1) g is a sum of terms of either sign: where they cancel, one fp32 rounding of the larger terms
+  # (6e-8 relative to THEM) is a large relative error of the small result.  So mu is held to a few ulps of the largest
+  # element in absolute terms, and per element only to 2e-3 with the 1e-5 max|mu| floor (the worst element of 9 M sat at
+  # 0.99e-4 on one box and 1.1e-4 on another in round 3: the old 1e-4 bound was a coin flip, not a check).
   e_mu = ((got_mu - ref_mu).abs() / (ref_mu.abs() + 1e-5 * ref_mu.abs().max() + 1e-30)).max().item()
+  e_mu_abs = ((got_mu - ref_mu).abs().max() / (ref_mu.abs().max() + 1e-30)).item()
   e_nu = ((got_nu - ref_nu).abs() / (ref_nu.abs() + 1e-5 * ref_nu.abs().max() + 1e-30)).max().item()
   # the update itself, relative to the learning rate (|update| <= ~lr): 1e-3 lr absolute + fp32 rounding of the parameter
   upd_err = ((got_p - ref_p).abs() - 2.0 ** -23 * ref_p.abs()).clamp_min(0).max().item() / lr
-  print(f'{what}Adam vs oracle on the kernel gradient: mu rel {e_mu:.2e}, nu rel {e_nu:.2e}, |update err| / lr {upd_err:.2e} (lr {lr:.3e})')
-  assert e_mu < 1e-4 and e_nu < 2e-4 and upd_err < 1e-3, (e_mu, e_nu, upd_err)
+  print(f'{what}Adam vs oracle on the kernel gradient: mu rel {e_mu:.2e} (abs / max {e_mu_abs:.2e}), nu rel {e_nu:.2e}, |update err| / lr {upd_err:.2e} (lr {lr:.3e})')
+  assert e_mu < 2e-3 and e_mu_abs < 1e-6 and e_nu < 2e-4 and upd_err < 1e-3, (e_mu, e_mu_abs, e_nu, upd_err)
   return state2.mu.detach().clone(), state2.nu.detach().clone(), state2.step
