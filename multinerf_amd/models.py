@@ -43,6 +43,11 @@ _USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused
 # buffers) the dX chain runs ahead and the dW launches fill the CUs each dX launch's tail leaves idle (and the other way
 # round); both are full-size launches, nothing is partitioned.
 _DW_STREAM = _os.environ.get('MNR_DW_STREAM', '0') != '0'
+# A/B switch: the backward pass of ALL proposal levels as one pass (they share PropMLP_0 and the sample count, reference
+# models.py:120-121,166): their features / activations / mask bits sit in consecutive row blocks of one buffer per kind, so
+# one dX chain and one weight-gradient GEMM per layer cover L*M rows (half the launches and half the 256 KiB atomic
+# epilogues of the per-level form at 360.gin).
+_MERGE_PROPS = _os.environ.get('MNR_MERGE_PROPS', '1') != '0'
 
 
 class _SideLaunch:
@@ -561,6 +566,24 @@ class Model:
       self._ws[k] = t
     return t
 
+  def _lvl_buf(self, tag, name, rows, cols, dtype, group=None):
+    """A per-level [rows, *cols] buffer.  group = (i, L): rows [i*rows, (i+1)*rows) of ONE buffer the L proposal levels
+    share (training), so that their backward pass can run over all L*rows rows at once (`backward_prop_levels`)."""
+    if group is None:
+      return self._buf((tag, name), (rows,) + tuple(cols), dtype)
+    i, Lg = group
+    whole = self._buf((('lvl', 'props', Lg), name), (Lg * rows,) + tuple(cols), dtype)
+    return whole[i * rows:(i + 1) * rows]
+
+  def _props_group(self, keep_for_backward):
+    """Number of proposal levels whose training buffers are grouped (0 = not grouped): more than one proposal level on
+    the fused chain with the shared density-only PropMLP_0."""
+    Lg = self.num_levels - 1
+    if not (keep_for_backward and _MERGE_PROPS and Lg >= 2 and not self.single_mlp):
+      return 0
+    plan = self.prop_plan
+    return Lg if (self._chain_ok(plan) and not plan.has_rgb) else 0
+
   # ------------------------------------------------------------------ forward
 
   def apply(self, variables, rng, rays, train_frac, compute_extras, zero_glo=True, **kw):
@@ -640,6 +663,7 @@ class Model:
         gen = torch.Generator(device=dev).manual_seed(int(rng))
 
     renderings, ray_history, saved = [], [], []
+    n_group = self._props_group(keep_for_backward)
     for (i_level, is_prop, n, prod_prev) in self._level_plan():
       plan = self.prop_plan if is_prop else self.nerf_plan
       hp = plan.hp
@@ -678,7 +702,8 @@ class Model:
       # --- featurise + MLP
       M = Bp * n
       tag = ('lvl', i_level) if keep_for_backward else ('lvl', 'shared', is_prop)
-      feat = self._buf((tag, 'feat'), (M, plan.ldF), bf16)
+      group = (i_level, n_group) if (is_prop and n_group) else None
+      feat = self._lvl_buf(tag, 'feat', M, (plan.ldF,), bf16, group)
       ops.cast_rays_ipe(tdist, R.origins, R.directions, radii, plan.basis_dev, ray_shape=self.ray_shape,
                         warp_contract=(hp.warp_fn == 'contract'), min_deg=hp.min_deg_point,
                         max_deg=hp.max_deg_point, ld_feat=plan.ldF, disable_integration=self.disable_integration,
@@ -693,7 +718,8 @@ class Model:
           bnoise = bnoise.reshape(M, bw_).contiguous()
         else:
           bnoise = torch.randn((M, bw_), generator=gen, device=dev, dtype=f32)
-      mlp_out = self._mlp_forward(plan, flat, feat, M, n, R, tag, keep_for_backward, tdist=tdist, bnoise=bnoise)
+      mlp_out = self._mlp_forward(plan, flat, feat, M, n, R, tag, keep_for_backward, tdist=tdist, bnoise=bnoise,
+                                  group=group)
 
       # --- density noise (models.py:462-464), background colour (:241-254)
       dnoise = None
@@ -761,7 +787,7 @@ class Model:
           sdist=sdist[:B0].reshape(lead + (n + 1,)), weights=weights[:B0].reshape(lead + (n,)),
           tdist=tdist[:B0].reshape(lead + (n + 1,))))
       if keep_for_backward:
-        saved.append(dict(level=i_level, is_prop=is_prop, n=n, plan=plan, M=M, tag=tag, feat=feat, mlp=mlp_out,
+        saved.append(dict(level=i_level, is_prop=is_prop, n=n, plan=plan, M=M, tag=tag, feat=feat, mlp=mlp_out, group=group,
                           ccfg=ccfg, raw_density=raw_density, raw_rgb=raw_rgb, dnoise=dnoise, bg=bg,
                           tdist=tdist, sdist=sdist, weights=weights, rgb_out=rgb_out, expo=expo))
 
@@ -812,28 +838,32 @@ class Model:
     ops.mlp_chain_fwd(feat, plan.ldF, layers, M=M, W=W, acts=acts, bits=bits if need_bits else None, skip_layer=skip)
     return acts, bits
 
-  def _chain_forward(self, plan: MLPPlan, flat, feat, M, tag, keep):
+  def _chain_forward(self, plan: MLPPlan, flat, feat, M, tag, keep, group=None):
     """models.py:441-465 for a density-only MLP as ONE launch: every Dense + ReLU layer and the density head."""
     W, D = plan.W, len(plan.trunk)
-    acts = [self._buf((tag, 'act', i), (M, W), bf16) for i in range(D)] if keep else None
-    bits = [self._buf((tag, 'bits', i), (M, W // 8), torch.uint8) for i in range(D)] if keep else None
-    layers = []
-    for i, (d, _) in enumerate(plan.trunk):
+    acts = [self._lvl_buf(tag, ('act', i), M, (W,), bf16, group) for i in range(D)] if keep else None
+    bits = [self._lvl_buf(tag, ('bits', i), M, (W // 8,), torch.uint8, group) for i in range(D)] if keep else None
+    layers, skip = [], 0
+    for i, (d, concat) in enumerate(plan.trunk):
       e = plan.packed[('trunk', i)]
       layers.append((self._w(plan, e['f_off'], e['n_pad'], e['f_ld']), flat[d.bias_off:d.bias_off + d.fan_out]))
+      if concat:
+        skip = i
     e = plan.packed['density']
     d = plan.density
     raw_density = self._buf((tag, 'raw_density'), (M,), f32)
     ops.mlp_chain_fwd(feat, plan.ldF, layers, M=M, W=W, w_head=self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])[0],
-                      b_head=flat[d.bias_off:d.bias_off + 1], head_out=raw_density, acts=acts, bits=bits)
+                      b_head=flat[d.bias_off:d.bias_off + 1], head_out=raw_density, acts=acts, bits=bits,
+                      skip_layer=skip)
     return dict(acts=acts or [], bits=bits or [], raw_density=raw_density, chain=True)
 
-  def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep, tdist=None, bnoise=None):
+  def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep, tdist=None, bnoise=None, group=None):
     """MLP.__call__ (models.py:402-612) for the M = B*n samples of one level."""
     hp = plan.hp
     chain = self._chain_ok(plan)
     if chain and not plan.has_rgb:
-      return self._chain_forward(plan, flat, feat, M, tag, keep)
+      return self._chain_forward(plan, flat, feat, M, tag, keep, group)
+    assert group is None
     relu = hp.net_activation == 'relu'
     need_bits = ((keep and _USE_BITS) or plan.ref) and relu
     acts, bits, zs, vzs = [], [], [], []
@@ -1180,10 +1210,13 @@ class Model:
         ops.mlp_chain_bwd(g_raw_density.view(M), w_head, mlp['bits'], Bws, dYs, M=M, W=W)
         feat = lv['feat']
         with self._dw():
-          for i, (dl, _) in enumerate(plan.trunk):
+          for i, (dl, concat) in enumerate(plan.trunk):
             inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
             ops.gemm_tn(inp, dYs[i], gslice(dl.kernel_off, kv * W), M=M, K=in_w, N=W, lda=in_w, ldb=W, ldc=W,
                         k_valid=kv, n_valid=W, bias_out=gslice(dl.bias_off, W), bias_n_valid=W)
+            if concat:
+              ops.gemm_tn(feat, dYs[i], gslice(dl.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
+                          lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
         self._dw_join()
         return
       ops.small_head_bwd(x_last, W, g_raw_density.view(M, 1), flat[d.kernel_off:d.kernel_off + W].view(W, 1),
@@ -1232,6 +1265,48 @@ class Model:
         ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, **mask_kw(i - 1))
         act_vjp(mlp['zs'][i - 1] if not relu else None, other)
         dy = other
+    self._dw_join()
+
+  def backward_prop_levels(self, lvs, flat, grads, g_weights, losses):
+    """`backward_level` for ALL proposal levels in one pass (grouped buffers, `_props_group`): each level's compositing
+    VJP (with its losses) writes its slice of one head-gradient vector, then ONE head VJP, ONE dX chain and ONE
+    weight-gradient GEMM per layer run over the L*M rows.  The levels share PropMLP_0 (reference models.py:120-121), so
+    the sums over rows are the same sums, in a different order."""
+    Lg = len(lvs)
+    plan: MLPPlan = lvs[0]['plan']
+    M, W, D = lvs[0]['M'], plan.W, len(plan.trunk)
+    Mall = Lg * M
+    R = self._saved['rays']
+    g_all = self._buf(('bwd', 'g_props', Lg), (Mall,), f32)
+    for k, lv in enumerate(lvs):
+      assert lv['group'] == (k, Lg) and lv['M'] == M and lv['plan'] is plan and lv['mlp'].get('chain')
+      ops.composite_bwd(lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'],
+                        density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=None, g_weights=g_weights[k], want_f32=True,
+                        losses=losses[k], g_raw_density_out=g_all[k * M:(k + 1) * M].view(lv['raw_density'].shape))
+
+    def whole(name, cols, dtype):
+      return self._buf((('lvl', 'props', Lg), name), (Mall,) + cols, dtype)
+
+    acts = [whole(('act', i), (W,), bf16) for i in range(D)]
+    bits = [whole(('bits', i), (W // 8,), torch.uint8) for i in range(D)]
+    feat = whole('feat', (plan.ldF,), bf16)
+    d = plan.density
+    w_head = flat[d.kernel_off:d.kernel_off + W]
+    ops.small_head_bwd(acts[-1], W, g_all.view(Mall, 1), w_head.view(W, 1), M=Mall, K=W, Cn=1, dX=None,
+                       relu_mask=False, dW=grads[d.kernel_off:d.kernel_off + W], db=grads[d.bias_off:d.bias_off + 1])
+    dYs = [self._buf(('bwd', 'dYc', W, i, 'props'), (Mall, W), bf16) for i in range(D)]
+    Bws = [None] + [self._w(plan, plan.packed[('trunk', i)]['b_off'], _rup(W, 128), plan.packed[('trunk', i)]['b_ld'])
+                    for i in range(1, D)]
+    ops.mlp_chain_bwd(g_all, w_head, bits, Bws, dYs, M=Mall, W=W)
+    with self._dw():
+      for i, (dl, concat) in enumerate(plan.trunk):
+        inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
+        ops.gemm_tn(inp, dYs[i], grads[dl.kernel_off:dl.kernel_off + kv * W], M=Mall, K=in_w, N=W, lda=in_w, ldb=W,
+                    ldc=W, k_valid=kv, n_valid=W, bias_out=grads[dl.bias_off:dl.bias_off + W], bias_n_valid=W)
+        if concat:
+          o = dl.kernel_off + W * W
+          ops.gemm_tn(feat, dYs[i], grads[o:o + plan.F * W], M=Mall, K=plan.ldF, N=W, lda=plan.ldF, ldb=W, ldc=W,
+                      k_valid=plan.F, n_valid=W)
     self._dw_join()
 
   def _tangent_backward(self, plan, flat, grads, mlp, feat, M, g_raw_grad):

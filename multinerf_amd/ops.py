@@ -508,8 +508,9 @@ def composite_fwd(cfg, raw_density, tdist, dirs, *, raw_rgb=None, density_noise=
 
 def composite_bwd(cfg, raw_density, tdist, dirs, weights, *, raw_rgb=None, density_noise=None, bg=None,
                   exposure_scale=None, g_rgb_out=None, g_weights=None, g_den_bf16=None, ld_bf16=0,
-                  want_f32=True, g_exposure_scale=None, losses=None):
+                  want_f32=True, g_exposure_scale=None, losses=None, g_raw_density_out=None):
   """Compositing VJP; with `losses` the level's training losses are fused in front of it (mnr_level_bwd):
+  g_raw_density_out: optional [B, n] fp32 destination for d loss / d raw_density (else a fresh tensor).
   losses = dict(B_valid=..., data=dict(type, charb_padding, mult, rgb_out, gt, lossmult, denom, stats) | None,
                 weights=dict(mode='interlevel'|'distortion', mult, sdist, t_ref, w_ref, stat) | None)."""
   B, n = raw_density.shape
@@ -519,7 +520,12 @@ def composite_bwd(cfg, raw_density, tdist, dirs, weights, *, raw_rgb=None, densi
   for x, nm in ((g_rgb_out, 'g_rgb_out'), (g_weights, 'g_weights')):
     _chk(x, f32, nm, allow_none=True)
   _chk(g_den_bf16, bf16, 'g_den_bf16', allow_none=True)
-  g_raw_density = torch.empty((B, n), dtype=f32, device=dev) if want_f32 else None
+  if g_raw_density_out is not None:
+    _chk(g_raw_density_out, f32, 'g_raw_density_out')
+    assert want_f32 and g_raw_density_out.shape == (B, n) and g_raw_density_out.is_contiguous()
+    g_raw_density = g_raw_density_out
+  else:
+    g_raw_density = torch.empty((B, n), dtype=f32, device=dev) if want_f32 else None
   g_raw_rgb = torch.empty((B, n, 3), dtype=f32, device=dev) if cfg.has_rgb else None
   a = L.LevelBwdArgs()
   a.cfg = cfg

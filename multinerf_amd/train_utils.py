@@ -196,10 +196,29 @@ def create_train_step(model: models.Model, config, dataset=None):
               ops.weight_decay(flat, b, e, config.weight_decay_mults[name], grads, stats[4 * nlev + 5:4 * nlev + 6])
             early.append((b, e, mdist.all_reduce_sum_async(grads[b:e])))
 
+    def needs_grad(li):
+      return data_spec[li]['mult'] > 0 or w_spec[li] is not None or g_w[li] is not None
+
+    def props_backward(lis):
+      """The proposal levels `lis` (ascending): as ONE pass when their buffers are grouped (models.Model._props_group) and
+      every one of them receives gradient, else level by level."""
+      lvs = [levels[li] for li in lis]
+      if len(lis) > 1 and all(lv.get('group') == (k, len(lis)) for k, lv in enumerate(lvs)) and all(map(needs_grad, lis)):
+        model.backward_prop_levels(lvs, flat, grads, [g_w[li] for li in lis],
+                                   [dict(B_valid=B0, data=data_spec[li], weights=w_spec[li]) for li in lis])
+      else:
+        for li in lis:
+          level_backward(li)
+
     bs = backward_streams(dev)
+    prop_lis = list(range(nlev - 1))
     if bs is None:
-      for li in order:
-        level_backward(li)
+      if order[0] == nlev - 1:
+        level_backward(nlev - 1)
+        props_backward(prop_lis)
+      else:
+        props_backward(prop_lis)
+        level_backward(nlev - 1)
     else:
       # Two streams side by side: the proposal levels (HBM-bound) on `bs.prop`, the NeRF level (MFMA-bound) on `bs.nerf`
       # (or the caller's stream), each sized for its CU share; the caller's stream waits for both.
@@ -213,9 +232,7 @@ def create_train_step(model: models.Model, config, dataset=None):
       for si, ps in enumerate(bs.props):
         ps.wait_event(ready)
         with torch.cuda.stream(ps), mstreams.budget(bs.prop_budget):
-          for li in order:
-            if li != nlev - 1 and li % len(bs.props) == si:
-              level_backward(li)
+          props_backward([li for li in prop_lis if li % len(bs.props) == si])
           ev = torch.cuda.Event()
           ev.record(ps)
           done_props.append(ev)

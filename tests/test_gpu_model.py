@@ -128,6 +128,9 @@ CASES = [
                          'PropMLP.max_deg_point = 16', 'Config.interlevel_loss_mult = 1.0',
                          'Config.orientation_loss_mult = 0.0', 'Config.orientation_coarse_loss_mult = 0.0',
                          'Config.predicted_normal_loss_mult = 0.0', 'Config.predicted_normal_coarse_loss_mult = 0.0'], 12),
+    # PropMLP at the reference's default depth 8 (models.py:346,353): a density-only MLP WITH a skip concat on the fused chain
+    # (forward skip segment, the feature rows of the skip layer's weight gradient; a round-3 fix, first seen on the simulator)
+    ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'PropMLP.net_depth = 8'], 16),
 ]
 
 
@@ -330,3 +333,26 @@ def test_leading_dims_are_preserved():
   assert rend[-1]['rgb'].shape == (H, W, 3) and rend[-1]['acc'].shape == (H, W)
   assert hist[0]['sdist'].shape == (H, W, model.num_prop_samples + 1)
   np.testing.assert_allclose(rend[-1]['rgb'].reshape(-1, 3).cpu().numpy(), flat_rend[-1]['rgb'].cpu().numpy(), atol=1e-6)
+
+
+def test_proposal_levels_backward_as_one_pass_equals_level_by_level(monkeypatch):
+  """Model.backward_prop_levels (both proposal levels' rows through ONE head VJP, ONE dX chain and ONE weight-gradient GEMM
+  per layer; MNR_MERGE_PROPS, default on) against the level-by-level form: the same sums over rows, in another order."""
+  name, extra, B = CASES[0]
+  out = []
+  for merge in (True, False):
+    monkeypatch.setattr(models, '_MERGE_PROPS', merge)
+    cfg, model, _, params, flat, batch = _setup(name, extra, B)
+    assert model._props_group(True) == (2 if merge else 0)
+    noise = helpers.make_noise(model, B)
+    state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+    step = train_utils.create_train_step(model, cfg)
+    _, stats, _ = step(0, state, batch.map(lambda t: t.cuda()), None, 0.5, 0.0, noise=noise, return_grads=True)
+    torch.cuda.synchronize()
+    out.append((stats['_grads'].clone().cpu(), stats.materialize()['loss'], model.modules))
+  (g1, l1, mods), (g0, l0, _) = out
+  assert abs(l1 - l0) <= 1e-6 * abs(l0)
+  for mod, b, e in mods:
+    rel = ((g1[b:e].double() - g0[b:e].double()).norm() / (g0[b:e].double().norm() + 1e-30)).item()
+    print(f'{mod}: one pass vs level by level: rel {rel:.2e}')
+    assert rel < 1e-5, (mod, rel)

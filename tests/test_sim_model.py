@@ -127,3 +127,42 @@ def _run(name, extra, B, variant):
     big = g_ref.abs() > 1e-3 * g_ref.abs().max()
     agree = (torch.sign((state2.params['flat'] - flat)[big]) == torch.sign((ref_flat - flat)[big])).float().mean().item()
     assert agree > 0.97 and state2.step == 1
+
+
+def _grads_of_one_step(name, extra, B, merge):
+  from multinerf_amd import models as M_
+  old = M_._MERGE_PROPS
+  M_._MERGE_PROPS = merge
+  try:
+    cfg, model, _, params, flat, batch = _setup(name, extra, B)
+    noise = helpers.make_noise(model, B)
+    state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+    _, stats, _ = train_utils.create_train_step(model, cfg)(0, state, batch, None, 0.4, 0.0, noise=noise, return_grads=True)
+    return model, stats['_grads'].clone(), stats.materialize()
+  finally:
+    M_._MERGE_PROPS = old
+
+
+def test_proposal_levels_backward_as_one_pass_equals_level_by_level():
+  """models.Model.backward_prop_levels (all proposal levels' rows through ONE dX chain and ONE dW GEMM per layer) against
+  the per-level form: same sums over rows in a different order (fp32 atomics), same losses."""
+  with S.simulated_device() as sim:
+    model, g1, s1 = _grads_of_one_step(*CASES[0], merge=True)
+    sim.check()
+    assert model._props_group(True) == 2
+    _, g0, s0 = _grads_of_one_step(*CASES[0], merge=False)
+    sim.check()
+  assert abs(s1['loss'] - s0['loss']) <= 1e-6 * abs(s0['loss'])
+  for mod, b, e in model.modules:
+    a, r = g1[b:e].double(), g0[b:e].double()
+    rel = ((a - r).norm() / (r.norm() + 1e-30)).item()
+    print(f'{mod}: merged vs per-level rel {rel:.2e}')
+    assert rel < 1e-5, (mod, rel)
+
+
+def test_density_only_mlp_with_a_skip_concat_on_the_fused_chain():
+  """PropMLP at the reference's DEFAULT depth 8 (models.py:346,353: a skip concat into layer 5) is chain-eligible since the
+  round-3 kernels take one skip: the density-only path has to pass it on, forward (skip_layer) and in the weight gradient
+  (the feature rows of the skip layer's kernel)."""
+  _run('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'PropMLP.net_depth = 8',
+               'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 8, VARIANTS[0])
