@@ -238,6 +238,24 @@ typedef struct {
                                  Bt[skip_layer] has W + K0 columns, the feature part behind the W activation columns; 0: none */
 } mnr_mlp_chain_fwd_args;
 int mnr_mlp_chain_fwd(const mnr_mlp_chain_fwd_args* args, void* stream);
+
+/* The same forward chain with layer 0's A operand PRODUCED IN THE KERNEL (inference: no per-layer outputs, no skip concat):
+ * render.cast_rays (render.py:103-127), coord.track_linearize(coord.contract) (coord.py:21-60), lift_and_diagonalize
+ * (:129-133) and integrated_pos_enc (:102-126) are evaluated per 256-sample tile straight into the LDS tile the MFMAs read,
+ * four encoding degrees (one "group") at a time; the [M, 2KL] feature matrix of mnr_cast_rays_ipe never exists.
+ * chain->feat / ld_feat / K0 are unused; acts[i] / bits[i] must be NULL except acts[depth-1]; chain->Bt[0] is layer 0's
+ * kernel^T with its K columns REORDERED group-major (L = max_deg - min_deg, K = basis_k, G = MNR_CHAIN_IPE_GROUP_COLS):
+ *   column g*G + dl*2K + s*K + k  =  kernel row  s*K*L + (4g+dl)*K + k     (s = 0 sin / 1 cos, dl = 0..3, k < K)
+ * and columns [8K, G) of every group zero; chain->ldb[0] >= (L/4)*G.  Needs L % 4 == 0 and K <= 24.  The features are bit-identical to mnr_cast_rays_ipe's rows; only the order
+ * of the fp32 MFMA accumulation over layer 0's K differs from mnr_mlp_chain_fwd on that matrix. */
+#define MNR_CHAIN_IPE_GROUP_COLS 192
+typedef struct {
+  mnr_ipe_cfg cfg;
+  int n;                       /* samples per ray: row r of the level is sample r % n of ray r / n */
+  const float* tdist;          /* [M/n, n+1] */
+  const float* origins; const float* directions; const float* radii; const float* basis;   /* as mnr_cast_rays_ipe */
+} mnr_chain_ipe_args;
+int mnr_mlp_chain_fwd_ipe(const mnr_mlp_chain_fwd_args* chain, const mnr_chain_ipe_args* ipe, void* stream);
 /* A/B switch of both chain kernels: 1 (default) = a layer's copy-out (activation / gradient rows, mask bits) is issued from
  * inside the NEXT layer's MFMA pass, behind that pass's last weight request; 0 = in front of the pass.  Bitwise equal. */
 int mnr_mlp_chain_set_deferred(int on);

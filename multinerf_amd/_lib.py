@@ -86,6 +86,14 @@ class MlpChainFwdArgs(C.Structure):
               ('acts', vp * CHAIN_MAX_DEPTH), ('bits', vp * CHAIN_MAX_DEPTH), ('skip_layer', C.c_int)]
 
 
+CHAIN_IPE_GROUP_COLS = 192          # MNR_CHAIN_IPE_GROUP_COLS
+
+
+class ChainIpeArgs(C.Structure):
+  _fields_ = [('cfg', IpeCfg), ('n', C.c_int), ('tdist', vp), ('origins', vp), ('directions', vp), ('radii', vp),
+              ('basis', vp)]
+
+
 class MlpChainBwdArgs(C.Structure):
   _fields_ = [('M', C.c_int64), ('W', C.c_int), ('depth', C.c_int),
               ('g_head', vp), ('w_head', vp),
@@ -154,6 +162,7 @@ _PROTOS = {
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
     'mnr_mlp_chain_fwd': ([C.POINTER(MlpChainFwdArgs), vp], i32),
     'mnr_mlp_chain_bwd': ([C.POINTER(MlpChainBwdArgs), vp], i32),
+    'mnr_mlp_chain_fwd_ipe': ([C.POINTER(MlpChainFwdArgs), C.POINTER(ChainIpeArgs), vp], i32),
     'mnr_debug_chain_timeline': ([vp], i32),
     'mnr_mlp_chain_set_deferred': ([i32], i32),
     'mnr_gemm_tn_set_config': ([i32], i32),

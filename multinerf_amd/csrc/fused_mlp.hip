@@ -22,6 +22,8 @@
 // [256][64] = 32 KiB, row pitch 128 B, 16-byte slot s of row r stored at slot position s ^ ((r >> 1) & 7).
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #define FM_ROWS 256
@@ -680,6 +682,233 @@ extern "C" int mnr_mlp_chain_bwd(const mnr_mlp_chain_bwd_args* a, void* stream) 
   } else {
     (void)hipFuncSetAttribute((const void*)mlp_chain_bwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, FmCfg<128>::LDS_BYTES);
     hipLaunchKernelGGL(mlp_chain_bwd_kernel<128>, dim3(grid), dim3(512), FmCfg<128>::LDS_BYTES, (hipStream_t)stream, *a, g_fm_defer);
+  }
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Inference chain with layer 0's features produced in the kernel (mnr_mlp_chain_fwd_ipe).
+//
+// mnr_cast_rays_ipe writes the level's [M, 2KL] bf16 feature matrix (1 GB per 64-sample proposal level of 360.gin) only for
+// layer 0 to stream it back in: rendering needs it nowhere else.  Here a workgroup evaluates the encoding of its 256 samples
+// itself: one thread per sample for the (warped) Gaussian, then, four encoding degrees (one "group" = 8K feature columns,
+// zero-padded to 192 = three LDS K-tiles, so that every loop below has a compile-time trip count) at a time, one thread per (sample, basis direction) exactly as in cast_rays_ipe_kernel (anchor
+// sin / cos / attenuation at the group's first degree, three double-angle steps), the bf16 features written straight into the
+// LDS K-tiles the MFMAs read; the group's slice of the (group-major reordered) layer-0 weights goes global -> registers
+// while the VALUs work.  Layer 0 costs ~3.5k VALU instructions per thread and tile instead of a 256 KiB HBM stream.
+//
+// No floating-point contraction from here on: the encoding must round like features.hip (see ipe_math.h).
+#pragma clang fp contract(off)
+#include "ipe_math.h"
+
+#define FM_IPE_MAX_KS (MNR_CHAIN_IPE_GROUP_COLS / 16)      // k-steps of one group (192 columns = three K-tiles)
+#define FM_IPE_MAX_K 24
+
+template <int W>
+struct FmIpeCfg {
+  typedef FmCfg<W> C;
+  static constexpr int GROUP_BYTES = 3 * FM_KT_BYTES;
+  static constexpr int MAIN = C::X_BYTES > GROUP_BYTES ? C::X_BYTES : GROUP_BYTES;
+  static constexpr int BIAS_OFF = MAIN;                                            // [MNR_CHAIN_MAX_DEPTH][W] fp32
+  static constexpr int GS_OFF = BIAS_OFF + MNR_CHAIN_MAX_DEPTH * W * 4;            // FeSample[256]
+  static constexpr int BASIS_OFF = GS_OFF + FM_ROWS * (int)sizeof(FeSample);       // float[3 * FM_IPE_MAX_K]
+  static constexpr int LDS_BYTES = BASIS_OFF + 3 * FM_IPE_MAX_K * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(sizeof(FeSample) % 4 == 0 && GS_OFF % 16 == 0, "alignment");
+};
+
+template <int W>
+__global__ __launch_bounds__(512) void mlp_chain_fwd_ipe_kernel(mnr_mlp_chain_fwd_args p, mnr_chain_ipe_args q) {
+  typedef FmCfg<W> C;
+  typedef FmIpeCfg<W> I;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = wave % C::NW, rg = wave / C::NW;
+  const int64_t tiles = p.M / FM_ROWS;
+  const int K = q.cfg.basis_k;
+  const int ngroups = (q.cfg.max_deg - q.cfg.min_deg) / 4;
+  const int pad_slots = MNR_CHAIN_IPE_GROUP_COLS / 8 - K;   // 16-byte slots [K, 24) of a row: never written by the encoding
+  const unsigned no_bits[C::RB] = {};
+  const float b_head = (p.w_head && p.b_head) ? p.b_head[0] : 0.0f;
+  FeSample* gs = (FeSample*)(smem + I::GS_OFF);
+  float* bs = (float*)(smem + I::BASIS_OFF);
+  for (int i = tid; i < p.depth * W; i += 512) ((float*)(smem + I::BIAS_OFF))[i] = p.bias[i / W][i % W];
+  for (int i = tid; i < K * 3; i += 512) bs[i] = q.basis[i];
+  const bf16* Bt0 = (const bf16*)p.Bt[0];
+  const int rpi = 512 / K;                      // encoding: rows per pass of the 512 threads (one thread per row and direction)
+
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t m0 = tile * FM_ROWS;
+    const bool tl_on = g_fm_timeline != nullptr && tid == 0 && tile == (int64_t)blockIdx.x + gridDim.x;
+    FM_STAMP(0);
+    if (tl_on) g_fm_timeline[32 * (int64_t)blockIdx.x + 30] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();                                    // the previous tile's head is done reading the activation tile
+    // ---- the tile's 256 Gaussians (render.cast_rays + the contraction), one thread per sample
+    if (tid < FM_ROWS) {
+      const int64_t s = m0 + tid;
+      const int64_t ray = s / q.n;
+      const int j = (int)(s - ray * q.n);
+      const float t0 = q.tdist[ray * (q.n + 1) + j], t1 = q.tdist[ray * (q.n + 1) + j + 1];
+      float o[3], d[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        o[i] = q.origins[ray * 3 + i];
+        d[i] = q.directions[ray * 3 + i];
+      }
+      FeSample g;
+      fe_gaussian(q.cfg, t0, t1, o, d, q.radii[ray], g);
+      gs[tid] = g;
+    }
+    for (int e = tid; e < FM_ROWS * pad_slots; e += 512) {
+      const int r = e / pad_slots, sl = K + e % pad_slots;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      *(u32x4*)(smem + (sl >> 3) * FM_KT_BYTES + fm_off(r, sl & 7)) = z;
+    }
+    f32x16 acc[C::RB];
+#pragma unroll
+    for (int rb = 0; rb < C::RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    __syncthreads();
+
+    // ---- layer 0, one group of four degrees at a time
+    // coord.py:129-133 + :102-126 for degrees 4g .. 4g+3 of rows [r_lo, r_hi) (the loop body of cast_rays_ipe_kernel, same
+    // operations in the same order, math.safe_sin's wrap through fe_wrap_100pi; feature (dl, sin/cos, k) lands in group
+    // column dl*2K + {0, K} + k)
+    auto encode = [&](int g, int r_lo, int r_hi) {
+      const float sc0 = ldexpf(1.0f, q.cfg.min_deg + 4 * g);
+      // thread et handles direction ek = et % K of rows r_lo + er0, + rpi, ... (re-derived per call: kept across the tile loop,
+      // these and everything hipcc hoists with them would be spilled around the Gaussian phase)
+      const int et = fm_opaque(tid);
+      const int er0 = et / K, ek = et - er0 * K;
+      if (et < rpi * K) {
+        const float px = bs[ek * 3 + 0], py = bs[ek * 3 + 1], pz = bs[ek * 3 + 2];
+        for (int si = r_lo + er0; si < r_hi; si += rpi) {
+          const FeSample gsm = gs[si];
+          const float lm = gsm.mean[0] * px + gsm.mean[1] * py + gsm.mean[2] * pz;
+          const float cx = gsm.cov[0] * px + gsm.cov[1] * py + gsm.cov[2] * pz;
+          const float cy = gsm.cov[1] * px + gsm.cov[3] * py + gsm.cov[4] * pz;
+          const float cz = gsm.cov[2] * px + gsm.cov[4] * py + gsm.cov[5] * pz;
+          const float lv = px * cx + py * cy + pz * cz;
+          const float vscale = -0.5f * 1.44269504088896340736f * lv;
+          float sc = sc0;
+          float sn, cs;
+          fe_sincos_wrapped(fe_wrap_100pi(lm * sc), &sn, &cs);
+          float att = exp2f(vscale * sc * sc);
+          char* rowp = smem + si * 128;
+          const int sw = (si >> 1) & 7;
+          int c = ek;
+#pragma unroll
+          for (int dl = 0; dl < 4; ++dl) {
+            const float fs = att * sn;
+            const float fc = att * cs;
+            const f32x2 pr = {fs, fc};
+            const bf16x2 pb = __builtin_convertvector(pr, bf16x2);
+            const int c2 = c + K;
+            *(bf16*)(rowp + (c >> 6) * FM_KT_BYTES + ((((c & 63) >> 3) ^ sw) << 4) + (c & 7) * 2) = pb[0];
+            *(bf16*)(rowp + (c2 >> 6) * FM_KT_BYTES + ((((c2 & 63) >> 3) ^ sw) << 4) + (c2 & 7) * 2) = pb[1];
+            c += 2 * K;
+            const float s2 = 2.0f * sn * cs;
+            cs = 1.0f - 2.0f * sn * sn;
+            sn = s2;
+            const float a2 = att * att;
+            att = a2 * a2;
+            sc *= 2.0f;
+          }
+        }
+      }
+    };
+    // the group's slice of the (group-major) layer-0 weights for this wave's 32 columns: global -> registers, L2-resident
+    // (k-steps [0, 4) are requested in front of the encoding, the other eight behind it, under the first MFMAs: twelve fragments
+    // do not fit next to the encoding's registers)
+    auto load_w = [&](int g, auto lo_c, auto hi_c, bf16x8 (&wq)[FM_IPE_MAX_KS]) {
+      const int ln = fm_opaque(lane);
+      const bf16* wsrc = Bt0 + (int64_t)(cw * 32) * p.ldb[0] + g * MNR_CHAIN_IPE_GROUP_COLS + (unsigned)((ln & 31) * p.ldb[0] + (ln >> 5) * 8);
+#pragma unroll
+      for (int ks = decltype(lo_c)::value; ks < decltype(hi_c)::value; ++ks) wq[ks] = *(const bf16x8*)(wsrc + ks * 16);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 4> I4;
+    typedef std::integral_constant<int, FM_IPE_MAX_KS> IN;
+    for (int g = 0; g < ngroups; ++g) {
+      bf16x8 wq[FM_IPE_MAX_KS];
+      load_w(g, I0{}, I4{}, wq);
+      encode(g, 0, FM_ROWS);
+      fm_lds_barrier();                               // the group's feature tile is complete
+      {
+        load_w(g, I4{}, IN{}, wq);
+        const int ln = fm_opaque(lane), frow = ln & 31, khalf = ln >> 5;
+        const int sw = (frow >> 1) & 7;
+        const char* xrow = smem + (rg * C::RB * 32 + frow) * 128;
+#pragma unroll
+        for (int ks = 0; ks < FM_IPE_MAX_KS; ++ks) {
+          const char* base = xrow + (ks >> 2) * FM_KT_BYTES + ((((ks & 3) * 2 + khalf) ^ sw) << 4);
+          bf16x8 fa[C::RB];
+#pragma unroll
+          for (int rb = 0; rb < C::RB; ++rb) fa[rb] = *(const bf16x8*)(base + rb * 4096);
+#pragma unroll
+          for (int rb = 0; rb < C::RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks], fa[rb], acc[rb], 0, 0, 0);
+        }
+      }
+      fm_lds_barrier();                               // every wave is done reading the group: the next one overwrites it
+    }
+
+    FM_STAMP(1);
+    bf16x8 w0[FM_WCHUNK];
+    if (p.depth > 1) {
+      const int ln = fm_opaque(lane);
+      fm_load_wchunk((const bf16*)p.Bt[1], p.ldb[1], cw, ln & 31, ln >> 5, 0, w0);
+    }
+    for (int li = 0; li < p.depth; ++li) {
+      if (li > 0) {
+        fm_layer_mfma<W, 0>(smem, (const bf16*)p.Bt[li], p.ldb[li], cw, rg, lane, w0, acc);
+        if (li + 1 < p.depth) {
+          const int ln = fm_opaque(lane);
+          fm_load_wchunk((const bf16*)p.Bt[li + 1], p.ldb[li + 1], cw, ln & 31, ln >> 5, 0, w0);
+        }
+      }
+      FM_STAMP(2 + 3 * li);
+      fm_lds_barrier();
+      fm_epilogue<W, false>(smem, cw, rg, lane, acc, (const float*)(smem + I::BIAS_OFF) + li * W, no_bits);
+      fm_lds_barrier();
+      FM_STAMP(3 + 3 * li);
+      if (li == p.depth - 1)
+        fm_copy_out_dispatch<W>(smem, tid, m0, (bf16*)p.acts[li], nullptr, (const bf16*)p.w_head, b_head, p.head_out);
+      FM_STAMP(4 + 3 * li);
+    }
+    if (tl_on) g_fm_timeline[32 * (int64_t)blockIdx.x + 31] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+extern "C" int mnr_mlp_chain_fwd_ipe(const mnr_mlp_chain_fwd_args* a, const mnr_chain_ipe_args* q, void* stream) {
+  MNR_CHECK_ARG(a != nullptr && q != nullptr, "mnr_mlp_chain_fwd_ipe: null args");
+  if (int s = fm_check_common("mnr_mlp_chain_fwd_ipe", a->M, a->W, a->depth)) return s;
+  const int K = q->cfg.basis_k, L = q->cfg.max_deg - q->cfg.min_deg;
+  MNR_CHECK_ARG(q->cfg.ray_shape == 0 || q->cfg.ray_shape == 1, "ray_shape must be 'cone' or 'cylinder'");   // render.py:124
+  MNR_CHECK_ARG(K >= 1 && K <= FM_IPE_MAX_K && L >= 4 && L <= 32 && L % 4 == 0,
+                "mnr_mlp_chain_fwd_ipe: basis_k=%d (1..%d) / degrees=%d (a multiple of 4) out of range", K, FM_IPE_MAX_K, L);
+  MNR_CHECK_ARG(q->n > 0 && a->M % q->n == 0 && q->tdist && q->origins && q->directions && q->radii && q->basis,
+                "mnr_mlp_chain_fwd_ipe: rays missing, or M is not a whole number of rays of n samples");
+  MNR_CHECK_ARG(a->skip_layer <= 0, "mnr_mlp_chain_fwd_ipe: no skip concat");
+  for (int i = 0; i < a->depth; ++i) {
+    MNR_CHECK_ARG(a->Bt[i] && a->bias[i] && a->ldb[i] % 8 == 0 && a->ldb[i] >= (i == 0 ? (L / 4) * MNR_CHAIN_IPE_GROUP_COLS : a->W),
+                  "mnr_mlp_chain_fwd_ipe: layer %d operand", i);
+    MNR_CHECK_ARG(((uintptr_t)a->bias[i] % 16) == 0 && ((uintptr_t)a->Bt[i] % 16) == 0,
+                  "mnr_mlp_chain_fwd_ipe: layer %d pointers must be 16-byte aligned", i);
+    MNR_CHECK_ARG(!a->bits[i] && (!a->acts[i] || (i == a->depth - 1 && ((uintptr_t)a->acts[i] % 16) == 0)),
+                  "mnr_mlp_chain_fwd_ipe: inference only (per-layer outputs are mnr_mlp_chain_fwd's)");
+  }
+  MNR_CHECK_ARG(a->w_head ? (a->head_out && ((uintptr_t)a->w_head % 16) == 0) : a->acts[a->depth - 1] != nullptr,
+                "mnr_mlp_chain_fwd_ipe: needs a head (with head_out) or acts[depth-1]");
+  const int grid = fm_grid(a->M / FM_ROWS);
+  if (a->W == 256) {
+    (void)hipFuncSetAttribute((const void*)mlp_chain_fwd_ipe_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, FmIpeCfg<256>::LDS_BYTES);
+    hipLaunchKernelGGL(mlp_chain_fwd_ipe_kernel<256>, dim3(grid), dim3(512), FmIpeCfg<256>::LDS_BYTES, (hipStream_t)stream, *a, *q);
+  } else {
+    (void)hipFuncSetAttribute((const void*)mlp_chain_fwd_ipe_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, FmIpeCfg<128>::LDS_BYTES);
+    hipLaunchKernelGGL(mlp_chain_fwd_ipe_kernel<128>, dim3(grid), dim3(512), FmIpeCfg<128>::LDS_BYTES, (hipStream_t)stream, *a, *q);
   }
   MNR_CHECK_LAUNCH();
   return MNR_OK;

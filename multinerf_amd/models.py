@@ -38,6 +38,7 @@ def _rup(x, m):
 import os as _os
 _USE_BITS = _os.environ.get('MNR_RELU_BITS', '1') != '0'   # A/B switch: 1-bit ReLU masks vs re-reading activations
 _USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused per-level Dense chain vs one GEMM per layer
+_FUSED_IPE = _os.environ.get('MNR_FUSED_IPE', '1') != '0'   # A/B switch: rendering builds the proposal levels' IPE features inside the chain kernel
 # A/B switch: the weight-gradient GEMMs (dW_l = x_{l-1}^T dY_l) on a second HIP stream behind the dX chain.  dW_l and the
 # dX GEMM that turns dY_l into dY_{l-1} are independent, so with one dY buffer per layer (instead of two ping-pong
 # buffers) the dX chain runs ahead and the dW launches fill the CUs each dX launch's tail leaves idle (and the other way
@@ -478,6 +479,23 @@ class Model:
       p.packed['head4'] = dict(f_off=fo, f_ld=p.W, n_pad=128)
     else:
       pack_layer('density', p.density, [(0, p.W, 0, p.W)], 128)
+    # Inference image of trunk layer 0 for the chain with the in-kernel IPE producer (mnr_mlp_chain_fwd_ipe): kernel^T with
+    # its K columns group-major (four degrees per group of MNR_CHAIN_IPE_GROUP_COLS columns, include/mnerf.h); packed by a
+    # table of its own, only when a forward pass without a backward pass asks for it.
+    p.pack_descs_ipe = []
+    if (not p.has_rgb) and p.L % 4 == 0 and p.K <= 24 and not any(c for _, c in p.trunk):
+      G = L.CHAIN_IPE_GROUP_COLS
+      d0 = p.trunk[0][0]
+      n_pad = _rup(d0.fan_out, 128)
+      ld = (p.L // 4) * G
+      fo = alloc(n_pad, ld)
+      for l in range(p.L):
+        for sc in range(2):
+          col = (l // 4) * G + (l % 4) * 2 * p.K + sc * p.K
+          p.pack_descs_ipe.append(L.PackDesc(d0.kernel_off + (sc * p.K * p.L + l * p.K) * d0.fan_out, p.K, d0.fan_out, fo, ld, 0, col, 1))
+      p.packed['trunk0_ipe'] = dict(f_off=fo, f_ld=ld, n_pad=n_pad)
+      arr = (L.PackDesc * len(p.pack_descs_ipe))(*p.pack_descs_ipe)
+      p.pack_descs_ipe_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
     p.packed_elems = off
     p.pack_descs = descs
     arr = (L.PackDesc * len(descs))(*descs)
@@ -489,10 +507,13 @@ class Model:
     if p.ref:
       p.ide = ops.IdeTablesDev(p.hp.deg_view, self.device)
 
-  def pack_weights(self, flat_params):
-    """fp32 master parameters -> bf16 GEMM operands (one launch per MLP)."""
+  def pack_weights(self, flat_params, ipe=False):
+    """fp32 master parameters -> bf16 GEMM operands (one launch per MLP; `ipe`: also the group-major layer-0 image of the
+    chain with the in-kernel IPE producer)."""
     for p in self._plans:
       ops.pack_weights(flat_params, p.pack_descs_dev, len(p.pack_descs), p.pack_max_elems, p.wbf)
+      if ipe and p.pack_descs_ipe:
+        ops.pack_weights(flat_params, p.pack_descs_ipe_dev, len(p.pack_descs_ipe), p.K * p.trunk[0][0].fan_out, p.wbf)
       if p.has_rgb:
         for (d, c0) in p.head_segs:
           p.head_bias[c0:c0 + d.fan_out].copy_(flat_params[d.bias_off:d.bias_off + d.fan_out])
@@ -615,8 +636,9 @@ class Model:
     noise['u_jitter'][level] uniform [0,1) of shape [B,1] / [B,n]."""
     if not self._built:
       self.build(flat.device)
+    fused_ipe = _FUSED_IPE and not keep_for_backward
     if repack:
-      self.pack_weights(flat)
+      self.pack_weights(flat, ipe=fused_ipe)
     dev = self.device
     lead = rays.origins.shape[:-1]
     flat_rays = rays.map(lambda r: r.reshape(-1, r.shape[-1]).contiguous())
@@ -703,11 +725,14 @@ class Model:
       M = Bp * n
       tag = ('lvl', i_level) if keep_for_backward else ('lvl', 'shared', is_prop)
       group = (i_level, n_group) if (is_prop and n_group) else None
-      feat = self._lvl_buf(tag, 'feat', M, (plan.ldF,), bf16, group)
-      ops.cast_rays_ipe(tdist, R.origins, R.directions, radii, plan.basis_dev, ray_shape=self.ray_shape,
-                        warp_contract=(hp.warp_fn == 'contract'), min_deg=hp.min_deg_point,
-                        max_deg=hp.max_deg_point, ld_feat=plan.ldF, disable_integration=self.disable_integration,
-                        out=feat)
+      ipe_in_chain = fused_ipe and self._ipe_chain_ok(plan)
+      feat = None
+      if not ipe_in_chain:
+        feat = self._lvl_buf(tag, 'feat', M, (plan.ldF,), bf16, group)
+        ops.cast_rays_ipe(tdist, R.origins, R.directions, radii, plan.basis_dev, ray_shape=self.ray_shape,
+                          warp_contract=(hp.warp_fn == 'contract'), min_deg=hp.min_deg_point,
+                          max_deg=hp.max_deg_point, ld_feat=plan.ldF, disable_integration=self.disable_integration,
+                          out=feat)
       bnoise = None
       if randomized and plan.has_rgb and plan.use_viewdirs and hp.bottleneck_noise > 0:      # models.py:530-533
         bw_ = hp.bottleneck_width
@@ -718,8 +743,11 @@ class Model:
           bnoise = bnoise.reshape(M, bw_).contiguous()
         else:
           bnoise = torch.randn((M, bw_), generator=gen, device=dev, dtype=f32)
-      mlp_out = self._mlp_forward(plan, flat, feat, M, n, R, tag, keep_for_backward, tdist=tdist, bnoise=bnoise,
-                                  group=group)
+      if ipe_in_chain:
+        mlp_out = self._chain_forward_ipe(plan, flat, tdist, R, radii, M, tag)
+      else:
+        mlp_out = self._mlp_forward(plan, flat, feat, M, n, R, tag, keep_for_backward, tdist=tdist, bnoise=bnoise,
+                                    group=group)
 
       # --- density noise (models.py:462-464), background colour (:241-254)
       dnoise = None
@@ -856,6 +884,30 @@ class Model:
                       b_head=flat[d.bias_off:d.bias_off + 1], head_out=raw_density, acts=acts, bits=bits,
                       skip_layer=skip)
     return dict(acts=acts or [], bits=bits or [], raw_density=raw_density, chain=True)
+
+  @classmethod
+  def _ipe_chain_ok(cls, plan: MLPPlan):
+    """A density-only MLP on the fused chain without a skip concat (the proposal MLP of every BASELINE config), with an
+    encoding the in-kernel producer covers (groups of four degrees, at most 24 basis directions)."""
+    return cls._chain_ok(plan) and 'trunk0_ipe' in plan.packed
+
+  def _chain_forward_ipe(self, plan: MLPPlan, flat, tdist, R, radii, M, tag):
+    """models.py:441-465 for a density-only MLP AND its featurisation (render.cast_rays + integrated_pos_enc,
+    models.py:413-431) as ONE launch; inference only (nothing is kept for a backward pass)."""
+    hp, W = plan.hp, plan.W
+    layers = []
+    for i, (d, _) in enumerate(plan.trunk):
+      e = plan.packed['trunk0_ipe' if i == 0 else ('trunk', i)]
+      layers.append((self._w(plan, e['f_off'], e['n_pad'], e['f_ld']), flat[d.bias_off:d.bias_off + d.fan_out]))
+    e = plan.packed['density']
+    d = plan.density
+    raw_density = self._buf((tag, 'raw_density'), (M,), f32)
+    ops.mlp_chain_fwd_ipe(tdist, R.origins, R.directions, radii, plan.basis_dev, layers, M=M, W=W, ray_shape=self.ray_shape,
+                          warp_contract=(hp.warp_fn == 'contract'), min_deg=hp.min_deg_point, max_deg=hp.max_deg_point,
+                          disable_integration=self.disable_integration,
+                          w_head=self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])[0], b_head=flat[d.bias_off:d.bias_off + 1],
+                          head_out=raw_density)
+    return dict(acts=[], bits=[], raw_density=raw_density, chain=True)
 
   def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep, tdist=None, bnoise=None, group=None):
     """MLP.__call__ (models.py:402-612) for the M = B*n samples of one level."""

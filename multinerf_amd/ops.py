@@ -364,6 +364,44 @@ def mlp_chain_fwd(feat, K0, layers, *, M, W, w_head=None, b_head=None, head_out=
   PROFILE.stop(_e)
 
 
+def mlp_chain_fwd_ipe(tdist, origins, directions, radii, basis, layers, *, M, W, ray_shape, warp_contract, min_deg,
+                      max_deg, disable_integration=False, w_head=None, b_head=None, head_out=None, act_last=None):
+  """The inference chain with layer 0's IPE features produced in the kernel (csrc/fused_mlp.hip, mnr_mlp_chain_fwd_ipe):
+  no feature matrix.  layers[0][0] is the group-major reordered kernel^T (include/mnerf.h); tdist [B, n+1] with B*n = M."""
+  depth = len(layers)
+  if not 1 <= depth <= L.CHAIN_MAX_DEPTH:
+    raise ValueError(f'mlp_chain_fwd_ipe: depth {depth}')
+  for x, nm in ((tdist, 'tdist'), (origins, 'origins'), (directions, 'directions'), (radii, 'radii'), (basis, 'basis')):
+    _chk(x, f32, nm)
+  _chk(w_head, bf16, 'w_head', allow_none=True)
+  _chk(b_head, f32, 'b_head', allow_none=True)
+  _chk(head_out, f32, 'head_out', allow_none=True)
+  B, n1 = tdist.shape
+  assert B * (n1 - 1) == M and origins.shape[0] == B and directions.shape[0] == B and radii.numel() == B
+  a = L.MlpChainFwdArgs()
+  a.M, a.W, a.depth, a.skip_layer = M, W, depth, 0
+  for i, (Bt, bias) in enumerate(layers):
+    _chk(Bt, bf16, f'Bt[{i}]')
+    _chk(bias, f32, f'bias[{i}]')
+    assert Bt.shape[0] >= W and bias.numel() == W
+    a.Bt[i], a.ldb[i], a.bias[i] = Bt.data_ptr(), Bt.stride(0), bias.data_ptr()
+  if act_last is not None:
+    _chk(act_last, bf16, 'act_last')
+    assert act_last.shape == (M, W)
+    a.acts[depth - 1] = act_last.data_ptr()
+  if w_head is not None:
+    assert w_head.numel() >= W and head_out is not None and head_out.numel() == M
+    a.w_head, a.head_out = w_head.data_ptr(), head_out.data_ptr()
+    a.b_head = b_head.data_ptr() if b_head is not None else None
+  q = L.ChainIpeArgs()
+  q.cfg = _ipe_cfg(ray_shape, warp_contract, disable_integration, basis, min_deg, max_deg)
+  q.n = n1 - 1
+  q.tdist, q.origins, q.directions, q.radii, q.basis = _ptr(tdist), _ptr(origins), _ptr(directions), _ptr(radii), _ptr(basis)
+  _e = PROFILE.start()
+  L.check(lib().mnr_mlp_chain_fwd_ipe(C.byref(a), C.byref(q), _stream()))
+  PROFILE.stop(_e)
+
+
 def mlp_chain_bwd(g_head, w_head, bits, Bws, dYs, *, M, W, dY_in=None):
   """The dX chain of the fused Dense stack: dY[last] = mask * (g_head (x) w_head), dY[i-1] = mask_{i-1} * (dY[i] W_i^T).
   Bws[i] (i >= 1): [W, ldb] bf16 kernel as stored (rows = inputs); Bws[0] unused."""

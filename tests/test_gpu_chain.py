@@ -189,3 +189,93 @@ def test_fused_trunk_with_skip_equals_per_layer_path(preset, bindings, B, monkey
     rel = ((x - y).norm() / (y.norm() + 1e-30)).item()
     print(f'{preset} {name}: |g(fused trunk) - g(per-layer)| / |g| = {rel:.2e}')
     assert rel < (1e-4 if a['first'] == 0 and cfg.interlevel_loss_mult == 0 and model.single_mlp else 0.2), (name, rel)
+
+
+@pytest.mark.parametrize('bindings,B,n', [
+    ([], 12, 64),                                                                      # 360.gin's PropMLP: K = 21, L = 12, W = 256, contract
+    (['PropMLP.net_width = 128', 'PropMLP.net_depth = 2', 'PropMLP.warp_fn = None', 'PropMLP.basis_shape = "octahedron"',
+      'PropMLP.basis_subdivisions = 1', 'PropMLP.max_deg_point = 16', 'Model.ray_shape = "cylinder"'], 8, 32),   # K = 9? / L = 16, W = 128, no warp
+])
+def test_chain_with_in_kernel_ipe_equals_feature_matrix_path(bindings, B, n):
+  """mnr_mlp_chain_fwd_ipe (layer 0's IPE features built in LDS, four degrees at a time; render.py:103-127 + coord.py:102-133
+  fused with models.py:441-465) against mnr_cast_rays_ipe + mnr_mlp_chain_fwd.  The features are the same bf16 values; only
+  layer 0's fp32 accumulation order differs (group-major K), so its bf16 output differs by at most one ulp on a small fraction
+  of the elements, and the head stays within 5e-3 of its scale (mean error < 1e-4)."""
+  cfg = configs.load_preset('360', ['NerfMLP.net_width = 128'] + bindings)
+  model = models.Model(config=cfg).build('cuda')
+  plan = model.prop_plan
+  assert models.Model._ipe_chain_ok(plan)
+  hp, W, D = plan.hp, plan.W, len(plan.trunk)
+  flat = model.init_flat_params(seed=3)
+  g = torch.Generator().manual_seed(4)
+  for d in plan.dense:
+    flat[d.bias_off:d.bias_off + d.fan_out] = (0.05 * torch.randn((d.fan_out,), generator=g)).cuda()
+  model.pack_weights(flat, ipe=True)
+  ops = models.ops
+  M = B * n
+  origins = (torch.randn((B, 3), generator=g) * 0.3).cuda()
+  directions = torch.nn.functional.normalize(torch.randn((B, 3), generator=g), dim=-1).cuda() * 1.3
+  radii = (0.002 + 0.002 * torch.rand((B,), generator=g)).cuda()
+  tdist = torch.cumsum(0.02 + torch.rand((B, n + 1), generator=g) * 0.3, dim=-1).cuda().contiguous()     # in and beyond the unit ball
+  kw = dict(ray_shape=model.ray_shape, warp_contract=(hp.warp_fn == 'contract'), min_deg=hp.min_deg_point, max_deg=hp.max_deg_point)
+  feat = ops.cast_rays_ipe(tdist, origins, directions, radii, plan.basis_dev, ld_feat=plan.ldF, **kw)
+  bias = lambda d: flat[d.bias_off:d.bias_off + d.fan_out]
+  lay = lambda key: model._w(plan, plan.packed[key]['f_off'], plan.packed[key]['n_pad'], plan.packed[key]['f_ld'])
+  ref_layers = [(lay(('trunk', i)), bias(d)) for i, (d, _) in enumerate(plan.trunk)]
+  ipe_layers = [(lay('trunk0_ipe'), bias(plan.trunk[0][0]))] + ref_layers[1:]
+  w_head = lay('density')[0]
+  b_head = flat[plan.density.bias_off:plan.density.bias_off + 1]
+  # layer 0 alone
+  x_ref = torch.empty((M, W), dtype=torch.bfloat16, device='cuda')
+  x_ipe = torch.empty((M, W), dtype=torch.bfloat16, device='cuda')
+  ops.mlp_chain_fwd(feat, plan.ldF, ref_layers[:1], M=M, W=W, acts=[x_ref])
+  ops.mlp_chain_fwd_ipe(tdist, origins, directions, radii, plan.basis_dev, ipe_layers[:1], M=M, W=W, act_last=x_ipe, **kw)
+  torch.cuda.synchronize()
+  a, b = x_ref.cpu().float(), x_ipe.cpu().float()
+  frac = (a != b).float().mean().item()
+  # one bf16 ulp of the larger value, or (cancellation: a pre-activation near zero) 1e-5 of the layer's scale
+  excess = ((a - b).abs() - torch.maximum(torch.maximum(a.abs(), b.abs()) * 2.0 ** -7, torch.full_like(a, 1e-5 * a.abs().max().item()))).max().item()
+  print(f'layer 0: {frac:.2e} of the bf16 outputs differ; max |diff| {(a - b).abs().max().item():.2e} (|x| <= {a.abs().max().item():.2e})')
+  assert excess <= 0 and frac < 5e-3
+  assert x_ref.float().abs().max().item() > 0.1                                      # (not a comparison of zeros)
+  # the whole chain with its density head
+  h_ref = torch.empty((M,), dtype=torch.float32, device='cuda')
+  h_ipe = torch.empty((M,), dtype=torch.float32, device='cuda')
+  ops.mlp_chain_fwd(feat, plan.ldF, ref_layers, M=M, W=W, w_head=w_head, b_head=b_head, head_out=h_ref)
+  ops.mlp_chain_fwd_ipe(tdist, origins, directions, radii, plan.basis_dev, ipe_layers, M=M, W=W, w_head=w_head, b_head=b_head,
+                        head_out=h_ipe, **kw)
+  torch.cuda.synchronize()
+  scale = h_ref.abs().max().item()
+  err = (h_ref - h_ipe).abs()
+  print(f'head: max |fused - matrix| = {err.max().item():.2e}, mean {err.mean().item():.2e} (|raw| <= {scale:.2e})')
+  assert err.max().item() <= 5e-3 * scale and err.mean().item() <= 1e-4 * scale
+
+
+def test_render_with_in_kernel_ipe_equals_feature_matrix_path(monkeypatch):
+  """Model.__call__ without a backward pass (render / eval): the proposal levels on mnr_mlp_chain_fwd_ipe against the same
+  forward pass with the feature matrices (MNR_FUSED_IPE=0); the composed oracle parity of this path is
+  tests/test_gpu_model.py::test_forward_parity, which runs it by default."""
+  cfg = configs.load_preset('360', ['NerfMLP.net_width = 128'])
+  B = 24
+  batch = helpers.synthetic_rays(B, near=cfg.near, far=cfg.far)
+  out = {}
+  for on in (True, False):
+    monkeypatch.setattr(models, '_FUSED_IPE', on)
+    model = models.Model(config=cfg).build('cuda')
+    flat = model.init_flat_params(seed=3)
+    calls = []
+    real = models.ops.mlp_chain_fwd_ipe
+    monkeypatch.setattr(models.ops, 'mlp_chain_fwd_ipe', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    renderings, hist = model.apply({'flat': flat}, None, batch.rays.map(lambda t: t.cuda()), 0.5, True)
+    torch.cuda.synchronize()
+    monkeypatch.setattr(models.ops, 'mlp_chain_fwd_ipe', real)
+    assert len(calls) == (2 if on else 0)
+    out[on] = (renderings[-1]['rgb'].cpu(), [h['sdist'].cpu() for h in hist], renderings[-1]['distance_median'].cpu())
+  rgb_a, sd_a, dm_a = out[True]
+  rgb_b, sd_b, dm_b = out[False]
+  print(f'rgb |fused - matrix| = {(rgb_a - rgb_b).abs().max().item():.2e}, sdist {max((x - y).abs().max().item() for x, y in zip(sd_a, sd_b)):.2e}')
+  # (the densities differ in their last bf16-induced digits, the resampled positions move with them)
+  for x, y in zip(sd_a, sd_b):
+    np.testing.assert_allclose(x.numpy(), y.numpy(), atol=1e-3)
+  np.testing.assert_allclose(rgb_a.numpy(), rgb_b.numpy(), atol=5e-3)
+  np.testing.assert_allclose(dm_a.numpy(), dm_b.numpy(), rtol=2e-2, atol=1e-3)

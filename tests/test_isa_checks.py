@@ -42,7 +42,8 @@ def test_the_shipped_mfma_kernels_are_all_there(report):
   assert sum('gemm_nt_wres_kernel' in n for n in names) == 2
   assert sum('gemm_tn_kernel' in n for n in names) == 2          # TnBig / TnSmall
   assert sum('mlp_chain_fwd_kernel' in n for n in names) == 2 and sum('mlp_chain_bwd_kernel' in n for n in names) == 2   # W = 128 / 256
-  assert len(names) == 14, names
+  assert sum('mlp_chain_fwd_ipe_kernel' in n for n in names) == 2      # the inference chain with the in-kernel IPE producer
+  assert len(names) == 16, names
 
 
 def test_tiled_gemm_k_loops_carry_only_the_hand_counted_vmcnt_waits(report):
