@@ -102,13 +102,7 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
     float sn = 0.0f, cs = 1.0f, att = 1.0f;
     for (int l = 0; l < L; ++l) {
       if ((l & 3) == 0) {
-        float y = lm * sc;
-        if (!(fabsf(y) < FE_100PI)) {
-          float m = fmodf(y, FE_100PI);
-          if (m != 0.0f && (m < 0.0f)) m += FE_100PI;
-          y = m;
-        }
-        fe_sincos_wrapped(y, &sn, &cs);
+        fe_sincos_wrapped(fe_wrap_100pi(lm * sc), &sn, &cs);
         att = exp2f(vscale * sc * sc);
       }
       const float fs = att * sn;

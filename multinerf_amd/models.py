@@ -39,6 +39,7 @@ import os as _os
 _USE_BITS = _os.environ.get('MNR_RELU_BITS', '1') != '0'   # A/B switch: 1-bit ReLU masks vs re-reading activations
 _USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused per-level Dense chain vs one GEMM per layer
 _FUSED_IPE = _os.environ.get('MNR_FUSED_IPE', '1') != '0'   # A/B switch: rendering builds the proposal levels' IPE features inside the chain kernel
+_HEAD_K64 = _os.environ.get('MNR_HEAD_K64', '1') != '0'    # A/B switch: the merged head's dX GEMM over 320 instead of 384 K columns
 # A/B switch: the weight-gradient GEMMs (dW_l = x_{l-1}^T dY_l) on a second HIP stream behind the dX chain.  dW_l and the
 # dX GEMM that turns dY_l into dY_{l-1} are independent, so with one dY buffer per layer (instead of two ping-pong
 # buffers) the dX chain runs ahead and the dW launches fill the CUs each dX launch's tail leaves idle (and the other way
@@ -1242,7 +1243,8 @@ class Model:
           ops.scatter_add(tmpW, nh, 0, c0, W, d.fan_out, gslice(d.kernel_off, W * d.fan_out), d.fan_out)
           ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
       Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
-      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=nh, Cb=dA, ldcb=W, nb=W, **mask_kw(len(acts) - 1))
+      # (K = the head's columns rounded to the GEMM's 64-column K granule, not to the buffers' 128: 320 instead of 384 at 360.gin)
+      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=_rup(plan.head_cols, 64) if _HEAD_K64 else nh, Cb=dA, ldcb=W, nb=W, **mask_kw(len(acts) - 1))
       act_vjp(mlp['zs'][-1] if not relu else None, dA)
     else:
       g_raw_density, _ = ops.composite_bwd(
