@@ -272,7 +272,7 @@ def main():
             'global_batch': B * world,
             'parallelism': f'dp{world}',
             'train_frac': train_frac,
-            'params': model.num_params,
+            'params': model.num_params, 'workspace_GiB': round(model.workspace_bytes() / 2 ** 30, 2),
             'backward_streams': mstreams.describe_env() if not model.single_mlp else {'side_stream': False, 'side_cus': 0},
             'algorithmic_train_mflop_per_ray': train_flops / 1e6,
             'algorithmic_fwd_mflop_per_ray': fwd_flops / 1e6,

@@ -567,7 +567,14 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
     splits = ((target_wgs + tiles - 1) / tiles + 7) / 8 * 8;
   }
   if (splits < unit) splits = unit;
-  while (splits > unit && (total_steps + splits - 1) / splits < 4) splits -= unit;
+  // (every workgroup ends with an atomic epilogue of its whole fp32 tile: a split must be long enough to pay for it)
+  static int min_steps = -1;
+  if (min_steps < 0) {
+    const char* e = getenv("MNR_TN_MIN_STEPS");
+    min_steps = e ? atoi(e) : 4;
+    if (min_steps < 1) min_steps = 1;
+  }
+  while (splits > unit && (total_steps + splits - 1) / splits < min_steps) splits -= unit;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   const int64_t grid = (int64_t)splits * tiles;
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)

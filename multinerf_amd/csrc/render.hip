@@ -138,13 +138,16 @@ static int g_level_bwd_quad = 1;
 // Largest LDS footprint (bytes per single-wave workgroup) at which the four-lanes-per-ray kernels are used.  Up to 40 KiB four
 // workgroups (one per SIMD) fit a CU; rays of 128 samples need 49 KiB (forward) / 66 KiB (backward), i.e. three / two
 // workgroups per CU, and are still faster there than on the lane-per-ray kernels: round-3 same-box A/B with the limit at
-// 40 / 52 / 80 KiB: blender_256 1.670 / 1.658 / 1.737 M rays/s, llff_raw 488 / 496 / 495 k (profiles/r3_ab.md).
+// 40 / 52 / 80 KiB: blender_256 1.670 / 1.658 / 1.737 M rays/s, llff_raw 488 / 496 / 495 k (profiles/r3_ab.md).  The levels of
+// llff_raw (128 samples WITH rgb, RawNeRF loss, exposure scaling) need 82 / 99 KiB, one workgroup per CU, and are the ones the
+// lane-per-ray stream hurts most: with the limit at 80 / 88 / 104 / 160 KiB llff_raw runs 512 / 545 / 545 / 544 k rays/s,
+// blender_refnerf 150.8 / - / 152.6 / - k, blender_256 1.771 / - / 1.765 / - M (three pairs, inside the noise): 104 KiB.
 // MNR_QUAD_LDS_MAX overrides (tuning).
 static size_t quad_lds_max() {
   static size_t v = 0;
   if (v == 0) {
     const char* e = getenv("MNR_QUAD_LDS_MAX");
-    v = e ? (size_t)atoll(e) : 80 * 1024;
+    v = e ? (size_t)atoll(e) : 104 * 1024;
     if (v < 1024) v = 1024;
     if (v > 160 * 1024) v = 160 * 1024;
   }

@@ -346,9 +346,14 @@ class Model:
       raise ValueError('num_glo_features > 0 is incompatible with single_mlp')
     if self.raydist_fn not in L.RAYDIST:
       bad.append(f'raydist_fn={self.raydist_fn}')
-    if self.num_prop_samples % 32 or self.num_nerf_samples % 32:
-      bad.append('sample counts must be multiples of 32')
     return bad
+
+  def _ray_pad_unit(self):
+    unit = 8
+    for n in (self.num_prop_samples, self.num_nerf_samples):
+      u = 256 // math.gcd(int(n), 256)
+      unit = unit * u // math.gcd(unit, u)
+    return unit
 
   def build(self, device='cuda'):
     """Lay out parameters and device-side constant tables (flax `init` without the RNG part)."""
@@ -588,6 +593,13 @@ class Model:
       self._ws[k] = t
     return t
 
+  def workspace_bytes(self):
+    """Bytes of the per-level / backward workspace allocated so far (features, activations, masks, gradients: everything
+    `_buf` hands out; bench.py reports it).  The fused chain's backward keeps one dY matrix per layer (the weight-gradient
+    GEMMs read them after the one dX launch) where the per-layer path ping-pongs two: depth * M * W * 2 bytes per level,
+    2 GiB instead of 1 GiB per proposal level of 360.gin at 16384 rays, 8 GiB for the 8 x 256 trunk of llff_raw."""
+    return sum(t.numel() * t.element_size() for t in self._ws.values())
+
   def _lvl_buf(self, tag, name, rows, cols, dtype, group=None):
     """A per-level [rows, *cols] buffer.  group = (i, L): rows [i*rows, (i+1)*rows) of ONE buffer the L proposal levels
     share (training), so that their backward pass can run over all L*rows rows at once (`backward_prop_levels`)."""
@@ -644,8 +656,9 @@ class Model:
     lead = rays.origins.shape[:-1]
     flat_rays = rays.map(lambda r: r.reshape(-1, r.shape[-1]).contiguous())
     B0 = flat_rays.origins.shape[0]
-    # Pad to a multiple of 8 rays so every level's row count is a multiple of 256 (GEMM tiles).
-    Bp = _rup(B0, 8)
+    # Pad the rays so that every level's row count B * n is a multiple of 256 (GEMM tiles): a multiple of 8 rays for sample
+    # counts that are multiples of 32 (every BASELINE config), of 256 / gcd(n, 256) in general.
+    Bp = _rup(B0, self._ray_pad_unit())
     if Bp != B0:
       pad = Bp - B0
       flat_rays = flat_rays.map(lambda r: torch.cat([r, r[-1:].expand(pad, r.shape[-1])], 0).contiguous())

@@ -58,6 +58,8 @@ def lib():
       L.check(L.load().mnr_mlp_chain_set_deferred(int(os.environ['MNR_CHAIN_DEFER'])))
     if os.environ.get('MNR_NT_STORES'):         # A/B switch: streaming stores of the NT GEMM's output tile (1: on)
       L.check(L.load().mnr_gemm_nt_set_nt_stores(int(os.environ['MNR_NT_STORES'])))
+    if os.environ.get('MNR_TN_BIG_MIN_TILES'):  # tuning: the 256x256 dW tile only for outputs of at least this many tiles (default 1)
+      L.check(L.load().mnr_gemm_tn_set_config(int(os.environ['MNR_TN_BIG_MIN_TILES'])))
     if os.environ.get('MNR_NT_WRES'):           # A/B switch: weights-resident kernel for the short-K layers (0: off)
       L.check(L.load().mnr_gemm_nt_set_wres(int(os.environ['MNR_NT_WRES'])))
   return L.load()

@@ -131,6 +131,9 @@ CASES = [
     # PropMLP at the reference's default depth 8 (models.py:346,353): a density-only MLP WITH a skip concat on the fused chain
     # (forward skip segment, the feature rows of the skip layer's weight gradient; a round-3 fix, first seen on the simulator)
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'PropMLP.net_depth = 8'], 16),
+    # sample counts that are not multiples of 32 (models.py:58-59 takes any): the rays are padded to a multiple of
+    # 256 / gcd(n, 256) (here 32) so that every level still fills whole 256-row GEMM tiles; 21 rays -> 11 padded ones
+    ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_prop_samples = 40', 'Model.num_nerf_samples = 24'], 21),
 ]
 
 
