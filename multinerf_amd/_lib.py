@@ -72,7 +72,7 @@ class GemmTNArgs(C.Structure):
               ('B', vp), ('ldb', C.c_int), ('N', C.c_int),
               ('M', C.c_int64), ('C', vp), ('ldc', C.c_int),
               ('k_valid', C.c_int), ('n_valid', C.c_int),
-              ('bias_out', vp), ('bias_n_valid', C.c_int)]
+              ('bias_out', vp), ('bias_n_valid', C.c_int), ('gcol', vp), ('gcol_out', vp)]
 
 
 CHAIN_MAX_DEPTH = 8

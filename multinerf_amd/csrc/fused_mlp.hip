@@ -785,6 +785,15 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_ipe_kernel(mnr_mlp_chain_fw
       const int er0 = et / K, ek = et - er0 * K;
       if (et < rpi * K) {
         const float px = bs[ek * 3 + 0], py = bs[ek * 3 + 1], pz = bs[ek * 3 + 2];
+        // byte offsets of this thread's eight feature columns inside a row of the group tile, before the row's swizzle:
+        // K-tile (bits 15+), 16-byte slot (bits 4-6), element (bits 1-3).  The swizzle XORs the slot with (row >> 1) & 7, i.e.
+        // the offset with that value << 4: one XOR per store instead of rebuilding the address from the column.
+        unsigned cb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = ek + j * K;                      // sin of degree j / 2 for even j, its cos for odd j
+          cb[j] = (unsigned)((c >> 6) * FM_KT_BYTES + (((c & 63) >> 3) << 4) + (c & 7) * 2);
+        }
         for (int si = r_lo + er0; si < r_hi; si += rpi) {
           const FeSample gsm = gs[si];
           const float lm = gsm.mean[0] * px + gsm.mean[1] * py + gsm.mean[2] * pz;
@@ -798,18 +807,15 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_ipe_kernel(mnr_mlp_chain_fw
           fe_sincos_wrapped(fe_wrap_100pi(lm * sc), &sn, &cs);
           float att = exp2f(vscale * sc * sc);
           char* rowp = smem + si * 128;
-          const int sw = (si >> 1) & 7;
-          int c = ek;
+          const unsigned sw4 = (unsigned)((si >> 1) & 7) << 4;
 #pragma unroll
           for (int dl = 0; dl < 4; ++dl) {
             const float fs = att * sn;
             const float fc = att * cs;
             const f32x2 pr = {fs, fc};
             const bf16x2 pb = __builtin_convertvector(pr, bf16x2);
-            const int c2 = c + K;
-            *(bf16*)(rowp + (c >> 6) * FM_KT_BYTES + ((((c & 63) >> 3) ^ sw) << 4) + (c & 7) * 2) = pb[0];
-            *(bf16*)(rowp + (c2 >> 6) * FM_KT_BYTES + ((((c2 & 63) >> 3) ^ sw) << 4) + (c2 & 7) * 2) = pb[1];
-            c += 2 * K;
+            *(bf16*)(rowp + (cb[2 * dl] ^ sw4)) = pb[0];
+            *(bf16*)(rowp + (cb[2 * dl + 1] ^ sw4)) = pb[1];
             const float s2 = 2.0f * sn * cs;
             cs = 1.0f - 2.0f * sn * sn;
             sn = s2;

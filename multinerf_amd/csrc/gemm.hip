@@ -545,10 +545,19 @@ static inline int mnr_gcd(int a, int b) {
 
 template <class CFG>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
+  constexpr bool GCOL = false;
 #include "gemm_tn_body.inc"
 }
 
+// The same with one more column of B supplied as an fp32 vector (mnr_gemm_tn_args.gcol): a kernel of its own, so that the
+// weight-gradient GEMMs without it keep their registers and schedule.
 template <class CFG>
+__global__ __launch_bounds__(CFG::THREADS) void gemm_tn_gcol_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
+  constexpr bool GCOL = true;
+#include "gemm_tn_body.inc"
+}
+
+template <class CFG, bool G = false>
 static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   const int tiles = (a->K / CFG::BKO) * (a->N / CFG::BNO);
   const int total_steps = (int)(a->M / TN_BM);
@@ -579,10 +588,15 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   const int64_t grid = (int64_t)splits * tiles;
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
   if (mnr_attr_needed(&attr_set)) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    if constexpr (G) (void)hipFuncSetAttribute((const void*)gemm_tn_gcol_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    else (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
   }
-  hipLaunchKernelGGL(gemm_tn_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
-                     *a, splits, steps_per_split);
+  if constexpr (G)
+    hipLaunchKernelGGL(gemm_tn_gcol_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
+                       *a, splits, steps_per_split);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
+                       *a, splits, steps_per_split);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
@@ -611,6 +625,9 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
     // 512 -> 256 workgroups = 398k -> 407k rays/s end to end, 1024: 390k.
     tn_target = e ? atoi(e) : 256;
   }
+  MNR_CHECK_ARG(!a->gcol || (a->gcol_out && a->K % 256 == 0 && a->N % 256 == 0 && ((uintptr_t)a->gcol % 64) == 0),
+                "mnr_gemm_tn_bf16: gcol needs gcol_out, K and N multiples of 256 and a 64-byte-aligned vector");
+  if (a->gcol) return tn_launch<TnBig, true>(a, tn_target, stream);
   if (big) return tn_launch<TnBig>(a, tn_target, stream);
   static int tn_small_target = -1;
   if (tn_small_target < 0) {

@@ -40,6 +40,7 @@ _USE_BITS = _os.environ.get('MNR_RELU_BITS', '1') != '0'   # A/B switch: 1-bit R
 _USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused per-level Dense chain vs one GEMM per layer
 _FUSED_IPE = _os.environ.get('MNR_FUSED_IPE', '1') != '0'   # A/B switch: rendering builds the proposal levels' IPE features inside the chain kernel
 _HEAD_K64 = _os.environ.get('MNR_HEAD_K64', '1') != '0'    # A/B switch: the merged head's dX GEMM over 320 instead of 384 K columns
+_HEAD_GCOL = _os.environ.get('MNR_HEAD_GCOL', '1') != '0'  # A/B switch: the density head's weight gradient as an extra column of the bottleneck's dW GEMM (N = 256, 256x256 tiles) instead of a merged N = 384 GEMM on 128x128 tiles
 # A/B switch: the weight-gradient GEMMs (dW_l = x_{l-1}^T dY_l) on a second HIP stream behind the dX chain.  dW_l and the
 # dX GEMM that turns dY_l into dY_{l-1} are independent, so with one dY buffer per layer (instead of two ping-pong
 # buffers) the dX chain runs ahead and the dW launches fill the CUs each dX launch's tail leaves idle (and the other way
@@ -1160,10 +1161,13 @@ class Model:
       e = plan.packed['head']
       nh = e['nb_pad']
       dHB = self._buf(('bwd', 'dHB', nh), (M, nh), bf16, zero=True)   # columns beyond head_cols stay zero
-      _, g_rgb = ops.composite_bwd(
+      # (the plain merged head [bottleneck | density] of 360.gin: the density column's weight gradient rides in the bottleneck's
+      # dW GEMM as a vector, below; it then also leaves the compositing VJP as the fp32 vector that GEMM reads)
+      head_gcol = (_HEAD_GCOL and not plan.ref and len(plan.head_segs) == 2 and bw % 256 == 0 and W % 256 == 0)
+      g_den_f32, g_rgb = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], raw_rgb=lv['raw_rgb'],
           density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights,
-          g_den_bf16=dHB.view(-1)[bw:], ld_bf16=nh, want_f32=False, exposure_scale=lv['expo'],
+          g_den_bf16=dHB.view(-1)[bw:], ld_bf16=nh, want_f32=head_gcol, exposure_scale=lv['expo'],
           g_exposure_scale=g_expo if lv['expo'] is not None else None, losses=losses)
       g_raw_rgb = g_rgb.view(M, 3)
       if plan.ref:
@@ -1246,15 +1250,23 @@ class Model:
       # merged head: dW, db, dX_last
       e = plan.packed['head']
       with self._dw():
-        tmpW = self._buf(('bwd', 'tmpW', W, nh), (W, nh), f32)
-        tmpW.zero_()
-        tmpb = self._buf(('bwd', 'tmpb', nh), (nh,), f32)
-        tmpb.zero_()
-        ops.gemm_tn(x_last, dHB, tmpW, M=M, K=W, N=nh, lda=W, ldb=nh, ldc=nh, bias_out=tmpb,
-                    bias_n_valid=plan.head_cols)
-        for (d, c0) in plan.head_segs:
-          ops.scatter_add(tmpW, nh, 0, c0, W, d.fan_out, gslice(d.kernel_off, W * d.fan_out), d.fan_out)
-          ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
+        if head_gcol:
+          # dW_bottleneck += x^T dHB[:, :bw] straight into the flat gradient (256x256 tiles), dw_density += x^T g as one more
+          # column of the same launch, db_density from the strided column (33 MB of 64-byte sectors)
+          db_, dd_ = plan.bottleneck, plan.density
+          ops.gemm_tn(x_last, dHB, gslice(db_.kernel_off, W * bw), M=M, K=W, N=bw, lda=W, ldb=nh, ldc=bw,
+                      bias_out=gslice(db_.bias_off, bw), bias_n_valid=bw, gcol=g_den_f32.view(-1), gcol_out=gslice(dd_.kernel_off, W))
+          ops.colsum(dHB.view(-1)[bw:], M, 1, gslice(dd_.bias_off, 1), ld=nh)
+        else:
+          tmpW = self._buf(('bwd', 'tmpW', W, nh), (W, nh), f32)
+          tmpW.zero_()
+          tmpb = self._buf(('bwd', 'tmpb', nh), (nh,), f32)
+          tmpb.zero_()
+          ops.gemm_tn(x_last, dHB, tmpW, M=M, K=W, N=nh, lda=W, ldb=nh, ldc=nh, bias_out=tmpb,
+                      bias_n_valid=plan.head_cols)
+          for (d, c0) in plan.head_segs:
+            ops.scatter_add(tmpW, nh, 0, c0, W, d.fan_out, gslice(d.kernel_off, W * d.fan_out), d.fan_out)
+            ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
       Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
       # (K = the head's columns rounded to the GEMM's 64-column K granule, not to the buffers' 128: 320 instead of 384 at 360.gin)
       ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=_rup(plan.head_cols, 64) if _HEAD_K64 else nh, Cb=dA, ldcb=W, nb=W, **mask_kw(len(acts) - 1))

@@ -413,6 +413,33 @@ def test_gemm_tn(ops, M, K, N):
   assert (got[K - 5:] == 0).all() and (got[:, N - 3:] == 0).all()
 
 
+@pytest.mark.parametrize('M,K,N,ldb', [(4096, 256, 256, 384), (8192 + 64, 512, 256, 256), (2048, 256, 512, 512)])
+def test_gemm_tn_extra_column(ops, M, K, N, ldb):
+  """mnr_gemm_tn_bf16 with `gcol`: one more column of B as an fp32 vector (the density head's gradient next to the
+  bottleneck's, models.py:460 / :527): gcol_out[k] += sum_m A[m,k] bf16(g[m]), exact products in fp32 like every other
+  column; C, the fused bias gradient and the k_valid bound unchanged by it."""
+  gen = torch.Generator().manual_seed(17)
+  A = _bf(torch.randn((M, K), generator=gen))
+  Bfull = _bf(torch.randn((M, ldb), generator=gen))
+  g = torch.randn((M,), generator=gen) * 0.37
+  ref = A.double().T @ Bfull[:, :N].double()
+  ref_g = A.double().T @ _bf(g).double()
+  Cout = torch.ones((K, N), dtype=torch.float32).cuda()
+  bsum = torch.zeros((N,)).cuda()
+  gout = torch.full((K,), 3.0).cuda()
+  kv = K - 5
+  ops.gemm_tn(dev(A), dev(Bfull), Cout, M=M, K=K, N=N, ldb=ldb, k_valid=kv, bias_out=bsum, bias_n_valid=N, gcol=dev(g), gcol_out=gout)
+  got = Cout.cpu().double()
+  np.testing.assert_allclose(got[:kv].numpy(), (ref[:kv] + 1).numpy(), rtol=1e-4, atol=1e-3 * math.sqrt(M))
+  assert (got[kv:] == 1).all()
+  np.testing.assert_allclose(bsum.cpu().double().numpy(), Bfull[:, :N].double().sum(0).numpy(), rtol=1e-5, atol=1e-3 * math.sqrt(M))
+  gg = gout.cpu().double()
+  np.testing.assert_allclose(gg[:kv].numpy(), (ref_g[:kv] + 3).numpy(), rtol=1e-4, atol=1e-3 * math.sqrt(M))
+  assert (gg[kv:] == 3).all()
+  with pytest.raises(ValueError, match='gcol'):
+    ops.gemm_tn(dev(A), dev(Bfull), Cout, M=M, K=K, N=128, ldb=ldb, gcol=dev(g), gcol_out=gout)
+
+
 @pytest.mark.parametrize('K1,K2,bits', [(1024, 0, False), (1024, 512, False), (1024, 0, True)])
 def test_gemm_nt_trunk_shapes(ops, K1, K2, bits):
   """The 360.gin trunk's own GEMM shapes (1024-wide layers, the 1536-wide skip layer, a dX layer with 1-bit masks) at
