@@ -286,8 +286,8 @@ typedef struct {
   int k_valid, n_valid;                /* only k < k_valid, n < n_valid are written */
   float* bias_out; int bias_n_valid;   /* optional: bias_out[n] += sum_m B[m,n] for n < bias_n_valid
                                           (the Dense bias gradient, fused: B is read once) */
-  const float* gcol; float* gcol_out;  /* optional (K, N multiples of 256): one more column of B given as an fp32 vector [M]:
-                                          gcol_out[k] += sum_m A[m,k] bf16(gcol[m]) for k < k_valid.  The Dense(1) density head
+  const uint16_t* gcol; float* gcol_out;  /* optional (K, N multiples of 256): one more column of B given as a contiguous bf16
+                                          vector [M] (32-byte aligned): gcol_out[k] += sum_m A[m,k] gcol[m] for k < k_valid.  The Dense(1) density head
                                           of the merged NeRF head (models.py:460 next to :527): its gradient column rides in
                                           the bottleneck's weight-gradient GEMM as one extra MFMA per k-step instead of
                                           widening N from 256 to 384 */

@@ -625,8 +625,8 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
     // 512 -> 256 workgroups = 398k -> 407k rays/s end to end, 1024: 390k.
     tn_target = e ? atoi(e) : 256;
   }
-  MNR_CHECK_ARG(!a->gcol || (a->gcol_out && a->K % 256 == 0 && a->N % 256 == 0 && ((uintptr_t)a->gcol % 64) == 0),
-                "mnr_gemm_tn_bf16: gcol needs gcol_out, K and N multiples of 256 and a 64-byte-aligned vector");
+  MNR_CHECK_ARG(!a->gcol || (a->gcol_out && a->K % 256 == 0 && a->N % 256 == 0 && ((uintptr_t)a->gcol % 32) == 0),
+                "mnr_gemm_tn_bf16: gcol needs gcol_out, K and N multiples of 256 and a 32-byte-aligned vector");
   if (a->gcol) return tn_launch<TnBig, true>(a, tn_target, stream);
   if (big) return tn_launch<TnBig>(a, tn_target, stream);
   static int tn_small_target = -1;

@@ -1254,8 +1254,10 @@ class Model:
           # dW_bottleneck += x^T dHB[:, :bw] straight into the flat gradient (256x256 tiles), dw_density += x^T g as one more
           # column of the same launch, db_density from the strided column (33 MB of 64-byte sectors)
           db_, dd_ = plan.bottleneck, plan.density
+          g_vec = self._buf(('bwd', 'g_den_vec'), (M,), bf16)          # the density column of dHB once more, contiguous
+          ops.cast_f32_to_bf16(g_den_f32.view(-1), 1, M, 1, g_vec, 1, 0)
           ops.gemm_tn(x_last, dHB, gslice(db_.kernel_off, W * bw), M=M, K=W, N=bw, lda=W, ldb=nh, ldc=bw,
-                      bias_out=gslice(db_.bias_off, bw), bias_n_valid=bw, gcol=g_den_f32.view(-1), gcol_out=gslice(dd_.kernel_off, W))
+                      bias_out=gslice(db_.bias_off, bw), bias_n_valid=bw, gcol=g_vec, gcol_out=gslice(dd_.kernel_off, W))
           ops.colsum(dHB.view(-1)[bw:], M, 1, gslice(dd_.bias_off, 1), ld=nh)
         else:
           tmpW = self._buf(('bwd', 'tmpW', W, nh), (W, nh), f32)

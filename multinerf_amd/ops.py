@@ -313,9 +313,9 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
 def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, n_valid=None, bias_out=None,
             bias_n_valid=0, gcol=None, gcol_out=None):
   """Cout[k,n] += sum_m A[m,k] B[m,n]; optionally bias_out[n] += sum_m B[m,n] (fused bias gradient) and
-  gcol_out[k] += sum_m A[m,k] bf16(gcol[m]) (one more column of B given as an fp32 vector [M])."""
+  gcol_out[k] += sum_m A[m,k] gcol[m] (one more column of B given as a contiguous bf16 vector [M])."""
   _chk(bias_out, f32, 'bias_out', allow_none=True)
-  _chk(gcol, f32, 'gcol', allow_none=True)
+  _chk(gcol, bf16, 'gcol', allow_none=True)
   _chk(gcol_out, f32, 'gcol_out', allow_none=True)
   assert (gcol is None) == (gcol_out is None) and (gcol is None or (gcol.numel() == M and gcol.is_contiguous()))
   _chk(A, bf16, 'A')

@@ -416,7 +416,7 @@ def test_gemm_tn(ops, M, K, N):
 @pytest.mark.parametrize('M,K,N,ldb', [(4096, 256, 256, 384), (8192 + 64, 512, 256, 256), (2048, 256, 512, 512)])
 def test_gemm_tn_extra_column(ops, M, K, N, ldb):
   """mnr_gemm_tn_bf16 with `gcol`: one more column of B as an fp32 vector (the density head's gradient next to the
-  bottleneck's, models.py:460 / :527): gcol_out[k] += sum_m A[m,k] bf16(g[m]), exact products in fp32 like every other
+  bottleneck's, models.py:460 / :527; a contiguous bf16 vector): gcol_out[k] += sum_m A[m,k] g[m], exact products in fp32 like every other
   column; C, the fused bias gradient and the k_valid bound unchanged by it."""
   gen = torch.Generator().manual_seed(17)
   A = _bf(torch.randn((M, K), generator=gen))
@@ -428,7 +428,7 @@ def test_gemm_tn_extra_column(ops, M, K, N, ldb):
   bsum = torch.zeros((N,)).cuda()
   gout = torch.full((K,), 3.0).cuda()
   kv = K - 5
-  ops.gemm_tn(dev(A), dev(Bfull), Cout, M=M, K=K, N=N, ldb=ldb, k_valid=kv, bias_out=bsum, bias_n_valid=N, gcol=dev(g), gcol_out=gout)
+  ops.gemm_tn(dev(A), dev(Bfull), Cout, M=M, K=K, N=N, ldb=ldb, k_valid=kv, bias_out=bsum, bias_n_valid=N, gcol=dev(_bf(g)), gcol_out=gout)
   got = Cout.cpu().double()
   np.testing.assert_allclose(got[:kv].numpy(), (ref[:kv] + 1).numpy(), rtol=1e-4, atol=1e-3 * math.sqrt(M))
   assert (got[kv:] == 1).all()
@@ -437,7 +437,7 @@ def test_gemm_tn_extra_column(ops, M, K, N, ldb):
   np.testing.assert_allclose(gg[:kv].numpy(), (ref_g[:kv] + 3).numpy(), rtol=1e-4, atol=1e-3 * math.sqrt(M))
   assert (gg[kv:] == 3).all()
   with pytest.raises(ValueError, match='gcol'):
-    ops.gemm_tn(dev(A), dev(Bfull), Cout, M=M, K=K, N=128, ldb=ldb, gcol=dev(g), gcol_out=gout)
+    ops.gemm_tn(dev(A), dev(Bfull), Cout, M=M, K=K, N=128, ldb=ldb, gcol=dev(_bf(g)), gcol_out=gout)
 
 
 @pytest.mark.parametrize('K1,K2,bits', [(1024, 0, False), (1024, 512, False), (1024, 0, True)])

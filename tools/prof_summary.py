@@ -71,6 +71,40 @@ def stats(args):
       print(f'| `{k}` | {g} | {len(ds)} | {sum(ds) / len(ds):.1f} | {min(ds):.1f} | {sum(ds):.0f} |')
 
 
+def seq(args):
+  """The launches of the LAST train step in start order (a step = the launches between two clip_adam_kernel groups), with
+  start offsets: which kernel is which layer's, and what overlaps what."""
+  rowsq = []
+  for db in find(args.dir, '*_results.db'):
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    kt = [t for t in tabs if t == 'kernels' or t.startswith('kernels')]
+    cols = [r[1] for r in cur.execute(f'pragma table_info({kt[0]})')]
+    namecol = 'name' if 'name' in cols else 'kernel_name'
+    gcols = 'grid_x, grid_y, grid_z' if 'grid_x' in cols else 'grid_size_x, grid_size_y, grid_size_z'
+    for name, st, en, gx, gy, gz in cur.execute(f'select {namecol}, start, end, {gcols} from {kt[0]}'):
+      rowsq.append((st, en, short(name, 90), gx * max(gy, 1) * max(gz, 1)))
+  rowsq.sort()
+  ends = [i for i, r in enumerate(rowsq) if 'clip_adam_kernel' in r[2]]
+  # the last clip_adam launch closes the last step; the one before the previous group closes the step before it
+  groups = [i for k, i in enumerate(ends) if k == 0 or i - ends[k - 1] > 3]
+  lo = groups[-2] if len(groups) >= 2 else 0
+  step = [r for r in rowsq[lo:ends[-1] + 1]]
+  # drop the previous step's trailing optimizer launches
+  first = next(i for i, r in enumerate(step) if 'clip_adam' not in r[2] and 'grad_sqnorm' not in r[2])
+  step = step[first:]
+  t0 = step[0][0]
+  print(f'# {args.title}\n')
+  if args.command:
+    print(f'Command: `{args.command}`\n')
+  print(f'{len(step)} launches, {(step[-1][1] - t0) / 1e6:.3f} ms from the first start to the last end.\n')
+  print('| # | start us | duration us | grid threads | kernel |')
+  print('|---|---|---|---|---|')
+  for i, (st, en, k, g) in enumerate(step):
+    print(f'| {i} | {(st - t0) / 1e3:.1f} | {(en - st) / 1e3:.1f} | {g} | `{k}` |')
+
+
 def pmc(args):
   acc = collections.defaultdict(lambda: collections.defaultdict(float))
   calls = collections.defaultdict(lambda: collections.defaultdict(int))
@@ -97,10 +131,10 @@ def pmc(args):
 
 if __name__ == '__main__':
   ap = argparse.ArgumentParser()
-  ap.add_argument('mode', choices=['stats', 'pmc'])
+  ap.add_argument('mode', choices=['stats', 'pmc', 'seq'])
   ap.add_argument('dir')
   ap.add_argument('--title', default='rocprofv3 summary')
   ap.add_argument('--command', default='')
   ap.add_argument('--top', type=int, default=30)
   a = ap.parse_args()
-  (stats if a.mode == 'stats' else pmc)(a)
+  {'stats': stats, 'pmc': pmc, 'seq': seq}[a.mode](a)
