@@ -193,11 +193,6 @@ typedef struct {
   const uint8_t* mask_bits_in; int ld_bits_in;
   int64_t bits_row_mod;               /* > 0: row m reads the bits of row m % bits_row_mod (tangent rows
                                          c*M + s share the primal mask of sample s) */
-  /* Dense(1) on this layer's OUTPUT, fused (models.py:460 on the last trunk layer of :455-459): rowdot_out[m] +=
-   * sum_n bf16(out[m,n]) * rowdot_w[n] in fp32 (one atomic per row and 256-column tile; the caller initialises rowdot_out,
-   * e.g. with the bias).  256x256 tiles with the whole tile in the bf16 output (nb == N, N a multiple of 256), no mask.
-   * The merged NeRF head then is the bottleneck alone (N = 256) instead of 257 columns padded to 512. */
-  const uint16_t* rowdot_w; float* rowdot_out;
 } mnr_gemm_nt_args;
 
 /* C[M,N] = epilogue([A1|A2] * Bt^T). */

@@ -64,7 +64,7 @@ class GemmNTArgs(C.Structure):
               ('Cf', vp), ('ldcf', C.c_int), ('f0', C.c_int), ('nf', C.c_int),
               ('mask_bits_out', vp), ('ld_bits_out', C.c_int),
               ('mask_bits_in', vp), ('ld_bits_in', C.c_int),
-              ('bits_row_mod', C.c_int64), ('rowdot_w', vp), ('rowdot_out', vp)]
+              ('bits_row_mod', C.c_int64)]
 
 
 class GemmTNArgs(C.Structure):

@@ -166,22 +166,8 @@ extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
   return MNR_OK;
 }
 
-// The forward kernel with a Dense(1) on its own output fused into the store loop (mnr_gemm_nt_args.rowdot_w): a kernel of its
-// own, so that every other launch keeps its store loop.
-template <class CFG>
-__global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_rowdot_kernel(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
-  constexpr bool BITS_IN = false, ROWDOT = true;
-  const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  unsigned long long* const tl = g_nt_timeline;
-  for (int64_t vbid = blockIdx.x; vbid < vtotal; vbid += gridDim.x) {
-#include "gemm_nt_body.inc"
-    if (vbid + gridDim.x < vtotal) __syncthreads();
-  }
-}
-
 template <class CFG, bool BITS_IN>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
-  constexpr bool ROWDOT = false;
   // the wave index lives in an SGPR across the tile loop and the lane index is re-derived per tile (mbcnt): with
   // threadIdx.x itself kept alive across the loop, hipcc spills it and reloads it (behind a vmcnt(0)) at every tile
   const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -237,18 +223,6 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
   }
-  if constexpr (CFG::PIPE && CFG::DBG == 0 && CFG::EPI_BATCH > 0 && CFG::BM == 256 && CFG::BN == 256) {
-    if (a->rowdot_w) {
-      static unsigned long long attr_rd = 0;
-      if (mnr_attr_needed(&attr_rd))
-        (void)hipFuncSetAttribute((const void*)gemm_nt_rowdot_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-      hipLaunchKernelGGL((gemm_nt_rowdot_kernel<CFG>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
-                         (hipStream_t)stream, *a, fast_epi, (long long)vtotal);
-      MNR_CHECK_LAUNCH();
-      return MNR_OK;
-    }
-  }
-  MNR_CHECK_ARG(!a->rowdot_w, "mnr_gemm_nt_bf16: rowdot_w needs the pipelined 256x256 tile");
   if (a->mask_bits_in) {
     hipLaunchKernelGGL((gemm_nt_kernel<CFG, true>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
                        (hipStream_t)stream, *a, fast_epi, (long long)vtotal);
@@ -513,10 +487,7 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   const int fast_epi = (int)((!a->Cb || (a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0)) &&
                              (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0))) |
                        (g_nt_nt_stores ? 2 : 0);     // bit 1: streaming stores of the bf16 output tile (A/B switch)
-  MNR_CHECK_ARG(!a->rowdot_w || (a->rowdot_out && a->Cb && a->nb == a->N && a->N % 256 == 0 && a->M % 256 == 0 && !a->mask &&
-                                 !a->mask_bits_in && (fast_epi & 1) && g_nt_pipe == 1 && ((uintptr_t)a->rowdot_w % 16) == 0),
-                "mnr_gemm_nt_bf16: rowdot_w needs rowdot_out, a full-width 16-byte-aligned bf16 output of 256x256 tiles and no mask");
-  if (g_nt_wres > 0 && !a->rowdot_w && nt_wres_eligible(a, fast_epi)) return nt_wres_launch(a, g_nt_wres, stream);
+  if (g_nt_wres > 0 && nt_wres_eligible(a, fast_epi)) return nt_wres_launch(a, g_nt_wres, stream);
 #ifdef MNR_NT_DEBUG_VARIANTS      // probe build (tools/nt_pipe_probe.py): the pipelined loop with one ingredient removed
   if (a->M % 256 == 0 && a->N % 256 == 0) {
     if (g_nt_pipe == 11) return nt_launch<NtCfg<4, 2, 2, 4, 8, 1, 1, 1, 32, 4>>(a, fast_epi, stream);      // no DMA

@@ -41,7 +41,6 @@ _USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused
 _FUSED_IPE = _os.environ.get('MNR_FUSED_IPE', '1') != '0'   # A/B switch: rendering builds the proposal levels' IPE features inside the chain kernel
 _HEAD_K64 = _os.environ.get('MNR_HEAD_K64', '1') != '0'    # A/B switch: the merged head's dX GEMM over 320 instead of 384 K columns
 _HEAD_GCOL = _os.environ.get('MNR_HEAD_GCOL', '1') != '0'  # A/B switch: the density head's weight gradient as an extra column of the bottleneck's dW GEMM (N = 256, 256x256 tiles) instead of a merged N = 384 GEMM on 128x128 tiles
-_HEAD_ROWDOT = _os.environ.get('MNR_HEAD_ROWDOT', '1') != '0'  # A/B switch: the density head as a row-dot in the last trunk layer's store loop; the head GEMM is then the bottleneck alone (N = 256 instead of 257 -> 512)
 # A/B switch: the weight-gradient GEMMs (dW_l = x_{l-1}^T dY_l) on a second HIP stream behind the dX chain.  dW_l and the
 # dX GEMM that turns dY_l into dY_{l-1} are independent, so with one dY buffer per layer (instead of two ping-pong
 # buffers) the dX chain runs ahead and the dW launches fill the CUs each dX launch's tail leaves idle (and the other way
@@ -943,12 +942,6 @@ class Model:
       zlist.append(z)
       return z
 
-    raw_density = self._buf((tag, 'raw_density'), (M,), f32)
-    # the plain merged head [bottleneck | density] behind a per-layer ReLU trunk of 256-column tiles (360.gin): see below
-    head_rowdot = (_HEAD_ROWDOT and not chain and relu and plan.has_rgb and plan.use_viewdirs and not plan.ref and
-                   hp.bottleneck_width % 256 == 0 and plan.W % 256 == 0 and M % 256 == 0 and len(plan.trunk) >= 2 and
-                   not plan.trunk[-1][1])
-    rowdot_done = False
     if chain:
       acts, bits = self._chain_trunk(plan, flat, feat, M, tag, keep, need_bits)
       x = acts[-1]
@@ -968,15 +961,6 @@ class Model:
       elif concat:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, A2=feat, K2=plan.ldF, bias=bias, n_bias=d.fan_out,
                     relu=relu, Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo)
-      elif i == len(plan.trunk) - 1 and head_rowdot:
-        # the density head (models.py:460) rides in this layer's store loop: raw_density = b + out . w_density
-        dd = plan.density
-        raw_density.copy_(flat[dd.bias_off:dd.bias_off + 1].expand(M))
-        eh = plan.packed['head']
-        w_den = self._w(plan, eh['f_off'], eh['n_pad'], eh['f_ld'])[hp.bottleneck_width]
-        ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=bias, n_bias=d.fan_out, relu=relu,
-                    Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo, rowdot_w=w_den, rowdot_out=raw_density)
-        rowdot_done = True
       else:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=bias, n_bias=d.fan_out, relu=relu,
                     Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo)
@@ -985,6 +969,7 @@ class Model:
       acts.append(out)
       x = out
     res = dict(acts=acts, bits=bits, chain_trunk=chain, zs=zs, vzs=vzs)
+    raw_density = self._buf((tag, 'raw_density'), (M,), f32)
     if plan.has_rgb and not plan.use_viewdirs:
       # models.py:585 with x = the trunk output: one 4-column head [raw_density | raw_rgb] as an fp32 side output
       e = plan.packed['head4']
@@ -1036,9 +1021,6 @@ class Model:
                                                  bw, plan.ldVI)
         res.update(small=small, T_feat=T_feat, T_acts=T_acts, raw_grad=raw_grad, normals=normals, npred=npred,
                    rough=rough)
-      elif rowdot_done:
-        ops.gemm_nt(x, Bt, M=M, N=bw, K1=plan.W, bias=plan.head_bias, n_bias=bw, relu=False, Cb=VI, ldcb=plan.ldVI, nb=bw)
-        ops.viewdir_enc_fill(R.viewdirs, n, hp.deg_view, VI, bw, plan.ldVI)
       else:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=bw + 1, relu=False,
                     Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=raw_density, ldcf=1, f0=bw, nf=1)

@@ -282,9 +282,8 @@ def glo_bwd(g_a, g_b, cam_idx, B, n, grad_table, num_embeddings, G):
 
 def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, bias=None, n_bias=0,
             relu=False, mask=None, ldmask=0, Cb=None, ldcb=0, nb=0, Cf=None, ldcf=0, f0=0, nf=0,
-            bits_out=None, bits_in=None, bits_row_mod=0, rowdot_w=None, rowdot_out=None):
-  """C[M,N] = epilogue([A1|A2] @ Bt^T).  Pointers may be views with explicit leading dimensions.
-  rowdot_w [N] bf16 / rowdot_out [M] fp32: a Dense(1) on the bf16 output fused into the store loop (rowdot_out += out . w)."""
+            bits_out=None, bits_in=None, bits_row_mod=0):
+  """C[M,N] = epilogue([A1|A2] @ Bt^T).  Pointers may be views with explicit leading dimensions."""
   _chk(A1, bf16, 'A1')
   _chk(Bt, bf16, 'Bt')
   _chk(A2, bf16, 'A2', allow_none=True)
@@ -306,11 +305,6 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
   a.mask_bits_out, a.ld_bits_out = (bits_out.data_ptr(), bits_out.stride(0)) if bits_out is not None else (None, 0)
   a.mask_bits_in, a.ld_bits_in = (bits_in.data_ptr(), bits_in.stride(0)) if bits_in is not None else (None, 0)
   a.bits_row_mod = bits_row_mod
-  _chk(rowdot_w, bf16, 'rowdot_w', allow_none=True)
-  _chk(rowdot_out, f32, 'rowdot_out', allow_none=True)
-  if rowdot_w is not None:
-    assert rowdot_out is not None and rowdot_w.numel() >= N and rowdot_w.is_contiguous() and rowdot_out.numel() == M
-    a.rowdot_w, a.rowdot_out = rowdot_w.data_ptr(), rowdot_out.data_ptr()
   _e = PROFILE.start()
   L.check(lib().mnr_gemm_nt_bf16(C.byref(a), _stream()))
   PROFILE.stop(_e)

@@ -413,34 +413,6 @@ def test_gemm_tn(ops, M, K, N):
   assert (got[K - 5:] == 0).all() and (got[:, N - 3:] == 0).all()
 
 
-@pytest.mark.parametrize('M,N,K,bits', [(512, 256, 128, True), (1024, 512, 320, False)])
-def test_gemm_nt_row_dot(ops, M, N, K, bits):
-  """mnr_gemm_nt_bf16 with rowdot_w: a Dense(1) on the layer's own bf16 output (models.py:460 on the output of :455-459),
-  rowdot_out[m] += relu(A Bt^T + b)[m, :] . w accumulated in fp32 on top of what the caller put there; the layer's output
-  and mask bits are what they are without it."""
-  gen = torch.Generator().manual_seed(23)
-  A = _bf(torch.randn((M, K), generator=gen))
-  Bt = _bf(torch.randn((N, K), generator=gen) / math.sqrt(K))
-  bias = torch.randn((N,), generator=gen) * 0.1
-  w = _bf(torch.randn((N,), generator=gen) * 0.2)
-  Cb = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
-  Cb0 = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
-  bo = torch.zeros((M, N // 8), dtype=torch.uint8).cuda() if bits else None
-  bo0 = torch.zeros((M, N // 8), dtype=torch.uint8).cuda() if bits else None
-  out = torch.full((M,), 0.75).cuda()
-  ops.gemm_nt(dev(A), dev(Bt), M=M, N=N, K1=K, bias=dev(bias), n_bias=N, relu=True, Cb=Cb, ldcb=N, nb=N, bits_out=bo,
-              rowdot_w=dev(w), rowdot_out=out)
-  ops.gemm_nt(dev(A), dev(Bt), M=M, N=N, K1=K, bias=dev(bias), n_bias=N, relu=True, Cb=Cb0, ldcb=N, nb=N, bits_out=bo0)
-  assert torch.equal(Cb.view(torch.int16), Cb0.view(torch.int16))
-  if bits:
-    assert torch.equal(bo, bo0)
-  want = Cb0.cpu().double() @ w.double() + 0.75
-  np.testing.assert_allclose(out.cpu().double().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
-  assert Cb0.float().abs().max().item() > 0.5
-  with pytest.raises(ValueError, match='rowdot_w'):
-    ops.gemm_nt(dev(A), dev(Bt), M=M, N=N, K1=K, Cb=Cb, ldcb=N, nb=N - 8, rowdot_w=dev(w), rowdot_out=out)
-
-
 @pytest.mark.parametrize('M,K,N,ldb', [(4096, 256, 256, 384), (8192 + 64, 512, 256, 256), (2048, 256, 512, 512)])
 def test_gemm_tn_extra_column(ops, M, K, N, ldb):
   """mnr_gemm_tn_bf16 with `gcol`: one more column of B as an fp32 vector (the density head's gradient next to the

@@ -134,9 +134,6 @@ CASES = [
     # sample counts that are not multiples of 32 (models.py:58-59 takes any): the rays are padded to a multiple of
     # 256 / gcd(n, 256) (here 32) so that every level still fills whole 256-row GEMM tiles; 21 rays -> 11 padded ones
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_prop_samples = 40', 'Model.num_nerf_samples = 24'], 21),
-    # a trunk too wide for the fused chain (512, as 360.gin's 1024): per-layer GEMMs, the density head as a row-dot in the last
-    # trunk layer's store loop (forward) and as a vector column of the bottleneck's weight-gradient GEMM (backward)
-    ('360', ['NerfMLP.net_width = 512', 'PropMLP.net_width = 128'], 16),
 ]
 
 
