@@ -134,6 +134,9 @@ CASES = [
     # sample counts that are not multiples of 32 (models.py:58-59 takes any): the rays are padded to a multiple of
     # 256 / gcd(n, 256) (here 32) so that every level still fills whole 256-row GEMM tiles; 21 rays -> 11 padded ones
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_prop_samples = 40', 'Model.num_nerf_samples = 24'], 21),
+    # a trunk too wide for the fused chain (512, as 360.gin's 1024): per-layer GEMMs on 256x256 tiles, the density head's weight
+    # gradient as a vector column of the bottleneck's dW GEMM (gemm_tn_gcol_kernel)
+    ('360', ['NerfMLP.net_width = 512', 'PropMLP.net_width = 128'], 16),
 ]
 
 
