@@ -9,7 +9,7 @@ import torch
 from multinerf_amd import ops
 
 dev = 'cuda'
-for (M, K, C, what) in ((1 << 20, 256, 1, 'prop density head'), (1 << 19, 128, 3, 'rgb head')):
+for (M, K, C, what) in ((1 << 20, 256, 1, 'prop density head'), (1 << 19, 128, 3, 'rgb head, 128-wide view MLP'), (1 << 19, 256, 3, 'rgb head of 360.gin')):
   H = torch.rand((M, K), device=dev).to(torch.bfloat16)
   g = torch.randn((M, C), device=dev)
   W = torch.randn((K, C), device=dev)
