@@ -43,7 +43,8 @@ def test_the_shipped_mfma_kernels_are_all_there(report):
   assert sum('gemm_tn_kernel' in n for n in names) == 2          # TnBig / TnSmall
   assert sum('mlp_chain_fwd_kernel' in n for n in names) == 2 and sum('mlp_chain_bwd_kernel' in n for n in names) == 2   # W = 128 / 256
   assert sum('mlp_chain_fwd_ipe_kernel' in n for n in names) == 2      # the inference chain with the in-kernel IPE producer
-  assert len(names) == 16, names
+  assert sum('gemm_tn_gcol_kernel' in n for n in names) == 1           # TnBig with one more B column from a vector
+  assert len(names) == 17, names
 
 
 def test_tiled_gemm_k_loops_carry_only_the_hand_counted_vmcnt_waits(report):
@@ -51,7 +52,7 @@ def test_tiled_gemm_k_loops_carry_only_the_hand_counted_vmcnt_waits(report):
   hipcc added: the counted `s_waitcnt vmcnt(N)` of the pipeline are inline asm, the step's barrier sits outside."""
   mod, bodies = report
   for name, body in bodies.items():
-    if 'gemm_nt_kernel' in name or 'gemm_tn_kernel' in name:
+    if 'gemm_nt_kernel' in name or 'gemm_tn_kernel' in name or 'gemm_tn_gcol_kernel' in name:
       span = _mfma_span(body)
       assert sum('v_mfma' in l for l in span) >= 16, name
       assert mod.compiler_vmcnt_waits(span) == [], (name, mod.compiler_vmcnt_waits(span))
