@@ -1163,13 +1163,23 @@ class Model:
       dHB = self._buf(('bwd', 'dHB', nh), (M, nh), bf16, zero=True)   # columns beyond head_cols stay zero
       # (the plain merged head [bottleneck | density] of 360.gin: the density column's weight gradient rides in the bottleneck's
       # dW GEMM as a vector, below; it then also leaves the compositing VJP as the fp32 vector that GEMM reads)
-      head_gcol = (_HEAD_GCOL and not plan.ref and len(plan.head_segs) == 2 and bw % 256 == 0 and W % 256 == 0)
+      # (for trunks of at least 512 columns: at 256 the merged N = 384 GEMM is six small tiles and the extra column buys nothing,
+      # blender_256 1.764 / 1.767 M rays/s merged against 1.749 / 1.764 M, llff_raw 546.0 against 545.9 k)
+      head_gcol = (_HEAD_GCOL and not plan.ref and len(plan.head_segs) == 2 and bw % 256 == 0 and W % 256 == 0 and W >= 512)
       g_den_f32, g_rgb = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], raw_rgb=lv['raw_rgb'],
           density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights,
           g_den_bf16=dHB.view(-1)[bw:], ld_bf16=nh, want_f32=head_gcol, exposure_scale=lv['expo'],
           g_exposure_scale=g_expo if lv['expo'] is not None else None, losses=losses)
       g_raw_rgb = g_rgb.view(M, 3)
+      if head_gcol:
+        # the density column of dHB once more as a contiguous bf16 vector, and the density bias gradient from the strided column
+        # (33 MB of 64-byte sectors): two small launches, issued HERE, before the proposal levels' persistent kernels fill
+        # the CUs from the side stream (behind them a 25-us launch of 512 small workgroups took 0.3-0.6 ms to get its CUs,
+        # with the main stream's next GEMM waiting for it: profiles/r3s3_step_seq_default.md)
+        g_vec = self._buf(('bwd', 'g_den_vec'), (M,), bf16)
+        ops.cast_f32_to_bf16(g_den_f32.view(-1), 1, M, 1, g_vec, 1, 0)
+        ops.colsum(dHB.view(-1)[bw:], M, 1, gslice(plan.density.bias_off, 1), ld=nh)
       if plan.ref:
         # colour combine VJP: -> d raw specular rgb, and the diffuse / tint columns of the head gradient
         g_raw_rgb = ops.ref_color_bwd(mlp['raw_rgb_pre'], mlp['small'], hp.rgb_premultiplier, hp.rgb_bias,
@@ -1252,13 +1262,10 @@ class Model:
       with self._dw():
         if head_gcol:
           # dW_bottleneck += x^T dHB[:, :bw] straight into the flat gradient (256x256 tiles), dw_density += x^T g as one more
-          # column of the same launch, db_density from the strided column (33 MB of 64-byte sectors)
+          # column of the same launch (db_density: above)
           db_, dd_ = plan.bottleneck, plan.density
-          g_vec = self._buf(('bwd', 'g_den_vec'), (M,), bf16)          # the density column of dHB once more, contiguous
-          ops.cast_f32_to_bf16(g_den_f32.view(-1), 1, M, 1, g_vec, 1, 0)
           ops.gemm_tn(x_last, dHB, gslice(db_.kernel_off, W * bw), M=M, K=W, N=bw, lda=W, ldb=nh, ldc=bw,
                       bias_out=gslice(db_.bias_off, bw), bias_n_valid=bw, gcol=g_vec, gcol_out=gslice(dd_.kernel_off, W))
-          ops.colsum(dHB.view(-1)[bw:], M, 1, gslice(dd_.bias_off, 1), ld=nh)
         else:
           tmpW = self._buf(('bwd', 'tmpW', W, nh), (W, nh), f32)
           tmpW.zero_()
