@@ -38,3 +38,10 @@ def test_kernel_level_gpu_tests_pass_on_the_simulator():
   # (the trunk-shaped GEMM cases need a real device: their fp64 references are 2 x 10^11 MACs)
   tail = _child(['tests/test_gpu_kernels.py', 'tests/test_gpu_refnerf.py', 'tests/test_gpu_camera.py', '-k', 'not trunk_shapes'], 1500)
   assert ' passed' in tail and 'failed' not in tail and 'skipped' not in tail, tail
+
+
+def test_in_kernel_ipe_chain_passes_on_the_simulator():
+  """The inference chain with the in-kernel IPE producer (mnr_mlp_chain_fwd_ipe) against mnr_cast_rays_ipe +
+  mnr_mlp_chain_fwd, leaf level and through Model.__call__ (tests/test_gpu_chain.py, ~25 s of simulator time)."""
+  tail = _child(['tests/test_gpu_chain.py', '-k', 'in_kernel_ipe'], 900)
+  assert ' passed' in tail and 'failed' not in tail and 'skipped' not in tail, tail
