@@ -262,9 +262,10 @@ def test_cast_rays_rejects_bad_shape(ops):
                       ray_shape='sphere', warp_contract=False, min_deg=0, max_deg=4, ld_feat=64)
 
 
-def test_viewdir_enc_fill(ops):
+@pytest.mark.parametrize('n', [8, 13, 32])       # (the kernel stores one evaluation into groups of 8 samples: whole, ragged, several)
+def test_viewdir_enc_fill(ops, n):
   gen = torch.Generator().manual_seed(5)
-  B, n = 37, 8
+  B = 37
   v = torch.randn((B, 3), generator=gen)
   v = (v / v.norm(dim=-1, keepdim=True)).float()
   ref = ocoord.pos_enc(v, 0, 4, append_identity=True)
