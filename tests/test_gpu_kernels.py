@@ -262,6 +262,25 @@ def test_cast_rays_rejects_bad_shape(ops):
                       ray_shape='sphere', warp_contract=False, min_deg=0, max_deg=4, ld_feat=64)
 
 
+def test_exposure_scale_bwd(ops):
+  """models.py:257-267's VJP w.r.t. exposure_scaling_offsets: g_offsets[idx[b], c] += ev[b] * g[b, c] for idx[b] > 0; the
+  kernel sums the lanes of a wave that share an index before its atomics (few distinct indices per batch)."""
+  gen = torch.Generator().manual_seed(9)
+  B = 1000 + 37
+  idx = torch.randint(-1, 6, (B,), generator=gen).to(torch.int32)
+  idx[100:164] = 3                                    # a whole wave on one index
+  idx[200:264] = torch.arange(64).to(torch.int32) + 7  # and one with 64 different ones
+  ev = 0.5 + torch.rand((B,), generator=gen)
+  g = torch.randn((B, 3), generator=gen)
+  out = torch.full((100, 3), 0.25).cuda()
+  ops.exposure_scale_bwd(dev(ev), dev(idx), dev(g), out.view(-1), B)
+  want = torch.full((100, 3), 0.25, dtype=torch.float64)
+  for b in range(B):
+    if idx[b] > 0:
+      want[idx[b]] += (ev[b] * g[b]).double()
+  np.testing.assert_allclose(out.cpu().double().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('n', [8, 13, 32])       # (the kernel stores one evaluation into groups of 8 samples: whole, ragged, several)
 def test_viewdir_enc_fill(ops, n):
   gen = torch.Generator().manual_seed(5)
