@@ -258,6 +258,10 @@ typedef NtCfg<8, 1, 1, 8> WresCfg;                  // 256 rows, 8 waves as 1 x 
 #define WRES_CPITCH (256 * 2 + NT_CPAD)
 #define WRES_BIAS_OFF (WRES_A_BYTES + WRES_STAGE_ROWS * WRES_CPITCH)
 #define WRES_LDS_BYTES (WRES_BIAS_OFF + 256 * 4)
+// dX flavour: the tile's ReLU-mask bits ([256 rows][32 bytes] = 8 KiB, contiguous in the bit matrix) ride along with the tile's
+// first activation K-tile as one more 16-byte LDS-DMA piece per thread, two buffers by tile parity
+#define WRES_BITS_OFF WRES_LDS_BYTES
+#define WRES_LDS_BYTES_BITS (WRES_BITS_OFF + 2 * 8192)
 
 template <bool BITS_IN>
 __global__ __launch_bounds__(512) void gemm_nt_wres_kernel(mnr_gemm_nt_args p) {
@@ -305,10 +309,24 @@ __global__ __launch_bounds__(512) void gemm_nt_wres_kernel(mnr_gemm_nt_args p) {
 
   f32x16 acc[8];
   const int64_t steps = my_tiles * nk;
+  // BITS_IN: the mask bits of a tile through LDS: the tile's 256 rows are one contiguous 8-KiB block of the bit matrix
+  // (32 bytes per row, and a row modulus that is a multiple of the tile).  As byte loads in the epilogue they were
+  // vector-memory operations issued BEHIND the next tile's LDS-DMA: vmcnt retires in order, so every epilogue waited for the
+  // next tile's 32 KiB to arrive from HBM before it could mask its first row (the dX layers of blender_refnerf's tangent
+  // network: 3.2 GB per launch at 2.6 TB/s, where the forward flavour of the same kernel streams 6 TB/s).
+  // (nt_wres_eligible sends a dX launch here only then; anything else takes the tiled kernel)
   auto stage = [&](int64_t g) {                           // activation tile of global step g into slot g & 1
     const int64_t tile = blockIdx.x + (g / nk) * gridDim.x;
     const int kt = (int)(g % nk);
     nt_stage_tile<WresCfg, 256>(A, p.lda1, tile * 256, kt * 64, smem + (g & 1) * 32768, wave, lane);
+    if constexpr (BITS_IN) {
+      if (kt == 0) {
+        int64_t brow = tile * 256;
+        if (p.bits_row_mod > 0) brow %= p.bits_row_mod;
+        const uint8_t* src = p.mask_bits_in + brow * 32 + (wave * 64 + lane) * 16;
+        __builtin_amdgcn_global_load_lds(MNR_GLOBAL_PTR(src), MNR_LDS_PTR(smem + WRES_BITS_OFF + ((g / nk) & 1) * 8192 + wave * 1024), 16, 0, 0);
+      }
+    }
   };
   stage(0);
   for (int64_t g = 0; g < steps; ++g) {
@@ -367,16 +385,9 @@ __global__ __launch_bounds__(512) void gemm_nt_wres_kernel(mnr_gemm_nt_args p) {
       const int64_t mfirst = m0 + h * WRES_STAGE_ROWS + row0;
       unsigned mbits[BITS_IN ? ITERS : 1];
       if (BITS_IN) {
-        // row of the bit matrix: m, or m mod bits_row_mod (one 64-bit division per pass, then increments: the pass's
-        // 128 rows wrap at most once because the launcher requires bits_row_mod >= 256 here)
-        const int64_t mod = p.bits_row_mod;
-        int64_t mrow = mod > 0 ? mfirst % mod : mfirst;
+        const uint8_t* bl = (const uint8_t*)smem + WRES_BITS_OFF + ((g / nk) & 1) * 8192 + (h * WRES_STAGE_ROWS + row0) * 32 + ch;
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-          mbits[it] = p.mask_bits_in[mrow * (int64_t)p.ld_bits_in + ch];
-          mrow += 16;
-          if (mod > 0 && mrow >= mod) mrow -= mod;
-        }
+        for (int it = 0; it < ITERS; ++it) mbits[it] = bl[it * 16 * 32];
       }
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
@@ -445,7 +456,8 @@ extern "C" int mnr_gemm_nt_set_wres(int max_wgs) {
 
 static bool nt_wres_eligible(const mnr_gemm_nt_args* a, int fast_epi) {
   return a->N == 256 && a->K2 == 0 && a->K1 <= 256 && a->M % 256 == 0 && !a->mask && !a->Cf && a->Cb && a->nb == a->N && (fast_epi & 1) &&
-         (!a->mask_bits_out || (a->ld_bits_out % 4 == 0)) && (!a->mask_bits_in || ((a->bits_row_mod == 0 || a->bits_row_mod >= 256) && !a->bias && !a->relu && !a->mask_bits_out));
+         (!a->mask_bits_out || (a->ld_bits_out % 4 == 0)) && (!a->mask_bits_in || ((a->bits_row_mod == 0 || a->bits_row_mod % 256 == 0) && a->ld_bits_in == 32 && ((uintptr_t)a->mask_bits_in % 16) == 0 &&
+                               !a->bias && !a->relu && !a->mask_bits_out));
 }
 
 static int nt_wres_launch(const mnr_gemm_nt_args* a, int max_wgs, void* stream) {
@@ -456,9 +468,9 @@ static int nt_wres_launch(const mnr_gemm_nt_args* a, int max_wgs, void* stream) 
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
   if (mnr_attr_needed(&attr_set)) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_wres_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_wres_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_wres_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRES_LDS_BYTES_BITS);
   }
-  if (a->mask_bits_in) hipLaunchKernelGGL(gemm_nt_wres_kernel<true>, dim3(grid), dim3(512), WRES_LDS_BYTES, (hipStream_t)stream, *a);
+  if (a->mask_bits_in) hipLaunchKernelGGL(gemm_nt_wres_kernel<true>, dim3(grid), dim3(512), WRES_LDS_BYTES_BITS, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL(gemm_nt_wres_kernel<false>, dim3(grid), dim3(512), WRES_LDS_BYTES, (hipStream_t)stream, *a);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
