@@ -194,22 +194,27 @@ def main():
   # ---- secondary measurements (reported under "aux", never as `value`)
   aux = {}
   if not args.no_aux and args.preset == '360' and not args.gin_bindings:
-    def timed(fn, warm, reps):
+    def timed(fn, warm, reps, rounds=3):
+      """Seconds per call: `rounds` timed blocks of `reps` calls each (barrier + synchronize on both sides, max over ranks),
+      the MEDIAN block (one 15-ms hiccup in a single block of ten 16-ms steps read as -10 % in round 3)."""
       for _ in range(warm):
         fn()
-      torch.cuda.synchronize()
-      mdist.barrier()
-      t0 = time.perf_counter()
-      for _ in range(reps):
-        fn()
-      torch.cuda.synchronize()
-      mdist.barrier()
-      dt = time.perf_counter() - t0
-      if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-      return dt / reps
+      blocks = []
+      for _ in range(rounds):
+        torch.cuda.synchronize()
+        mdist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+          fn()
+        torch.cuda.synchronize()
+        mdist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+          t = torch.tensor([dt], device=dev, dtype=torch.float64)
+          torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+          dt = float(t.item())
+        blocks.append(dt / reps)
+      return sorted(blocks)[len(blocks) // 2]
     # (i) render: deterministic forward with extras on one 16384-ray chunk per GPU (train_utils.py:377-396)
     rays_only = batch.rays
     dt = timed(lambda: render_eval_pfn(state.params, 1.0, None, rays_only), 2, 5)
