@@ -41,6 +41,7 @@ _USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused
 _FUSED_IPE = _os.environ.get('MNR_FUSED_IPE', '1') != '0'   # A/B switch: rendering builds the proposal levels' IPE features inside the chain kernel
 _HEAD_K64 = _os.environ.get('MNR_HEAD_K64', '1') != '0'    # A/B switch: the merged head's dX GEMM over 320 instead of 384 K columns
 _HEAD_GCOL = _os.environ.get('MNR_HEAD_GCOL', '1') != '0'  # A/B switch: the density head's weight gradient as an extra column of the bottleneck's dW GEMM (N = 256, 256x256 tiles) instead of a merged N = 384 GEMM on 128x128 tiles
+_CONST_CACHE = _os.environ.get('MNR_CONST_CACHE', '1') != '0'  # A/B switch: constant level-loop inputs cached on the device (no per-step host -> device copies)
 # A/B switch: the weight-gradient GEMMs (dW_l = x_{l-1}^T dY_l) on a second HIP stream behind the dX chain.  dW_l and the
 # dX GEMM that turns dY_l into dY_{l-1} are independent, so with one dY buffer per layer (instead of two ping-pong
 # buffers) the dX chain runs ahead and the dW launches fill the CUs each dX launch's tail leaves idle (and the other way
@@ -594,12 +595,25 @@ class Model:
       self._ws[k] = t
     return t
 
+  def _const(self, key, sig, make):
+    """A read-only device tensor kept across calls in ONE slot per `key` and rebuilt when its signature `sig` (the values
+    it was made from) changes: e.g. the initial sample distances under near-plane annealing change every step, and are then
+    simply rebuilt.  Nothing may write into what this returns."""
+    if not _CONST_CACHE:
+      return make()
+    k = ('const', key)
+    hit = self._ws.get(k)
+    if hit is None or hit[0] != sig:
+      hit = (sig, make())
+      self._ws[k] = hit
+    return hit[1]
+
   def workspace_bytes(self):
     """Bytes of the per-level / backward workspace allocated so far (features, activations, masks, gradients: everything
     `_buf` hands out; bench.py reports it).  The fused chain's backward keeps one dY matrix per layer (the weight-gradient
     GEMMs read them after the one dX launch) where the per-layer path ping-pongs two: depth * M * W * 2 bytes per level,
     2 GiB instead of 1 GiB per proposal level of 360.gin at 16384 rays, 8 GiB for the 8 x 256 trunk of llff_raw."""
-    return sum(t.numel() * t.element_size() for t in self._ws.values())
+    return sum(t.numel() * t.element_size() for t in self._ws.values() if torch.is_tensor(t))
 
   def _lvl_buf(self, tag, name, rows, cols, dtype, group=None):
     """A per-level [rows, *cols] buffer.  group = (i, L): rows [i*rows, (i+1)*rows) of ONE buffer the L proposal levels
@@ -684,8 +698,12 @@ class Model:
     init_s_near = 0. if self.near_anneal_rate is None else float(
         np.clip(1 - train_frac / self.near_anneal_rate, 0, self.near_anneal_init))
     init_s_far = 1.
-    sdist = torch.tensor([init_s_near, init_s_far], dtype=f32, device=dev).repeat(Bp, 1)
-    weights = torch.ones((Bp, 1), dtype=f32, device=dev)
+    # Constant inputs of the level loop live on the device across calls (`_const`): built per call they are host -> device
+    # copies from pageable memory, and torch synchronises the stream after each of those, i.e. the host stops running ahead of
+    # the GPU four times per step and every level starts with the GPU waiting for the next launches (A/B switch MNR_CONST_CACHE).
+    sdist = self._const('sdist0', (Bp, init_s_near, init_s_far),
+                        lambda: torch.tensor([init_s_near, init_s_far], dtype=f32, device=dev).repeat(Bp, 1))
+    weights = self._const('weights0', (Bp,), lambda: torch.ones((Bp, 1), dtype=f32, device=dev))
 
     randomized = (rng is not None) or (noise is not None)
     gen = None
@@ -719,7 +737,7 @@ class Model:
       if randomized:
         u_max = eps + (1 - eps) / n
         max_jitter = (1 - u_max) / (n - 1) - eps
-        u_base = torch.linspace(0, 1 - u_max, n, dtype=f32).to(dev)
+        u_base = self._const(('u_rand', i_level), (n, u_max), lambda: torch.linspace(0, 1 - u_max, n, dtype=f32).to(dev))
         d = 1 if self.single_jitter else n
         if noise is not None:
           jitter = noise['u_jitter'][i_level].to(dev).reshape(-1, d)
@@ -730,7 +748,7 @@ class Model:
           jitter = torch.rand((Bp, d), generator=gen, device=dev, dtype=f32)
       else:
         pad = 1 / (2 * n)
-        u_base = torch.linspace(pad, 1. - pad - eps, n, dtype=f32).to(dev)
+        u_base = self._const(('u_det', i_level), (n, pad, eps), lambda: torch.linspace(pad, 1. - pad - eps, n, dtype=f32).to(dev))
       sdist, tdist = ops.resample_level(
           sdist, weights, u_base, jitter, near, far, n_samples=n, use_dilation=use_dilation, dilation=dilation,
           domain=(init_s_near, init_s_far), anneal=anneal, resample_padding=self.resample_padding,
