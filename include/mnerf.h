@@ -193,7 +193,22 @@ typedef struct {
   const uint8_t* mask_bits_in; int ld_bits_in;
   int64_t bits_row_mod;               /* > 0: row m reads the bits of row m % bits_row_mod (tangent rows
                                          c*M + s share the primal mask of sample s) */
+  /* Storage of the activation operand A1 and of the bf16 result (MNR_LAYOUT_*).  MNR_LAYOUT_PANEL is the layout the
+   * 1024-wide trunk's activations and gradients live in between this library's own GEMMs (every producer and consumer
+   * of such a matrix is a kernel of this file; the reference's per-layer tensors models.py:441-465 never leave it):
+   * element (m, n) of an [M, W] matrix sits at ((m / 32) * (W / 16) + n / 16) * 512 + (m % 32) * 16 + n % 16, i.e.
+   * 1-KiB blocks of 32 rows x 16 columns, which an MFMA wave writes straight from its accumulators as whole blocks
+   * (no transposition through LDS) and which the next GEMM's LDS-DMA reads in 512-byte runs.  M %% 256 == 0, W %% 256 == 0.
+   * With c_layout = PANEL the 1-bit ReLU masks are in TILE order: 8 KiB per 256 x 256 output tile (tile index
+   * m_tile * (N / 256) + n_tile), thread t of the tile's 512 owns 16 bytes; byte (j * 4 + i) * 2 + h of thread
+   * t = (wm * 4 + wn) * 64 + kh * 32 + r covers row wm * 128 + i * 32 + r, columns wn * 64 + j * 32 + h * 16 + kh * 8 .. + 7
+   * of the tile (bit e = column + e); written by the forward layer, read by the dX layer of the same tile shape
+   * (ld_bits_* are ignored).  Restrictions of c_layout = PANEL: K1 + K2 >= 192, no fp32 side output, no bf16 mask,
+   * nb == N, forward layers carry a full bias (n_bias == N), bits_row_mod == 0; A2 and Bt are always row-major. */
+  int a1_layout; int c_layout;
 } mnr_gemm_nt_args;
+#define MNR_LAYOUT_ROWMAJOR 0
+#define MNR_LAYOUT_PANEL 1
 
 /* C[M,N] = epilogue([A1|A2] * Bt^T). */
 int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* args, void* stream);
@@ -213,6 +228,9 @@ int mnr_gemm_nt_set_nt_stores(int on);
  * output, no bf16 mask) go to the weights-resident persistent kernel (weights in registers, one workgroup per CU walking
  * the M tiles); n > 1 = the same with at most n workgroups; 0 = off. */
 int mnr_gemm_nt_set_wres(int max_wgs);
+/* Test hook of the panel-result kernel (c_layout = MNR_LAYOUT_PANEL, csrc/gemm_blk.hip): at most n persistent workgroups
+ * (every workgroup then walks several tiles at small sizes); 0 (default) = one per CU. */
+int mnr_gemm_nt_panel_set_max_wgs(int n);
 
 /* ---- Fused Dense chain (csrc/fused_mlp.hip): the trunk of internal/models.py:441-465 (Dense + ReLU layers, optionally
  * one skip concat of the input features, :458-459) and, for a density-only MLP, its Dense(1) head (:460) as ONE
@@ -291,6 +309,8 @@ typedef struct {
                                           of the merged NeRF head (models.py:460 next to :527): its gradient column rides in
                                           the bottleneck's weight-gradient GEMM as one extra MFMA per k-step instead of
                                           widening N from 256 to 384 */
+  int a_layout, b_layout;              /* MNR_LAYOUT_* of A and B (PANEL: lda == K resp. ldb == N of the whole matrix, K and N
+                                          multiples of 256; the 256 x 256 output tile only) */
 } mnr_gemm_tn_args;
 
 /* Weight gradient: C += A^T B (fp32 atomics; C must be initialised by the caller). */

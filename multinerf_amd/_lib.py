@@ -64,7 +64,7 @@ class GemmNTArgs(C.Structure):
               ('Cf', vp), ('ldcf', C.c_int), ('f0', C.c_int), ('nf', C.c_int),
               ('mask_bits_out', vp), ('ld_bits_out', C.c_int),
               ('mask_bits_in', vp), ('ld_bits_in', C.c_int),
-              ('bits_row_mod', C.c_int64)]
+              ('bits_row_mod', C.c_int64), ('a1_layout', C.c_int), ('c_layout', C.c_int)]
 
 
 class GemmTNArgs(C.Structure):
@@ -72,7 +72,8 @@ class GemmTNArgs(C.Structure):
               ('B', vp), ('ldb', C.c_int), ('N', C.c_int),
               ('M', C.c_int64), ('C', vp), ('ldc', C.c_int),
               ('k_valid', C.c_int), ('n_valid', C.c_int),
-              ('bias_out', vp), ('bias_n_valid', C.c_int), ('gcol', vp), ('gcol_out', vp)]
+              ('bias_out', vp), ('bias_n_valid', C.c_int), ('gcol', vp), ('gcol_out', vp),
+              ('a_layout', C.c_int), ('b_layout', C.c_int)]
 
 
 CHAIN_MAX_DEPTH = 8
@@ -159,6 +160,7 @@ _PROTOS = {
     'mnr_level_bwd_set_quad': ([i32], i32),
     'mnr_gemm_nt_set_pipelined': ([i32], i32),
     'mnr_gemm_nt_set_wres': ([i32], i32),
+    'mnr_gemm_nt_panel_set_max_wgs': ([i32], i32),
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
     'mnr_mlp_chain_fwd': ([C.POINTER(MlpChainFwdArgs), vp], i32),
     'mnr_mlp_chain_bwd': ([C.POINTER(MlpChainBwdArgs), vp], i32),

@@ -16,7 +16,7 @@ void mnr_set_error(const char* fmt, ...) {
 
 extern "C" const char* mnr_last_error(void) { return g_err; }
 
-extern "C" int mnr_abi_version(void) { return 13; }
+extern "C" int mnr_abi_version(void) { return 14; }
 
 int g_mnr_cu_budget = 0;
 

@@ -125,6 +125,36 @@ __device__ __forceinline__ unsigned mnr_relu_mask_byte(unsigned w0, unsigned w1,
   return ((t >> 15) & 0xaau) | (t & 0x55u);
 }
 
+// ---- helpers of the hand-pipelined GEMM loops (gemm.hip, gemm_blk.hip) ----
+__device__ __forceinline__ void nt_wait_lgkmcnt0() { MNR_GPU_ONLY(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")); }
+
+// A value the optimiser cannot see through: address arithmetic derived from it is recomputed where it is used instead of
+// being hoisted out of the tile loop and kept (or spilled) across it.
+__device__ __forceinline__ int mnr_opaque(int v) {
+  MNR_GPU_ONLY(asm volatile("" : "+v"(v)));
+  return v;
+}
+
+// lane index 0..63 from the exec-mask prefix count over an opaque zero (not derived from threadIdx.x, not hoistable)
+__device__ __forceinline__ int mnr_lane_id() {
+#ifdef MNR_HIPSIM
+  return (int)threadIdx.x & 63;
+#else
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)mnr_opaque(0)));
+#endif
+}
+__device__ __forceinline__ int mnr_opaque_s(int v) {
+  MNR_GPU_ONLY(asm volatile("" : "+s"(v)));
+  return v;
+}
+__device__ __forceinline__ void nt_launder(bf16x8& f) { MNR_GPU_ONLY(asm volatile("" : "+v"(f))); }
+
+template <int N>
+__device__ __forceinline__ void nt_wait_vmcnt() {
+  MNR_GPU_ONLY(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"));
+  MNR_SIM_HOOK(hipsim::wait_vmcnt(N));
+}
+
 __device__ __forceinline__ float mnr_softplus(float x) {
   // jax.nn.softplus = logaddexp(x, 0) = max(x,0) + log1p(exp(-|x|)).
   return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));

@@ -120,36 +120,6 @@ __device__ __forceinline__ bf16x8 nt_read_frag(const char* lds_tile, int row, in
   return *(const bf16x8*)(lds_tile + off);
 }
 
-__device__ __forceinline__ void nt_wait_lgkmcnt0() { MNR_GPU_ONLY(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")); }
-
-// A value the optimiser cannot see through: address arithmetic derived from it is recomputed where it is used instead of
-// being hoisted out of the tile loop and kept (or spilled) across it.
-__device__ __forceinline__ int mnr_opaque(int v) {
-  MNR_GPU_ONLY(asm volatile("" : "+v"(v)));
-  return v;
-}
-
-// lane index 0..63 from the exec-mask prefix count over an opaque zero (not derived from threadIdx.x, not hoistable)
-__device__ __forceinline__ int mnr_lane_id() {
-#ifdef MNR_HIPSIM
-  return (int)threadIdx.x & 63;
-#else
-  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)mnr_opaque(0)));
-#endif
-}
-__device__ __forceinline__ int mnr_opaque_s(int v) {
-  MNR_GPU_ONLY(asm volatile("" : "+s"(v)));
-  return v;
-}
-__device__ __forceinline__ void nt_launder(bf16x8& f) { MNR_GPU_ONLY(asm volatile("" : "+v"(f))); }
-
-template <int N>
-__device__ __forceinline__ void nt_wait_vmcnt() {
-  MNR_GPU_ONLY(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"));
-  MNR_SIM_HOOK(hipsim::wait_vmcnt(N));
-}
-
-
 // Profiling hook (tools/step_timeline.py): when set, wave 0 of every workgroup records s_memtime at
 // kernel entry, K-loop start, K-loop end and kernel exit into g_nt_timeline[16 * blockIdx.x + 0..3], s_memrealtime
 // (100 MHz) at entry / exit into [4], [5], XCC_ID << 32 | HW_ID into [6]; epilogue pass h: staged [8+2h], stored [9+2h].
@@ -166,7 +136,7 @@ extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
   return MNR_OK;
 }
 
-template <class CFG, bool BITS_IN>
+template <class CFG, bool BITS_IN, bool A1_PANEL = false>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
   // the wave index lives in an SGPR across the tile loop and the lane index is re-derived per tile (mbcnt): with
   // threadIdx.x itself kept alive across the loop, hipcc spills it and reloads it (behind a vmcnt(0)) at every tile
@@ -200,7 +170,7 @@ extern "C" int mnr_gemm_nt_set_persistent(int wgs_per_cu) {
   return MNR_OK;
 }
 
-template <class CFG>
+template <class CFG, bool A1_PANEL = false>
 static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   MNR_CHECK_ARG(a->M % CFG::BM == 0 && a->N % CFG::BN == 0, "mnr_gemm_nt_bf16: M=%lld / N=%d not multiples of the %dx%d tile",
                 (long long)a->M, a->N, CFG::BM, CFG::BN);
@@ -219,6 +189,14 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
     if (grid > cap && cap >= 8) grid = cap / 8 * 8;
   }
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if constexpr (A1_PANEL) {
+    if (mnr_attr_needed(&attr_set))
+      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    hipLaunchKernelGGL((gemm_nt_kernel<CFG, false, true>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
+                       (hipStream_t)stream, *a, fast_epi, (long long)vtotal);
+    MNR_CHECK_LAUNCH();
+    return MNR_OK;
+  }
   if (mnr_attr_needed(&attr_set)) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
@@ -476,8 +454,13 @@ static int nt_wres_launch(const mnr_gemm_nt_args* a, int max_wgs, void* stream) 
   return MNR_OK;
 }
 
+int mnr_gemm_nt_panel_launch(const mnr_gemm_nt_args* a, void* stream);      // gemm_blk.hip
+
 extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   MNR_CHECK_ARG(a != nullptr, "mnr_gemm_nt_bf16: null args");
+  MNR_CHECK_ARG((a->a1_layout == MNR_LAYOUT_ROWMAJOR || a->a1_layout == MNR_LAYOUT_PANEL) &&
+                    (a->c_layout == MNR_LAYOUT_ROWMAJOR || a->c_layout == MNR_LAYOUT_PANEL),
+                "mnr_gemm_nt_bf16: unknown layout %d / %d", a->a1_layout, a->c_layout);
   MNR_CHECK_ARG(a->M > 0 && a->M % 128 == 0, "mnr_gemm_nt_bf16: M=%lld must be a positive multiple of 128", (long long)a->M);
   MNR_CHECK_ARG(a->N > 0 && a->N % 128 == 0, "mnr_gemm_nt_bf16: N=%d must be a positive multiple of 128", a->N);
   MNR_CHECK_ARG(a->K1 > 0 && a->K1 % 64 == 0 && a->K2 >= 0 && a->K2 % 64 == 0,
@@ -492,13 +475,21 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   MNR_CHECK_ARG(!a->bias || a->n_bias >= 1, "mnr_gemm_nt_bf16: bias needs n_bias >= 1");
   MNR_CHECK_ARG(!a->mask_bits_in || (!a->bias && !a->relu), "mnr_gemm_nt_bf16: mask_bits_in (a dX layer) takes no bias and no ReLU");
   MNR_CHECK_ARG(!a->mask_bits_in || a->bits_row_mod == 0 || a->bits_row_mod >= 256, "mnr_gemm_nt_bf16: bits_row_mod must be 0 or >= 256");
-  MNR_CHECK_ARG(!a->mask_bits_out || (a->Cb && a->nb == a->N && a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0 &&
-                                      a->ld_bits_out % 4 == 0 && ((uintptr_t)a->mask_bits_out % 4) == 0),
+  MNR_CHECK_ARG(!a->mask_bits_out || a->c_layout == MNR_LAYOUT_PANEL ||
+                    (a->Cb && a->nb == a->N && a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0 &&
+                     a->ld_bits_out % 4 == 0 && ((uintptr_t)a->mask_bits_out % 4) == 0),
                 "mnr_gemm_nt_bf16: mask_bits_out needs a full-width, 16-byte-aligned bf16 output and a 4-byte-aligned bit matrix");
   // 16-byte row segments in the epilogue need 8-element-aligned output / mask pitches and bases.
   const int fast_epi = (int)((!a->Cb || (a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0)) &&
                              (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0))) |
                        (g_nt_nt_stores ? 2 : 0);     // bit 1: streaming stores of the bf16 output tile (A/B switch)
+  if (a->c_layout == MNR_LAYOUT_PANEL) return mnr_gemm_nt_panel_launch(a, stream);
+  if (a->a1_layout == MNR_LAYOUT_PANEL) {
+    // a panel-layout activation into a row-major result (the merged head behind the trunk): the pipelined tiled kernel
+    MNR_CHECK_ARG(a->M % 256 == 0 && a->N % 256 == 0 && a->lda1 == a->K1 && a->K1 % 32 == 0 && !a->mask_bits_in,
+                  "mnr_gemm_nt_bf16: a panel-layout A1 needs M, N multiples of 256, lda1 == K1 and a forward epilogue");
+    return nt_launch<NtBigP, true>(a, fast_epi, stream);
+  }
   if (g_nt_wres > 0 && nt_wres_eligible(a, fast_epi)) return nt_wres_launch(a, g_nt_wres, stream);
 #ifdef MNR_NT_DEBUG_VARIANTS      // probe build (tools/nt_pipe_probe.py): the pipelined loop with one ingredient removed
   if (a->M % 256 == 0 && a->N % 256 == 0) {
@@ -555,7 +546,7 @@ static inline int mnr_gcd(int a, int b) {
   return a;
 }
 
-template <class CFG>
+template <class CFG, bool A_PANEL = false, bool B_PANEL = false>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
   constexpr bool GCOL = false;
 #include "gemm_tn_body.inc"
@@ -563,13 +554,13 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
 
 // The same with one more column of B supplied as an fp32 vector (mnr_gemm_tn_args.gcol): a kernel of its own, so that the
 // weight-gradient GEMMs without it keep their registers and schedule.
-template <class CFG>
+template <class CFG, bool A_PANEL = false, bool B_PANEL = false>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_gcol_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
   constexpr bool GCOL = true;
 #include "gemm_tn_body.inc"
 }
 
-template <class CFG, bool G = false>
+template <class CFG, bool G = false, bool AP = false, bool BP = false>
 static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   const int tiles = (a->K / CFG::BKO) * (a->N / CFG::BNO);
   const int total_steps = (int)(a->M / TN_BM);
@@ -598,16 +589,19 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   while (splits > unit && (total_steps + splits - 1) / splits < min_steps) splits -= unit;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   const int64_t grid = (int64_t)splits * tiles;
+  // LDS: a panel operand's stage image carries 128 bytes of padding per 1-KiB block (gemm_tn_body.inc)
+  constexpr int lds = CFG::STAGES * ((AP ? (CFG::BKO / 16) * 1152 : CFG::A_BYTES) + (BP ? (CFG::BNO / 16) * 1152 : CFG::B_BYTES));
+  static_assert(lds <= 160 * 1024, "LDS");
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
   if (mnr_attr_needed(&attr_set)) {
-    if constexpr (G) (void)hipFuncSetAttribute((const void*)gemm_tn_gcol_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
-    else (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
+    if constexpr (G) (void)hipFuncSetAttribute((const void*)gemm_tn_gcol_kernel<CFG, AP, BP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<CFG, AP, BP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   if constexpr (G)
-    hipLaunchKernelGGL(gemm_tn_gcol_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
+    hipLaunchKernelGGL((gemm_tn_gcol_kernel<CFG, AP, BP>), dim3((unsigned)grid), dim3(CFG::THREADS), lds, (hipStream_t)stream,
                        *a, splits, steps_per_split);
   else
-    hipLaunchKernelGGL(gemm_tn_kernel<CFG>, dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, (hipStream_t)stream,
+    hipLaunchKernelGGL((gemm_tn_kernel<CFG, AP, BP>), dim3((unsigned)grid), dim3(CFG::THREADS), lds, (hipStream_t)stream,
                        *a, splits, steps_per_split);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
@@ -639,6 +633,21 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
   }
   MNR_CHECK_ARG(!a->gcol || (a->gcol_out && a->K % 256 == 0 && a->N % 256 == 0 && ((uintptr_t)a->gcol % 32) == 0),
                 "mnr_gemm_tn_bf16: gcol needs gcol_out, K and N multiples of 256 and a 32-byte-aligned vector");
+  const bool ap = a->a_layout == MNR_LAYOUT_PANEL, bp = a->b_layout == MNR_LAYOUT_PANEL;
+  MNR_CHECK_ARG((ap || a->a_layout == MNR_LAYOUT_ROWMAJOR) && (bp || a->b_layout == MNR_LAYOUT_ROWMAJOR), "mnr_gemm_tn_bf16: unknown layout");
+  if (ap || bp) {
+    // panel operands: the 256 x 256 tile only (the 1024-wide trunk's weight gradients)
+    MNR_CHECK_ARG(a->K % 256 == 0 && a->N % 256 == 0 && (!ap || a->lda % 16 == 0) && (!bp || a->ldb % 16 == 0) &&
+                      ((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->B % 16) == 0,
+                  "mnr_gemm_tn_bf16: panel operands need K, N multiples of 256, leading dimensions multiples of 16, 16-byte-aligned bases");
+    if (a->gcol) {
+      MNR_CHECK_ARG(ap && !bp, "mnr_gemm_tn_bf16: the extra column goes with a panel A and a row-major B");
+      return tn_launch<TnBig, true, true, false>(a, tn_target, stream);
+    }
+    if (ap && bp) return tn_launch<TnBig, false, true, true>(a, tn_target, stream);
+    if (bp) return tn_launch<TnBig, false, false, true>(a, tn_target, stream);
+    return tn_launch<TnBig, false, true, false>(a, tn_target, stream);
+  }
   if (a->gcol) return tn_launch<TnBig, true>(a, tn_target, stream);
   if (big) return tn_launch<TnBig>(a, tn_target, stream);
   static int tn_small_target = -1;

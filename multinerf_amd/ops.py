@@ -280,10 +280,46 @@ def glo_bwd(g_a, g_b, cam_idx, B, n, grad_table, num_embeddings, G):
   L.check(lib().mnr_glo_bwd(B, n, G, _ptr(g_a), _ptr(g_b), _ptr(cam_idx), num_embeddings, _ptr(grad_table), _stream()))
 
 
+LAYOUT_ROWMAJOR, LAYOUT_PANEL = 0, 1      # include/mnerf.h MNR_LAYOUT_*
+
+
+def to_panel(x):
+  """Row-major [M, W] -> the same storage in MNR_LAYOUT_PANEL (include/mnerf.h): 1-KiB blocks of 32 rows x 16 columns,
+  element (m, n) at ((m // 32) * (W // 16) + n // 16) * 512 + (m % 32) * 16 + n % 16.  Layout conversions are for tests and
+  tools: on the product path every producer and consumer of a panel matrix is one of the library's own GEMMs."""
+  M, W = x.shape
+  assert M % 32 == 0 and W % 16 == 0
+  return x.reshape(M // 32, 32, W // 16, 16).permute(0, 2, 1, 3).contiguous().view(M, W)
+
+
+def from_panel(x):
+  """Inverse of `to_panel`."""
+  M, W = x.shape
+  assert M % 32 == 0 and W % 16 == 0
+  return x.reshape(M // 32, W // 16, 32, 16).permute(0, 2, 1, 3).contiguous().view(M, W)
+
+
+def bits_to_tile_order(bits, N):
+  """Row-major 1-bit masks [M, N/8] (bit n & 7 of byte [m, n // 8]) -> the TILE order of a panel-result GEMM (include/mnerf.h:
+  8 KiB per 256 x 256 tile, 16 bytes per thread); returns a flat uint8 tensor of M * N / 8 bytes.  Tests / tools only."""
+  M = bits.shape[0]
+  assert M % 256 == 0 and N % 256 == 0 and bits.shape[1] == N // 8
+  # row = (mt, wm, i, r), byte column = (nt, wn, j, h, kh)   ->   (mt, nt, wm, wn, kh, r, j, i, h)
+  v = bits.reshape(M // 256, 2, 4, 32, N // 256, 4, 2, 2, 2)
+  return v.permute(0, 4, 1, 5, 8, 3, 6, 2, 7).contiguous().view(-1)
+
+
+def bits_from_tile_order(tile_bits, M, N):
+  """Inverse of `bits_to_tile_order`: -> [M, N/8]."""
+  v = tile_bits.reshape(M // 256, N // 256, 2, 4, 2, 32, 2, 4, 2)      # (mt, nt, wm, wn, kh, r, j, i, h)
+  return v.permute(0, 2, 7, 5, 1, 3, 6, 8, 4).contiguous().view(M, N // 8)
+
+
 def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, bias=None, n_bias=0,
             relu=False, mask=None, ldmask=0, Cb=None, ldcb=0, nb=0, Cf=None, ldcf=0, f0=0, nf=0,
-            bits_out=None, bits_in=None, bits_row_mod=0):
-  """C[M,N] = epilogue([A1|A2] @ Bt^T).  Pointers may be views with explicit leading dimensions."""
+            bits_out=None, bits_in=None, bits_row_mod=0, a1_layout=LAYOUT_ROWMAJOR, c_layout=LAYOUT_ROWMAJOR):
+  """C[M,N] = epilogue([A1|A2] @ Bt^T).  Pointers may be views with explicit leading dimensions.  a1_layout / c_layout:
+  LAYOUT_PANEL for the wide trunk's activations and gradients (include/mnerf.h; the bits are then in tile order)."""
   _chk(A1, bf16, 'A1')
   _chk(Bt, bf16, 'Bt')
   _chk(A2, bf16, 'A2', allow_none=True)
@@ -305,13 +341,14 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
   a.mask_bits_out, a.ld_bits_out = (bits_out.data_ptr(), bits_out.stride(0)) if bits_out is not None else (None, 0)
   a.mask_bits_in, a.ld_bits_in = (bits_in.data_ptr(), bits_in.stride(0)) if bits_in is not None else (None, 0)
   a.bits_row_mod = bits_row_mod
+  a.a1_layout, a.c_layout = a1_layout, c_layout
   _e = PROFILE.start()
   L.check(lib().mnr_gemm_nt_bf16(C.byref(a), _stream()))
   PROFILE.stop(_e)
 
 
 def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, n_valid=None, bias_out=None,
-            bias_n_valid=0, gcol=None, gcol_out=None):
+            bias_n_valid=0, gcol=None, gcol_out=None, a_layout=LAYOUT_ROWMAJOR, b_layout=LAYOUT_ROWMAJOR):
   """Cout[k,n] += sum_m A[m,k] B[m,n]; optionally bias_out[n] += sum_m B[m,n] (fused bias gradient) and
   gcol_out[k] += sum_m A[m,k] gcol[m] (one more column of B given as a contiguous bf16 vector [M])."""
   _chk(bias_out, f32, 'bias_out', allow_none=True)
@@ -332,6 +369,7 @@ def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, 
   a.bias_n_valid = bias_n_valid
   a.gcol = gcol.data_ptr() if gcol is not None else None
   a.gcol_out = gcol_out.data_ptr() if gcol_out is not None else None
+  a.a_layout, a.b_layout = a_layout, b_layout
   _e = PROFILE.start()
   L.check(lib().mnr_gemm_tn_bf16(C.byref(a), _stream()))
   PROFILE.stop(_e)

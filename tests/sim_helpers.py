@@ -46,11 +46,13 @@ def ptr(t):
 
 
 def sim_gemm_nt(lib, A1, Bt, A2=None, bias=None, relu=False, mask=None, out_bf16=True, out_f32=None, bits_out=False,
-                bits_in=None, bits_row_mod=0, nb=None):
-  """C = epi([A1|A2] Bt^T) through the simulated mnr_gemm_nt_bf16; returns (Cb, Cf, bits)."""
+                bits_in=None, bits_row_mod=0, nb=None, a1_layout=0, c_layout=0):
+  """C = epi([A1|A2] Bt^T) through the simulated mnr_gemm_nt_bf16; returns (Cb, Cf, bits).  a1_layout / c_layout = 1: A1 is
+  given / Cb and the bits come back in MNR_LAYOUT_PANEL storage (the bits in tile order, flat)."""
   M, K1 = A1.shape
   N = Bt.shape[0]
   a = L.GemmNTArgs()
+  a.a1_layout, a.c_layout = a1_layout, c_layout
   a.A1, a.lda1, a.K1 = ptr(A1), A1.stride(0), K1
   if A2 is not None:
     a.A2, a.lda2, a.K2 = ptr(A2), A2.stride(0), A2.shape[1]
@@ -73,16 +75,20 @@ def sim_gemm_nt(lib, A1, Bt, A2=None, bias=None, relu=False, mask=None, out_bf16
     bits = torch.zeros((M, N // 8), dtype=torch.uint8)
     a.mask_bits_out, a.ld_bits_out = ptr(bits), bits.stride(0)
   if bits_in is not None:
-    a.mask_bits_in, a.ld_bits_in, a.bits_row_mod = ptr(bits_in), bits_in.stride(0), bits_row_mod
+    a.mask_bits_in, a.ld_bits_in, a.bits_row_mod = ptr(bits_in), (bits_in.stride(0) if bits_in.dim() == 2 else 0), bits_row_mod
   sim_check(lib, lib.mnr_gemm_nt_bf16(C.byref(a), None))
   return Cb, Cf, bits
 
 
-def sim_gemm_tn(lib, A, B, C_acc, bias_out=None, k_valid=None, n_valid=None):
-  """C_acc[K,N] += A^T B (and bias_out += column sums of B) through the simulated mnr_gemm_tn_bf16."""
+def sim_gemm_tn(lib, A, B, C_acc, bias_out=None, k_valid=None, n_valid=None, a_layout=0, b_layout=0, gcol=None, gcol_out=None):
+  """C_acc[K,N] += A^T B (and bias_out += column sums of B) through the simulated mnr_gemm_tn_bf16.  a_layout / b_layout = 1:
+  the operand is given in MNR_LAYOUT_PANEL storage; gcol [M] bf16 / gcol_out [K] fp32: the extra column of B."""
   M, K = A.shape
   N = B.shape[1]
   a = L.GemmTNArgs()
+  a.a_layout, a.b_layout = a_layout, b_layout
+  if gcol is not None:
+    a.gcol, a.gcol_out = ptr(gcol), ptr(gcol_out)
   a.A, a.lda, a.K = ptr(A), A.stride(0), K
   a.B, a.ldb, a.N = ptr(B), B.stride(0), N
   a.M, a.C, a.ldc = M, ptr(C_acc), C_acc.stride(0)

@@ -239,3 +239,91 @@ def test_simulator_flags_lds_overflow_and_bad_arguments(sim):
   sim.hipsim_reset(0, 0)
   with pytest.raises(RuntimeError, match='multiple of 128'):
     S.sim_gemm_nt(sim, A, Bt)
+
+
+# ---- panel layout (include/mnerf.h MNR_LAYOUT_PANEL): csrc/gemm_blk.hip and the panel operands of the tiled kernels ----
+
+from multinerf_amd import ops as _ops  # noqa: E402  (layout helpers only: pure torch)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('a1_panel', [0, 1])
+def test_nt_panel_kernel_forward_and_dx(sim, a1_panel, mode):
+  """gemm_nt_panel_kernel: one LDS-DMA pipeline across the tiles a persistent workgroup walks, the epilogue of tile t
+  interleaved with the first k-step of tile t + 1, results / masks in panel / tile order: BITWISE the tiled kernel's result after
+  un-blocking (forward with a skip segment, bias, ReLU, masks; dX with the masks it wrote), with LDS-DMA landing late / early and
+  different wave orders, 8 and 16 workgroups over 12 tiles (walks of one and two tiles, padded M-tile slots)."""
+  g = torch.Generator().manual_seed(3)
+  M, N, K1, K2 = 768, 512, 192, 64
+  A1 = torch.randn((M, K1), generator=g).bfloat16()
+  A2 = torch.randn((M, K2), generator=g).bfloat16()
+  Bt = (torch.randn((N, K1 + K2), generator=g) * 0.1).bfloat16()
+  bias = torch.randn(N, generator=g)
+  dY = torch.randn((M, 256), generator=g).bfloat16()
+  Wt = (torch.randn((N, 256), generator=g) * 0.1).bfloat16()
+  sim.mnr_gemm_nt_set_wres(0)
+  try:
+    sim.hipsim_reset(*mode)
+    C0, _, b0 = S.sim_gemm_nt(sim, A1, Bt, A2=A2, bias=bias, relu=True, bits_out=True)
+    sim.hipsim_reset(*mode)
+    D0, _, _ = S.sim_gemm_nt(sim, dY, Wt, bits_in=b0)
+    for wgs in (8, 16):
+      sim.mnr_gemm_nt_panel_set_max_wgs(wgs)
+      sim.hipsim_reset(*mode)
+      Cp, _, bp = S.sim_gemm_nt(sim, _ops.to_panel(A1) if a1_panel else A1, Bt, A2=A2, bias=bias, relu=True, bits_out=True,
+                                a1_layout=a1_panel, c_layout=1)
+      assert torch.equal(_ops.from_panel(Cp).view(torch.int16), C0.view(torch.int16))
+      assert torch.equal(_ops.bits_from_tile_order(bp.view(-1), M, N), b0)
+      sim.hipsim_reset(*mode)
+      Dp, _, _ = S.sim_gemm_nt(sim, _ops.to_panel(dY) if a1_panel else dY, Wt, bits_in=bp.view(-1), a1_layout=a1_panel, c_layout=1)
+      assert torch.equal(_ops.from_panel(Dp).view(torch.int16), D0.view(torch.int16))
+  finally:
+    sim.mnr_gemm_nt_panel_set_max_wgs(0)
+    sim.mnr_gemm_nt_set_wres(1)
+  ref = torch.relu(torch.cat([A1, A2], 1).float() @ Bt.float().T + bias)
+  np.testing.assert_allclose(C0.float().numpy(), ref.numpy(), atol=3e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize('mode', [MODES[1], MODES[3]])
+def test_nt_tiled_kernel_reads_a_panel_activation(sim, mode):
+  """The merged head behind a panel-layout trunk: the pipelined tiled kernel with A1 in panel storage, row-major bf16 result
+  narrower than N plus an fp32 side column: bitwise the row-major call."""
+  g = torch.Generator().manual_seed(4)
+  M, N, K = 512, 512, 256
+  X = torch.randn((M, K), generator=g).bfloat16()
+  Bt = (torch.randn((N, K), generator=g) * 0.1).bfloat16()
+  bias = torch.randn(257, generator=g)
+  sim.hipsim_reset(*mode)
+  C0, F0, _ = S.sim_gemm_nt(sim, X, Bt, bias=bias, nb=256, out_f32=(256, 1))
+  sim.hipsim_reset(*mode)
+  C1, F1, _ = S.sim_gemm_nt(sim, _ops.to_panel(X), Bt, bias=bias, nb=256, out_f32=(256, 1), a1_layout=1)
+  assert torch.equal(C0.view(torch.int16), C1.view(torch.int16)) and torch.equal(F0, F1)
+
+
+@pytest.mark.parametrize('mode', [MODES[1], MODES[2]])
+@pytest.mark.parametrize('ap,bp', [(1, 1), (0, 1), (1, 0)])
+def test_tn_panel_operands(sim, ap, bp, mode):
+  """Weight gradients from panel-layout activations / gradients (gemm_tn_body.inc A_PANEL / B_PANEL: a 32-row stage of a panel
+  operand is 16 consecutive 1-KiB blocks, padded by 128 bytes per block in LDS): the row-major call's sums, the bias gradient,
+  and with (panel A, row-major B) the extra vector column of the merged head."""
+  g = torch.Generator().manual_seed(6)
+  M, K, N = 512, 512, 256
+  A = torch.randn((M, K), generator=g).bfloat16()
+  B = torch.randn((M, N), generator=g).bfloat16()
+  gcol = torch.randn((M,), generator=g).bfloat16() if (ap and not bp) else None
+  C0 = torch.zeros((K, N))
+  C1 = torch.zeros((K, N))
+  db0, db1 = torch.zeros(N), torch.zeros(N)
+  g0, g1 = (torch.zeros(K), torch.zeros(K)) if gcol is not None else (None, None)
+  sim.hipsim_reset(*mode)
+  S.sim_gemm_tn(sim, A, B, C0, bias_out=db0, gcol=gcol, gcol_out=g0)
+  sim.hipsim_reset(*mode)
+  S.sim_gemm_tn(sim, _ops.to_panel(A) if ap else A, _ops.to_panel(B) if bp else B, C1, bias_out=db1, a_layout=ap, b_layout=bp,
+                gcol=gcol, gcol_out=g1)
+  ref = A.float().T @ B.float()
+  np.testing.assert_allclose(C1.numpy(), ref.numpy(), atol=2e-3, rtol=1e-4)
+  np.testing.assert_allclose(C1.numpy(), C0.numpy(), atol=1e-3, rtol=1e-5)      # (the atomics' order differs between launches)
+  np.testing.assert_allclose(db1.numpy(), B.float().sum(0).numpy(), atol=2e-3, rtol=1e-4)
+  if gcol is not None:
+    np.testing.assert_allclose(g1.numpy(), (A.float().T @ gcol.float()).numpy(), atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(g1.numpy(), g0.numpy(), atol=1e-3, rtol=1e-5)

@@ -133,6 +133,7 @@ namespace hipsim {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 struct ThreadCtx {
   dim3 tid3, bid3, bdim3, gdim3;
@@ -145,11 +146,13 @@ void launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function
 void barrier();                                  // s_barrier
 void syncthreads();                              // s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier
 void wait_vmcnt(int n);                          // s_waitcnt vmcnt(n)
+void vm_store();                                 // a global store enters the in-order vmcnt queue (kernels that count it by hand)
 void global_load_lds(const void* gptr, void* lds_wave_base, int size, int offset);
 s16x4_t ds_read_tr16_b64(const void* lds_ptr);   // ds_read_b64_tr_b16
 f32x16_t mfma_f32_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c);
 int update_dpp(int old, int src, int dpp_ctrl, int row_mask, int bank_mask, bool bound_ctrl);
 int readfirstlane(int v);
+u32x2_t permlane32_swap(unsigned vdst, unsigned src);   // v_permlane32_swap_b32: lanes 32-63 of vdst <-> lanes 0-31 of src
 float shfl(float v, int src_lane, int width);
 int shfl_i(int v, int src_lane, int width);
 unsigned long long ballot(int pred);
@@ -174,6 +177,7 @@ unsigned long long clock64();
 #define __builtin_amdgcn_s_memrealtime() hipsim::clock64()
 #define __builtin_amdgcn_s_getreg(x) 0u
 #define __builtin_amdgcn_readfirstlane(x) hipsim::readfirstlane(x)
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) hipsim::permlane32_swap(a, b)
 #define __builtin_amdgcn_sbfe(src, off, width) ((int)((int32_t)((uint32_t)(src) << (32 - (off) - (width))) >> (32 - (width))))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipsim::update_dpp(old, src, ctrl, rm, bm, bc)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipsim::mfma_f32_32x32x16_bf16(a, b, c)

@@ -14,6 +14,7 @@
 //   ds_read_b64_tr_b16        per 16-lane group: lane p supplies the address of 4 consecutive 16-bit elements,
 //                             row p/4, columns 4*(p%4)..+3 of a [4][16] block; lane c receives column c (4 rows)
 //   DPP quad_perm             lane l reads lane (l & ~3) | perm[l & 3]
+//   v_permlane32_swap_b32     lanes 32-63 of vdst are exchanged with lanes 0-31 of src, the other two halves stay
 #include <stdarg.h>
 #include <stdio.h>
 #include <sys/mman.h>
@@ -125,7 +126,7 @@ __attribute__((format(printf, 1, 2))) void fail(const char* fmt, ...) {
 void land(Fiber& f, size_t keep) {
   while (f.dma.size() > keep) {
     const PendingDma& d = f.dma.front();
-    memcpy(d.dst, d.data, d.size);
+    if (d.size) memcpy(d.dst, d.data, d.size);
     f.dma.pop_front();
   }
 }
@@ -264,6 +265,25 @@ void op_readfirstlane(Wave& w) {
   for (int l = 0; l < 64; ++l) memcpy(w.out[l], &v, 4);
 }
 
+void op_permlane32_swap(Wave& w) {
+  // in[l] = {vdst, src}; out[l] = {new vdst, new src}: vdst[32 + k] <-> src[k]
+  for (int l = 0; l < 64; ++l) {
+    unsigned mine[2] = {0, 0}, other[2] = {0, 0};
+    if (w.present[l]) memcpy(mine, w.in[l], 8);
+    const int o = l ^ 32;
+    if (w.present[o]) memcpy(other, w.in[o], 8);
+    unsigned out[2];
+    if (l < 32) {
+      out[0] = mine[0];            // lower half of vdst stays
+      out[1] = other[0];           // lower half of src <- upper half of vdst
+    } else {
+      out[0] = other[1];           // upper half of vdst <- lower half of src
+      out[1] = mine[1];            // upper half of src stays
+    }
+    memcpy(w.out[l], out, 8);
+  }
+}
+
 void op_shfl(Wave& w) {
   for (int l = 0; l < 64; ++l) {
     int in[2] = {0, 0};                              // value bits, source lane
@@ -300,6 +320,16 @@ void barrier() {
 }
 
 void wait_vmcnt(int n) { land(*g_fiber, (size_t)n); }
+
+// A global store of a kernel that counts its vector-memory queue by hand: on gfx950 stores retire through the same in-order
+// vmcnt as loads and LDS-DMA, so a counted wait behind them has to allow for them (gemm_blk.hip).
+void vm_store() {
+  if (!g_dma_late) return;
+  PendingDma d;
+  d.dst = nullptr;
+  d.size = 0;
+  g_fiber->dma.push_back(d);
+}
 
 void syncthreads() {
   wait_vmcnt(0);
@@ -370,6 +400,13 @@ int update_dpp(int old, int src, int dpp_ctrl, int row_mask, int bank_mask, bool
   (void)bound_ctrl;
   int in[3] = {old, src, dpp_ctrl}, out = 0;
   wave_op(op_dpp, "dpp quad_perm", in, 12, &out, 4);
+  return out;
+}
+
+u32x2_t permlane32_swap(unsigned vdst, unsigned src) {
+  unsigned in[2] = {vdst, src};
+  u32x2_t out = {0u, 0u};
+  wave_op(op_permlane32_swap, "v_permlane32_swap", in, 8, &out, 8);
   return out;
 }
 

@@ -1,0 +1,100 @@
+"""Panel-layout NT kernel (csrc/gemm_blk.hip) against the tiled kernel (gemm.hip, NtBigP) at the trunk's shapes: bitwise
+screen after un-blocking (values and the 1-bit masks), race screen (repeated launches must agree with themselves), timing.
+
+    python tools/panel_probe.py            # the 360.gin trunk shapes at 16384 rays
+    SMALL=1 python tools/panel_probe.py    # a quick functional screen (few tiles, every workgroup walks several)
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multinerf_amd import ops  # noqa: E402
+
+dev = 'cuda'
+bf = torch.bfloat16
+g = torch.Generator(device=dev).manual_seed(0)
+PAN = ops.LAYOUT_PANEL
+
+
+def timed(fn, reps=10):
+  for _ in range(2):
+    fn()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    fn()
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def case(M, N, K1, K2=0, fwd=True, a1_panel=True, reps=10, a_rows=0):
+  A1 = torch.relu(torch.rand((M, K1), generator=g, device=dev) * 2 - 1).to(bf)        # post-ReLU: half zeros, as in the trunk
+  lda_kw = {}
+  if a_rows:
+    # cache-resident A (timing experiment): row-major A1 with a zero-ish leading dimension: every 256-row tile reads the same
+    # a_rows x K1 block (lda1 = 8 elements: rows overlap, the bytes a tile touches fit the L1 / L2)
+    assert not a1_panel
+    lda_kw = dict(lda1=8)
+  A2 = (torch.rand((M, K2), generator=g, device=dev) * 2 - 1).to(bf) if K2 else None
+  Bt = ((torch.rand((N, K1 + K2), generator=g, device=dev) * 2 - 1) * (6.0 / (K1 + K2)) ** 0.5).to(bf)
+  bias = 0.05 * torch.randn((N,), generator=g, device=dev)
+  bits_rm = torch.randint(0, 256, (M, N // 8), generator=g, device=dev, dtype=torch.uint8)
+  A1p = ops.to_panel(A1) if a1_panel else A1
+  bits_tile = ops.bits_to_tile_order(bits_rm, N)
+  C0 = torch.zeros((M, N), dtype=bf, device=dev)
+  b0 = torch.zeros((M, N // 8), dtype=torch.uint8, device=dev)
+  C1 = torch.zeros((M, N), dtype=bf, device=dev)
+  b1 = torch.zeros((M * N // 8,), dtype=torch.uint8, device=dev)
+  lay = dict(a1_layout=PAN if a1_panel else 0, c_layout=PAN)
+  if fwd:
+    old = lambda: ops.gemm_nt(A1, Bt, M=M, N=N, K1=K1, A2=A2, K2=K2, bias=bias, n_bias=N, relu=True, Cb=C0, ldcb=N, nb=N, bits_out=b0, **lda_kw)
+    new = lambda: ops.gemm_nt(A1p, Bt, M=M, N=N, K1=K1, A2=A2, K2=K2, bias=bias, n_bias=N, relu=True, Cb=C1, ldcb=N, nb=N, bits_out=b1, **lay, **lda_kw)
+  else:
+    old = lambda: ops.gemm_nt(A1, Bt, M=M, N=N, K1=K1, A2=A2, K2=K2, Cb=C0, ldcb=N, nb=N, bits_in=bits_rm)
+    new = lambda: ops.gemm_nt(A1p, Bt, M=M, N=N, K1=K1, A2=A2, K2=K2, Cb=C1, ldcb=N, nb=N, bits_in=bits_tile, **lay)
+  t_old, t_new, t_old2, t_new2 = timed(old, reps), timed(new, reps), timed(old, reps), timed(new, reps)
+  torch.cuda.synchronize()
+  same = torch.equal(ops.from_panel(C1).view(torch.int16), C0.view(torch.int16))
+  same_bits = (not fwd) or torch.equal(ops.bits_from_tile_order(b1, M, N), b0)
+  # race screen: the same launch again into fresh buffers must reproduce itself bit for bit
+  ref = C1.clone()
+  stable = True
+  for _ in range(3):
+    C1.zero_()
+    new()
+    torch.cuda.synchronize()
+    stable = stable and torch.equal(C1.view(torch.int16), ref.view(torch.int16))
+  fl = 2.0 * M * N * (K1 + K2)
+  print(f'M={M} N={N} K={K1}+{K2} {"fwd" if fwd else "dX "} A1 {"panel" if a1_panel else "rows "}: tiled {t_old:8.1f} / {t_old2:8.1f} us ({fl / t_old2 / 1e6:6.1f} TF/s)   '
+        f'panel {t_new:8.1f} / {t_new2:8.1f} us ({fl / t_new2 / 1e6:6.1f} TF/s)   {"bitwise equal" if same else "VALUES MISMATCH"}'
+        f'{"" if same_bits else " BITS MISMATCH"}{"" if stable else " UNSTABLE"}', flush=True)
+  return same and same_bits and stable
+
+
+ok = True
+if os.environ.get('TIMING_ONLY'):         # probe builds (MNR_LIB_PATH, -DPN_DBG=n): values are not meaningful
+  case(524288, 1024, 1024)
+  case(524288, 1024, 512, a1_panel=False)
+  case(524288, 1024, 1024, fwd=False)
+  case(524288, 1024, 1024, a1_panel=False)
+  case(524288, 1024, 1024, a1_panel=False, a_rows=1)
+  sys.exit(0)
+if os.environ.get('SMALL'):
+  ops.L.check(ops.lib().mnr_gemm_nt_panel_set_max_wgs(8))
+  for a1p in (True, False):
+    ok &= case(4096, 512, 256, 0, True, a1p, reps=2)
+    ok &= case(4096, 512, 192, 64, True, a1p, reps=2)
+    ok &= case(2304, 256, 320, 0, False, a1p, reps=2)
+  ops.L.check(ops.lib().mnr_gemm_nt_panel_set_max_wgs(0))
+ok &= case(524288, 1024, 1024)
+ok &= case(524288, 1024, 1024, fwd=False)
+ok &= case(524288, 1024, 512, a1_panel=False)
+ok &= case(524288, 1024, 1024, 512)
+ok &= case(524288, 1024, 320, fwd=False, a1_panel=False)
+ok &= case(262144, 1024, 1024)
+print('PANEL PROBE', 'OK' if ok else 'FAILED')
+sys.exit(0 if ok else 1)
