@@ -41,6 +41,10 @@ _USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused
 _FUSED_IPE = _os.environ.get('MNR_FUSED_IPE', '1') != '0'   # A/B switch: rendering builds the proposal levels' IPE features inside the chain kernel
 _HEAD_K64 = _os.environ.get('MNR_HEAD_K64', '1') != '0'    # A/B switch: the merged head's dX GEMM over 320 instead of 384 K columns
 _HEAD_GCOL = _os.environ.get('MNR_HEAD_GCOL', '1') != '0'  # A/B switch: the density head's weight gradient as an extra column of the bottleneck's dW GEMM (N = 256, 256x256 tiles) instead of a merged N = 384 GEMM on 128x128 tiles
+# A/B switch: the wide (>= 512) per-layer trunk keeps its activations, gradients and ReLU masks in the panel layout
+# (include/mnerf.h MNR_LAYOUT_PANEL; csrc/gemm_blk.hip): results leave the MFMA accumulators as whole 1-KiB blocks, the K loop
+# runs as one pipeline across output tiles
+_PANEL = _os.environ.get('MNR_PANEL', '1') != '0'
 _CONST_CACHE = _os.environ.get('MNR_CONST_CACHE', '1') != '0'  # A/B switch: constant level-loop inputs cached on the device (no per-step host -> device copies)
 # A/B switch: the weight-gradient GEMMs (dW_l = x_{l-1}^T dY_l) on a second HIP stream behind the dX chain.  dW_l and the
 # dX GEMM that turns dY_l into dY_{l-1} are independent, so with one dY buffer per layer (instead of two ping-pong
@@ -953,6 +957,12 @@ class Model:
     need_bits = ((keep and _USE_BITS) or plan.ref) and relu
     acts, bits, zs, vzs = [], [], [], []
     x = None
+    # panel layout for the trunk of this level (the layout of acts / bits / every trunk dY of the backward pass): every
+    # producer and consumer is then a panel-aware GEMM, which the plain merged head of a wide ReLU trunk guarantees
+    panel = self._panel_ok(plan, M, keep)
+    PAN = ops.LAYOUT_PANEL
+    lay_c = dict(c_layout=PAN) if panel else {}
+    lay_a = dict(a1_layout=PAN) if panel else {}
 
     def activate(z_key, out, n_cols, zlist):
       """Non-ReLU net_activation: the GEMM wrote the pre-activation into `out`'s twin buffer; apply act (models.py:457,578)."""
@@ -975,18 +985,18 @@ class Model:
       dst = out if relu else activate((tag, 'z', i if keep else i % 2), out, plan.W, zs)
       if i == 0:
         ops.gemm_nt(feat, Bt, M=M, N=e['n_pad'], K1=plan.ldF, bias=bias, n_bias=d.fan_out, relu=relu,
-                    Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo)
+                    Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo, **lay_c)
       elif concat:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, A2=feat, K2=plan.ldF, bias=bias, n_bias=d.fan_out,
-                    relu=relu, Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo)
+                    relu=relu, Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo, **lay_a, **lay_c)
       else:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=bias, n_bias=d.fan_out, relu=relu,
-                    Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo)
+                    Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo, **lay_a, **lay_c)
       if not relu:
         ops.act_fwd(hp.net_activation, dst, out)
       acts.append(out)
       x = out
-    res = dict(acts=acts, bits=bits, chain_trunk=chain, zs=zs, vzs=vzs)
+    res = dict(acts=acts, bits=bits, chain_trunk=chain, zs=zs, vzs=vzs, panel=panel)
     raw_density = self._buf((tag, 'raw_density'), (M,), f32)
     if plan.has_rgb and not plan.use_viewdirs:
       # models.py:585 with x = the trunk output: one 4-column head [raw_density | raw_rgb] as an fp32 side output
@@ -1041,7 +1051,7 @@ class Model:
                    rough=rough)
       else:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=bw + 1, relu=False,
-                    Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=raw_density, ldcf=1, f0=bw, nf=1)
+                    Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=raw_density, ldcf=1, f0=bw, nf=1, **lay_a)
         ops.viewdir_enc_fill(R.viewdirs, n, hp.deg_view, VI, bw, plan.ldVI)
       if plan.glo > 0:
         ops.glo_fill(self._glo_table(flat), self._glo_cam, M // n, n, VI, plan.glo_col)
@@ -1088,6 +1098,24 @@ class Model:
                   bias=flat[d.bias_off:d.bias_off + 1], n_bias=1, relu=False, Cf=raw_density, ldcf=1, f0=0, nf=1)
     res['raw_density'] = raw_density
     return res
+
+  def _head_gcol(self, plan: MLPPlan):
+    """The merged head's weight gradient as the bottleneck's 256-column GEMM plus the density column as a vector (backward_level)."""
+    W, bw = plan.W, plan.hp.bottleneck_width
+    return bool(_HEAD_GCOL and plan.has_rgb and plan.use_viewdirs and not plan.ref and len(plan.head_segs) == 2 and
+                bw % 256 == 0 and W % 256 == 0 and W >= 512)
+
+  def _panel_ok(self, plan: MLPPlan, M, keep):
+    """True when this level's per-layer trunk runs in the panel layout: a ReLU trunk of width >= 512 (a multiple of 256: the
+    narrower ones take the fused chain / weights-resident kernels) under the plain merged head of models.py:494-585, whose
+    forward GEMM, dX GEMM and weight-gradient GEMM (with the density column as a vector) all read or write panel storage."""
+    if not (_PANEL and _USE_BITS and plan.hp.net_activation == 'relu' and plan.W % 256 == 0 and plan.W >= 512 and M % 256 == 0):
+      return False
+    if self._chain_ok(plan) or plan.ref or not (plan.has_rgb and plan.use_viewdirs):
+      return False
+    if plan.ldF % 32 != 0 or plan.ldF < 192 or plan.packed['head']['n_pad'] % 256 != 0:
+      return False
+    return (not keep) or self._head_gcol(plan)
 
   def _dw(self):
     return _SideLaunch(self)
@@ -1139,6 +1167,12 @@ class Model:
       return grads[off:off + size]
 
     relu = hp.net_activation == 'relu'
+    panel = bool(mlp.get('panel'))                        # the trunk's activations / masks / gradients are in panel storage
+    PAN = ops.LAYOUT_PANEL
+    lay_c = dict(c_layout=PAN) if panel else {}
+    lay_ac = dict(a1_layout=PAN, c_layout=PAN) if panel else {}
+    tn_a = dict(a_layout=PAN) if panel else {}
+    tn_b = dict(b_layout=PAN) if panel else {}
 
     def act_vjp(z, d):
       """Non-ReLU activations: d (gradient w.r.t. a layer's activation, just written without a mask) *= act'(z)."""
@@ -1183,7 +1217,8 @@ class Model:
       # dW GEMM as a vector, below; it then also leaves the compositing VJP as the fp32 vector that GEMM reads)
       # (for trunks of at least 512 columns: at 256 the merged N = 384 GEMM is six small tiles and the extra column buys nothing,
       # blender_256 1.764 / 1.767 M rays/s merged against 1.749 / 1.764 M, llff_raw 546.0 against 545.9 k)
-      head_gcol = (_HEAD_GCOL and not plan.ref and len(plan.head_segs) == 2 and bw % 256 == 0 and W % 256 == 0 and W >= 512)
+      head_gcol = self._head_gcol(plan)
+      assert head_gcol or not panel
       g_den_f32, g_rgb = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], raw_rgb=lv['raw_rgb'],
           density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights,
@@ -1283,7 +1318,7 @@ class Model:
           # column of the same launch (db_density: above)
           db_, dd_ = plan.bottleneck, plan.density
           ops.gemm_tn(x_last, dHB, gslice(db_.kernel_off, W * bw), M=M, K=W, N=bw, lda=W, ldb=nh, ldc=bw,
-                      bias_out=gslice(db_.bias_off, bw), bias_n_valid=bw, gcol=g_vec, gcol_out=gslice(dd_.kernel_off, W))
+                      bias_out=gslice(db_.bias_off, bw), bias_n_valid=bw, gcol=g_vec, gcol_out=gslice(dd_.kernel_off, W), **tn_a)
         else:
           tmpW = self._buf(('bwd', 'tmpW', W, nh), (W, nh), f32)
           tmpW.zero_()
@@ -1296,7 +1331,8 @@ class Model:
             ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
       Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
       # (K = the head's columns rounded to the GEMM's 64-column K granule, not to the buffers' 128: 320 instead of 384 at 360.gin)
-      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=_rup(plan.head_cols, 64) if _HEAD_K64 else nh, Cb=dA, ldcb=W, nb=W, **mask_kw(len(acts) - 1))
+      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=_rup(plan.head_cols, 64) if _HEAD_K64 else nh, Cb=dA, ldcb=W, nb=W,
+                  **mask_kw(len(acts) - 1), **lay_c)
       act_vjp(mlp['zs'][-1] if not relu else None, dA)
     else:
       g_raw_density, _ = ops.composite_bwd(
@@ -1358,17 +1394,17 @@ class Model:
       with self._dw():
         if i == 0:
           ops.gemm_tn(feat, dy, gslice(d.kernel_off, plan.F * W), M=M, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
-                      ldc=W, k_valid=plan.F, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W)
+                      ldc=W, k_valid=plan.F, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_b)
         else:
           ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W,
-                      bias_out=gslice(d.bias_off, W), bias_n_valid=W)
+                      bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_a, **tn_b)
           if concat:
             ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
-                        lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
+                        lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W, **tn_b)
       if i > 0:
         Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
         other = dy_buf(i - 1)
-        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, **mask_kw(i - 1))
+        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, **mask_kw(i - 1), **lay_ac)
         act_vjp(mlp['zs'][i - 1] if not relu else None, other)
         dy = other
     self._dw_join()

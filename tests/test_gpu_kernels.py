@@ -399,6 +399,90 @@ def test_gemm_nt_pipelined_loop_is_bitwise_the_two_stage_loop(ops, K1, K2):
   np.testing.assert_allclose(outs[0][0].view(torch.bfloat16).double().numpy(), want.numpy(), rtol=2**-7, atol=1e-2)
 
 
+@pytest.mark.parametrize('K1,K2,a1_panel', [(192, 0, False), (256, 64, True), (1024, 0, True), (512, 512, True), (320, 0, False)])
+def test_gemm_nt_panel_kernel_is_bitwise_the_tiled_kernel(ops, K1, K2, a1_panel):
+  """The panel-layout NT kernel (csrc/gemm_blk.hip: results stored as 1-KiB blocks straight from the accumulators, one LDS-DMA
+  pipeline across output tiles, the epilogue interleaved with the next tile's first k-step, ReLU masks in tile order) against the
+  tiled kernel: forward layer (bias, ReLU, masks, [A1 | A2]) and the dX layer reading those masks, after un-blocking bit for bit;
+  launches capped at 8 workgroups (each walks three of the 24 tiles) and uncapped; the shortest K the kernel takes, both A1
+  layouts, the head dX shape (K = 320 from a row-major operand); and the values against an fp64 reference."""
+  gen = torch.Generator().manual_seed(68)
+  M, N = 1536, 1024
+  A1 = _bf(torch.relu(torch.randn((M, K1), generator=gen)))
+  A2 = dev(_bf(torch.randn((M, K2), generator=gen))) if K2 else None
+  Bt = dev(_bf(torch.randn((N, K1 + K2), generator=gen) / math.sqrt(K1 + K2)))
+  bias = dev(0.1 * torch.randn((N,), generator=gen))
+  G = _bf(torch.randn((M, N), generator=gen))
+  W2 = dev(_bf(torch.randn((N, N), generator=gen) / math.sqrt(N)))
+  PAN = ops.LAYOUT_PANEL
+  act0 = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
+  bits0 = torch.zeros((M, N // 8), dtype=torch.uint8).cuda()
+  dx0 = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
+  ops.gemm_nt(dev(A1), Bt, M=M, N=N, K1=K1, A2=A2, K2=K2, bias=bias, n_bias=N, relu=True, Cb=act0, ldcb=N, nb=N, bits_out=bits0)
+  ops.gemm_nt(dev(G), W2, M=M, N=N, K1=N, bits_in=bits0, Cb=dx0, ldcb=N, nb=N)
+  A1p = dev(ops.to_panel(A1) if a1_panel else A1)
+  try:
+    for cap in (8, 0):
+      ops.L.check(ops.lib().mnr_gemm_nt_panel_set_max_wgs(cap))
+      act = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
+      bits = torch.zeros((M * N // 8,), dtype=torch.uint8).cuda()
+      dx = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
+      ops.gemm_nt(A1p, Bt, M=M, N=N, K1=K1, A2=A2, K2=K2, bias=bias, n_bias=N, relu=True, Cb=act, ldcb=N, nb=N, bits_out=bits,
+                  a1_layout=PAN if a1_panel else 0, c_layout=PAN)
+      ops.gemm_nt(dev(ops.to_panel(G)), W2, M=M, N=N, K1=N, bits_in=bits, Cb=dx, ldcb=N, nb=N, a1_layout=PAN, c_layout=PAN)
+      assert torch.equal(ops.from_panel(act).view(torch.int16), act0.view(torch.int16)), cap
+      assert torch.equal(ops.bits_from_tile_order(bits, M, N), bits0), cap
+      assert torch.equal(ops.from_panel(dx).view(torch.int16), dx0.view(torch.int16)), cap
+  finally:
+    ops.L.check(ops.lib().mnr_gemm_nt_panel_set_max_wgs(0))
+  A = A1.float() if A2 is None else torch.cat([A1.float(), A2.cpu().float()], -1)
+  want = torch.relu(A.double() @ Bt.cpu().double().T + bias.cpu().double())
+  np.testing.assert_allclose(act0.cpu().double().numpy(), want.numpy(), rtol=2**-7, atol=1e-2)
+  # the merged head behind a panel trunk: the tiled kernel reading a panel-layout activation into row-major outputs
+  if K2 == 0 and K1 % 256 == 0:
+    Nh = 512
+    Bh = dev(_bf(torch.randn((Nh, K1), generator=gen) / math.sqrt(K1)))
+    bh = dev(0.1 * torch.randn((Nh,), generator=gen))
+    outs = []
+    for lay in (0, PAN):
+      vi = torch.zeros((M, 384), dtype=torch.bfloat16).cuda()
+      den = torch.zeros((M,), dtype=torch.float32).cuda()
+      ops.gemm_nt(dev(ops.to_panel(A1)) if lay else dev(A1), Bh, M=M, N=Nh, K1=K1, bias=bh, n_bias=257, relu=False, Cb=vi, ldcb=384, nb=256,
+                  Cf=den, ldcf=1, f0=256, nf=1, a1_layout=lay)
+      outs.append((vi.cpu().view(torch.int16), den.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize('ap,bp', [(1, 1), (0, 1), (1, 0)])
+def test_gemm_tn_panel_operands(ops, ap, bp):
+  """Weight gradients from panel-layout operands (gemm_tn_body.inc A_PANEL / B_PANEL): against fp64 and against the row-major
+  call (same sums, the order of the atomics aside), the fused bias gradient, the k_valid bound of the feature rows, and with a
+  panel A and a row-major B the extra vector column of the merged head (gemm_tn_gcol_kernel)."""
+  gen = torch.Generator().manual_seed(19)
+  M, K, N = 8192 + 64, 512, 256
+  ldb = 384 if not bp else N
+  A = _bf(torch.randn((M, K), generator=gen))
+  Bfull = _bf(torch.randn((M, ldb), generator=gen))
+  Bm = Bfull[:, :N]
+  gvec = _bf(0.37 * torch.randn((M,), generator=gen)) if (ap and not bp) else None
+  ref = A.double().T @ Bm.double()
+  PAN = ops.LAYOUT_PANEL
+  Ad = dev(ops.to_panel(A) if ap else A)
+  Bd = dev(ops.to_panel(Bm.contiguous()) if bp else Bfull)
+  Cout = torch.ones((K, N), dtype=torch.float32).cuda()
+  bsum = torch.zeros((N,)).cuda()
+  gout = torch.zeros((K,)).cuda() if gvec is not None else None
+  ops.gemm_tn(Ad, Bd, Cout, M=M, K=K, N=N, lda=K, ldb=ldb, ldc=N, k_valid=K - 8, bias_out=bsum, bias_n_valid=N,
+              gcol=None if gvec is None else dev(gvec), gcol_out=gout, a_layout=PAN if ap else 0, b_layout=PAN if bp else 0)
+  got = Cout.cpu().double()
+  np.testing.assert_allclose(got[:K - 8].numpy(), (ref + 1)[:K - 8].numpy(), rtol=1e-4, atol=1e-3 * math.sqrt(M))
+  assert (got[K - 8:] == 1).all()
+  np.testing.assert_allclose(bsum.cpu().double().numpy(), Bm.double().sum(0).numpy(), rtol=1e-5, atol=1e-3 * math.sqrt(M))
+  if gvec is not None:
+    want_g = A.double().T @ gvec.double()
+    np.testing.assert_allclose(gout.cpu().double()[:K - 8].numpy(), want_g[:K - 8].numpy(), rtol=1e-4, atol=1e-3 * math.sqrt(M))
+
+
 def test_gemm_nt_rejects_bad_shapes(ops):
   a = torch.zeros((128, 64), dtype=torch.bfloat16).cuda()
   with pytest.raises(ValueError, match='multiple of 128'):

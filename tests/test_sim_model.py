@@ -33,7 +33,12 @@ CASES = [
     ('blender_refnerf', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 4),
     # RawNeRF: NDC cylinders, exposure scaling, safe_exp colours, rawnerf loss with a Bayer lossmult
     ('llff_raw', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 4),
+    # a 512-wide NeRF trunk: the panel-layout path of 360.gin's 1024-wide trunk (csrc/gemm_blk.hip; panel operands of the merged
+    # head, its dX / weight-gradient GEMMs and the trunk's weight-gradient GEMMs), with the skip concat
+    ('360', ['NerfMLP.net_width = 512', 'NerfMLP.net_depth = 6', 'PropMLP.net_width = 128', 'PropMLP.net_depth = 2',
+             'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 8),
 ]
+PANEL_CASE = CASES[3]
 
 
 def _setup(name, extra, B, seed=3):
@@ -166,3 +171,31 @@ def test_density_only_mlp_with_a_skip_concat_on_the_fused_chain():
   (the feature rows of the skip layer's kernel)."""
   _run('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'PropMLP.net_depth = 8',
                'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 8, VARIANTS[0])
+
+
+def test_panel_trunk_equals_row_major_trunk():
+  """MNR_PANEL (models._PANEL): the wide trunk in panel storage against the same trunk in row-major storage: the forward pass
+  bit for bit (the panel kernel is bitwise the tiled kernel), the gradients up to the order of the weight-gradient atomics."""
+  from multinerf_amd import models as M_
+  name, extra, B = PANEL_CASE
+  out = {}
+  with S.simulated_device() as sim:
+    sim.lib.hipsim_reset(1, 3)
+    for on in (True, False):
+      old = M_._PANEL
+      M_._PANEL = on
+      try:
+        cfg, model, _, params, flat, batch = _setup(name, extra, B)
+        noise = helpers.make_noise(model, B)
+        rend, hist = model.apply({'flat': flat}, None, batch.rays, 0.4, True, zero_glo=False, noise=noise)
+        state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+        _, stats, _ = train_utils.create_train_step(model, cfg)(0, state, batch, None, 0.4, 0.0, noise=noise, return_grads=True)
+        sim.check()
+        used = bool(model._saved['levels'][-1]['mlp'].get('panel'))
+        out[on] = (rend[-1]['rgb'].clone(), hist[-1]['weights'].clone(), stats['_grads'].clone(), used)
+      finally:
+        M_._PANEL = old
+  assert out[True][3] and not out[False][3]
+  assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+  a, b = out[True][2].double(), out[False][2].double()
+  assert ((a - b).norm() / b.norm()).item() < 1e-5
