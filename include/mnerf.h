@@ -231,6 +231,9 @@ int mnr_gemm_nt_set_wres(int max_wgs);
 /* Test hook of the panel-result kernel (c_layout = MNR_LAYOUT_PANEL, csrc/gemm_blk.hip): at most n persistent workgroups
  * (every workgroup then walks several tiles at small sizes); 0 (default) = one per CU. */
 int mnr_gemm_nt_panel_set_max_wgs(int n);
+/* A/B switch of the same kernel: 1 (default) = consecutive launches walk the M-tiles in alternating directions (a layer starts
+ * with the rows the previous layer wrote last); 0 = always ascending.  Resets the direction of the next launch to ascending. */
+int mnr_gemm_nt_panel_set_alternate(int on);
 
 /* ---- Fused Dense chain (csrc/fused_mlp.hip): the trunk of internal/models.py:441-465 (Dense + ReLU layers, optionally
  * one skip concat of the input features, :458-459) and, for a density-only MLP, its Dense(1) head (:460) as ONE

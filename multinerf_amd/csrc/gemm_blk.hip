@@ -29,7 +29,8 @@
 #include "common.h"
 
 // Probe builds (tools/panel_probe.py with MNR_LIB_PATH): 1 = the epilogue without its global stores, 2 = no epilogue at all
-// (K loop only), 3 = the epilogue without the mask bytes, 4 = no MFMAs (operand movement only).  0 in the product.
+// (K loop only), 3 = the epilogue without the mask bytes, 4 = no MFMAs (operand movement only), 5 = the counted waits of K-tiles 2
+// and 3 behind an epilogue also leave its stores outstanding (a RACE: timing only), 6 = every second store.  0 in the product.
 #ifndef PN_DBG
 #define PN_DBG 0
 #endif
@@ -73,7 +74,7 @@ __device__ __forceinline__ unsigned pn_nonzero_byte(unsigned w0, unsigned w1, un
 }  // namespace
 
 template <bool A1_PANEL, bool BITS_IN>
-__global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, long long vtotal) {
+__global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, long long vtotal, int rev) {
   constexpr int BM = PN_BM, BN = PN_BN, BK = PN_BK, STAGES = PN_STAGES, KS = PN_KS, MI = PN_MI, NJ = PN_NJ;
   constexpr int ROWB = PN_ROWB, A_BYTES = PN_A_BYTES, STAGE_BYTES = PN_STAGE_BYTES, LPS = PN_LPS, PPK = PN_PPK;
   constexpr int EXTRA = BITS_IN ? 8192 : 2048;           // per tile: the mask bits of a dX tile / two copies of the bias row
@@ -94,7 +95,10 @@ __global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, 
   // results pinned to SGPRs: hipcc evaluates integer divisions on the vector unit, and everything derived from them (six tile
   // base pointers, the epilogue's addresses) would live in VGPR pairs.
   const int vtot = (int)vtotal, gstep = (int)gridDim.x, mt32 = (int)mt;
-  auto decode = [&](int v, int& m_tile, int& n_tile) -> bool {
+  // rev: the M-tiles in descending order (the launcher alternates it between consecutive launches: a layer then starts with the
+  // rows the previous layer wrote last, which are the ones the 256 MB Infinity Cache still holds)
+  auto decode = [&](int v_, int& m_tile, int& n_tile) -> bool {
+    const int v = rev ? vtot - 1 - v_ : v_;
     const int q = v >> 3;
     m_tile = __builtin_amdgcn_readfirstlane((v & 7) + 8 * (q / nt));
     n_tile = __builtin_amdgcn_readfirstlane(q % nt);
@@ -268,8 +272,12 @@ __global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, 
         MNR_GPU_ONLY(asm volatile("" : "+v"(byte)));      // folded now: eight flag registers per block are not kept for later
         mout[bidx >> 2] |= byte << ((bidx & 3) * 8);
       }
-      if constexpr (PN_DBG == 1) {
-        MNR_GPU_ONLY(asm volatile("" ::"v"(w)));
+      if constexpr (PN_DBG == 1 || (PN_DBG == 6 && true)) {
+        if (PN_DBG == 1 || g == 1) {
+          MNR_GPU_ONLY(asm volatile("" ::"v"(w)));
+        } else {
+          *(pn_u32x4*)(ec_p + (j * 2 + g) * 1024) = w;
+        }
       } else {
         *(pn_u32x4*)(ec_p + (j * 2 + g) * 1024) = w;
       }
@@ -390,6 +398,13 @@ __global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, 
     const bf16* n2t = A2 + (int64_t)nm * BM * lda2;
     const bf16* nbt = Bt + (int64_t)nn * BN * ldb;
     int kt = 2;
+    if constexpr (PN_DBG == 5) {
+      if (gk > 0) {
+        ktile(gk + 2, F(), F(), T(), T(), PN_I(STD + PN_NST), F(), a1t, a2t, bt, 5 * BK, 0, 0, 0);
+        ktile(gk + 3, F(), F(), T(), T(), PN_I(STD + PN_NST), F(), a1t, a2t, bt, 6 * BK, 0, 0, 0);
+        kt = 4;
+      }
+    }
     for (; kt < nk - 3; ++kt) ktile(gk + kt, F(), F(), T(), T(), PN_I(STD), F(), a1t, a2t, bt, (kt + 3) * BK, 0, 0, 0);
     // nk-3: pieces of (next, 0), then the next tile's extras; nk-2: (next, 1), the extras among the younger ones; nk-1: (next, 2)
     ktile(gk + kt, F(), F(), T(), T(), PN_I(STD), T(), n1t, n2t, nbt, 0, nm, nn, par ^ 1);
@@ -418,6 +433,14 @@ __global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, 
 #undef PN_I
 }
 
+// Consecutive launches walk the M-tiles in alternating directions (default on; same-box A/B 31.21 / 31.21 -> 31.12 / 31.12 ms per
+// step at 360.gin: the rows a layer reads first are the ones the previous layer wrote last)
+static int g_panel_alternate = 1, g_panel_rev_next = 0;
+extern "C" int mnr_gemm_nt_panel_set_alternate(int on) {
+  g_panel_alternate = on;
+  g_panel_rev_next = 0;
+  return MNR_OK;
+}
 static int g_panel_max_wgs = 0;                           // tests: at most this many workgroups (0: one per CU)
 extern "C" int mnr_gemm_nt_panel_set_max_wgs(int n) {
   g_panel_max_wgs = n;
@@ -431,7 +454,8 @@ static int panel_launch_t(const mnr_gemm_nt_args* a, int64_t grid, int64_t vtota
   if (mnr_attr_needed(&attr_set))
     (void)hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<A1_PANEL, BITS_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL((gemm_nt_panel_kernel<A1_PANEL, BITS_IN>), dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, *a,
-                     (long long)vtotal);
+                     (long long)vtotal, g_panel_rev_next);
+  if (g_panel_alternate) g_panel_rev_next ^= 1;
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }

@@ -62,6 +62,8 @@ def lib():
       L.check(L.load().mnr_gemm_tn_set_config(int(os.environ['MNR_TN_BIG_MIN_TILES'])))
     if os.environ.get('MNR_NT_WRES'):           # A/B switch: weights-resident kernel for the short-K layers (0: off)
       L.check(L.load().mnr_gemm_nt_set_wres(int(os.environ['MNR_NT_WRES'])))
+    if os.environ.get('MNR_PANEL_ALTERNATE'):   # A/B switch: consecutive panel-kernel launches walk the M-tiles in alternating directions
+      L.check(L.load().mnr_gemm_nt_panel_set_alternate(int(os.environ['MNR_PANEL_ALTERNATE'])))
   return L.load()
 
 

@@ -267,6 +267,7 @@ def test_nt_panel_kernel_forward_and_dx(sim, a1_panel, mode):
     C0, _, b0 = S.sim_gemm_nt(sim, A1, Bt, A2=A2, bias=bias, relu=True, bits_out=True)
     sim.hipsim_reset(*mode)
     D0, _, _ = S.sim_gemm_nt(sim, dY, Wt, bits_in=b0)
+    sim.mnr_gemm_nt_panel_set_alternate(1)          # (the second launch of each pair below walks the M-tiles in descending order)
     for wgs in (8, 16):
       sim.mnr_gemm_nt_panel_set_max_wgs(wgs)
       sim.hipsim_reset(*mode)
