@@ -59,6 +59,7 @@ def case(M, N, K1, K2=0, fwd=True, a1_panel=True, reps=10, a_rows=0):
   t_old, t_new, t_old2, t_new2 = timed(old, reps), timed(new, reps), timed(old, reps), timed(new, reps)
   torch.cuda.synchronize()
   same = torch.equal(ops.from_panel(C1).view(torch.int16), C0.view(torch.int16))
+  maxdiff = (ops.from_panel(C1).float() - C0.float()).abs().max().item()
   same_bits = (not fwd) or torch.equal(ops.bits_from_tile_order(b1, M, N), b0)
   # race screen: the same launch again into fresh buffers must reproduce itself bit for bit
   ref = C1.clone()
@@ -70,7 +71,7 @@ def case(M, N, K1, K2=0, fwd=True, a1_panel=True, reps=10, a_rows=0):
     stable = stable and torch.equal(C1.view(torch.int16), ref.view(torch.int16))
   fl = 2.0 * M * N * (K1 + K2)
   print(f'M={M} N={N} K={K1}+{K2} {"fwd" if fwd else "dX "} A1 {"panel" if a1_panel else "rows "}: tiled {t_old:8.1f} / {t_old2:8.1f} us ({fl / t_old2 / 1e6:6.1f} TF/s)   '
-        f'panel {t_new:8.1f} / {t_new2:8.1f} us ({fl / t_new2 / 1e6:6.1f} TF/s)   {"bitwise equal" if same else "VALUES MISMATCH"}'
+        f'panel {t_new:8.1f} / {t_new2:8.1f} us ({fl / t_new2 / 1e6:6.1f} TF/s)   {"bitwise equal" if same else f"VALUES MISMATCH (max |diff| {maxdiff:.3g})"}'
         f'{"" if same_bits else " BITS MISMATCH"}{"" if stable else " UNSTABLE"}', flush=True)
   return same and same_bits and stable
 
