@@ -278,7 +278,7 @@ def main():
             'parallelism': f'dp{world}',
             'train_frac': train_frac,
             'params': model.num_params, 'workspace_GiB': round(model.workspace_bytes() / 2 ** 30, 2),
-            'backward_streams': mstreams.describe_env() if not model.single_mlp else {'side_stream': False, 'side_cus': 0},
+            'backward_streams': mstreams.describe_env() if not model.single_mlp else {'side_stream': False},
             'algorithmic_train_mflop_per_ray': train_flops / 1e6,
             'algorithmic_fwd_mflop_per_ray': fwd_flops / 1e6,
             'whole_step_tflops_per_gpu': train_flops * B / (ms_per_step * 1e-3) / 1e12,

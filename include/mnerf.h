@@ -41,17 +41,6 @@ const char* mnr_last_error(void);
 int mnr_abi_version(void);
 /* Device properties the host needs to size launches: fills cu_count, lds_bytes, gcn arch name. */
 int mnr_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
-/* CU budget of the launches that follow (0 = the whole device, the default): the persistent kernels (Dense GEMMs, fused
- * chain) size their grids for `cus` compute units instead of all of them.  For a caller that runs two streams side by
- * side on disjoint CU sets (hipExtStreamCreateWithCUMask): in this code base the proposal levels' backward pass
- * (HBM-bound) next to the NeRF level's (MFMA-bound); the reference expresses the same independence through
- * stop_gradient between levels (models.py:200-201) and leaves the scheduling to XLA.  Process-wide, not thread-safe:
- * set it from the thread that issues the launches. */
-int mnr_set_cu_budget(int cus);
-/* A HIP stream whose kernels run only on the compute units set in `cu_mask` (hipExtStreamCreateWithCUMask; bit i of the
- * mask = CU i in the driver's numbering, which interleaves the XCDs).  The caller owns the stream. */
-int mnr_stream_create_cu_mask(const uint32_t* cu_mask, int mask_words, void** stream_out);
-int mnr_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Sampling  (replaces models.py:153-204 = stepfun.max_dilate_weights
@@ -222,8 +211,6 @@ int mnr_debug_gemm_timeline(unsigned long long* device_buffer);
    MFMAs), 0 = the two-stage BK = 64 loop.  Bitwise equal results. */
 int mnr_gemm_nt_set_pipelined(int on);
 int mnr_gemm_nt_set_persistent(int wgs_per_cu);
-/* A/B switch: 1 = the bf16 output tile (and its 1-bit masks) leaves with streaming (non-temporal) stores; 0 (default) = plain. */
-int mnr_gemm_nt_set_nt_stores(int on);
 /* A/B switch: 1 (default) = eligible short-K launches (N = 256, K1 <= 256, K2 = 0, full-width bf16 output, no fp32 side
  * output, no bf16 mask) go to the weights-resident persistent kernel (weights in registers, one workgroup per CU walking
  * the M tiles); n > 1 = the same with at most n workgroups; 0 = off. */

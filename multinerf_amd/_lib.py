@@ -140,9 +140,6 @@ class AdamCfg(C.Structure):
 i64, i32, f32 = C.c_int64, C.c_int, C.c_float
 _PROTOS = {
     'mnr_abi_version': ([], i32),
-    'mnr_set_cu_budget': ([i32], i32),
-    'mnr_stream_create_cu_mask': ([C.POINTER(C.c_uint32), i32, C.POINTER(vp)], i32),
-    'mnr_stream_destroy': ([vp], i32),
     'mnr_device_info': ([i32, C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32], i32),
     'mnr_resample_level': ([C.POINTER(ResampleCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_sorted_interp': ([i64, i32, i32, vp, vp, vp, vp, vp, vp], i32),
@@ -169,7 +166,6 @@ _PROTOS = {
     'mnr_debug_chain_timeline': ([vp], i32),
     'mnr_mlp_chain_set_deferred': ([i32], i32),
     'mnr_gemm_tn_set_config': ([i32], i32),
-    'mnr_gemm_nt_set_nt_stores': ([i32], i32),
     'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),
     'mnr_pack_weights_bf16': ([vp, vp, i32, i32, vp, vp], i32),
     'mnr_scatter_add_f32': ([vp, i32, i32, i32, i32, i32, vp, i32, vp], i32),

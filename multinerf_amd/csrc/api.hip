@@ -16,37 +16,7 @@ void mnr_set_error(const char* fmt, ...) {
 
 extern "C" const char* mnr_last_error(void) { return g_err; }
 
-extern "C" int mnr_abi_version(void) { return 14; }
-
-int g_mnr_cu_budget = 0;
-
-extern "C" int mnr_set_cu_budget(int cus) {
-  MNR_CHECK_ARG(cus >= 0, "mnr_set_cu_budget: %d", cus);
-  g_mnr_cu_budget = cus;
-  return MNR_OK;
-}
-
-extern "C" int mnr_stream_create_cu_mask(const uint32_t* cu_mask, int mask_words, void** stream_out) {
-  MNR_CHECK_ARG(cu_mask && mask_words > 0 && stream_out, "mnr_stream_create_cu_mask: null argument");
-  hipStream_t s = nullptr;
-  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask_words, cu_mask);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    mnr_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
-    return MNR_ERR_HIP;
-  }
-  *stream_out = (void*)s;
-  return MNR_OK;
-}
-
-extern "C" int mnr_stream_destroy(void* stream) {
-  hipError_t e = hipStreamDestroy((hipStream_t)stream);
-  if (e != hipSuccess) {
-    mnr_set_error("hipStreamDestroy: %s", hipGetErrorString(e));
-    return MNR_ERR_HIP;
-  }
-  return MNR_OK;
-}
+extern "C" int mnr_abi_version(void) { return 15; }
 
 extern "C" int mnr_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch_name,
                                int arch_name_len) {

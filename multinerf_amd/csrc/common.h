@@ -66,15 +66,6 @@ static inline int mnr_cu_count() {
   return cus;
 }
 
-// CU budget of the launches that follow (mnr_set_cu_budget): persistent kernels size their grids with it instead of the
-// whole chip when the caller runs two streams side by side on disjoint sets of CUs (multinerf_amd/streams.py: the
-// HBM-bound proposal levels' backward next to the MFMA-bound NeRF level's).  0 = the whole device.
-extern int g_mnr_cu_budget;
-static inline int mnr_cu_budget() {
-  const int cus = mnr_cu_count();
-  return (g_mnr_cu_budget > 0 && g_mnr_cu_budget < cus) ? g_mnr_cu_budget : cus;
-}
-
 // Lane-per-ray kernels (resample, compositing, the fused level backward) run one long dependent instruction stream per
 // wave whatever the number of active lanes, so a batch is spread over `mnr_ray_wave_target()` single-wave workgroups =
 // one per SIMD of the chip (4 per CU), each walking B / target rays.  Measured (round 2, 16384 rays, ms per step of the

@@ -621,7 +621,7 @@ extern "C" int mnr_mlp_chain_set_deferred(int on) {
 }
 
 static int fm_grid(int64_t tiles) {
-  const int cus = mnr_cu_budget();
+  const int cus = mnr_cu_count();
   return (int)(tiles < cus ? tiles : cus);
 }
 

@@ -159,12 +159,6 @@ extern "C" int mnr_gemm_nt_set_pipelined(int on) {
   return MNR_OK;
 }
 
-static int g_nt_nt_stores = 0;
-extern "C" int mnr_gemm_nt_set_nt_stores(int on) {
-  g_nt_nt_stores = on;
-  return MNR_OK;
-}
-
 extern "C" int mnr_gemm_nt_set_persistent(int wgs_per_cu) {
   g_nt_persist = wgs_per_cu;
   return MNR_OK;
@@ -185,7 +179,7 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   // tile's K loop instead of in front of the workgroup's retirement, and the per-workgroup launch gap goes away.
   int64_t grid = vtotal;
   if (g_nt_persist != 0 && CFG::LDS_BYTES > 80 * 1024) {
-    const int64_t cap = g_nt_persist > 0 ? (int64_t)g_nt_persist * mnr_cu_budget() : -(int64_t)g_nt_persist;
+    const int64_t cap = g_nt_persist > 0 ? (int64_t)g_nt_persist * mnr_cu_count() : -(int64_t)g_nt_persist;
     if (grid > cap && cap >= 8) grid = cap / 8 * 8;
   }
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
@@ -439,7 +433,7 @@ static bool nt_wres_eligible(const mnr_gemm_nt_args* a, int fast_epi) {
 }
 
 static int nt_wres_launch(const mnr_gemm_nt_args* a, int max_wgs, void* stream) {
-  const int cus = mnr_cu_budget();
+  const int cus = mnr_cu_count();
   const int64_t mt = a->M / 256;
   const int cap = max_wgs > 1 ? max_wgs : cus;            // MNR_NT_WRES = 1: one workgroup per CU; n > 1: at most n workgroups
   const int grid = (int)(mt < cap ? mt : cap);
@@ -481,8 +475,7 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
                 "mnr_gemm_nt_bf16: mask_bits_out needs a full-width, 16-byte-aligned bf16 output and a 4-byte-aligned bit matrix");
   // 16-byte row segments in the epilogue need 8-element-aligned output / mask pitches and bases.
   const int fast_epi = (int)((!a->Cb || (a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0)) &&
-                             (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0))) |
-                       (g_nt_nt_stores ? 2 : 0);     // bit 1: streaming stores of the bf16 output tile (A/B switch)
+                             (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0)));
   if (a->c_layout == MNR_LAYOUT_PANEL) return mnr_gemm_nt_panel_launch(a, stream);
   if (a->a1_layout == MNR_LAYOUT_PANEL) {
     // a panel-layout activation into a row-major result (the merged head behind the trunk): the pipelined tiled kernel
@@ -567,17 +560,8 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   // Enough M-splits for ~target_wgs workgroups.  The grid (splits x tiles) is a multiple of 8 and workgroup b belongs to
   // XCD b % 8: the kernel hands XCD x the (split, tile) pairs [x * grid / 8, (x + 1) * grid / 8) in split-major order, so
   // the tiles of one split (which share its operand rows) run on one XCD (two when a split straddles a boundary).
-  // With the whole chip as the budget that is the round-1 rule (a multiple of 8 splits, >= target); under a CU budget
-  // (mnr_set_cu_budget: two streams side by side) the grid must not EXCEED the budget, or the surplus workgroups run as a
-  // second round behind the first.
   const int unit = 8 / mnr_gcd(tiles, 8);                  // splits come in multiples of this
-  int splits;
-  if (g_mnr_cu_budget > 0 && target_wgs <= mnr_cu_count()) {
-    const int budget = target_wgs < mnr_cu_budget() ? target_wgs : mnr_cu_budget();
-    splits = budget / tiles / unit * unit;
-  } else {
-    splits = ((target_wgs + tiles - 1) / tiles + 7) / 8 * 8;
-  }
+  int splits = ((target_wgs + tiles - 1) / tiles + 7) / 8 * 8;
   if (splits < unit) splits = unit;
   // (every workgroup ends with an atomic epilogue of its whole fp32 tile: a split must be long enough to pay for it)
   static int min_steps = -1;
@@ -655,9 +639,7 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
     const char* e = getenv("MNR_TN_SMALL_TARGET_WGS");
     tn_small_target = e ? atoi(e) : 768;
   }
-  // (the 64-KiB small tile runs two or three workgroups per CU: its target scales with the CU budget)
-  const int small_target = g_mnr_cu_budget > 0 ? (int)((long long)tn_small_target * mnr_cu_budget() / mnr_cu_count()) : tn_small_target;
-  return tn_launch<TnSmall>(a, small_target, stream);
+  return tn_launch<TnSmall>(a, tn_small_target, stream);
 }
 
 // ---------------------------------------------------------------------------

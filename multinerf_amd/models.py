@@ -46,42 +46,11 @@ _HEAD_GCOL = _os.environ.get('MNR_HEAD_GCOL', '1') != '0'  # A/B switch: the den
 # runs as one pipeline across output tiles
 _PANEL = _os.environ.get('MNR_PANEL', '1') != '0'
 _CONST_CACHE = _os.environ.get('MNR_CONST_CACHE', '1') != '0'  # A/B switch: constant level-loop inputs cached on the device (no per-step host -> device copies)
-# A/B switch: the weight-gradient GEMMs (dW_l = x_{l-1}^T dY_l) on a second HIP stream behind the dX chain.  dW_l and the
-# dX GEMM that turns dY_l into dY_{l-1} are independent, so with one dY buffer per layer (instead of two ping-pong
-# buffers) the dX chain runs ahead and the dW launches fill the CUs each dX launch's tail leaves idle (and the other way
-# round); both are full-size launches, nothing is partitioned.
-_DW_STREAM = _os.environ.get('MNR_DW_STREAM', '0') != '0'
 # A/B switch: the backward pass of ALL proposal levels as one pass (they share PropMLP_0 and the sample count, reference
 # models.py:120-121,166): their features / activations / mask bits sit in consecutive row blocks of one buffer per kind, so
 # one dX chain and one weight-gradient GEMM per layer cover L*M rows (half the launches and half the 256 KiB atomic
 # epilogues of the per-level form at 360.gin).
 _MERGE_PROPS = _os.environ.get('MNR_MERGE_PROPS', '1') != '0'
-
-
-class _SideLaunch:
-  """`with model._dw():` the launches inside go to the weight-gradient stream, ordered after everything enqueued on the
-  current stream so far; a no-op context when the switch is off (or on the kernel-source simulator's host tensors)."""
-
-  def __init__(self, model):
-    self.model = model
-
-  def __enter__(self):
-    s2 = self.model._dw_stream
-    if s2 is None:
-      return self
-    cur = torch.cuda.current_stream(self.model.device)
-    ev = torch.cuda.Event()
-    ev.record(cur)
-    s2.wait_event(ev)
-    self.ctx = torch.cuda.stream(s2)
-    self.ctx.__enter__()
-    self.model._dw_pending = True
-    return self
-
-  def __exit__(self, *exc):
-    if self.model._dw_stream is not None:
-      self.ctx.__exit__(*exc)
-    return False
 
 
 # =============================================================================
@@ -395,8 +364,6 @@ class Model:
       p.basis_dev = torch.as_tensor(p.basis, dtype=f32, device=self.device).contiguous()
       self._layout_packed(p)
     self._ws: Dict[Any, torch.Tensor] = {}
-    self._dw_stream = torch.cuda.Stream(device=self.device) if (_DW_STREAM and self.device.type == 'cuda') else None
-    self._dw_pending = False
     self._built = True
     return self
 
@@ -573,6 +540,27 @@ class Model:
       n = self.num_glo_embeddings * 3
       tree['exposure_scaling_offsets'] = {'embedding': flat[self.expo_off:self.expo_off + n].view(-1, 3)}
     return tree
+
+  def param_ranges(self):
+    """{key: (begin, end)} of the flat parameter vector for every key `train_utils.summarize_tree` (train_utils.py:60-68,
+    max_depth 3) gives the reference's `params` tree: 'NerfMLP_0', 'NerfMLP_0/Dense_3', 'NerfMLP_0/Dense_3/kernel', ...,
+    'Embed_0', 'Embed_0/embedding'.  A Dense's kernel and bias are adjacent in the flat vector, so every key is one range."""
+    out = {}
+    for name, b, e in self.modules:
+      out[name] = (b, e)
+    for p in self._plans:
+      for d in p.dense:
+        kb, ke = d.kernel_off, d.kernel_off + d.fan_in * d.fan_out
+        bb, be = d.bias_off, d.bias_off + d.fan_out
+        assert bb == ke, 'kernel and bias of a Dense are adjacent (Model._plan_params)'
+        out[f'{p.module_name}/{d.name}'] = (kb, be)
+        out[f'{p.module_name}/{d.name}/kernel'] = (kb, ke)
+        out[f'{p.module_name}/{d.name}/bias'] = (bb, be)
+    if self.glo_off is not None:
+      out['Embed_0/embedding'] = out['Embed_0']
+    if self.expo_off is not None:
+      out['exposure_scaling_offsets/embedding'] = out['exposure_scaling_offsets']
+    return out
 
   def flat_from_tree(self, tree, device=None):
     """Inverse of params_tree for externally supplied parameters (e.g. the oracle's)."""
@@ -1117,18 +1105,6 @@ class Model:
       return False
     return (not keep) or self._head_gcol(plan)
 
-  def _dw(self):
-    return _SideLaunch(self)
-
-  def _dw_join(self):
-    """The current stream waits for the weight-gradient launches enqueued so far (end of a level's backward pass: the
-    gradient vector is complete, the per-level buffers they read may be overwritten)."""
-    if self._dw_stream is not None and self._dw_pending:
-      ev = torch.cuda.Event()
-      ev.record(self._dw_stream)
-      torch.cuda.current_stream(self.device).wait_event(ev)
-      self._dw_pending = False
-
   def _glo_table(self, flat):
     G = self.num_glo_features
     return flat[self.glo_off:self.glo_off + self.num_glo_embeddings * G].view(self.num_glo_embeddings, G)
@@ -1147,18 +1123,18 @@ class Model:
     x_last = acts[-1]
     W = plan.W
     D = len(plan.trunk)
-    per_layer = self._dw_stream is not None                # one dY buffer per layer: the dX chain may run ahead of the dW launches
+    # Workspace of this pass, keyed by the stream it runs on: the proposal levels' backward runs on a side stream next to the
+    # NeRF level's (train_utils.create_train_step), and a proposal MLP that takes this per-layer path (not chain-eligible:
+    # non-ReLU activation, odd widths, MNR_FUSED_CHAIN=0) with the NeRF MLP's width and row count would otherwise share dA / dB /
+    # dV / dHB / ... with it.  Levels that run one after the other on the same stream share their buffers.
+    slot = 'nerf' if lv['level'] == self.num_levels - 1 else 'prop'
 
     def dy_buf(i):
-      """dY of trunk layer i's output: two ping-pong buffers shared across levels, or one per layer (dW stream)."""
-      if per_layer:
-        return self._buf(('bwd', 'dY', W, i), (M, W), bf16)
-      return self._buf(('bwd', 'dA' if (D - 1 - i) % 2 == 0 else 'dB', W), (M, W), bf16)
+      """dY of trunk layer i's output: two ping-pong buffers shared by the levels of a stream."""
+      return self._buf(('bwd', slot, 'dA' if (D - 1 - i) % 2 == 0 else 'dB', W), (M, W), bf16)
 
     def dv_buf(i, nv):
-      if per_layer:
-        return self._buf(('bwd', 'dV', WV, i), (M, WV), bf16)
-      return self._buf(('bwd', 'dV0' if (nv - 1 - i) % 2 == 0 else 'dV1', WV), (M, WV), bf16)
+      return self._buf(('bwd', slot, 'dV0' if (nv - 1 - i) % 2 == 0 else 'dV1', WV), (M, WV), bf16)
 
     if not mlp.get('chain'):
       dA = dy_buf(D - 1)
@@ -1194,14 +1170,14 @@ class Model:
           density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights, want_f32=True,
           exposure_scale=lv['expo'], g_exposure_scale=g_expo if lv['expo'] is not None else None, losses=losses)
       # the 4-column head [density | rgb]: dX into the trunk, dW / db scattered to the two Dense layers
-      g4 = self._buf(('bwd', 'g4'), (M, 4), f32)
+      g4 = self._buf(('bwd', slot, 'g4'), (M, 4), f32)
       g4[:, 0].copy_(g_raw_density.view(M))
       g4[:, 1:4].copy_(g_rgb.view(M, 3))
       dn, dr = plan.density, plan.rgb
-      w4 = self._buf(('bwd', 'w4', W), (W, 4), f32)
+      w4 = self._buf(('bwd', slot, 'w4', W), (W, 4), f32)
       w4[:, 0].copy_(flat[dn.kernel_off:dn.kernel_off + W])
       w4[:, 1:4].copy_(flat[dr.kernel_off:dr.kernel_off + 3 * W].view(W, 3))
-      t4 = self._buf(('bwd', 't4', W), (W + 1, 4), f32)
+      t4 = self._buf(('bwd', slot, 't4', W), (W + 1, 4), f32)
       t4.zero_()
       ops.small_head_bwd(x_last, W, g4, w4, M=M, K=W, Cn=4, dX=dA, lddx=W, relu_mask=relu, dW=t4[:W].view(-1), db=t4[W])
       act_vjp(mlp['zs'][-1] if not relu else None, dA)
@@ -1212,7 +1188,7 @@ class Model:
       bw = hp.bottleneck_width
       e = plan.packed['head']
       nh = e['nb_pad']
-      dHB = self._buf(('bwd', 'dHB', nh), (M, nh), bf16, zero=True)   # columns beyond head_cols stay zero
+      dHB = self._buf(('bwd', slot, 'dHB', nh), (M, nh), bf16, zero=True)   # columns beyond head_cols stay zero
       # (the plain merged head [bottleneck | density] of 360.gin: the density column's weight gradient rides in the bottleneck's
       # dW GEMM as a vector, below; it then also leaves the compositing VJP as the fp32 vector that GEMM reads)
       # (for trunks of at least 512 columns: at 256 the merged N = 384 GEMM is six small tiles and the extra column buys nothing,
@@ -1230,7 +1206,7 @@ class Model:
         # (33 MB of 64-byte sectors): two small launches, issued HERE, before the proposal levels' persistent kernels fill
         # the CUs from the side stream (behind them a 25-us launch of 512 small workgroups took 0.3-0.6 ms to get its CUs,
         # with the main stream's next GEMM waiting for it: profiles/r3s3_step_seq_default.md)
-        g_vec = self._buf(('bwd', 'g_den_vec'), (M,), bf16)
+        g_vec = self._buf(('bwd', slot, 'g_den_vec'), (M,), bf16)
         ops.cast_f32_to_bf16(g_den_f32.view(-1), 1, M, 1, g_vec, 1, 0)
         ops.colsum(dHB.view(-1)[bw:], M, 1, gslice(plan.density.bias_off, 1), ld=nh)
       if plan.ref:
@@ -1252,7 +1228,7 @@ class Model:
       VI = mlp['VI']
       dVIa = dVIb = None
       want_glo = plan.glo > 0 and self._glo_cam is not None
-      gGa = self._buf(('bwd', 'gGa'), (M, plan.glo), f32) if want_glo else None
+      gGa = self._buf(('bwd', slot, 'gGa'), (M, plan.glo), f32) if want_glo else None
       gGb = None
       glo_kw = lambda t: dict(Cf=t, ldcf=plan.glo, f0=plan.glo_col, nf=plan.glo) if want_glo else {}
       for i in reversed(range(len(plan.view))):
@@ -1261,20 +1237,19 @@ class Model:
         inp = VI if i == 0 else vacts[i - 1]
         in_w = plan.ldVI if i == 0 else WV
         # dW (rows of the first input segment; then the skip-concat rows), db
-        with self._dw():
-          ops.gemm_tn(inp, dy, gslice(d.kernel_off, d.fan_in * d.fan_out), M=M, K=in_w, N=WV,
-                      lda=inp.stride(0), ldb=WV, ldc=d.fan_out,
-                      k_valid=(plan.vi_width if i == 0 else WV), n_valid=d.fan_out,
-                      bias_out=gslice(d.bias_off, d.fan_out), bias_n_valid=d.fan_out)
-          if concat:
-            ops.gemm_tn(VI, dy, gslice(d.kernel_off + WV * d.fan_out, plan.vi_width * d.fan_out), M=M,
-                        K=plan.ldVI, N=WV, lda=plan.ldVI, ldb=WV, ldc=d.fan_out, k_valid=plan.vi_width,
-                        n_valid=d.fan_out)
+        ops.gemm_tn(inp, dy, gslice(d.kernel_off, d.fan_in * d.fan_out), M=M, K=in_w, N=WV,
+                    lda=inp.stride(0), ldb=WV, ldc=d.fan_out,
+                    k_valid=(plan.vi_width if i == 0 else WV), n_valid=d.fan_out,
+                    bias_out=gslice(d.bias_off, d.fan_out), bias_n_valid=d.fan_out)
+        if concat:
+          ops.gemm_tn(VI, dy, gslice(d.kernel_off + WV * d.fan_out, plan.vi_width * d.fan_out), M=M,
+                      K=plan.ldVI, N=WV, lda=plan.ldVI, ldb=WV, ldc=d.fan_out, k_valid=plan.vi_width,
+                      n_valid=d.fan_out)
         if concat:
           # the view input also receives gradient through the skip concat (bottleneck, IDE / n.v / GLO columns)
           first_skip = dVIb is None
-          tVI = self._buf(('bwd', 'dVIb', 0 if first_skip else 1), (M, plan.ldVI), bf16)
-          tG = self._buf(('bwd', 'gGb', 0 if first_skip else 1), (M, plan.glo), f32) if want_glo else None
+          tVI = self._buf(('bwd', slot, 'dVIb', 0 if first_skip else 1), (M, plan.ldVI), bf16)
+          tG = self._buf(('bwd', slot, 'gGb', 0 if first_skip else 1), (M, plan.glo), f32) if want_glo else None
           B2 = self._w(plan, e['b2_off'], plan.ldVI, e['b_ld'])
           ops.gemm_nt(dy, B2, M=M, N=plan.ldVI, K1=e['b_ld'], Cb=tVI, ldcb=plan.ldVI, nb=plan.ldVI, **glo_kw(tG))
           if first_skip:
@@ -1286,7 +1261,7 @@ class Model:
         Bw = self._w(plan, e['b_off'], e['b_rows'], e['b_ld'])
         if i == 0:
           if plan.ref:
-            dVIa = self._buf(('bwd', 'dVIa'), (M, plan.ldVI), bf16)
+            dVIa = self._buf(('bwd', slot, 'dVIa'), (M, plan.ldVI), bf16)
             ops.gemm_nt(dy, Bw, M=M, N=e['b_rows'], K1=e['b_ld'], Cb=dVIa, ldcb=plan.ldVI, nb=plan.ldVI, **glo_kw(gGa))
           else:
             ops.gemm_nt(dy, Bw, M=M, N=e['b_rows'], K1=e['b_ld'], Cb=dHB, ldcb=nh, nb=bw, **glo_kw(gGa))
@@ -1312,23 +1287,22 @@ class Model:
                                       dVIa, dVIb, bw, g_npred, g_normals, dHB, bw + 1, bw + 10)
       # merged head: dW, db, dX_last
       e = plan.packed['head']
-      with self._dw():
-        if head_gcol:
-          # dW_bottleneck += x^T dHB[:, :bw] straight into the flat gradient (256x256 tiles), dw_density += x^T g as one more
-          # column of the same launch (db_density: above)
-          db_, dd_ = plan.bottleneck, plan.density
-          ops.gemm_tn(x_last, dHB, gslice(db_.kernel_off, W * bw), M=M, K=W, N=bw, lda=W, ldb=nh, ldc=bw,
-                      bias_out=gslice(db_.bias_off, bw), bias_n_valid=bw, gcol=g_vec, gcol_out=gslice(dd_.kernel_off, W), **tn_a)
-        else:
-          tmpW = self._buf(('bwd', 'tmpW', W, nh), (W, nh), f32)
-          tmpW.zero_()
-          tmpb = self._buf(('bwd', 'tmpb', nh), (nh,), f32)
-          tmpb.zero_()
-          ops.gemm_tn(x_last, dHB, tmpW, M=M, K=W, N=nh, lda=W, ldb=nh, ldc=nh, bias_out=tmpb,
-                      bias_n_valid=plan.head_cols)
-          for (d, c0) in plan.head_segs:
-            ops.scatter_add(tmpW, nh, 0, c0, W, d.fan_out, gslice(d.kernel_off, W * d.fan_out), d.fan_out)
-            ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
+      if head_gcol:
+        # dW_bottleneck += x^T dHB[:, :bw] straight into the flat gradient (256x256 tiles), dw_density += x^T g as one more
+        # column of the same launch (db_density: above)
+        db_, dd_ = plan.bottleneck, plan.density
+        ops.gemm_tn(x_last, dHB, gslice(db_.kernel_off, W * bw), M=M, K=W, N=bw, lda=W, ldb=nh, ldc=bw,
+                    bias_out=gslice(db_.bias_off, bw), bias_n_valid=bw, gcol=g_vec, gcol_out=gslice(dd_.kernel_off, W), **tn_a)
+      else:
+        tmpW = self._buf(('bwd', slot, 'tmpW', W, nh), (W, nh), f32)
+        tmpW.zero_()
+        tmpb = self._buf(('bwd', slot, 'tmpb', nh), (nh,), f32)
+        tmpb.zero_()
+        ops.gemm_tn(x_last, dHB, tmpW, M=M, K=W, N=nh, lda=W, ldb=nh, ldc=nh, bias_out=tmpb,
+                    bias_n_valid=plan.head_cols)
+        for (d, c0) in plan.head_segs:
+          ops.scatter_add(tmpW, nh, 0, c0, W, d.fan_out, gslice(d.kernel_off, W * d.fan_out), d.fan_out)
+          ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
       Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
       # (K = the head's columns rounded to the GEMM's 64-column K granule, not to the buffers' 128: 320 instead of 384 at 360.gin)
       ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=_rup(plan.head_cols, 64) if _HEAD_K64 else nh, Cb=dA, ldcb=W, nb=W,
@@ -1346,20 +1320,18 @@ class Model:
                            relu_mask=False, dW=gslice(d.kernel_off, W), db=gslice(d.bias_off, 1))
         D = len(plan.trunk)
         # (keyed by level: the proposal levels' backward passes may run side by side on streams of their own)
-        dYs = [self._buf(('bwd', 'dYc', W, i, lv['level']), (M, W), bf16) for i in range(D)]
+        dYs = [self._buf(('bwd', slot, 'dYc', W, i, lv['level']), (M, W), bf16) for i in range(D)]
         Bws = [None] + [self._w(plan, plan.packed[('trunk', i)]['b_off'], _rup(W, 128), plan.packed[('trunk', i)]['b_ld'])
                         for i in range(1, D)]
         ops.mlp_chain_bwd(g_raw_density.view(M), w_head, mlp['bits'], Bws, dYs, M=M, W=W)
         feat = lv['feat']
-        with self._dw():
-          for i, (dl, concat) in enumerate(plan.trunk):
-            inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
-            ops.gemm_tn(inp, dYs[i], gslice(dl.kernel_off, kv * W), M=M, K=in_w, N=W, lda=in_w, ldb=W, ldc=W,
-                        k_valid=kv, n_valid=W, bias_out=gslice(dl.bias_off, W), bias_n_valid=W)
-            if concat:
-              ops.gemm_tn(feat, dYs[i], gslice(dl.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
-                          lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
-        self._dw_join()
+        for i, (dl, concat) in enumerate(plan.trunk):
+          inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
+          ops.gemm_tn(inp, dYs[i], gslice(dl.kernel_off, kv * W), M=M, K=in_w, N=W, lda=in_w, ldb=W, ldc=W,
+                      k_valid=kv, n_valid=W, bias_out=gslice(dl.bias_off, W), bias_n_valid=W)
+          if concat:
+            ops.gemm_tn(feat, dYs[i], gslice(dl.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
+                        lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
         return
       ops.small_head_bwd(x_last, W, g_raw_density.view(M, 1), flat[d.kernel_off:d.kernel_off + W].view(W, 1),
                          M=M, K=W, Cn=1, dX=dA, lddx=W, relu_mask=relu,
@@ -1367,23 +1339,21 @@ class Model:
       act_vjp(mlp['zs'][-1] if not relu else None, dA)
     feat = lv['feat']
     if g_raw_grad is not None:
-      self._tangent_backward(plan, flat, grads, mlp, feat, M, g_raw_grad)
+      self._tangent_backward(plan, flat, grads, mlp, feat, M, g_raw_grad, slot)
     if mlp.get('chain_trunk'):
       # fused dX chain from the dY_last the head GEMMs left in dA; then dW_i = [x_{i-1} | feat]^T dY_i per layer
-      dYs = [self._buf(('bwd', 'dYc', W, i), (M, W), bf16) for i in range(D - 1)] + [None]
+      dYs = [self._buf(('bwd', slot, 'dYc', W, i), (M, W), bf16) for i in range(D - 1)] + [None]
       Bws = [None] + [self._w(plan, plan.packed[('trunk', i)]['b_off'], _rup(W, 128), plan.packed[('trunk', i)]['b_ld'])
                       for i in range(1, D)]
       ops.mlp_chain_bwd(None, None, mlp['bits'], Bws, dYs, M=M, W=W, dY_in=dA)
       dYs[D - 1] = dA
-      with self._dw():
-        for i, (d, concat) in enumerate(plan.trunk):
-          inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
-          ops.gemm_tn(inp, dYs[i], gslice(d.kernel_off, kv * W), M=M, K=in_w, N=W, lda=in_w, ldb=W, ldc=W,
-                      k_valid=kv, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W)
-          if concat:
-            ops.gemm_tn(feat, dYs[i], gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
-                        lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
-      self._dw_join()
+      for i, (d, concat) in enumerate(plan.trunk):
+        inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
+        ops.gemm_tn(inp, dYs[i], gslice(d.kernel_off, kv * W), M=M, K=in_w, N=W, lda=in_w, ldb=W, ldc=W,
+                    k_valid=kv, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W)
+        if concat:
+          ops.gemm_tn(feat, dYs[i], gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
+                      lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
       return
     # trunk: per layer its dW (independent of the dX chain: on the dW stream when that switch is on), then the dX GEMM the
     # next layer waits for
@@ -1391,23 +1361,21 @@ class Model:
     for i in reversed(range(len(plan.trunk))):
       d, concat = plan.trunk[i]
       e = plan.packed[('trunk', i)]
-      with self._dw():
-        if i == 0:
-          ops.gemm_tn(feat, dy, gslice(d.kernel_off, plan.F * W), M=M, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
-                      ldc=W, k_valid=plan.F, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_b)
-        else:
-          ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W,
-                      bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_a, **tn_b)
-          if concat:
-            ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
-                        lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W, **tn_b)
+      if i == 0:
+        ops.gemm_tn(feat, dy, gslice(d.kernel_off, plan.F * W), M=M, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
+                    ldc=W, k_valid=plan.F, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_b)
+      else:
+        ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W,
+                    bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_a, **tn_b)
+        if concat:
+          ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
+                      lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W, **tn_b)
       if i > 0:
         Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
         other = dy_buf(i - 1)
         ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, **mask_kw(i - 1), **lay_ac)
         act_vjp(mlp['zs'][i - 1] if not relu else None, other)
         dy = other
-    self._dw_join()
 
   def backward_prop_levels(self, lvs, flat, grads, g_weights, losses):
     """`backward_level` for ALL proposal levels in one pass (grouped buffers, `_props_group`): each level's compositing
@@ -1440,18 +1408,16 @@ class Model:
     Bws = [None] + [self._w(plan, plan.packed[('trunk', i)]['b_off'], _rup(W, 128), plan.packed[('trunk', i)]['b_ld'])
                     for i in range(1, D)]
     ops.mlp_chain_bwd(g_all, w_head, bits, Bws, dYs, M=Mall, W=W)
-    with self._dw():
-      for i, (dl, concat) in enumerate(plan.trunk):
-        inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
-        ops.gemm_tn(inp, dYs[i], grads[dl.kernel_off:dl.kernel_off + kv * W], M=Mall, K=in_w, N=W, lda=in_w, ldb=W,
-                    ldc=W, k_valid=kv, n_valid=W, bias_out=grads[dl.bias_off:dl.bias_off + W], bias_n_valid=W)
-        if concat:
-          o = dl.kernel_off + W * W
-          ops.gemm_tn(feat, dYs[i], grads[o:o + plan.F * W], M=Mall, K=plan.ldF, N=W, lda=plan.ldF, ldb=W, ldc=W,
-                      k_valid=plan.F, n_valid=W)
-    self._dw_join()
+    for i, (dl, concat) in enumerate(plan.trunk):
+      inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
+      ops.gemm_tn(inp, dYs[i], grads[dl.kernel_off:dl.kernel_off + kv * W], M=Mall, K=in_w, N=W, lda=in_w, ldb=W,
+                  ldc=W, k_valid=kv, n_valid=W, bias_out=grads[dl.bias_off:dl.bias_off + W], bias_n_valid=W)
+      if concat:
+        o = dl.kernel_off + W * W
+        ops.gemm_tn(feat, dYs[i], grads[o:o + plan.F * W], M=Mall, K=plan.ldF, N=W, lda=plan.ldF, ldb=W, ldc=W,
+                    k_valid=plan.F, n_valid=W)
 
-  def _tangent_backward(self, plan, flat, grads, mlp, feat, M, g_raw_grad):
+  def _tangent_backward(self, plan, flat, grads, mlp, feat, M, g_raw_grad, slot):
     """Backward pass through the tangent network T_l = bits_l * (T_{l-1} W_l), raw_grad = T_last w_density
     (the "double backward" of the density-gradient normals): the network is linear in each W_l with
     fixed masks, so dW_l += T_{l-1}^T G_l and G_{l-1} = bits_{l-1} * (G_l W_l^T) on 3*M rows."""
@@ -1462,8 +1428,8 @@ class Model:
     def gslice(off, size):
       return grads[off:off + size]
 
-    gA = self._buf(('bwd', 'gTA', W), (M3, W), bf16)
-    gB = self._buf(('bwd', 'gTB', W), (M3, W), bf16)
+    gA = self._buf(('bwd', slot, 'gTA', W), (M3, W), bf16)
+    gB = self._buf(('bwd', slot, 'gTB', W), (M3, W), bf16)
     d = plan.density
     # G_last = bits_last * (g_raw_grad[:, None] w_density^T);  dW_density += T_last^T g_raw_grad
     ops.small_head_bwd(T_acts[-1], W, g_raw_grad.view(M3, 1), flat[d.kernel_off:d.kernel_off + W].view(W, 1),

@@ -56,8 +56,6 @@ def lib():
       L.check(L.load().mnr_level_bwd_set_quad(int(os.environ['MNR_LEVEL_BWD_QUAD'])))
     if os.environ.get('MNR_CHAIN_DEFER'):       # A/B switch: fused chain's copy-outs inside the next layer's MFMA pass (0: in front of it)
       L.check(L.load().mnr_mlp_chain_set_deferred(int(os.environ['MNR_CHAIN_DEFER'])))
-    if os.environ.get('MNR_NT_STORES'):         # A/B switch: streaming stores of the NT GEMM's output tile (1: on)
-      L.check(L.load().mnr_gemm_nt_set_nt_stores(int(os.environ['MNR_NT_STORES'])))
     if os.environ.get('MNR_TN_BIG_MIN_TILES'):  # tuning: the 256x256 dW tile only for outputs of at least this many tiles (default 1)
       L.check(L.load().mnr_gemm_tn_set_config(int(os.environ['MNR_TN_BIG_MIN_TILES'])))
     if os.environ.get('MNR_NT_WRES'):           # A/B switch: weights-resident kernel for the short-K layers (0: off)

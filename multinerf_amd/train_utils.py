@@ -75,6 +75,16 @@ def create_train_step(model: models.Model, config, dataset=None):
   lr_fn = lambda step: learning_rate_decay(step, config.lr_init, config.lr_final, config.max_steps,
                                            config.lr_delay_steps, config.lr_delay_mult)
   side_cache = {}
+  ranges = model.param_ranges()
+
+  def wd_range(key):
+    if key not in ranges:
+      raise KeyError(f'Config.weight_decay_mults: {key!r} is not a key of the parameter tree (module, module/Dense_k or '
+                     f'module/Dense_k/kernel|bias); modules: {[m for m, _, _ in model.modules]}')
+    return ranges[key]
+
+  for _k in (config.weight_decay_mults or {}):
+    wd_range(_k)
 
   def backward_streams(dev):
     """The proposal levels' backward on its own stream next to the NeRF level's (multinerf_amd/streams.py); None = off."""
@@ -85,7 +95,7 @@ def create_train_step(model: models.Model, config, dataset=None):
     return side_cache['v']
 
   def train_step(rng, state: TrainState, batch, cameras, train_frac, loss_threshold, noise=None,
-                 return_grads=False):
+                 return_grads=False, tree_stats=False):
     flat = state.params['flat']
     dev = flat.device
     rays = batch.rays
@@ -192,8 +202,11 @@ def create_train_step(model: models.Model, config, dataset=None):
       if overlap and li == nlev - 1:
         for name, b, e in model.modules:
           if name in ('NerfMLP_0', 'Embed_0'):
-            if config.weight_decay_mults and name in config.weight_decay_mults:
-              ops.weight_decay(flat, b, e, config.weight_decay_mults[name], grads, stats[4 * nlev + 5:4 * nlev + 6])
+            # (weight decay of every key inside this module goes in before its reduce: train_utils.py:300-305)
+            for key, mult in (config.weight_decay_mults or {}).items():
+              kb, ke = wd_range(key)
+              if b <= kb and ke <= e:
+                ops.weight_decay(flat, kb, ke, mult, grads, stats[4 * nlev + 5:4 * nlev + 6])
             early.append((b, e, mdist.all_reduce_sum_async(grads[b:e])))
 
     def needs_grad(li):
@@ -220,44 +233,31 @@ def create_train_step(model: models.Model, config, dataset=None):
         props_backward(prop_lis)
         level_backward(nlev - 1)
     else:
-      # Two streams side by side: the proposal levels (HBM-bound) on `bs.prop`, the NeRF level (MFMA-bound) on `bs.nerf`
-      # (or the caller's stream), each sized for its CU share; the caller's stream waits for both.
+      # Two streams side by side: the proposal levels (HBM-bound) on `bs.prop`, the NeRF level (MFMA-bound) on the caller's
+      # stream, which then waits for the side stream.
       cur = torch.cuda.current_stream(dev)
       ready = torch.cuda.Event()
       ready.record(cur)
-      nerf_stream = bs.nerf if bs.nerf is not None else cur
-      if bs.nerf is not None:
-        bs.nerf.wait_event(ready)
-      done_props = []
-      for si, ps in enumerate(bs.props):
-        ps.wait_event(ready)
-        with torch.cuda.stream(ps), mstreams.budget(bs.prop_budget):
-          props_backward([li for li in prop_lis if li % len(bs.props) == si])
-          ev = torch.cuda.Event()
-          ev.record(ps)
-          done_props.append(ev)
-      with torch.cuda.stream(nerf_stream), mstreams.budget(bs.nerf_budget):
-        level_backward(nlev - 1)
-        if bs.nerf is not None:
-          done_nerf = torch.cuda.Event()
-          done_nerf.record(bs.nerf)
-          cur.wait_event(done_nerf)
-      for ev in done_props:
-        cur.wait_event(ev)
+      bs.prop.wait_event(ready)
+      with torch.cuda.stream(bs.prop):
+        props_backward(prop_lis)
+        done_props = torch.cuda.Event()
+        done_props.record(bs.prop)
+      level_backward(nlev - 1)
+      cur.wait_event(done_props)
     if g_expo is not None:
       n_off = model.num_glo_embeddings * 3
       ops.exposure_scale_bwd(R.exposure_values.reshape(-1).contiguous().float(),
                              R.exposure_idx.reshape(-1).to(torch.int32).contiguous(), g_expo,
                              grads[model.expo_off:model.expo_off + n_off], B0)
 
-    if config.weight_decay_mults:                                      # train_utils.py:300-305
-      mods = {name: (b, e) for name, b, e in model.modules}
-      for name, mult in config.weight_decay_mults.items():
-        if name not in mods:
-          raise KeyError(name)
-        if any(b == mods[name][0] for b, _, _ in early):
-          continue                                                     # added before that module's early reduce
-        ops.weight_decay(flat, mods[name][0], mods[name][1], mult, grads, stats[4 * nlev + 5:4 * nlev + 6])
+    # losses['weight'] = sum_k mult_k * |params[k]|^2 over the summarize_tree keys k of the parameter tree (train_utils.py:60-68,
+    # 300-305: a module, a Dense inside it, or one kernel / bias); its gradient 2 * mult_k * params[k] goes into the same ranges
+    for key, mult in (config.weight_decay_mults or {}).items():
+      kb, ke = wd_range(key)
+      if any(b <= kb and ke <= e for b, e, _ in early):
+        continue                                                       # added before that module's early reduce
+      ops.weight_decay(flat, kb, ke, mult, grads, stats[4 * nlev + 5:4 * nlev + 6])
 
     # pmean over the 'batch' axis (train_utils.py:319-321): RCCL all-reduce of the flat buffers.
     if early:
@@ -273,7 +273,8 @@ def create_train_step(model: models.Model, config, dataset=None):
       mdist.all_reduce_mean_(grads)
     mdist.all_reduce_mean_(stats)
 
-    raw_grads = grads.clone() if return_grads else None
+    raw_grads = grads.clone() if (return_grads or tree_stats) else None
+    old_flat = flat.clone() if tree_stats else None                   # (logging steps only: stats['opt_update_*'], 'weight_l2s')
     # clip per top-level module, nan_to_num, Adam (train_utils.py:326-330)
     sq = model._buf(('train', 'sqnorm'), (len(model.modules),), f32)
     sq.zero_()
@@ -291,6 +292,9 @@ def create_train_step(model: models.Model, config, dataset=None):
                  '_normal': config.compute_normal_metrics}
     if return_grads:
       out_stats['_grads'] = raw_grads
+    if tree_stats:
+      # what train_utils.py:304,323-324,334-335 log per summarize_tree key: evaluated lazily in TrainStats.materialize
+      out_stats['_tree'] = dict(ranges=ranges, grads=raw_grads, old=old_flat, new=flat)
     return new_state, TrainStats(out_stats), rng
 
   return train_step
@@ -323,6 +327,20 @@ class TrainStats(dict):
     # per top-level module, AFTER the clip by value (what clip_adam's norm clip sees); the reference logs the
     # pre-clip norm (train_utils.py:323-324): identical whenever grad_max_val = 0, as in every shipped config
     out['grad_norms'] = np.sqrt(self['grad_sqnorms'].detach().cpu().numpy())
+    t = self.get('_tree')
+    if t is not None:
+      # train_utils.py:304 weight_l2s (squared norms of the parameters the step started from), :323-324 grad_norms / grad_maxes of
+      # the pmean'ed gradient before clipping, :332-335 opt_update_norms / opt_update_maxes of new - old parameters; one entry
+      # per summarize_tree key (module, module/Dense_k, module/Dense_k/kernel|bias)
+      delta = t['new'] - t['old']
+      l2, gn, gm, un, um = {}, {}, {}, {}, {}
+      for key, (b, e) in t['ranges'].items():
+        l2[key] = float((t['old'][b:e].double() ** 2).sum())
+        gn[key] = float(t['grads'][b:e].double().norm())
+        gm[key] = float(t['grads'][b:e].abs().max()) if e > b else 0.0
+        un[key] = float(delta[b:e].double().norm())
+        um[key] = float(delta[b:e].abs().max()) if e > b else 0.0
+      out.update(weight_l2s=l2, grad_norms=gn, grad_maxes=gm, opt_update_norms=un, opt_update_maxes=um)
     return out
 
 

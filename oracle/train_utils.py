@@ -276,6 +276,11 @@ def train_step(params, opt_state, model, nerf_mlp, prop_mlp, config, batch, trai
   grad = tree_map(lambda g: torch.nan_to_num(g), grad)
   with torch.no_grad():
     new_params, new_opt = adam_update(params, grad, opt_state, config)
+    # train_utils.py:332-335
+    it2 = iter([v for _, v in tree_leaves(new_params)])
+    opt_delta = tree_map(lambda p: next(it2) - p, params)
+    stats['opt_update_norms'] = summarize_tree(opt_delta, tree_norm)
+    stats['opt_update_maxes'] = summarize_tree(opt_delta, tree_abs_max)
   stats['psnrs'] = image.mse_to_psnr(stats['mses'])
   stats['psnr'] = stats['psnrs'][-1]
   return new_params, new_opt, stats, raw_grad

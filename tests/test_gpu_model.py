@@ -110,6 +110,8 @@ CASES = [
     ('blender_256', ['NerfMLP.net_depth_viewdirs = 6', 'NerfMLP.skip_layer_dir = 2'], 16),
     # weight regulariser per top-level module (train_utils.py:300-305)
     ('blender_256', ["Config.weight_decay_mults = {'NerfMLP_0': 3e-5, 'PropMLP_0': 1e-5}"], 16),
+    # ... and per summarize_tree key (train_utils.py:60-68: a Dense inside a module, one kernel), next to a module key
+    ('blender_256', ["Config.weight_decay_mults = {'NerfMLP_0/Dense_3': 3e-4, 'PropMLP_0/Dense_1/kernel': 1e-3, 'PropMLP_0': 1e-5}"], 16),
     # the north-star's synthetic shape: 192 samples per ray = levels (64, 64, 64)
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_nerf_samples = 64'], 16),
     # bottleneck noise (models.py:530-533; the reference's 360 training default is 0, its goldens use 0.4)
@@ -206,10 +208,21 @@ def test_train_step_parity(name, extra, B):
   state, lr_fn = train_utils.create_optimizer(cfg, variables)
   step = train_utils.create_train_step(model, cfg)
   batch_d = batch.map(lambda t: t.cuda())
-  state2, stats, _ = step(0, state, batch_d, None, tf, 0.0, noise=noise, return_grads=True)
+  want_tree = bool(cfg.weight_decay_mults)
+  state2, stats, _ = step(0, state, batch_d, None, tf, 0.0, noise=noise, return_grads=True, tree_stats=want_tree)
   torch.cuda.synchronize()
   g = stats['_grads'].cpu()
   s = stats.materialize()
+  if want_tree:
+    # the per-key logging statistics of train_utils.py:304,323-324,332-335 against the oracle's (same keys: summarize_tree)
+    assert set(s['weight_l2s']) == set(stats_o['weight_l2s']), set(s['weight_l2s']) ^ set(stats_o['weight_l2s'])
+    for k, v in stats_o['weight_l2s'].items():
+      assert abs(s['weight_l2s'][k] - float(v)) <= 1e-5 * float(v) + 1e-12, k
+    assert 'weight' in s['losses'] and abs(s['losses']['weight'] - float(stats_o['losses']['weight'])) <= 1e-4 * float(stats_o['losses']['weight'])
+    for k in ('NerfMLP_0', 'PropMLP_0', 'NerfMLP_0/Dense_3', 'NerfMLP_0/Dense_3/kernel', 'PropMLP_0/Dense_1/bias'):
+      for name_, tol_ in (('grad_norms', 0.05), ('grad_maxes', 0.1), ('opt_update_norms', 0.05), ('opt_update_maxes', 0.05)):
+        want_v = float(stats_o[name_][k])
+        assert abs(s[name_][k] - want_v) <= tol_ * abs(want_v) + 1e-9, (name_, k, s[name_][k], want_v)
   print(f'{name}: loss kernel {s["loss"]:.6f} oracle_bf16 {float(stats_o["loss"]):.6f} oracle_fp32 {float(stats_32["loss"]):.6f}')
   assert abs(s['loss'] - float(stats_o['loss'])) <= 0.02 * abs(float(stats_o['loss'])) + 1e-5
   np.testing.assert_allclose(s['mses'], stats_o['mses'].detach().numpy(), rtol=0.03, atol=1e-5)

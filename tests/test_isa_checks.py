@@ -14,7 +14,7 @@ import shutil
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VALIDATED = os.path.join(ROOT, 'profiles', 'r3_validated_isa.json')
+VALIDATED = os.path.join(ROOT, 'profiles', 'r4_validated_isa.json')
 
 pytestmark = pytest.mark.skipif(not os.path.exists('/opt/rocm/bin/hipcc') and not shutil.which('hipcc'), reason='needs hipcc')
 
@@ -25,7 +25,7 @@ def report():
   mod = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(mod)
   bodies = {}
-  for f in ('gemm.hip', 'fused_mlp.hip'):
+  for f in ('gemm.hip', 'gemm_blk.hip', 'fused_mlp.hip'):
     bodies.update({n: b for n, b in mod.all_kernel_bodies(mod.compile_file(f)).items() if any('v_mfma' in l for l in b)})
   return mod, bodies
 
@@ -38,13 +38,14 @@ def _mfma_span(body):
 def test_the_shipped_mfma_kernels_are_all_there(report):
   _, bodies = report
   names = sorted(bodies)
-  assert sum('gemm_nt_kernel' in n for n in names) == 6          # NtBigP (pipelined) / NtBig / NtSmall, with / without bit-mask input
+  assert sum('gemm_nt_kernel' in n for n in names) == 7          # NtBigP (pipelined) / NtBig / NtSmall, with / without bit-mask input; NtBigP reading a panel A1
+  assert sum('gemm_nt_panel_kernel' in n for n in names) == 4    # panel result: forward / dX, A1 row-major / panel
   assert sum('gemm_nt_wres_kernel' in n for n in names) == 2
-  assert sum('gemm_tn_kernel' in n for n in names) == 2          # TnBig / TnSmall
+  assert sum('gemm_tn_kernel' in n for n in names) == 5          # TnBig / TnSmall; TnBig with panel A, panel B, both
   assert sum('mlp_chain_fwd_kernel' in n for n in names) == 2 and sum('mlp_chain_bwd_kernel' in n for n in names) == 2   # W = 128 / 256
   assert sum('mlp_chain_fwd_ipe_kernel' in n for n in names) == 2      # the inference chain with the in-kernel IPE producer
-  assert sum('gemm_tn_gcol_kernel' in n for n in names) == 1           # TnBig with one more B column from a vector
-  assert len(names) == 17, names
+  assert sum('gemm_tn_gcol_kernel' in n for n in names) == 2           # TnBig with one more B column from a vector; the same with a panel A
+  assert len(names) == 26, names
 
 
 def test_tiled_gemm_k_loops_carry_only_the_hand_counted_vmcnt_waits(report):
@@ -66,7 +67,7 @@ def test_pipelined_nt_loop_spreads_its_dma_between_the_mfmas(report):
   tile's reads)."""
   _, bodies = report
   pipe = {n: b for n, b in bodies.items() if 'gemm_nt_kernel' in n and 'Li32ELi4EE' in n}
-  assert len(pipe) == 2
+  assert len(pipe) == 3                                          # forward / dX with mask bits / forward from a panel A1
   for name, body in pipe.items():
     code = [l.split(';')[0].rstrip() for l in body]
     w = next(k for k, l in enumerate(code) if 's_waitcnt vmcnt(6)' in l)
@@ -96,6 +97,35 @@ def test_pipelined_nt_loop_spreads_its_dma_between_the_mfmas(report):
       run = run + 1 if 'global_load_lds' in l else 0
       longest = max(longest, run)
     assert longest <= 1, (name, longest)
+
+
+def test_panel_kernel_walk_has_no_spills_and_only_counted_waits(report):
+  """gemm_nt_panel_kernel (csrc/gemm_blk.hip): the whole walk over the tiles is one MFMA stream, so NOTHING may spill (with two
+  sets of tail flavours hipcc spilled per-lane constants and reloaded them, behind a vmcnt(0), in every K-tile; with 64-bit
+  integer divisions in the tile decode it kept six tile pointers in VGPR pairs); no wait of hipcc's own between the first and
+  the last MFMA; the steady-state K-tile block holds 16 MFMAs with its 4 LDS-DMA pieces spread between them; the interleaved
+  epilogue block holds the tile's 16 (+ 1 mask) stores and 32 half-wave exchanges between MFMAs."""
+  mod, bodies = report
+  pan = {n: b for n, b in bodies.items() if 'gemm_nt_panel_kernel' in n}
+  assert len(pan) == 4
+  for name, body in pan.items():
+    assert not any('scratch_' in l for l in body), name
+    assert mod.compiler_vmcnt_waits(_mfma_span(body)) == [], (name, mod.compiler_vmcnt_waits(_mfma_span(body)))
+    code = [l.split(';')[0].rstrip() for l in body]
+    starts = [k for k, l in enumerate(code) if l.startswith('.LBB')] + [len(code)]
+    blocks = [code[a:b] for a, b in zip(starts[:-1], starts[1:])]
+    steady = [b for b in blocks if sum('v_mfma' in l for l in b) == 16 and sum('global_load_lds' in l for l in b) == 4]
+    assert steady, name
+    for blk in steady:
+      ops = [l for l in blk if 'v_mfma' in l or 'global_load_lds' in l]
+      run = longest = 0
+      for l in ops:
+        run = run + 1 if 'global_load_lds' in l else 0
+        longest = max(longest, run)
+      assert longest <= 1, (name, longest)
+    epi = [b for b in blocks if sum('v_permlane32_swap' in l for l in b) == 32 and any('v_mfma' in l for l in b)]
+    assert len(epi) == 1, (name, len(epi))
+    assert sum('global_store_dwordx4' in l for l in epi[0]) in (16, 17), name
 
 
 def test_no_spills_inside_the_mfma_loops(report):
@@ -143,9 +173,9 @@ def test_fused_chain_weight_chunks_are_prefetched_not_waited_for_on_the_spot(rep
 
 
 def test_shipped_kernels_are_the_ones_validated_on_the_gpu(report):
-  """profiles/r3_validated_isa.json holds digests of the device code of every kernel as it ran the round-3 GPU suite and
+  """profiles/r4_validated_isa.json holds digests of the device code of every kernel as it ran the round-4 GPU suite and
   bench.  Host-side or simulator work must not change them; an intended kernel change re-validates on the GPU and rewrites
-  the file (python tools/isa_report.py --write-digests profiles/r3_validated_isa.json)."""
+  the file (python tools/isa_report.py --write-digests profiles/r4_validated_isa.json)."""
   mod, _ = report
   want = json.load(open(VALIDATED))['kernels']
   got = mod.all_digests()

@@ -199,3 +199,33 @@ def test_panel_trunk_equals_row_major_trunk():
   assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
   a, b = out[True][2].double(), out[False][2].double()
   assert ((a - b).norm() / b.norm()).item() < 1e-5
+
+
+def test_weight_decay_per_tree_key_and_logging_statistics():
+  """Config.weight_decay_mults with summarize_tree keys (train_utils.py:60-68,300-305: a module, a Dense inside one, one kernel)
+  and the per-key logging statistics (weight_l2s, grad_norms, grad_maxes, opt_update_norms / _maxes, :304,323-324,332-335)
+  against the oracle, on the simulator."""
+  name, extra, B = 'llff_raw', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32',
+                                "Config.weight_decay_mults = {'NerfMLP_0/Dense_2': 3e-3, 'NerfMLP_0/Dense_1/kernel': 1e-3, 'NerfMLP_0': 1e-5}"], 4
+  with S.simulated_device() as sim:
+    sim.lib.hipsim_reset(0, 0)
+    cfg, model, (om, on, op), params, flat, batch = _setup(name, extra, B)
+    noise = helpers.make_noise(model, B)
+    st = otrain.init_opt_state(params)
+    _, _, stats_o, _ = otrain.train_step(params, st, om, on, op, cfg, batch, 0.4, noise=noise, dense_dtype=torch.bfloat16)
+    state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+    _, stats, _ = train_utils.create_train_step(model, cfg)(0, state, batch, None, 0.4, 0.0, noise=noise, tree_stats=True)
+    sim.check()
+    s = stats.materialize()
+  assert set(s['weight_l2s']) == set(stats_o['weight_l2s'])
+  for k, v in stats_o['weight_l2s'].items():
+    assert abs(s['weight_l2s'][k] - float(v)) <= 1e-5 * float(v) + 1e-12, k
+  assert abs(s['losses']['weight'] - float(stats_o['losses']['weight'])) <= 1e-4 * float(stats_o['losses']['weight'])
+  for k in ('NerfMLP_0', 'NerfMLP_0/Dense_2', 'NerfMLP_0/Dense_1/kernel', 'NerfMLP_0/Dense_5/bias'):
+    for what, tol in (('grad_norms', 0.05), ('grad_maxes', 0.1), ('opt_update_norms', 0.05), ('opt_update_maxes', 0.05)):
+      want = float(stats_o[what][k])
+      assert abs(s[what][k] - want) <= tol * abs(want) + 1e-9, (what, k, s[what][k], want)
+  with pytest.raises(KeyError, match='not a key of the parameter tree'):
+    with S.simulated_device():
+      cfg2, model2, *_ = _setup(name, extra[:3] + ["Config.weight_decay_mults = {'NerfMLP_0/Dense_99': 1.0}"], B)
+      train_utils.create_train_step(model2, cfg2)

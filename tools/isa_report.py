@@ -1,4 +1,4 @@
-"""Device ISA of the MFMA kernels (csrc/gemm.hip, csrc/fused_mlp.hip), without a GPU: registers, spills, and the hot loops.
+"""Device ISA of the MFMA kernels (csrc/gemm.hip, csrc/gemm_blk.hip, csrc/fused_mlp.hip), without a GPU: registers, spills, and the hot loops.
 
     python tools/isa_report.py [--loop]                           # report
     python tools/isa_report.py --write-digests profiles/rN_validated_isa.json
@@ -145,7 +145,7 @@ def compile_file(name):
   return text
 
 
-KERNEL_FILES = ('gemm.hip', 'fused_mlp.hip', 'resample.hip', 'features.hip', 'render.hip', 'losses.hip', 'optim.hip', 'refnerf.hip',
+KERNEL_FILES = ('gemm.hip', 'gemm_blk.hip', 'fused_mlp.hip', 'resample.hip', 'features.hip', 'render.hip', 'losses.hip', 'optim.hip', 'refnerf.hip',
                 'camera.hip')
 
 
@@ -168,7 +168,7 @@ def main():
     print('wrote', path)
     return
   show_loop = '--loop' in sys.argv
-  for f in ('gemm.hip', 'fused_mlp.hip'):
+  for f in ('gemm.hip', 'gemm_blk.hip', 'fused_mlp.hip'):
     s = compile_file(f)
     meta = {}
     for m in re.finditer(r'- \.agpr_count:\s+(\d+)(.*?)\.wavefront_size', s, re.S):
