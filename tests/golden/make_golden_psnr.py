@@ -3,6 +3,11 @@
 
     python tests/golden/make_golden_psnr.py [--seed S]  # ~10 min on 8 cores; writes tests/golden/psnr360.json (seed 360) or
                                                         # psnr360_s<S>.json; the committed seeds are 360, 361, 362
+    python tests/golden/make_golden_psnr.py [--seed S] --dense_dtype bfloat16
+                                                        # the same run with the Dense operands rounded to bf16 (the oracle's
+                                                        # emulation of the MFMA inputs): psnr360_bf16[_s<S>].json; what of the
+                                                        # HIP - fp32-oracle difference is the precision the reference's own TPU
+                                                        # default pays (internal/math.py:21-23)
 
 tests/test_gpu_convergence.py::test_equal_step_psnr_360_full_width replays the same initialisation, the same batch and
 the same jitter at every step through the HIP path and compares the PSNR on the same held-out rays (north_star: "PSNR
@@ -43,9 +48,11 @@ def eval_rays(seed=None):
   return synthetic.unbounded_scene_rays(EVAL_RAYS, seed=seed * 100000 + 99999)
 
 
-def golden_path(seed):
-  """psnr360.json for the original seed, psnr360_s<seed>.json for the further ones (round 3: three seeds)."""
-  name = 'psnr360.json' if seed == SEED else f'psnr360_s{seed}.json'
+def golden_path(seed, bf16=False):
+  """psnr360.json for the original seed, psnr360_s<seed>.json for the further ones (round 3: three seeds); psnr360_bf16*.json
+  for the bf16-emulating oracle (round 4)."""
+  stem = 'psnr360_bf16' if bf16 else 'psnr360'
+  name = f'{stem}.json' if seed == SEED else f'{stem}_s{seed}.json'
   return os.path.join(ROOT, 'tests', 'golden', name)
 
 
@@ -55,9 +62,12 @@ def psnr(rgb, gt):
 
 def main():
   seed = int(sys.argv[sys.argv.index('--seed') + 1]) if '--seed' in sys.argv else SEED
+  dd_name = sys.argv[sys.argv.index('--dense_dtype') + 1] if '--dense_dtype' in sys.argv else None
+  assert dd_name in (None, 'bfloat16'), dd_name
+  dd = torch.bfloat16 if dd_name else None
   from multinerf_amd import configs, models
   from oracle import bridge, models as omodels, train_utils as otrain
-  torch.set_num_threads(os.cpu_count())
+  torch.set_num_threads(int(os.environ.get('PSNR_THREADS', os.cpu_count())))
   cfg = configs.load_preset('360', BINDINGS)
   model = models.Model(config=cfg)
   om, on, op = bridge.oracle_hparams(model)
@@ -68,16 +78,18 @@ def main():
   t0 = time.time()
   for step in range(1, STEPS + 1):
     batch, noise, tf = protocol(model, cfg, step, seed)
-    params, st, stats, _ = otrain.train_step(params, st, om, on, op, cfg, batch, tf, noise=noise)
+    params, st, stats, _ = otrain.train_step(params, st, om, on, op, cfg, batch, tf, noise=noise, dense_dtype=dd)
     if step % 50 == 0 or step == 1:
       with torch.no_grad():
-        rend, _ = omodels.model_apply(om, on, op, params, ev.rays, 1.0, False)
+        rend, _ = omodels.model_apply(om, on, op, params, ev.rays, 1.0, False, dense_dtype=dd)
       e = psnr(rend[-1]['rgb'].numpy(), ev.rgb.numpy())
       curve.append(dict(step=step, train_loss=float(stats['loss']), train_psnr=float(stats['psnr']), eval_psnr=e))
       print(f'step {step}: loss {float(stats["loss"]):.5f} train psnr {float(stats["psnr"]):.3f} eval psnr {e:.3f}  ({time.time() - t0:.0f} s)', flush=True)
   out = dict(steps=STEPS, rays=RAYS, eval_rays=EVAL_RAYS, seed=seed, bindings=BINDINGS, curve=curve,
-             note='oracle (fp32 torch-CPU restatement of the reference), configs/360.gin as is, procedural unbounded scene')
-  with open(golden_path(seed), 'w') as f:
+             dense_dtype=dd_name or 'float32',
+             note=('oracle (torch-CPU restatement of the reference' + (', Dense operands rounded to bf16' if dd else ', fp32') +
+                   '), configs/360.gin as is, procedural unbounded scene'))
+  with open(golden_path(seed, bf16=dd is not None), 'w') as f:
     json.dump(out, f, indent=1)
 
 
