@@ -221,17 +221,6 @@ int mnr_gemm_nt_panel_set_max_wgs(int n);
 /* A/B switch of the same kernel: 1 (default) = consecutive launches walk the M-tiles in alternating directions (a layer starts
  * with the rows the previous layer wrote last); 0 = always ascending.  Resets the direction of the next launch to ascending. */
 int mnr_gemm_nt_panel_set_alternate(int on);
-/* A/B switch (default on; environment MNR_WARM / MNR_WARM_AHEAD read at the first launch): the streamed operand of a wide trunk
- * GEMM is read ahead of the GEMM by a second, tiny kernel on a stream of the library's own (csrc/warm.h), so that the GEMM finds
- * it in the 256 MB Infinity Cache instead of waiting for HBM; `ahead` > 0 = progress units the reader may be in front (default 2,
- * NT: rounds of output tiles = 32 MiB of the operand each); on = 2 (tests) = also operands below 256 MB.  Results are bitwise the same
- * either way. */
-int mnr_set_warm(int on, int ahead);
-/* Tools: copies the 64 x 128 dwords of the warmers' progress ring to the host (dword 0 of a slot: id << 12 | progress; dwords 64..69:
- * units fetched, exit reason (0 all units, 1 GEMM over, 2 gave up), polls, 100 MHz ticks, units skipped, id).  Synchronises the device. */
-int mnr_warm_debug(unsigned* host_out);
-/* Tools: the warmers read this buffer (at least as large as the operand) instead of the operand; NULL = off. */
-int mnr_warm_set_decoy(const void* p);
 
 /* ---- Fused Dense chain (csrc/fused_mlp.hip): the trunk of internal/models.py:441-465 (Dense + ReLU layers, optionally
  * one skip concat of the input features, :458-459) and, for a density-only MLP, its Dense(1) head (:460) as ONE

@@ -159,9 +159,6 @@ _PROTOS = {
     'mnr_gemm_nt_set_wres': ([i32], i32),
     'mnr_gemm_nt_panel_set_max_wgs': ([i32], i32),
     'mnr_gemm_nt_panel_set_alternate': ([i32], i32),
-    'mnr_set_warm': ([i32, i32], i32),
-    'mnr_warm_debug': ([vp], i32),
-    'mnr_warm_set_decoy': ([vp], i32),
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
     'mnr_mlp_chain_fwd': ([C.POINTER(MlpChainFwdArgs), vp], i32),
     'mnr_mlp_chain_bwd': ([C.POINTER(MlpChainBwdArgs), vp], i32),

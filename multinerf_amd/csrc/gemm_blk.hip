@@ -27,7 +27,6 @@
 #include <type_traits>
 
 #include "common.h"
-#include "warm.h"
 
 // Probe builds (tools/panel_probe.py with MNR_LIB_PATH): 1 = the epilogue without its global stores, 2 = no epilogue at all
 // (K loop only), 3 = the epilogue without the mask bytes, 4 = no MFMAs (operand movement only), 5 = the counted waits of K-tiles 2
@@ -78,7 +77,7 @@ __device__ __forceinline__ unsigned pn_nonzero_byte(unsigned w0, unsigned w1, un
 }  // namespace
 
 template <bool A1_PANEL, bool BITS_IN>
-__global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, long long vtotal, int rev, unsigned* prog, unsigned prog_id) {
+__global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, long long vtotal, int rev) {
   constexpr int BM = PN_BM, BN = PN_BN, BK = PN_BK, STAGES = PN_STAGES, KS = PN_KS, MI = PN_MI, NJ = PN_NJ;
   constexpr int ROWB = PN_ROWB, A_BYTES = PN_A_BYTES, STAGE_BYTES = PN_STAGE_BYTES, LPS = PN_LPS, PPK = PN_PPK;
   constexpr int EXTRA = BITS_IN ? 8192 : 2048;           // per tile: the mask bits of a dX tile / two copies of the bias row
@@ -389,14 +388,9 @@ __global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, 
   // blocks).
   constexpr int STD = (STAGES - 3) * LPS + (KS - 1) * PPK;           // younger operations behind a K-tile in steady state
   int gk = 0;
-  // progress for the Infinity-Cache warmer of this launch (warm.h): workgroup 0 publishes the round of tiles it has started
-  const bool publish = prog != nullptr && blockIdx.x == 0 && wave == 0;
-  unsigned round = 0;
   ktile(gk, T(), F(), T(), T(), PN_I(STD), F(), a1t, a2t, bt, 3 * BK, 0, 0, 0);
   ktile(gk + 1, F(), F(), T(), T(), PN_I(STD), F(), a1t, a2t, bt, 4 * BK, 0, 0, 0);
   for (;;) {
-    if (publish) mnr_warm_publish(prog, prog_id, round);
-    ++round;
     int nv = v + gstep, nm = 0, nn = 0;
     while (nv < vtot && !decode(nv, nm, nn)) nv += gstep;
     const bool has_next = nv < vtot;
@@ -439,7 +433,6 @@ __global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, 
 #pragma unroll
     for (int q = 0; q < MI * NJ; ++q) epi_block(q % NJ, q / NJ);
   }
-  if (publish) mnr_warm_publish(prog, prog_id, MNR_WARM_DONE);
   nt_wait_vmcnt<0>();
 #undef PN_I
 }
@@ -464,22 +457,8 @@ static int panel_launch_t(const mnr_gemm_nt_args* a, int64_t grid, int64_t vtota
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
   if (mnr_attr_needed(&attr_set))
     (void)hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<A1_PANEL, BITS_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  // Infinity-Cache warmer of the streamed operand(s) (warm.h): round r of the walk reads the A rows of `grid / nt` consecutive
-  // M-tiles; it needs whole rounds and operands whose M-tiles are contiguous (panel A1 or lda == K)
-  mnr_warm_ticket tk = {nullptr, 0};
-  {
-    const int nt = a->N / PN_BN;
-    const int64_t mt = a->M / PN_BM;
-    const int64_t per = grid / nt;                        // M-tiles per round
-    const bool whole = grid % (8 * nt) == 0 && per > 0 && mt % per == 0 && vtotal == mt * nt;
-    const bool c1 = a->lda1 == a->K1, c2 = a->K2 == 0 || a->lda2 == a->K2;
-    if (whole && c1 && c2 && (int64_t)a->M * (a->K1 + a->K2) * 2 >= mnr_warm_min_bytes()) {
-      mnr_warm_tensor t[2] = {{a->A1, per * PN_BM * (long long)a->K1 * 2, 0}, {a->A2, per * PN_BM * (long long)a->K2 * 2, 0}};
-      tk = mnr_warm_begin(t, a->K2 ? 2 : 1, (int)(mt / per), 1, g_panel_rev_next, stream);
-    }
-  }
   hipLaunchKernelGGL((gemm_nt_panel_kernel<A1_PANEL, BITS_IN>), dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, *a,
-                     (long long)vtotal, g_panel_rev_next, tk.slot, tk.id);
+                     (long long)vtotal, g_panel_rev_next);
   if (g_panel_alternate) g_panel_rev_next ^= 1;
   MNR_CHECK_LAUNCH();
   return MNR_OK;

@@ -286,36 +286,6 @@ def test_nt_panel_kernel_forward_and_dx(sim, a1_panel, mode):
 
 
 @pytest.mark.parametrize('mode', [MODES[1], MODES[3]])
-def test_nt_panel_kernel_publishes_its_progress_for_the_warmer(sim, mode):
-  """csrc/warm.h: workgroup 0 of a warmed launch publishes the round of tiles it has started (one more store in wave 0's vmcnt
-  queue: the counted waits get more conservative, never less) and MNR_WARM_DONE at its end.  mnr_set_warm(2, .) drops the size
-  threshold; the simulator runs no warmer, it checks the waits and the values.  16 workgroups over 32 tiles: two whole rounds of
-  8 M-tiles, two activation segments, ascending and descending."""
-  g = torch.Generator().manual_seed(5)
-  M, N, K1, K2 = 4096, 512, 128, 64
-  A1 = torch.randn((M, K1), generator=g).bfloat16()
-  A2 = torch.randn((M, K2), generator=g).bfloat16()
-  Bt = (torch.randn((N, K1 + K2), generator=g) * 0.1).bfloat16()
-  bias = torch.randn(N, generator=g)
-  sim.mnr_gemm_nt_set_wres(0)
-  try:
-    sim.mnr_set_warm(0, 2)
-    sim.mnr_gemm_nt_panel_set_alternate(1)
-    sim.mnr_gemm_nt_panel_set_max_wgs(16)
-    sim.hipsim_reset(*mode)
-    C0, _, b0 = S.sim_gemm_nt(sim, _ops.to_panel(A1), Bt, A2=A2, bias=bias, relu=True, bits_out=True, a1_layout=1, c_layout=1)
-    sim.mnr_set_warm(2, 2)
-    for _ in range(2):                                # ascending, then descending
-      sim.hipsim_reset(*mode)
-      C1, _, b1 = S.sim_gemm_nt(sim, _ops.to_panel(A1), Bt, A2=A2, bias=bias, relu=True, bits_out=True, a1_layout=1, c_layout=1)
-      assert torch.equal(C1.view(torch.int16), C0.view(torch.int16)) and torch.equal(b1, b0)
-  finally:
-    sim.mnr_set_warm(1, 2)
-    sim.mnr_gemm_nt_panel_set_max_wgs(0)
-    sim.mnr_gemm_nt_set_wres(1)
-
-
-@pytest.mark.parametrize('mode', [MODES[1], MODES[3]])
 def test_nt_tiled_kernel_reads_a_panel_activation(sim, mode):
   """The merged head behind a panel-layout trunk: the pipelined tiled kernel with A1 in panel storage, row-major bf16 result
   narrower than N plus an fp32 side column: bitwise the row-major call."""

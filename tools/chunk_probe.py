@@ -56,42 +56,6 @@ def timed(fn, reps=3):
   return e0.elapsed_time(e1) * 1e3 / reps
 
 
-# read-warming: a reduction over the chunk (HBM -> Infinity Cache) right in front of the GEMM launch that reads it
-def run_warm(R, warm, gemm=True):
-  for l in range(L):
-    for r0 in range(0, M, R):
-      if warm:
-        torch.amax(acts[l][r0 * W:(r0 + R) * W].view(torch.int16))
-      if gemm:
-        layer(l, r0, R)
-
-
-if os.environ.get('DECOY'):
-  decoy = torch.zeros((M * W,), dtype=bf, device=dev)
-  ops.L.check(ops.lib().mnr_warm_set_decoy(decoy.data_ptr()))
-if os.environ.get('FULL_ONLY'):              # the product's order only (A/B of the Infinity-Cache warmer: MNR_WARM, MNR_WARM_AHEAD)
-  for _ in range(3):
-    t = timed(lambda: run(M), reps=5)
-    print(f'layer-major, whole launches: {t / L:8.1f} us per layer of {M} rows ({2.0 * M * W * W * L / t / 1e6:6.1f} TF/s)', flush=True)
-  if os.environ.get('MNR_WARM', '1') != '0':
-    import ctypes, numpy as np
-    buf = np.zeros(64 * 128, dtype=np.uint32)
-    ops.L.check(ops.lib().mnr_warm_debug(buf.ctypes.data_as(ctypes.c_void_p)))
-    b = buf.reshape(64, 128)
-    rows = [(int(r[69]), int(r[0]) >> 12, int(r[0]) & 0xfff, int(r[64]), int(r[65]), int(r[66]), int(r[67]) / 100.0, int(r[68])) for r in b if r[69]]
-    rows.sort()
-    for r in rows[-8:]:
-      print('  warmer id %d: slot id %d progress %x, fetched %d units, exit reason %d, polls %d, %.1f us, skipped %d' % r)
-  sys.exit(0)
-for R in (65536, 32768):
-  t_w = timed(lambda: run_warm(R, True))
-  t_r = timed(lambda: run_warm(R, True, gemm=False))
-  t_g = timed(lambda: run_warm(R, False))
-  print(f'read-warmed layer-major R = {R}: reads + GEMMs {t_w / L:8.1f} us per layer, the reads alone {t_r / L:8.1f}, the GEMMs alone (cold) {t_g / L:8.1f}'
-        f'  -> GEMMs behind a warming read {(t_w - t_r) / L:8.1f}', flush=True)
-if os.environ.get('WARM_ONLY'):
-  sys.exit(0)
-
 ref = None
 for R, cm in ((M, True), (131072, True), (131072, False), (65536, True), (65536, False), (32768, True), (32768, False), (16384, True), (16384, False),
               (65536, True), (65536, False), (M, True)):

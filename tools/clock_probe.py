@@ -1,7 +1,6 @@
 """Shader clock and board power under the trunk GEMMs (tools/clock_probe.hip: a sampler kernel that runs NEXT to the GEMMs).
 
     python tools/clock_probe.py            # the forward stack of tools/chunk_probe.py, whole launches
-    DECOY=1 python tools/clock_probe.py    # the same with the warmers reading 1 GB of unrelated memory per launch
     MNR_LIB_PATH=.../libmnerf_hip_pn11.so python tools/clock_probe.py    # A operand out of the Infinity Cache (probe build)
 """
 import ctypes
@@ -26,9 +25,6 @@ acts = [torch.relu(torch.rand((M * W,), generator=g, device=dev) * 2 - 1).to(bf)
 bits = [torch.zeros((M * W // 8,), dtype=torch.uint8, device=dev) for _ in range(L)]
 Bts = [((torch.rand((W, W), generator=g, device=dev) * 2 - 1) * (6.0 / W) ** 0.5).to(bf) for _ in range(L)]
 biases = [0.05 * torch.randn((W,), generator=g, device=dev) for _ in range(L)]
-if os.environ.get('DECOY'):
-  decoy = torch.zeros((M * W,), dtype=bf, device=dev)
-  ops.L.check(ops.lib().mnr_warm_set_decoy(decoy.data_ptr()))
 
 
 def stack():
