@@ -108,12 +108,16 @@ def _u_base(n, jittered):
   return torch.linspace(pad, 1. - pad - eps, n), 0.0
 
 
-@pytest.mark.parametrize('case', ['level0_det', 'level1_360_jit1', 'level2_360_jit1', 'nodil_jitn', 'b256_dil'])
-def test_resample_level(ops, case):
-  gen = torch.Generator().manual_seed(3)
-  B = 200
+@pytest.mark.parametrize('case,B', [('level0_det', 200), ('level1_360_jit1', 200), ('level2_360_jit1', 200), ('nodil_jitn', 200), ('b256_dil', 200),
+                                    # every level of configs/360.gin at the benchmark's batch (round-3 verdict: 200 rays were the whole
+                                    # evidence for "bit-exact indices"): 1.0 M / 1.0 M / 0.5 M indices, half of the rays with the peaked
+                                    # weights a trained proposal network produces
+                                    ('level0_jit1', 16384), ('level1_360_jit1', 16384), ('level2_360_jit1', 16384)])
+def test_resample_level(ops, case, B):
+  gen = torch.Generator().manual_seed(3 + B)
   cfgs = {
       'level0_det': dict(np_=1, n=64, use_dil=False, dil=0.5025, anneal=0.9090909, pad=0.0, single=True, jit=False, raydist='reciprocal', near=0.2, far=1e6),
+      'level0_jit1': dict(np_=1, n=64, use_dil=False, dil=0.5025, anneal=0.9090909, pad=0.0, single=True, jit=True, raydist='reciprocal', near=0.2, far=1e6),
       'level1_360_jit1': dict(np_=64, n=64, use_dil=True, dil=0.0103125, anneal=0.9090909, pad=0.0, single=True, jit=True, raydist='reciprocal', near=0.2, far=1e6),
       'level2_360_jit1': dict(np_=64, n=32, use_dil=True, dil=0.00262207, anneal=1.0, pad=0.0, single=True, jit=True, raydist='reciprocal', near=0.2, far=1e6),
       'nodil_jitn': dict(np_=128, n=128, use_dil=False, dil=0.0, anneal=1.0, pad=0.01, single=False, jit=True, raydist=None, near=2.0, far=6.0),
@@ -125,6 +129,11 @@ def test_resample_level(ops, case):
     w = torch.ones((B, 1))
   else:
     sd, w = rand_stepfun(gen, B, c['np_'])
+    if B > 1000:
+      # half of the rays: one or two narrow peaks over a floor of tiny weights (a surface hit), incl. exact zeros
+      peaked = torch.softmax(torch.randn((B, c['np_']), generator=gen) * 12, -1)
+      peaked[peaked < 1e-7] = 0.0
+      w = torch.where((torch.arange(B) % 2 == 0)[:, None], w, peaked)
     w = w * 0.98   # alpha-compositing weights sum to <= 1
   near = torch.full((B, 1), c['near'])
   far = torch.full((B, 1), c['far'])
@@ -143,7 +152,7 @@ def test_resample_level(ops, case):
   # Sample indices are bit-exact (north_star) BY CONSTRUCTION: every operation between the inputs and the index is an
   # individually rounded IEEE fp32 +, -, *, / or comparison in a documented order (blocked sums; the path's own exp / log,
   # csrc/resample.hip rs_exp / rs_log = oracle/math.py kexp / klog), restated operation for operation in the oracle.
-  print(f'{case}: index mismatch rate {mismatch:.2e} ({int((idx.cpu() != idx_ref).sum())} of {idx_ref.numel()})')
+  print(f'{case} B={B}: index mismatch rate {mismatch:.2e} ({int((idx.cpu() != idx_ref).sum())} of {idx_ref.numel()})')
   assert mismatch == 0
   # ... and, REPORTED rather than assumed zero (SURVEY hard part 3 iii): the same kernel output against the oracle evaluated in
   # the REFERENCE's association order (left-to-right sums / cumsum, the host library's exp / log: stepfun.py:146,156)
@@ -151,12 +160,22 @@ def test_resample_level(ops, case):
     s_ro, _, idx_ro = _resample_ref(sd, w, u_jit, near, far, n=c['n'], use_dil=c['use_dil'], dil=c['dil'],
                                     anneal=c['anneal'], pad=c['pad'], single=c['single'], raydist=c['raydist'])
   mism_ro = int((idx.cpu() != idx_ro).sum())
-  print(f'{case}: vs the oracle in REFERENCE order: index mismatches {mism_ro} of {idx_ro.numel()} '
+  print(f'{case} B={B}: vs the oracle in REFERENCE order: index mismatches {mism_ro} of {idx_ro.numel()} '
         f'({mism_ro / idx_ro.numel():.2e}); max |s - s_ref_order| {(s.cpu() - s_ro).abs().max().item():.2e}')
-  assert mism_ro / idx_ro.numel() < 5e-3
-  np.testing.assert_allclose(s.cpu().numpy(), s_ro.numpy(), atol=2e-4, rtol=0)      # measured <= 6.6e-5 (level2_360_jit1)
+  assert mism_ro / idx_ro.numel() < (5e-3 if B < 1000 else 1e-4)
+  # (positions where the index agrees; a sample that lands in the neighbouring bin sits a bin width away: up to 1.4e-3 with the
+  # peaked weights of the full-batch cases)
+  ok_ro = torch.nn.functional.pad(idx.cpu() == idx_ro, (1, 1), value=True)
+  edge_ok = ok_ro[..., :-1] & ok_ro[..., 1:]                      # interval edges whose two neighbouring samples agree
+  d_ok = (s.cpu() - s_ro)[edge_ok].abs().max().item()
+  print(f'{case} B={B}: max |s - s_ref_order| where the indices agree {d_ok:.2e}')
+  # measured <= 6.6e-5 at 200 rays (level2_360_jit1); the peaked weights of the full-batch cases have bins whose CDF step is a few
+  # ulps, inside which (u - cw0) / (cw1 - cw0) turns a 1-ulp softmax difference into a fraction of the (narrow) bin
+  assert d_ok < (2e-4 if B < 1000 else 2e-3)
+  assert (s.cpu() - s_ro).abs().max().item() < 5e-3
   same = (idx.cpu() == idx_ref).all(-1)
   # (u - cw0)/(cw1 - cw0) amplifies the <=1-ulp softmax differences inside narrow bins: 5e-5 in s.
+  print(f'{case} B={B}: max |s - s_kernel_order| {(s.cpu() - s_ref).abs().max().item():.2e}')
   np.testing.assert_allclose(s.cpu().numpy(), s_ref.numpy(), atol=5e-5, rtol=0)
   rel = ((t.cpu() - t_ref).abs() / t_ref.abs().clamp_min(1e-6))
   # reciprocal warp amplifies 1-ulp s differences near s=1 (t ~ 1e5..1e6): relative tolerance there.

@@ -82,6 +82,24 @@ TOL32 = {
 # blender_refnerf 3.1e-4 / 4.0e-4 / 7.6e-4 / 0.020)
 
 
+# Composed extras of the final level (render.py:176-213), max relative difference against the bf16-emulating oracle (floor 1e-3
+# on the denominator): 2 x the maximum measured over the cases of a preset in round 4 (profiles/r4e_model_fwd_s.log, the EXTRA
+# lines, which also print the distance to the plain fp32 oracle), floors 1e-5 for `acc` (a sum of weights: 1 up to rounding with an
+# opaque background) and 5e-4 for the distances.  The distances are weighted means / percentiles of t: a weight difference of d
+# moves a percentile by d / (weight of its bin) bins, so the percentiles of the 360 preset (t up to 1e6, reduced test widths)
+# carry the largest numbers.  Round 3 held every key of every preset to 5e-2.
+EXTRA_TOL = {
+    # measured: acc 3.6e-7, mean 6.0e-3, median 9.1e-3, p5 4.1e-3, p95 1.9e-2
+    '360': dict(acc=1e-5, distance_mean=1.2e-2, distance_median=1.9e-2, distance_percentile_5=8.5e-3, distance_percentile_95=3.8e-2),
+    # measured: 3.8e-4, 4.8e-4, 1.0e-3, 2.2e-4, 2.5e-3
+    'blender_256': dict(acc=8e-4, distance_mean=1e-3, distance_median=2.1e-3, distance_percentile_5=5e-4, distance_percentile_95=5e-3),
+    # measured: 8.3e-7, 5.9e-5, 0, 4.8e-4, 0
+    'llff_raw': dict(acc=1e-5, distance_mean=5e-4, distance_median=5e-4, distance_percentile_5=1e-3, distance_percentile_95=5e-4),
+    # measured: 9.7e-6, 1.5e-4, 2.9e-4, 3.3e-5, 2.9e-4
+    'blender_refnerf': dict(acc=2e-5, distance_mean=5e-4, distance_median=6e-4, distance_percentile_5=5e-4, distance_percentile_95=6e-4),
+}
+
+
 def _tols(name, extra):
   """(TOL, TOL32) of a case.  Non-ReLU activations run as GEMM (bf16 pre-activation) + activation kernel: two bf16
   roundings per layer where the ReLU epilogue has one, so those cases get twice the forward tolerances (measured on the
@@ -182,7 +200,9 @@ def test_forward_parity(name, extra, B, randomized):
   for k in ('acc', 'distance_mean', 'distance_median', 'distance_percentile_5', 'distance_percentile_95'):
     a, b = rend[-1][k].cpu(), r_bf[-1][k]
     rel = ((a - b).abs() / b.abs().clamp_min(1e-3)).max().item()
-    assert rel < 0.05, (k, rel)
+    rel32 = ((a - r_32[-1][k]).abs() / r_32[-1][k].abs().clamp_min(1e-3)).max().item()
+    print(f'{name} rand={randomized}: EXTRA {k} rel |kernel - oracle_bf16| {rel:.2e}, |kernel - oracle_fp32| {rel32:.2e}')
+    assert rel < EXTRA_TOL[name][k], (k, rel)
   assert rend[0]['ray_sdist'].shape == r_bf[0]['ray_sdist'].shape
   assert rend[0]['ray_rgbs'].shape == r_bf[0]['ray_rgbs'].shape
 

@@ -89,14 +89,33 @@ def test_full_batch_rows_are_the_small_batch_and_the_small_batch_is_the_oracle(s
   assert err <= max(5e-3, 3 * cost)
 
 
-N_TRAIN = int(os.environ.get('MNR_FULLSIZE_TRAIN_RAYS', '32'))
-# Stated tolerances of the full-width gradient (relative L2 per top-level module / per Dense kernel), against the
-# bf16-emulating oracle and against the plain fp32 oracle; measured values are printed next to them (round 3, first
-# GPU call: see DESIGN.md section 2).
-# Measured (gpurun_out/r3_gpu_tests1.log, 32 rays): NerfMLP_0 3.5e-2 / 8.2e-2 (bf16 cost 8.3e-2), PropMLP_0 1.2e-2 / 2.8e-2;
-# per Dense the error grows with the distance from the output: trunk layer 7 2.1e-2 / 4.8e-2 ... layer 0 1.6e-1 / 3.8e-1
-# (where the oracle's own bf16 cost is 3.8e-1): about 1.5x headroom.
-GRAD_TOL = dict(module_bf16=0.06, module_fp32=0.13, dense_bf16=0.25, dense_fp32=0.55)
+N_TRAIN = int(os.environ.get('MNR_FULLSIZE_TRAIN_RAYS', '256'))
+# Stated tolerances of the full-width gradient (relative L2 per top-level module / per Dense kernel) against the bf16-emulating
+# oracle and against the plain fp32 oracle: 1.5 x the values measured on 256 rays in round 4 (profiles/r4e_fullsize_s.log, the
+# FULLWIDTH lines; round 3 ran 32 rays, where the oracle's own bf16 cost was 0.38 on trunk layer 0 and the bound 0.25 / 0.55 for
+# every layer).  The error grows with the distance from the output; the oracle's own bf16-vs-fp32 distance (printed as "bf16
+# cost") is what the fp32 column is made of.
+GRAD_TOL_MODULE = {'NerfMLP_0': (1.8e-2, 4.1e-2), 'PropMLP_0': (5.5e-3, 1.8e-2)}      # measured 1.15e-2 / 2.69e-2 and 3.6e-3 / 1.19e-2
+GRAD_TOL_DENSE = {                                                                   # measured (bf16 / fp32)
+    'NerfMLP_0/Dense_0': (0.135, 0.31),      # 9.0e-2 / 2.05e-1   [504 x 1024]
+    'NerfMLP_0/Dense_1': (0.062, 0.142),     # 4.1e-2 / 9.5e-2
+    'NerfMLP_0/Dense_2': (0.042, 0.097),     # 2.8e-2 / 6.5e-2
+    'NerfMLP_0/Dense_3': (0.029, 0.070),     # 1.9e-2 / 4.7e-2
+    'NerfMLP_0/Dense_4': (0.0225, 0.053),    # 1.5e-2 / 3.5e-2
+    'NerfMLP_0/Dense_5': (0.022, 0.051),     # 1.45e-2 / 3.4e-2   [1528 x 1024], the skip layer
+    'NerfMLP_0/Dense_6': (0.015, 0.035),     # 1.0e-2 / 2.3e-2
+    'NerfMLP_0/Dense_7': (0.011, 0.0255),    # 7.3e-3 / 1.7e-2
+    'NerfMLP_0/Dense_8': (0.0095, 0.046),    # 6.3e-3 / 3.1e-2    density head [1024 x 1]
+    'NerfMLP_0/Dense_9': (0.0083, 0.0192),   # 5.5e-3 / 1.3e-2    bottleneck
+    'NerfMLP_0/Dense_10': (0.009, 0.020),    # 6.0e-3 / 1.3e-2    view MLP
+    'NerfMLP_0/Dense_11': (0.0057, 0.0133),  # 3.8e-3 / 8.8e-3    rgb head
+    'PropMLP_0/Dense_0': (0.0176, 0.053),    # 1.17e-2 / 3.5e-2
+    'PropMLP_0/Dense_1': (0.0082, 0.0242),   # 5.5e-3 / 1.6e-2
+    'PropMLP_0/Dense_2': (0.0056, 0.0168),   # 3.7e-3 / 1.1e-2
+    'PropMLP_0/Dense_3': (0.0045, 0.014),    # 3.0e-3 / 9.4e-3
+    'PropMLP_0/Dense_4': (0.0025, 0.0137),   # 1.7e-3 / 9.1e-3
+}
+GRAD_TOL_BIAS = 0.25        # bias gradients (8+ entries): the round-3 bound, they were not tabulated
 
 
 def test_full_width_train_step_gradient_is_the_oracles(setup):
@@ -131,7 +150,8 @@ def test_full_width_train_step_gradient_is_the_oracles(setup):
     cos = (g[b:e] @ g_bf[b:e] / (g[b:e].norm() * g_bf[b:e].norm() + 1e-30)).item()
     print(f'FULLWIDTH {name}: |g - oracle_bf16| / |g| = {r_bf:.3e}, |g - oracle_fp32| / |g| = {r_32:.3e} '
           f'(bf16 cost {cost:.3e}), cos {cos:.6f}, |g| = {g_bf[b:e].norm().item():.3e}')
-    assert cos > 0.995 and r_bf <= GRAD_TOL['module_bf16'] and r_32 <= GRAD_TOL['module_fp32'], (name, cos, r_bf, r_32)
+    tb, t32 = GRAD_TOL_MODULE.get(name, (0.06, 0.13))
+    assert cos > 0.999 and r_bf <= tb and r_32 <= t32, (name, cos, r_bf, r_32)
   worst_bf = worst_32 = 0.0
   for p in model._plans:
     for d in p.dense:
@@ -141,11 +161,16 @@ def test_full_width_train_step_gradient_is_the_oracles(setup):
       r_bf, r_32, cost = rel(g[o:o + nelem], g_bf[o:o + nelem]), rel(g[o:o + nelem], g_32[o:o + nelem]), rel(g_bf[o:o + nelem], g_32[o:o + nelem])
       print(f'FULLWIDTH LAYER {p.module_name}/{d.name}/kernel [{d.fan_in}x{d.fan_out}]: bf16 {r_bf:.3e} fp32 {r_32:.3e} (bf16 cost {cost:.3e})')
       worst_bf, worst_32 = max(worst_bf, r_bf), max(worst_32, r_32)
+      if N_TRAIN >= 256:
+        tb, t32 = GRAD_TOL_DENSE[f'{p.module_name}/{d.name}']
+        assert r_bf <= tb and r_32 <= t32, (p.module_name, d.name, r_bf, tb, r_32, t32)
       ob, nb_ = d.bias_off, d.fan_out
       if nb_ >= 8:
-        worst_bf = max(worst_bf, rel(g[ob:ob + nb_], g_bf[ob:ob + nb_]))
+        rb = rel(g[ob:ob + nb_], g_bf[ob:ob + nb_])
+        print(f'FULLWIDTH LAYER {p.module_name}/{d.name}/bias [{nb_}]: bf16 {rb:.3e}')
+        assert rb <= GRAD_TOL_BIAS, (p.module_name, d.name, rb)
   print(f'FULLWIDTH worst Dense: bf16 {worst_bf:.3e} fp32 {worst_32:.3e}')
-  assert worst_bf <= GRAD_TOL['dense_bf16'] and worst_32 <= GRAD_TOL['dense_fp32'], (worst_bf, worst_32)
+  assert worst_bf <= 0.25 and worst_32 <= 0.55, (worst_bf, worst_32)                     # (any ray count)
   # one numeric Adam step at 9.0 M parameters on the kernel's own gradient
   helpers.assert_adam_matches_oracle(model, cfg, flat.float().cpu(), g.float(), None, state2, what='full width: ')
 
