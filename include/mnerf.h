@@ -484,6 +484,13 @@ int mnr_ref_losses(int64_t B_valid, int n, float mult_orientation, float mult_pr
                    const float* weights, const float* normals, const float* normals_pred, const float* viewdirs,
                    float* stats, float* g_weights, float* g_normals, float* g_normals_pred, void* stream);
 /* out[b,c] = sum_i weights[b,i] values[b,i,c]  (render.py:187-190 extras). */
+/* Predicted normals without the rest of the Ref-NeRF head (internal/models.py:494-503 with enable_pred_normals only):
+ * normals_pred[M,3] = -l2_normalize(small[:, col .. col+2]) (ref_utils.py:40-42) from the head GEMM's fp32 side output [M, ld];
+ * _bwd: the VJP of the same into columns col_g .. col_g+2 of the head's bf16 gradient matrix [M, lddhb].
+ * mnr_ref_losses takes normals = NULL for such an MLP (mult_pred_normal == 0, target_is_pred = 1, g_normals = NULL). */
+int mnr_pred_normals_fwd(int64_t M, const float* small, int ld, int col, float* normals_pred_out, void* stream);
+int mnr_pred_normals_bwd(int64_t M, const float* small, int ld, int col, const float* g_normals_pred, uint16_t* dhb, int lddhb,
+                         int col_g, void* stream);
 int mnr_weighted_sum(int64_t B, int n, int C, const float* weights, const float* values, float* out, void* stream);
 
 /* ------------------------------------------------------------------------- *

@@ -188,6 +188,8 @@ _PROTOS = {
     'mnr_ref_color_bwd': ([i64, vp, vp, f32, f32, f32, i32, vp, vp, vp, i32, i32, i32, vp], i32),
     'mnr_ref_losses': ([i64, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_weighted_sum': ([i64, i32, i32, vp, vp, vp, vp], i32),
+    'mnr_pred_normals_fwd': ([i64, vp, i32, i32, vp, vp], i32),
+    'mnr_pred_normals_bwd': ([i64, vp, i32, i32, vp, vp, i32, i32, vp], i32),
     'mnr_lossmult_sum': ([i64, vp, i32, vp, vp], i32),
     'mnr_render_metrics': ([i64, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_data_loss': ([i32, f32, f32, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp], i32),

@@ -317,6 +317,49 @@ extern "C" int mnr_ref_head_bwd(int64_t M, int n, const float* small, const floa
 }
 
 // ---------------------------------------------------------------------------
+// Predicted normals WITHOUT the rest of the Ref-NeRF head (models.py:494-503 with enable_pred_normals only): normals_pred =
+// -l2_normalize(grad_pred) from three columns of the head's fp32 side output, and the VJP into the head's gradient matrix.
+
+__global__ void pred_normals_kernel(int64_t M, const float* __restrict__ small, int ld, int col, float* __restrict__ npred_out,
+                                    const float* __restrict__ g_npred, bf16* __restrict__ dhb, int lddhb, int col_g) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= M) return;
+  const float gp[3] = {small[s * ld + col], small[s * ld + col + 1], small[s * ld + col + 2]};
+  float np[3], r;
+  bool c;
+  rf_neg_normalize(gp, np, r, c);                              // models.py:498
+  if (npred_out) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) npred_out[s * 3 + i] = np[i];
+  }
+  if (g_npred) {
+    const float g[3] = {g_npred[s * 3], g_npred[s * 3 + 1], g_npred[s * 3 + 2]};
+    float gx[3];
+    rf_neg_normalize_bwd(gp, r, c, g, gx);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dhb[s * lddhb + col_g + i] = (bf16)gx[i];
+  }
+}
+
+extern "C" int mnr_pred_normals_fwd(int64_t M, const float* small, int ld, int col, float* normals_pred_out, void* stream) {
+  MNR_CHECK_ARG(M > 0 && small && normals_pred_out && col >= 0 && col + 3 <= ld, "mnr_pred_normals_fwd: bad argument");
+  hipLaunchKernelGGL(pred_normals_kernel, dim3(mnr_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, M, small, ld, col,
+                     normals_pred_out, (const float*)nullptr, (bf16*)nullptr, 0, 0);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+extern "C" int mnr_pred_normals_bwd(int64_t M, const float* small, int ld, int col, const float* g_normals_pred, uint16_t* dhb,
+                                    int lddhb, int col_g, void* stream) {
+  MNR_CHECK_ARG(M > 0 && small && g_normals_pred && dhb && col >= 0 && col + 3 <= ld && col_g >= 0 && col_g + 3 <= lddhb,
+                "mnr_pred_normals_bwd: bad argument");
+  hipLaunchKernelGGL(pred_normals_kernel, dim3(mnr_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, M, small, ld, col,
+                     (float*)nullptr, g_normals_pred, (bf16*)dhb, lddhb, col_g);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Colour combine (models.py:584-602 with use_diffuse_color / use_specular_tint; image.py:48-56).
 
 __device__ __forceinline__ float rf_linear_to_srgb(float lin) {
@@ -395,19 +438,22 @@ __global__ void ref_losses_kernel(int64_t B_valid, int n, float mult_orient, flo
       const float* nt = (target_is_pred ? npred : normals) + s * 3;
       const float ndv = nt[0] * v[0] + nt[1] * v[1] + nt[2] * v[2];
       const float neg = fminf(0.0f, ndv);
-      const float dot = normals[s * 3] * npred[s * 3] + normals[s * 3 + 1] * npred[s * 3 + 1] +
-                        normals[s * 3 + 2] * npred[s * 3 + 2];
+      // (normals == NULL: an MLP with predicted normals only, models.py:494-503 with disable_density_normals; the host admits it
+      // with mult_pred == 0 and the predicted normals as the orientation target)
+      const float dot = normals ? normals[s * 3] * npred[s * 3] + normals[s * 3 + 1] * npred[s * 3 + 1] +
+                                      normals[s * 3 + 2] * npred[s * 3 + 2]
+                                : 1.0f;
       lo += w * neg * neg;                                     // :173
       lp += w * (1.0f - dot);                                  // :192
       if (g_w) g_w[s] += (mult_orient * neg * neg + mult_pred * (1.0f - dot)) * invB;
-      if (g_n) {
+      if (g_npred) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           float gn = -mult_pred * w * npred[s * 3 + c] * invB;
-          float gp = -mult_pred * w * normals[s * 3 + c] * invB;
+          float gp = normals ? -mult_pred * w * normals[s * 3 + c] * invB : 0.0f;
           const float go = mult_orient * w * 2.0f * neg * v[c] * invB;
           if (target_is_pred) gp += go; else gn += go;
-          g_n[s * 3 + c] = gn;
+          if (g_n) g_n[s * 3 + c] = gn;
           g_npred[s * 3 + c] = gp;
         }
       }
@@ -428,9 +474,10 @@ extern "C" int mnr_ref_losses(int64_t B_valid, int n, float mult_orientation, fl
                               int target_is_pred, const float* weights, const float* normals,
                               const float* normals_pred, const float* viewdirs, float* stats, float* g_weights,
                               float* g_normals, float* g_normals_pred, void* stream) {
-  MNR_CHECK_ARG(B_valid > 0 && n > 0 && weights && normals && normals_pred && viewdirs && stats,
-                "mnr_ref_losses: null argument");
-  MNR_CHECK_ARG((g_normals == nullptr) == (g_normals_pred == nullptr), "mnr_ref_losses: g_normals and g_normals_pred go together");
+  MNR_CHECK_ARG(B_valid > 0 && n > 0 && weights && normals_pred && viewdirs && stats, "mnr_ref_losses: null argument");
+  MNR_CHECK_ARG(normals || (mult_pred_normal == 0.0f && target_is_pred && !g_normals),
+                "mnr_ref_losses: without density-gradient normals only the orientation loss on the predicted normals is defined");
+  MNR_CHECK_ARG(!normals || (g_normals == nullptr) == (g_normals_pred == nullptr), "mnr_ref_losses: g_normals and g_normals_pred go together");
   hipLaunchKernelGGL(ref_losses_kernel, dim3(mnr_cdiv(B_valid, 64)), dim3(64), 0, (hipStream_t)stream, B_valid, n,
                      mult_orientation, mult_pred_normal, target_is_pred, weights, normals, normals_pred, viewdirs,
                      stats, g_weights, g_normals, g_normals_pred);

@@ -115,9 +115,16 @@ class MLP:
     on = [f for f in ref_flags if getattr(self, f)]
     if not self.disable_density_normals:
       on.append('density normals')
-    if on and not self.is_ref():
-      # The Ref-NeRF branch is implemented as one unit (blender_refnerf.gin); partial mixes are not.
-      bad.append('partial Ref-NeRF feature set ' + str(on) + ' (all of them, or none)')
+    if self.use_directional_enc and not self.enable_pred_roughness:
+      # not a HIP-path restriction: the reference's IDE multiplies by the roughness (ref_utils.py:147: exp(-sigma * kappa_inv)
+      # with kappa_inv = None is a TypeError there)
+      bad.append('use_directional_enc without enable_pred_roughness (undefined in the reference: ref_utils.py:147)')
+    if self.use_n_dot_v and not self.enable_pred_normals and self.disable_density_normals:
+      bad.append('use_n_dot_v without normals (undefined in the reference: models.py:560-563)')
+    if on and not self.is_ref() and on != ['enable_pred_normals']:
+      # The Ref-NeRF branch is implemented as one unit (blender_refnerf.gin), plus predicted normals on their own
+      # (enable_pred_normals with disable_density_normals: a Dense(3) head, models.py:494-503); other partial mixes are not.
+      bad.append('partial Ref-NeRF feature set ' + str(on) + ' (all of them, predicted normals alone, or none)')
     if self.is_ref() and self.warp_fn is not None:
       bad.append('density-gradient normals with a warp_fn')
     if self.is_ref() and self.roughness_activation != 'softplus':
@@ -203,6 +210,7 @@ class MLPPlan:
     self.x_width = self.W + (self.F if concat else 0)
     self.density = add(self.x_width, 1)        # models.py:460
     self.ref = hp.is_ref()
+    self.pn = hp.enable_pred_normals and not self.ref      # predicted normals without the rest of the Ref-NeRF head
     self.view: List[Tuple[DenseSpec, bool]] = []
     self.bottleneck = None
     self.rgb = None
@@ -248,7 +256,9 @@ class MLPPlan:
         self.head_segs = [(self.bottleneck, 0), (self.density, bw)]
         if self.ref:
           self.head_segs += [(self.gradpred, bw + 1), (self.diffuse, bw + 4), (self.tint, bw + 7), (self.rough, bw + 10)]
-        self.head_cols = bw + (11 if self.ref else 1)
+        elif self.pn:
+          self.head_segs += [(self.gradpred, bw + 1)]
+        self.head_cols = bw + (11 if self.ref else 4 if self.pn else 1)
       else:
         # use_viewdirs = False (models.py:57,226,585): rgb = Dense(3)(trunk output); density and rgb share one 4-column head
         self.head_segs = [(self.density, 0), (self.rgb, 1)]
@@ -828,14 +838,16 @@ class Model:
           rendering['normals'] = ops.weighted_sum(weights, mlp_out['normals'])[:B0].reshape(lead + (3,))
           rendering['normals_pred'] = ops.weighted_sum(weights, mlp_out['npred'])[:B0].reshape(lead + (3,))
           rendering['roughness'] = ops.weighted_sum(weights, mlp_out['rough'])[:B0].reshape(lead + (1,))
+        elif plan.pn:
+          rendering['normals_pred'] = ops.weighted_sum(weights, mlp_out['npred'])[:B0].reshape(lead + (3,))
       renderings.append(rendering)
       rgb_hist = rgb[:B0] if rgb is not None else torch.zeros((B0, n, 3), dtype=f32, device=dev)
       ray_history.append(dict(
           density=density[:B0].reshape(lead + (n,)), rgb=rgb_hist.reshape(lead + (n, 3)),
           raw_grad_density=(mlp_out['raw_grad'].t().reshape(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.ref else None),
-          grad_pred=(mlp_out['small'][:, 1:4].reshape(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.ref else None),
+          grad_pred=(mlp_out['small'][:, 1:4].reshape(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if (plan.ref or plan.pn) else None),
           normals=(mlp_out['normals'].view(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.ref else None),
-          normals_pred=(mlp_out['npred'].view(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.ref else None),
+          normals_pred=(mlp_out['npred'].view(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if (plan.ref or plan.pn) else None),
           roughness=(mlp_out['rough'].view(Bp, n, 1)[:B0].reshape(lead + (n, 1)) if plan.ref else None),
           sdist=sdist[:B0].reshape(lead + (n + 1,)), weights=weights[:B0].reshape(lead + (n,)),
           tdist=tdist[:B0].reshape(lead + (n + 1,))))
@@ -1037,6 +1049,14 @@ class Model:
                                                  bw, plan.ldVI)
         res.update(small=small, T_feat=T_feat, T_acts=T_acts, raw_grad=raw_grad, normals=normals, npred=npred,
                    rough=rough)
+      elif plan.pn:
+        # [raw_density | grad_pred] as the fp32 side output; normals_pred = -l2_normalize(grad_pred) (models.py:494-503)
+        small = self._buf((tag, 'small_pn'), (M, 4), f32)
+        ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=plan.head_cols, relu=False,
+                    Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=small, ldcf=4, f0=bw, nf=4, **lay_a)
+        raw_density.copy_(small[:, 0])
+        ops.viewdir_enc_fill(R.viewdirs, n, hp.deg_view, VI, bw, plan.ldVI)
+        res.update(small=small, npred=ops.pred_normals_fwd(small, 1))
       else:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=bw + 1, relu=False,
                     Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=raw_density, ldcf=1, f0=bw, nf=1, **lay_a)
@@ -1280,6 +1300,9 @@ class Model:
       if dVIb is not None and not plan.ref:
         # bottleneck gradient through the skip concat (a view MLP deeper than skip_layer_dir)
         ops.add_cols_bf16(dHB, dVIb, dHB, bw)
+      if plan.pn and g_npred is not None:
+        # VJP of normals_pred = -l2_normalize(grad_pred) into the grad_pred columns of the head gradient (zero without a loss on them)
+        ops.pred_normals_bwd(mlp['small'], 1, g_npred.view(M, 3), dHB, bw + 1)
       if plan.ref:
         # IDE / reflection / normalisation VJP: fills the bottleneck (dVIa + dVIb), grad_pred and roughness
         # columns of dHB and returns the gradient w.r.t. d raw_density / d mean for the tangent network.

@@ -759,14 +759,32 @@ def ref_color_bwd(raw_rgb, small, premult, rgb_bias, pad, use_tint, g_rgb, dhb, 
   return g_raw_rgb
 
 
+def pred_normals_fwd(small, col):
+  """normals_pred = -l2_normalize(small[:, col:col+3]) (models.py:498)."""
+  _chk(small, f32, 'small')
+  M, ld = small.shape
+  out = torch.empty((M, 3), dtype=f32, device=small.device)
+  L.check(lib().mnr_pred_normals_fwd(M, _ptr(small), ld, col, _ptr(out), _stream()))
+  return out
+
+
+def pred_normals_bwd(small, col, g_npred, dhb, col_g):
+  _chk(small, f32, 'small')
+  _chk(g_npred, f32, 'g_npred')
+  _chk(dhb, bf16, 'dhb')
+  M, ld = small.shape
+  L.check(lib().mnr_pred_normals_bwd(M, _ptr(small), ld, col, _ptr(g_npred), _ptr(dhb), dhb.stride(0), col_g, _stream()))
+
+
 def ref_losses(mult_o, mult_p, target_is_pred, weights, normals, npred, viewdirs, stats, g_w, want_grad, *, B_valid):
-  for x, nm in ((weights, 'weights'), (normals, 'normals'), (npred, 'npred'), (viewdirs, 'viewdirs'), (stats, 'stats')):
+  for x, nm in ((weights, 'weights'), (npred, 'npred'), (viewdirs, 'viewdirs'), (stats, 'stats')):
     _chk(x, f32, nm)
+  _chk(normals, f32, 'normals', allow_none=True)
   B, n = weights.shape
-  g_n = torch.zeros_like(normals) if want_grad else None
+  g_n = torch.zeros_like(normals) if (want_grad and normals is not None) else None
   g_np = torch.zeros_like(npred) if want_grad else None
   L.check(lib().mnr_ref_losses(B_valid, n, float(mult_o), float(mult_p), int(target_is_pred), _ptr(weights),
-                               _ptr(normals), _ptr(npred), _ptr(viewdirs), _ptr(stats), _ptr(g_w), _ptr(g_n),
+                               _ptr(normals) if normals is not None else None, _ptr(npred), _ptr(viewdirs), _ptr(stats), _ptr(g_w), _ptr(g_n) if g_n is not None else None,
                                _ptr(g_np), _stream()))
   return g_n, g_np
 

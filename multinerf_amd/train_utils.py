@@ -164,9 +164,12 @@ def create_train_step(model: models.Model, config, dataset=None):
     g_nrm, g_npr = [None] * nlev, [None] * nlev
     if use_orient or use_prednorm:                                     # train_utils.py:162-197
       for li, lv in enumerate(levels):
-        if lv['mlp'].get('normals') is None:
-          raise ValueError('Normals cannot be None if orientation loss is on.' if use_orient else
-                           'Predicted normals and gradient normals cannot be None if predicted normal loss is on.')
+        # train_utils.py:162-197: the orientation loss needs its target field, the predicted-normal loss both fields
+        tgt = 'npred' if config.orientation_loss_target == 'normals_pred' else 'normals'
+        if use_orient and lv['mlp'].get(tgt) is None:
+          raise ValueError('Normals cannot be None if orientation loss is on.')
+        if use_prednorm and (lv['mlp'].get('normals') is None or lv['mlp'].get('npred') is None):
+          raise ValueError('Predicted normals and gradient normals cannot be None if predicted normal loss is on.')
         fine = li == nlev - 1
         mo = config.orientation_loss_mult if fine else config.orientation_coarse_loss_mult
         mp = config.predicted_normal_loss_mult if fine else config.predicted_normal_coarse_loss_mult
@@ -174,7 +177,7 @@ def create_train_step(model: models.Model, config, dataset=None):
           g_w[li] = model._buf(('train', 'g_w', li), (Bp, lv['n']), f32)
           g_w[li].zero_()
         g_nrm[li], g_npr[li] = ops.ref_losses(mo, mp, config.orientation_loss_target == 'normals_pred',
-                                              lv['weights'], lv['mlp']['normals'], lv['mlp']['npred'], R.viewdirs,
+                                              lv['weights'], lv['mlp'].get('normals'), lv['mlp']['npred'], R.viewdirs,
                                               stats[2 * nlev + 3:2 * nlev + 5], g_w[li], True, B_valid=B0)
 
     g_expo = None

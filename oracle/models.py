@@ -254,12 +254,37 @@ def param_count(params):
 # MLP.__call__ (models.py:402-612).
 
 
+class _DenseBf16FwdBwd(torch.autograd.Function):
+  """x @ kern with BOTH passes at the reference's TPU default precision (flax nn.Dense without a precision argument: every
+  matmul operand is rounded to bf16, the products accumulate in fp32): the forward rounds x and the kernel, the backward
+  rounds the incoming gradient as well (dX = g W^T, dW = x^T g with g in bf16).  That is also what the HIP path stores: `dY` in bf16."""
+
+  @staticmethod
+  def forward(ctx, x, kern):
+    bf = torch.bfloat16
+    xr, kr = x.to(bf).to(x.dtype), kern.to(bf).to(kern.dtype)
+    ctx.save_for_backward(xr, kr)
+    return rmath.matmul(xr, kr)
+
+  @staticmethod
+  def backward(ctx, g):
+    xr, kr = ctx.saved_tensors
+    gr = g.to(torch.bfloat16).to(g.dtype)
+    dx = rmath.matmul(gr, kr.t())
+    dk = rmath.matmul(xr.reshape(-1, xr.shape[-1]).t(), gr.reshape(-1, gr.shape[-1]))
+    return dx, dk
+
+
+BF16_FWD_BWD = 'bf16_fwd_bwd'      # dense_dtype value: bf16 operands in the forward AND the backward matmuls
+
+
 class _DenseCursor:
   """Hands out Dense_k in call order, like flax's auto-naming.
 
   `dense_dtype=torch.bfloat16` emulates the MFMA path (and the reference's own
   TPU default precision, math.py:21-23): both Dense operands are rounded to bf16,
   products accumulate in the working dtype, bias is added in the working dtype.
+  `dense_dtype=BF16_FWD_BWD` rounds the backward pass's incoming gradient too (`_DenseBf16FwdBwd`).
   """
 
   def __init__(self, p, dense_dtype=None):
@@ -269,6 +294,9 @@ class _DenseCursor:
     layer = self.p[f'Dense_{self.k}']
     self.k += 1
     kern = layer['kernel']
+    if isinstance(self.dd, str):
+      assert self.dd == BF16_FWD_BWD, self.dd
+      return _DenseBf16FwdBwd.apply(x, kern) + layer['bias']
     if self.dd is not None:
       x = x.to(self.dd).to(kern.dtype)
       kern = kern.to(self.dd).to(kern.dtype)

@@ -3,7 +3,7 @@
 
     python tests/golden/make_golden_psnr.py [--seed S]  # ~10 min on 8 cores; writes tests/golden/psnr360.json (seed 360) or
                                                         # psnr360_s<S>.json; the committed seeds are 360, 361, 362
-    python tests/golden/make_golden_psnr.py [--seed S] --dense_dtype bfloat16
+    python tests/golden/make_golden_psnr.py [--seed S] --dense_dtype bfloat16 | bf16_fwd_bwd
                                                         # the same run with the Dense operands rounded to bf16 (the oracle's
                                                         # emulation of the MFMA inputs): psnr360_bf16[_s<S>].json; what of the
                                                         # HIP - fp32-oracle difference is the precision the reference's own TPU
@@ -50,8 +50,8 @@ def eval_rays(seed=None):
 
 def golden_path(seed, bf16=False):
   """psnr360.json for the original seed, psnr360_s<seed>.json for the further ones (round 3: three seeds); psnr360_bf16*.json
-  for the bf16-emulating oracle (round 4)."""
-  stem = 'psnr360_bf16' if bf16 else 'psnr360'
+  for the bf16-emulating oracle (round 4; bf16=True: forward operands, bf16='bf16_fwd_bwd': the backward pass's gradients too)."""
+  stem = 'psnr360_bf16fb' if bf16 == 'bf16_fwd_bwd' else 'psnr360_bf16' if bf16 else 'psnr360'
   name = f'{stem}.json' if seed == SEED else f'{stem}_s{seed}.json'
   return os.path.join(ROOT, 'tests', 'golden', name)
 
@@ -63,8 +63,8 @@ def psnr(rgb, gt):
 def main():
   seed = int(sys.argv[sys.argv.index('--seed') + 1]) if '--seed' in sys.argv else SEED
   dd_name = sys.argv[sys.argv.index('--dense_dtype') + 1] if '--dense_dtype' in sys.argv else None
-  assert dd_name in (None, 'bfloat16'), dd_name
-  dd = torch.bfloat16 if dd_name else None
+  assert dd_name in (None, 'bfloat16', 'bf16_fwd_bwd'), dd_name
+  dd = {None: None, 'bfloat16': torch.bfloat16, 'bf16_fwd_bwd': 'bf16_fwd_bwd'}[dd_name]
   from multinerf_amd import configs, models
   from oracle import bridge, models as omodels, train_utils as otrain
   torch.set_num_threads(int(os.environ.get('PSNR_THREADS', os.cpu_count())))
@@ -87,9 +87,9 @@ def main():
       print(f'step {step}: loss {float(stats["loss"]):.5f} train psnr {float(stats["psnr"]):.3f} eval psnr {e:.3f}  ({time.time() - t0:.0f} s)', flush=True)
   out = dict(steps=STEPS, rays=RAYS, eval_rays=EVAL_RAYS, seed=seed, bindings=BINDINGS, curve=curve,
              dense_dtype=dd_name or 'float32',
-             note=('oracle (torch-CPU restatement of the reference' + (', Dense operands rounded to bf16' if dd else ', fp32') +
+             note=('oracle (torch-CPU restatement of the reference' + (', Dense operands and backward gradients rounded to bf16' if dd == 'bf16_fwd_bwd' else ', Dense operands rounded to bf16' if dd else ', fp32') +
                    '), configs/360.gin as is, procedural unbounded scene'))
-  with open(golden_path(seed, bf16=dd is not None), 'w') as f:
+  with open(golden_path(seed, bf16=('bf16_fwd_bwd' if dd == 'bf16_fwd_bwd' else dd is not None)), 'w') as f:
     json.dump(out, f, indent=1)
 
 
