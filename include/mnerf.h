@@ -305,9 +305,6 @@ typedef struct {
 
 /* Weight gradient: C += A^T B (fp32 atomics; C must be initialised by the caller). */
 int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* args, void* stream);
-/* Tuning hook: the 256x256 output tile is used when K,N are multiples of 256 and the output has at
- * least `big_min_tiles` such tiles (a huge value disables it). */
-int mnr_gemm_tn_set_config(int big_min_tiles);
 
 /* out[n] += sum_m X[m,n] for n < n_valid (bias gradient). X bf16 [M, ld]. */
 int mnr_colsum_bf16(const uint16_t* X, int ld, int64_t M, int n_valid, float* out, void* stream);
@@ -488,6 +485,11 @@ int mnr_ref_losses(int64_t B_valid, int n, float mult_orientation, float mult_pr
  * normals_pred[M,3] = -l2_normalize(small[:, col .. col+2]) (ref_utils.py:40-42) from the head GEMM's fp32 side output [M, ld];
  * _bwd: the VJP of the same into columns col_g .. col_g+2 of the head's bf16 gradient matrix [M, lddhb].
  * mnr_ref_losses takes normals = NULL for such an MLP (mult_pred_normal == 0, target_is_pred = 1, g_normals = NULL). */
+/* Density-gradient normals without the rest of the Ref-NeRF head (internal/models.py:478-492 with disable_density_normals = False
+ * only): normals[M,3] = -l2_normalize(raw_grad) from the tangent network's raw_grad [3, M] (component-major); _bwd: g_raw_grad [3, M].
+ * mnr_ref_losses takes normals_pred = NULL for such an MLP (mult_pred_normal == 0, target_is_pred = 0, g_normals_pred = NULL). */
+int mnr_density_normals_fwd(int64_t M, const float* raw_grad, float* normals_out, void* stream);
+int mnr_density_normals_bwd(int64_t M, const float* raw_grad, const float* g_normals, float* g_raw_grad, void* stream);
 int mnr_pred_normals_fwd(int64_t M, const float* small, int ld, int col, float* normals_pred_out, void* stream);
 int mnr_pred_normals_bwd(int64_t M, const float* small, int ld, int col, const float* g_normals_pred, uint16_t* dhb, int lddhb,
                          int col_g, void* stream);

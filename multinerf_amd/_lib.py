@@ -165,7 +165,6 @@ _PROTOS = {
     'mnr_mlp_chain_fwd_ipe': ([C.POINTER(MlpChainFwdArgs), C.POINTER(ChainIpeArgs), vp], i32),
     'mnr_debug_chain_timeline': ([vp], i32),
     'mnr_mlp_chain_set_deferred': ([i32], i32),
-    'mnr_gemm_tn_set_config': ([i32], i32),
     'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),
     'mnr_pack_weights_bf16': ([vp, vp, i32, i32, vp, vp], i32),
     'mnr_scatter_add_f32': ([vp, i32, i32, i32, i32, i32, vp, i32, vp], i32),
@@ -188,6 +187,8 @@ _PROTOS = {
     'mnr_ref_color_bwd': ([i64, vp, vp, f32, f32, f32, i32, vp, vp, vp, i32, i32, i32, vp], i32),
     'mnr_ref_losses': ([i64, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_weighted_sum': ([i64, i32, i32, vp, vp, vp, vp], i32),
+    'mnr_density_normals_fwd': ([i64, vp, vp, vp], i32),
+    'mnr_density_normals_bwd': ([i64, vp, vp, vp, vp], i32),
     'mnr_pred_normals_fwd': ([i64, vp, i32, i32, vp, vp], i32),
     'mnr_pred_normals_bwd': ([i64, vp, i32, i32, vp, vp, i32, i32, vp], i32),
     'mnr_lossmult_sum': ([i64, vp, i32, vp, vp], i32),

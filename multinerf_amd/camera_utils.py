@@ -167,20 +167,18 @@ def transform_poses_pca(poses):
   the camera centres onto x, y, z (largest spread first), keep the cameras' mean up-vector pointing to +z... i.e. a
   positive z component of the mean y axis, and scale the centres into [-1, 1]^3.  Returns (poses, 4x4 transform).
 
-  Principal axes from the SVD of the centred [N,3] centre matrix (its right singular vectors, already sorted by
-  spread).  An axis is only defined up to sign; the sign is fixed here by making every axis' largest-magnitude
-  component positive before the handedness / up-vector rules below are applied.  The reference takes its signs from
-  LAPACK's general eigen-solver instead, and its two fix-ups leave a 180-degree turn about z open: over the 12 captures of
-  tests/golden/pca_poses.npz (the reference's own outputs) this function's frame is identical to the reference's in 11
-  and differs by exactly diag(-1, -1, 1) in one (tests/test_oracle_camera.py).  Anything expressed in the normalised
-  frame (a checkpoint, a render path) is interchangeable with the reference's up to that turn only.
+  A principal axis is only defined up to sign, and the two fix-ups below (handedness, up-vector) leave a 180-degree turn
+  about z open.  Checkpoints and render paths are expressed in this frame, so the signs have to be the reference's: they are
+  whatever LAPACK's general eigen-solver returns for the 3x3 scatter matrix of the centres, which is why this function asks
+  the same solver the same question (`np.linalg.eig` of c^T c, camera_utils.py:205) instead of an SVD with a sign rule of its
+  own (rounds 1-3: identical to the reference on 11 of the 12 captures of tests/golden/pca_poses.npz, diag(-1, -1, 1) off on
+  one; now 12 of 12, tests/test_oracle_camera.py).
   """
   centres = poses[:, :3, 3]
   mean = centres.mean(0)
-  _, _, axes = np.linalg.svd(centres - mean, full_matrices=False)      # rows: principal directions
-  for k in range(3):
-    if axes[k, np.argmax(np.abs(axes[k]))] < 0:
-      axes[k] = -axes[k]
+  c = centres - mean
+  spread, vecs = np.linalg.eig(c.T @ c)
+  axes = vecs[:, np.argsort(spread)[::-1]].T                              # rows: principal directions, largest spread first
   if np.linalg.det(axes) < 0:                                           # keep a right-handed frame
     axes[2] = -axes[2]
   world_to_pca = np.eye(4)

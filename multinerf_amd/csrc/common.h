@@ -70,16 +70,8 @@ static inline int mnr_cu_count() {
 // wave whatever the number of active lanes, so a batch is spread over `mnr_ray_wave_target()` single-wave workgroups =
 // one per SIMD of the chip (4 per CU), each walking B / target rays.  Measured (round 2, 16384 rays, ms per step of the
 // fused level backward at 1024 / 2048 / 4096 / 8192 / 16384 waves): 0.64 / 0.81 / 1.13 / 2.2 / 3.9: beyond one wave per
-// SIMD the streams queue behind each other (issue-bound, not latency-bound).  MNR_RAY_WAVES overrides (tuning).
-static inline long long mnr_ray_wave_target() {
-  static long long t = 0;
-  if (t == 0) {
-    const char* e = getenv("MNR_RAY_WAVES");
-    t = e ? atoll(e) : 4ll * mnr_cu_count();
-    if (t < 1) t = 1;
-  }
-  return t;
-}
+// SIMD the streams queue behind each other (issue-bound, not latency-bound).
+static inline long long mnr_ray_wave_target() { return 4ll * mnr_cu_count(); }
 
 // hipFuncSetAttribute applies per device: a launcher's "attribute already set" flag is a bit mask over device ordinals
 // (a process that drives a second GPU sets the attribute there too).  True when the current device still needs it.

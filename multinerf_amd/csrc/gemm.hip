@@ -564,12 +564,7 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   int splits = ((target_wgs + tiles - 1) / tiles + 7) / 8 * 8;
   if (splits < unit) splits = unit;
   // (every workgroup ends with an atomic epilogue of its whole fp32 tile: a split must be long enough to pay for it)
-  static int min_steps = -1;
-  if (min_steps < 0) {
-    const char* e = getenv("MNR_TN_MIN_STEPS");
-    min_steps = e ? atoi(e) : 4;
-    if (min_steps < 1) min_steps = 1;
-  }
+  constexpr int min_steps = 4;
   while (splits > unit && (total_steps + splits - 1) / splits < min_steps) splits -= unit;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   const int64_t grid = (int64_t)splits * tiles;
@@ -591,12 +586,6 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   return MNR_OK;
 }
 
-static int g_tn_big_min_tiles = 1;
-extern "C" int mnr_gemm_tn_set_config(int big_min_tiles) {
-  g_tn_big_min_tiles = big_min_tiles;
-  return MNR_OK;
-}
-
 extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
   MNR_CHECK_ARG(a != nullptr, "mnr_gemm_tn_bf16: null args");
   MNR_CHECK_ARG(a->M > 0 && a->M % TN_BM == 0, "mnr_gemm_tn_bf16: M=%lld must be a positive multiple of 64", (long long)a->M);
@@ -604,17 +593,13 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
                 "mnr_gemm_tn_bf16: K=%d, N=%d must be multiples of 128", a->K, a->N);
   MNR_CHECK_ARG(a->A && a->B && a->C, "mnr_gemm_tn_bf16: null operand");
   MNR_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0, "mnr_gemm_tn_bf16: lda/ldb must be multiples of 8");
-  // The 256x256 tile halves operand traffic per MFMA but issues 4x the atomics per workgroup: use it
-  // when the output has enough tiles (the 1024-wide trunk); the narrow proposal layers keep 128x128.
-  const bool big = (a->K % 256 == 0) && (a->N % 256 == 0) && ((a->K / 256) * (a->N / 256) >= g_tn_big_min_tiles);
-  static int tn_target = -1;                             // tuning hook: workgroups per launch of the 256x256 tile
-  if (tn_target < 0) {
-    const char* e = getenv("MNR_TN_TARGET_WGS");
-    // one workgroup per CU: every workgroup ends with a 256 KiB fp32 atomic epilogue (21-88k cycles, bound by the
-    // L2's atomic rate, tools/step_timeline.py), so a second round of workgroups only adds epilogues:
-    // 512 -> 256 workgroups = 398k -> 407k rays/s end to end, 1024: 390k.
-    tn_target = e ? atoi(e) : 256;
-  }
+  // The 256x256 tile halves operand traffic per MFMA and issues 4x the atomics per workgroup: it is used whenever K and N are
+  // multiples of 256 (the 128x128 tile for the 256-wide layers measured slower in round 3, profiles/HISTORY.md).
+  const bool big = (a->K % 256 == 0) && (a->N % 256 == 0);
+  // one workgroup per CU: every workgroup ends with a 256 KiB fp32 atomic epilogue (21-88k cycles, bound by the
+  // L2's atomic rate, tools/step_timeline.py), so a second round of workgroups only adds epilogues:
+  // 512 -> 256 workgroups = 398k -> 407k rays/s end to end, 1024: 390k; 128 / 512 re-measured in round 3 (profiles/HISTORY.md).
+  const int tn_target = mnr_cu_count();
   MNR_CHECK_ARG(!a->gcol || (a->gcol_out && a->K % 256 == 0 && a->N % 256 == 0 && ((uintptr_t)a->gcol % 32) == 0),
                 "mnr_gemm_tn_bf16: gcol needs gcol_out, K and N multiples of 256 and a 32-byte-aligned vector");
   const bool ap = a->a_layout == MNR_LAYOUT_PANEL, bp = a->b_layout == MNR_LAYOUT_PANEL;
@@ -634,12 +619,7 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
   }
   if (a->gcol) return tn_launch<TnBig, true>(a, tn_target, stream);
   if (big) return tn_launch<TnBig>(a, tn_target, stream);
-  static int tn_small_target = -1;
-  if (tn_small_target < 0) {
-    const char* e = getenv("MNR_TN_SMALL_TARGET_WGS");
-    tn_small_target = e ? atoi(e) : 768;
-  }
-  return tn_launch<TnSmall>(a, tn_small_target, stream);
+  return tn_launch<TnSmall>(a, 3 * mnr_cu_count(), stream);         // (the 64-KiB tile: up to three workgroups per CU)
 }
 
 // ---------------------------------------------------------------------------
@@ -972,29 +952,17 @@ extern "C" int mnr_small_head_bwd(int64_t M, int K, int C, const uint16_t* H, in
   MNR_CHECK_ARG(M > 0 && K > 0 && C >= 1 && C <= 4 && H && g && W, "mnr_small_head_bwd: bad arguments (1 <= C <= 4)");
   MNR_CHECK_ARG(K % 8 == 0 && K / 8 <= 256 && ldh % 8 == 0 && (!dX || lddx % 8 == 0),
                 "mnr_small_head_bwd: K must be a multiple of 8 (<= 2048) and the pitches multiples of 8");
-  static int rows_env = -1, u_env = -1;                    // tuning hooks (tools/head_probe.py)
-  if (rows_env < 0) {
-    const char* e = getenv("MNR_SHB_ROWS");
-    rows_env = e ? atoi(e) : 0;
-    const char* u = getenv("MNR_SHB_UNROLL");
-    u_env = u ? atoi(u) : 0;
-  }
   // Every workgroup ends with K*C fp32 atomics onto the same few cache lines of dW: more than ~512 workgroups
   // and the kernel is bound by that serialisation (2048 workgroups: 508 us, 512: 291 us at M = 2^20, K = 256);
   // fewer than ~256 and it loses memory parallelism.  tools/head_probe.py.
   int rows_auto = (int)(((M + 511) / 512 + 63) / 64 * 64);
   if (rows_auto < 512) rows_auto = 512;
-  int rows_per_block = rows_env > 0 ? rows_env : rows_auto;
-  const int unroll = u_env > 0 ? u_env : 4;
+  int rows_per_block = rows_auto;
   // With scratch for per-workgroup partials (reduced by small_head_reduce_kernel) instead of K*C atomics per
   // workgroup: 295 -> 253-267 us (K = 256, C = 1), 245 -> 98 us (K = 128, C = 3).
   float* partials = nullptr;
-  if (scratch && dW && rows_env <= 0) {
-    static int blocks_env = -1;
-    if (blocks_env < 0) {
-      const char* e = getenv("MNR_SHB_BLOCKS");
-      blocks_env = e ? atoi(e) : 512;              // tools/head_probe.py: 256: 347 us, 512: 253-267, 1024: 291, 2048: 313 (M = 2^20, K = 256)
-    }
+  if (scratch && dW) {
+    constexpr int blocks_env = 512;                // tools/head_probe.py: 256: 347 us, 512: 253-267, 1024: 291, 2048: 313 (M = 2^20, K = 256)
     int rows_p = (int)(((M + blocks_env - 1) / blocks_env + 63) / 64 * 64);
     if (rows_p < 256) rows_p = 256;
     if ((int64_t)mnr_cdiv(M, rows_p) * (K * C + C) <= scratch_floats) {
@@ -1003,14 +971,8 @@ extern "C" int mnr_small_head_bwd(int64_t M, int K, int C, const uint16_t* H, in
     }
   }
   const int grid = mnr_cdiv(M, rows_per_block);
-#define MNR_SHB_LAUNCH(UU)                                                                                          \
-  hipLaunchKernelGGL(small_head_bwd_kernel<UU>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, C,             \
-                     (const bf16*)H, ldh, g, W, (bf16*)dX, lddx, apply_relu_mask, dW, db, rows_per_block, mask_bits, \
-                     ld_bits, bits_row_mod, partials)
-  if (unroll >= 4) MNR_SHB_LAUNCH(4);
-  else if (unroll >= 2) MNR_SHB_LAUNCH(2);
-  else MNR_SHB_LAUNCH(1);
-#undef MNR_SHB_LAUNCH
+  hipLaunchKernelGGL(small_head_bwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, C, (const bf16*)H, ldh, g, W,
+                     (bf16*)dX, lddx, apply_relu_mask, dW, db, rows_per_block, mask_bits, ld_bits, bits_row_mod, partials);
   MNR_CHECK_LAUNCH();
   if (partials) {
     const int n = K * C + C;

@@ -341,6 +341,46 @@ __global__ void pred_normals_kernel(int64_t M, const float* __restrict__ small, 
   }
 }
 
+// Density-gradient normals WITHOUT the rest of the Ref-NeRF head (models.py:478-492 with disable_density_normals = False only, what
+// configs/llff_raw.gin's comment asks for together with the orientation loss): normals = -l2_normalize(raw_grad) from the tangent
+// network's output raw_grad [3, M] (component-major), and the VJP back into g_raw_grad [3, M].
+__global__ void density_normals_kernel(int64_t M, const float* __restrict__ raw_grad, float* __restrict__ normals_out,
+                                       const float* __restrict__ g_normals, float* __restrict__ g_raw_grad) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= M) return;
+  const float rg[3] = {raw_grad[s], raw_grad[M + s], raw_grad[2 * M + s]};
+  float nrm[3], r;
+  bool c;
+  rf_neg_normalize(rg, nrm, r, c);                             // models.py:492
+  if (normals_out) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) normals_out[s * 3 + i] = nrm[i];
+  }
+  if (g_normals) {
+    const float g[3] = {g_normals[s * 3], g_normals[s * 3 + 1], g_normals[s * 3 + 2]};
+    float gx[3];
+    rf_neg_normalize_bwd(rg, r, c, g, gx);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g_raw_grad[i * M + s] = gx[i];
+  }
+}
+
+extern "C" int mnr_density_normals_fwd(int64_t M, const float* raw_grad, float* normals_out, void* stream) {
+  MNR_CHECK_ARG(M > 0 && raw_grad && normals_out, "mnr_density_normals_fwd: bad argument");
+  hipLaunchKernelGGL(density_normals_kernel, dim3(mnr_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, M, raw_grad, normals_out,
+                     (const float*)nullptr, (float*)nullptr);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+extern "C" int mnr_density_normals_bwd(int64_t M, const float* raw_grad, const float* g_normals, float* g_raw_grad, void* stream) {
+  MNR_CHECK_ARG(M > 0 && raw_grad && g_normals && g_raw_grad, "mnr_density_normals_bwd: bad argument");
+  hipLaunchKernelGGL(density_normals_kernel, dim3(mnr_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, M, raw_grad, (float*)nullptr,
+                     g_normals, g_raw_grad);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
 extern "C" int mnr_pred_normals_fwd(int64_t M, const float* small, int ld, int col, float* normals_pred_out, void* stream) {
   MNR_CHECK_ARG(M > 0 && small && normals_pred_out && col >= 0 && col + 3 <= ld, "mnr_pred_normals_fwd: bad argument");
   hipLaunchKernelGGL(pred_normals_kernel, dim3(mnr_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, M, small, ld, col,
@@ -440,21 +480,23 @@ __global__ void ref_losses_kernel(int64_t B_valid, int n, float mult_orient, flo
       const float neg = fminf(0.0f, ndv);
       // (normals == NULL: an MLP with predicted normals only, models.py:494-503 with disable_density_normals; the host admits it
       // with mult_pred == 0 and the predicted normals as the orientation target)
-      const float dot = normals ? normals[s * 3] * npred[s * 3] + normals[s * 3 + 1] * npred[s * 3 + 1] +
-                                      normals[s * 3 + 2] * npred[s * 3 + 2]
-                                : 1.0f;
+      // (npred == NULL: density-gradient normals only, models.py:478-492 without enable_pred_normals: mult_pred == 0 and
+      // the density normals as the orientation target)
+      const float dot = (normals && npred) ? normals[s * 3] * npred[s * 3] + normals[s * 3 + 1] * npred[s * 3 + 1] +
+                                                 normals[s * 3 + 2] * npred[s * 3 + 2]
+                                           : 1.0f;
       lo += w * neg * neg;                                     // :173
       lp += w * (1.0f - dot);                                  // :192
       if (g_w) g_w[s] += (mult_orient * neg * neg + mult_pred * (1.0f - dot)) * invB;
-      if (g_npred) {
+      if (g_npred || g_n) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          float gn = -mult_pred * w * npred[s * 3 + c] * invB;
+          float gn = npred ? -mult_pred * w * npred[s * 3 + c] * invB : 0.0f;
           float gp = normals ? -mult_pred * w * normals[s * 3 + c] * invB : 0.0f;
           const float go = mult_orient * w * 2.0f * neg * v[c] * invB;
           if (target_is_pred) gp += go; else gn += go;
           if (g_n) g_n[s * 3 + c] = gn;
-          g_npred[s * 3 + c] = gp;
+          if (g_npred) g_npred[s * 3 + c] = gp;
         }
       }
     }
@@ -474,10 +516,13 @@ extern "C" int mnr_ref_losses(int64_t B_valid, int n, float mult_orientation, fl
                               int target_is_pred, const float* weights, const float* normals,
                               const float* normals_pred, const float* viewdirs, float* stats, float* g_weights,
                               float* g_normals, float* g_normals_pred, void* stream) {
-  MNR_CHECK_ARG(B_valid > 0 && n > 0 && weights && normals_pred && viewdirs && stats, "mnr_ref_losses: null argument");
+  MNR_CHECK_ARG(B_valid > 0 && n > 0 && weights && (normals || normals_pred) && viewdirs && stats, "mnr_ref_losses: null argument");
   MNR_CHECK_ARG(normals || (mult_pred_normal == 0.0f && target_is_pred && !g_normals),
                 "mnr_ref_losses: without density-gradient normals only the orientation loss on the predicted normals is defined");
-  MNR_CHECK_ARG(!normals || (g_normals == nullptr) == (g_normals_pred == nullptr), "mnr_ref_losses: g_normals and g_normals_pred go together");
+  MNR_CHECK_ARG(normals_pred || (mult_pred_normal == 0.0f && !target_is_pred && !g_normals_pred),
+                "mnr_ref_losses: without predicted normals only the orientation loss on the density-gradient normals is defined");
+  MNR_CHECK_ARG(!(normals && normals_pred) || (g_normals == nullptr) == (g_normals_pred == nullptr),
+                "mnr_ref_losses: g_normals and g_normals_pred go together");
   hipLaunchKernelGGL(ref_losses_kernel, dim3(mnr_cdiv(B_valid, 64)), dim3(64), 0, (hipStream_t)stream, B_valid, n,
                      mult_orientation, mult_pred_normal, target_is_pred, weights, normals, normals_pred, viewdirs,
                      stats, g_weights, g_normals, g_normals_pred);

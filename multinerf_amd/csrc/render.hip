@@ -142,17 +142,7 @@ static int g_level_bwd_quad = 1;
 // llff_raw (128 samples WITH rgb, RawNeRF loss, exposure scaling) need 82 / 99 KiB, one workgroup per CU, and are the ones the
 // lane-per-ray stream hurts most: with the limit at 80 / 88 / 104 / 160 KiB llff_raw runs 512 / 545 / 545 / 544 k rays/s,
 // blender_refnerf 150.8 / - / 152.6 / - k, blender_256 1.771 / - / 1.765 / - M (three pairs, inside the noise): 104 KiB.
-// MNR_QUAD_LDS_MAX overrides (tuning).
-static size_t quad_lds_max() {
-  static size_t v = 0;
-  if (v == 0) {
-    const char* e = getenv("MNR_QUAD_LDS_MAX");
-    v = e ? (size_t)atoll(e) : 104 * 1024;
-    if (v < 1024) v = 1024;
-    if (v > 160 * 1024) v = 160 * 1024;
-  }
-  return v;
-}
+static size_t quad_lds_max() { return 104 * 1024; }
 extern "C" int mnr_level_bwd_set_quad(int on) {
   g_level_bwd_quad = on;
   return MNR_OK;

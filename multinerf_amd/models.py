@@ -39,13 +39,11 @@ import os as _os
 _USE_BITS = _os.environ.get('MNR_RELU_BITS', '1') != '0'   # A/B switch: 1-bit ReLU masks vs re-reading activations
 _USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused per-level Dense chain vs one GEMM per layer
 _FUSED_IPE = _os.environ.get('MNR_FUSED_IPE', '1') != '0'   # A/B switch: rendering builds the proposal levels' IPE features inside the chain kernel
-_HEAD_K64 = _os.environ.get('MNR_HEAD_K64', '1') != '0'    # A/B switch: the merged head's dX GEMM over 320 instead of 384 K columns
 _HEAD_GCOL = _os.environ.get('MNR_HEAD_GCOL', '1') != '0'  # A/B switch: the density head's weight gradient as an extra column of the bottleneck's dW GEMM (N = 256, 256x256 tiles) instead of a merged N = 384 GEMM on 128x128 tiles
 # A/B switch: the wide (>= 512) per-layer trunk keeps its activations, gradients and ReLU masks in the panel layout
 # (include/mnerf.h MNR_LAYOUT_PANEL; csrc/gemm_blk.hip): results leave the MFMA accumulators as whole 1-KiB blocks, the K loop
 # runs as one pipeline across output tiles
 _PANEL = _os.environ.get('MNR_PANEL', '1') != '0'
-_CONST_CACHE = _os.environ.get('MNR_CONST_CACHE', '1') != '0'  # A/B switch: constant level-loop inputs cached on the device (no per-step host -> device copies)
 # A/B switch: the backward pass of ALL proposal levels as one pass (they share PropMLP_0 and the sample count, reference
 # models.py:120-121,166): their features / activations / mask bits sit in consecutive row blocks of one buffer per kind, so
 # one dX chain and one weight-gradient GEMM per layer cover L*M rows (half the launches and half the 256 KiB atomic
@@ -121,17 +119,19 @@ class MLP:
       bad.append('use_directional_enc without enable_pred_roughness (undefined in the reference: ref_utils.py:147)')
     if self.use_n_dot_v and not self.enable_pred_normals and self.disable_density_normals:
       bad.append('use_n_dot_v without normals (undefined in the reference: models.py:560-563)')
-    if on and not self.is_ref() and on != ['enable_pred_normals']:
+    if on and not self.is_ref() and on not in (['enable_pred_normals'], ['density normals']):
       # The Ref-NeRF branch is implemented as one unit (blender_refnerf.gin), plus predicted normals on their own
-      # (enable_pred_normals with disable_density_normals: a Dense(3) head, models.py:494-503); other partial mixes are not.
-      bad.append('partial Ref-NeRF feature set ' + str(on) + ' (all of them, predicted normals alone, or none)')
-    if self.is_ref() and self.warp_fn is not None:
+      # (enable_pred_normals with disable_density_normals: a Dense(3) head, models.py:494-503) and density-gradient normals on
+      # their own (disable_density_normals = False: the tangent network, what configs/llff_raw.gin asks for with the orientation
+      # loss); other partial mixes are not.
+      bad.append('partial Ref-NeRF feature set ' + str(on) + ' (all of them, predicted normals alone, density normals alone, or none)')
+    if not self.disable_density_normals and self.warp_fn is not None:
       bad.append('density-gradient normals with a warp_fn')
     if self.is_ref() and self.roughness_activation != 'softplus':
       bad.append('roughness_activation != softplus')
     if self.net_activation not in ('relu', 'softplus', 'silu'):   # what the reference registers (configs.py:29-31)
       bad.append(f'net_activation={self.net_activation}')
-    if self.net_activation != 'relu' and self.is_ref():
+    if self.net_activation != 'relu' and not self.disable_density_normals:
       # the forward-mode tangent network of the density-gradient normals is built on ReLU's piecewise linearity
       bad.append(f'net_activation={self.net_activation} with density-gradient normals')
     if self.warp_fn not in (None, 'contract'):
@@ -211,6 +211,8 @@ class MLPPlan:
     self.density = add(self.x_width, 1)        # models.py:460
     self.ref = hp.is_ref()
     self.pn = hp.enable_pred_normals and not self.ref      # predicted normals without the rest of the Ref-NeRF head
+    self.dn = (not hp.disable_density_normals) and not self.ref   # density-gradient normals without it
+    self.tangent = self.ref or self.dn                     # the forward-mode tangent network runs next to the trunk
     self.view: List[Tuple[DenseSpec, bool]] = []
     self.bottleneck = None
     self.rgb = None
@@ -435,7 +437,7 @@ class Model:
         descs.append(L.PackDesc(d.kernel_off, p.W, d.fan_out, fo, p.W, c0, 0, 1))
         descs.append(L.PackDesc(d.kernel_off, p.W, d.fan_out, bo, nh, 0, c0, 0))
       p.packed['head'] = dict(f_off=fo, f_ld=p.W, n_pad=nh_f, nb_pad=nh, b_off=bo, b_ld=nh)
-      if p.ref:
+      if p.tangent:
         pack_layer('density', p.density, [(0, p.W, 0, p.W)], 128)   # tangent rows only need the density column
       WV = p.hp.net_width_viewdirs
       for i, (d, concat) in enumerate(p.view):
@@ -601,8 +603,6 @@ class Model:
     """A read-only device tensor kept across calls in ONE slot per `key` and rebuilt when its signature `sig` (the values
     it was made from) changes: e.g. the initial sample distances under near-plane annealing change every step, and are then
     simply rebuilt.  Nothing may write into what this returns."""
-    if not _CONST_CACHE:
-      return make()
     k = ('const', key)
     hit = self._ws.get(k)
     if hit is None or hit[0] != sig:
@@ -702,7 +702,7 @@ class Model:
     init_s_far = 1.
     # Constant inputs of the level loop live on the device across calls (`_const`): built per call they are host -> device
     # copies from pageable memory, and torch synchronises the stream after each of those, i.e. the host stops running ahead of
-    # the GPU four times per step and every level starts with the GPU waiting for the next launches (A/B switch MNR_CONST_CACHE).
+    # the GPU four times per step and every level starts with the GPU waiting for the next launches.
     sdist = self._const('sdist0', (Bp, init_s_near, init_s_far),
                         lambda: torch.tensor([init_s_near, init_s_far], dtype=f32, device=dev).repeat(Bp, 1))
     weights = self._const('weights0', (Bp,), lambda: torch.ones((Bp, 1), dtype=f32, device=dev))
@@ -838,15 +838,18 @@ class Model:
           rendering['normals'] = ops.weighted_sum(weights, mlp_out['normals'])[:B0].reshape(lead + (3,))
           rendering['normals_pred'] = ops.weighted_sum(weights, mlp_out['npred'])[:B0].reshape(lead + (3,))
           rendering['roughness'] = ops.weighted_sum(weights, mlp_out['rough'])[:B0].reshape(lead + (1,))
-        elif plan.pn:
-          rendering['normals_pred'] = ops.weighted_sum(weights, mlp_out['npred'])[:B0].reshape(lead + (3,))
+        else:
+          if plan.pn:
+            rendering['normals_pred'] = ops.weighted_sum(weights, mlp_out['npred'])[:B0].reshape(lead + (3,))
+          if plan.dn:
+            rendering['normals'] = ops.weighted_sum(weights, mlp_out['normals'])[:B0].reshape(lead + (3,))
       renderings.append(rendering)
       rgb_hist = rgb[:B0] if rgb is not None else torch.zeros((B0, n, 3), dtype=f32, device=dev)
       ray_history.append(dict(
           density=density[:B0].reshape(lead + (n,)), rgb=rgb_hist.reshape(lead + (n, 3)),
-          raw_grad_density=(mlp_out['raw_grad'].t().reshape(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.ref else None),
+          raw_grad_density=(mlp_out['raw_grad'].t().reshape(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.tangent else None),
           grad_pred=(mlp_out['small'][:, 1:4].reshape(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if (plan.ref or plan.pn) else None),
-          normals=(mlp_out['normals'].view(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.ref else None),
+          normals=(mlp_out['normals'].view(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.tangent else None),
           normals_pred=(mlp_out['npred'].view(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if (plan.ref or plan.pn) else None),
           roughness=(mlp_out['rough'].view(Bp, n, 1)[:B0].reshape(lead + (n, 1)) if plan.ref else None),
           sdist=sdist[:B0].reshape(lead + (n + 1,)), weights=weights[:B0].reshape(lead + (n,)),
@@ -946,6 +949,38 @@ class Model:
                           head_out=raw_density)
     return dict(acts=[], bits=[], raw_density=raw_density, chain=True)
 
+  def _tangent_forward(self, plan: MLPPlan, tdist, R, M, bits, keep, tag):
+    """Density-gradient normals by forward mode (models.py:473-492 without a second autodiff pass): the three
+    tangent feature rows d features / d mean_c of every sample run through the trunk as 3 * M extra GEMM rows whose ReLU is the
+    primal layer's 1-bit mask; the density column of the last layer gives raw_grad [3, M]."""
+    hp = plan.hp
+    T_feat = self._buf((tag, 'T_feat'), (3 * M, plan.ldF), bf16)
+    ops.cast_rays_ipe_tangent(tdist, R.origins, R.directions, R.radii.reshape(-1).contiguous(), plan.basis_dev,
+                              ray_shape=self.ray_shape, min_deg=hp.min_deg_point, max_deg=hp.max_deg_point,
+                              ld_feat=plan.ldF, out=T_feat)
+    T_acts = []
+    t = None
+    for i, (d, concat) in enumerate(plan.trunk):
+      e2 = plan.packed[('trunk', i)]
+      tout = self._buf((tag, 'T_act', i if keep else i % 2), (3 * M, plan.W), bf16)
+      Bt2 = self._w(plan, e2['f_off'], e2['n_pad'], e2['f_ld'])
+      if i == 0:
+        ops.gemm_nt(T_feat, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.ldF, bits_in=bits[i], bits_row_mod=M,
+                    Cb=tout, ldcb=plan.W, nb=plan.W)
+      elif concat:
+        ops.gemm_nt(t, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.W, A2=T_feat, K2=plan.ldF, bits_in=bits[i],
+                    bits_row_mod=M, Cb=tout, ldcb=plan.W, nb=plan.W)
+      else:
+        ops.gemm_nt(t, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.W, bits_in=bits[i], bits_row_mod=M,
+                    Cb=tout, ldcb=plan.W, nb=plan.W)
+      T_acts.append(tout)
+      t = tout
+    raw_grad = self._buf((tag, 'raw_grad'), (3, M), f32)
+    ed = plan.packed['density']
+    ops.gemm_nt(t, self._w(plan, ed['f_off'], ed['n_pad'], ed['f_ld']), M=3 * M, N=ed['n_pad'], K1=plan.W,
+                Cf=raw_grad, ldcf=1, f0=0, nf=1)
+    return T_feat, T_acts, raw_grad
+
   def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep, tdist=None, bnoise=None, group=None):
     """MLP.__call__ (models.py:402-612) for the M = B*n samples of one level."""
     hp = plan.hp
@@ -954,7 +989,7 @@ class Model:
       return self._chain_forward(plan, flat, feat, M, tag, keep, group)
     assert group is None
     relu = hp.net_activation == 'relu'
-    need_bits = ((keep and _USE_BITS) or plan.ref) and relu
+    need_bits = ((keep and _USE_BITS) or plan.tangent) and relu
     acts, bits, zs, vzs = [], [], [], []
     x = None
     # panel layout for the trunk of this level (the layout of acts / bits / every trunk dY of the backward pass): every
@@ -977,7 +1012,7 @@ class Model:
       e = plan.packed[('trunk', i)]
       out = self._buf((tag, 'act', i if keep else i % 2), (M, plan.W), bf16)
       # 1-bit ReLU mask: backward pass (training) and the tangent pass of the density-gradient normals
-      bo = self._buf((tag, 'bits', i if (keep or plan.ref) else i % 2), (M, plan.W // 8), torch.uint8) if need_bits else None
+      bo = self._buf((tag, 'bits', i if (keep or plan.tangent) else i % 2), (M, plan.W // 8), torch.uint8) if need_bits else None
       bits.append(bo)
       Bt = self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])
       bias = flat[d.bias_off:d.bias_off + d.fan_out]
@@ -1019,32 +1054,7 @@ class Model:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=plan.head_cols, relu=False,
                     Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=small, ldcf=11, f0=bw, nf=11)
         raw_density.copy_(small[:, 0])
-        # density-gradient normals by forward mode: tangent features -> tangent trunk (primal ReLU bits)
-        T_feat = self._buf((tag, 'T_feat'), (3 * M, plan.ldF), bf16)
-        ops.cast_rays_ipe_tangent(tdist, R.origins, R.directions, R.radii.reshape(-1).contiguous(), plan.basis_dev,
-                                  ray_shape=self.ray_shape, min_deg=hp.min_deg_point, max_deg=hp.max_deg_point,
-                                  ld_feat=plan.ldF, out=T_feat)
-        T_acts = []
-        t = None
-        for i, (d, concat) in enumerate(plan.trunk):
-          e2 = plan.packed[('trunk', i)]
-          tout = self._buf((tag, 'T_act', i if keep else i % 2), (3 * M, plan.W), bf16)
-          Bt2 = self._w(plan, e2['f_off'], e2['n_pad'], e2['f_ld'])
-          if i == 0:
-            ops.gemm_nt(T_feat, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.ldF, bits_in=bits[i], bits_row_mod=M,
-                        Cb=tout, ldcb=plan.W, nb=plan.W)
-          elif concat:
-            ops.gemm_nt(t, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.W, A2=T_feat, K2=plan.ldF, bits_in=bits[i],
-                        bits_row_mod=M, Cb=tout, ldcb=plan.W, nb=plan.W)
-          else:
-            ops.gemm_nt(t, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.W, bits_in=bits[i], bits_row_mod=M,
-                        Cb=tout, ldcb=plan.W, nb=plan.W)
-          T_acts.append(tout)
-          t = tout
-        raw_grad = self._buf((tag, 'raw_grad'), (3, M), f32)
-        ed = plan.packed['density']
-        ops.gemm_nt(t, self._w(plan, ed['f_off'], ed['n_pad'], ed['f_ld']), M=3 * M, N=ed['n_pad'], K1=plan.W,
-                    Cf=raw_grad, ldcf=1, f0=0, nf=1)
+        T_feat, T_acts, raw_grad = self._tangent_forward(plan, tdist, R, M, bits, keep, tag)
         normals, npred, rough = ops.ref_head_fwd(small, raw_grad, R.viewdirs, n, plan.ide, hp.roughness_bias, VI,
                                                  bw, plan.ldVI)
         res.update(small=small, T_feat=T_feat, T_acts=T_acts, raw_grad=raw_grad, normals=normals, npred=npred,
@@ -1061,6 +1071,11 @@ class Model:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=bw + 1, relu=False,
                     Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=raw_density, ldcf=1, f0=bw, nf=1, **lay_a)
         ops.viewdir_enc_fill(R.viewdirs, n, hp.deg_view, VI, bw, plan.ldVI)
+      if plan.dn:
+        # density-gradient normals without the rest of the Ref-NeRF head (models.py:478-492): for the renderings and the
+        # orientation loss; they do not enter the colour
+        T_feat, T_acts, raw_grad = self._tangent_forward(plan, tdist, R, M, bits, keep, tag)
+        res.update(T_feat=T_feat, T_acts=T_acts, raw_grad=raw_grad, normals=ops.density_normals_fwd(raw_grad))
       if plan.glo > 0:
         ops.glo_fill(self._glo_table(flat), self._glo_cam, M // n, n, VI, plan.glo_col)
       if bnoise is not None:
@@ -1119,7 +1134,7 @@ class Model:
     forward GEMM, dX GEMM and weight-gradient GEMM (with the density column as a vector) all read or write panel storage."""
     if not (_PANEL and _USE_BITS and plan.hp.net_activation == 'relu' and plan.W % 256 == 0 and plan.W >= 512 and M % 256 == 0):
       return False
-    if self._chain_ok(plan) or plan.ref or not (plan.has_rgb and plan.use_viewdirs):
+    if self._chain_ok(plan) or plan.tangent or plan.pn or not (plan.has_rgb and plan.use_viewdirs):
       return False
     if plan.ldF % 32 != 0 or plan.ldF < 192 or plan.packed['head']['n_pad'] % 256 != 0:
       return False
@@ -1300,6 +1315,8 @@ class Model:
       if dVIb is not None and not plan.ref:
         # bottleneck gradient through the skip concat (a view MLP deeper than skip_layer_dir)
         ops.add_cols_bf16(dHB, dVIb, dHB, bw)
+      if plan.dn and g_normals is not None:
+        g_raw_grad = ops.density_normals_bwd(mlp['raw_grad'], g_normals.view(M, 3))      # -> the tangent network, below
       if plan.pn and g_npred is not None:
         # VJP of normals_pred = -l2_normalize(grad_pred) into the grad_pred columns of the head gradient (zero without a loss on them)
         ops.pred_normals_bwd(mlp['small'], 1, g_npred.view(M, 3), dHB, bw + 1)
@@ -1328,7 +1345,7 @@ class Model:
           ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
       Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
       # (K = the head's columns rounded to the GEMM's 64-column K granule, not to the buffers' 128: 320 instead of 384 at 360.gin)
-      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=_rup(plan.head_cols, 64) if _HEAD_K64 else nh, Cb=dA, ldcb=W, nb=W,
+      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=_rup(plan.head_cols, 64), Cb=dA, ldcb=W, nb=W,
                   **mask_kw(len(acts) - 1), **lay_c)
       act_vjp(mlp['zs'][-1] if not relu else None, dA)
     else:

@@ -56,8 +56,6 @@ def lib():
       L.check(L.load().mnr_level_bwd_set_quad(int(os.environ['MNR_LEVEL_BWD_QUAD'])))
     if os.environ.get('MNR_CHAIN_DEFER'):       # A/B switch: fused chain's copy-outs inside the next layer's MFMA pass (0: in front of it)
       L.check(L.load().mnr_mlp_chain_set_deferred(int(os.environ['MNR_CHAIN_DEFER'])))
-    if os.environ.get('MNR_TN_BIG_MIN_TILES'):  # tuning: the 256x256 dW tile only for outputs of at least this many tiles (default 1)
-      L.check(L.load().mnr_gemm_tn_set_config(int(os.environ['MNR_TN_BIG_MIN_TILES'])))
     if os.environ.get('MNR_NT_WRES'):           # A/B switch: weights-resident kernel for the short-K layers (0: off)
       L.check(L.load().mnr_gemm_nt_set_wres(int(os.environ['MNR_NT_WRES'])))
     if os.environ.get('MNR_PANEL_ALTERNATE'):   # A/B switch: consecutive panel-kernel launches walk the M-tiles in alternating directions
@@ -759,6 +757,24 @@ def ref_color_bwd(raw_rgb, small, premult, rgb_bias, pad, use_tint, g_rgb, dhb, 
   return g_raw_rgb
 
 
+def density_normals_fwd(raw_grad):
+  """normals = -l2_normalize(raw_grad) (models.py:492); raw_grad [3, M] component-major."""
+  _chk(raw_grad, f32, 'raw_grad')
+  M = raw_grad.shape[1]
+  out = torch.empty((M, 3), dtype=f32, device=raw_grad.device)
+  L.check(lib().mnr_density_normals_fwd(M, _ptr(raw_grad), _ptr(out), _stream()))
+  return out
+
+
+def density_normals_bwd(raw_grad, g_normals):
+  _chk(raw_grad, f32, 'raw_grad')
+  _chk(g_normals, f32, 'g_normals')
+  M = raw_grad.shape[1]
+  out = torch.empty((3, M), dtype=f32, device=raw_grad.device)
+  L.check(lib().mnr_density_normals_bwd(M, _ptr(raw_grad), _ptr(g_normals), _ptr(out), _stream()))
+  return out
+
+
 def pred_normals_fwd(small, col):
   """normals_pred = -l2_normalize(small[:, col:col+3]) (models.py:498)."""
   _chk(small, f32, 'small')
@@ -777,14 +793,15 @@ def pred_normals_bwd(small, col, g_npred, dhb, col_g):
 
 
 def ref_losses(mult_o, mult_p, target_is_pred, weights, normals, npred, viewdirs, stats, g_w, want_grad, *, B_valid):
-  for x, nm in ((weights, 'weights'), (npred, 'npred'), (viewdirs, 'viewdirs'), (stats, 'stats')):
+  for x, nm in ((weights, 'weights'), (viewdirs, 'viewdirs'), (stats, 'stats')):
     _chk(x, f32, nm)
   _chk(normals, f32, 'normals', allow_none=True)
+  _chk(npred, f32, 'npred', allow_none=True)
   B, n = weights.shape
   g_n = torch.zeros_like(normals) if (want_grad and normals is not None) else None
-  g_np = torch.zeros_like(npred) if want_grad else None
+  g_np = torch.zeros_like(npred) if (want_grad and npred is not None) else None
   L.check(lib().mnr_ref_losses(B_valid, n, float(mult_o), float(mult_p), int(target_is_pred), _ptr(weights),
-                               _ptr(normals) if normals is not None else None, _ptr(npred), _ptr(viewdirs), _ptr(stats), _ptr(g_w), _ptr(g_n) if g_n is not None else None,
+                               _ptr(normals), _ptr(npred), _ptr(viewdirs), _ptr(stats), _ptr(g_w), _ptr(g_n),
                                _ptr(g_np), _stream()))
   return g_n, g_np
 

@@ -177,7 +177,7 @@ def create_train_step(model: models.Model, config, dataset=None):
           g_w[li] = model._buf(('train', 'g_w', li), (Bp, lv['n']), f32)
           g_w[li].zero_()
         g_nrm[li], g_npr[li] = ops.ref_losses(mo, mp, config.orientation_loss_target == 'normals_pred',
-                                              lv['weights'], lv['mlp'].get('normals'), lv['mlp']['npred'], R.viewdirs,
+                                              lv['weights'], lv['mlp'].get('normals'), lv['mlp'].get('npred'), R.viewdirs,
                                               stats[2 * nlev + 3:2 * nlev + 5], g_w[li], True, B_valid=B0)
 
     g_expo = None

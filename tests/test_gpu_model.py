@@ -133,6 +133,10 @@ CASES = [
                          'NerfMLP.enable_pred_roughness = False', 'NerfMLP.use_diffuse_color = False', 'NerfMLP.use_specular_tint = False',
                          'NerfMLP.use_n_dot_v = False', 'Config.predicted_normal_loss_mult = 0.0',
                          'Config.predicted_normal_coarse_loss_mult = 0.0', 'Config.compute_normal_metrics = False'], 12),
+    # density-gradient normals WITHOUT the rest of the Ref-NeRF head: what configs/llff_raw.gin's own comment asks for ("Turn this
+    # off if using orientation loss ... try .01"): the tangent network next to a plain RawNeRF MLP, the orientation loss on `normals`
+    ('llff_raw', ['NerfMLP.disable_density_normals = False', 'Config.orientation_loss_mult = 0.01',
+                  'Config.orientation_coarse_loss_mult = 0.001', "Config.orientation_loss_target = 'normals'"], 16),
     # 360_glo4.gin: per-camera GLO vectors appended to the view-MLP input (Embed_0 gets gradient)
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_glo_features = 4'], 24),
     # a view MLP deep enough to hit its own skip connection (models.py:579): bottleneck gradient joins two paths
@@ -329,6 +333,36 @@ def test_train_step_parity(name, extra, B):
   torch.cuda.synchronize()
   helpers.assert_adam_matches_oracle(model, cfg, flat1, stats3['_grads'], opt1, state3, what=f'{name} step 2: ')
   assert state3.step == 2
+
+
+def test_side_stream_equals_one_stream_when_both_mlps_share_a_workspace_shape(monkeypatch):
+  """Round-3 advisor finding: the proposal levels' backward runs on a side stream next to the NeRF level's; a proposal MLP that
+  takes the per-layer path (here: softplus, not chain-eligible) with the NeRF MLP's width AND row count would share its backward
+  workspace (dA / dB / dV / dHB ...) with it unless the buffers are keyed by the stream slot.  blender_256 with 128 NeRF samples:
+  both MLPs 256 wide, every level B x 128 rows.  The gradient with MNR_SIDE_STREAM=1 must be the one-stream gradient (up to
+  the arrival order of the fp32 atomics), and both the oracle's."""
+  extra = ['Model.num_nerf_samples = 128', 'PropMLP.net_activation = @jax.nn.softplus']
+  B = 16
+  cfg, model, (om, on, op), params, flat, batch = _setup('blender_256', extra, B)
+  noise = helpers.make_noise(model, B)
+  st = otrain.init_opt_state(params)
+  _, _, _, grads_o = otrain.train_step(params, st, om, on, op, cfg, batch, 0.3, noise=noise, dense_dtype=torch.bfloat16)
+  g_o = _flat_grads(model, grads_o).double()
+  got = {}
+  for side in ('0', '1'):
+    monkeypatch.setenv('MNR_SIDE_STREAM', side)
+    state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})
+    step = train_utils.create_train_step(model, cfg)
+    for _ in range(2):                                  # (twice: the second call runs with every buffer already allocated)
+      _, stats, _ = step(0, state, batch.map(lambda t: t.cuda()), None, 0.3, 0.0, noise=noise, return_grads=True)
+    torch.cuda.synchronize()
+    got[side] = stats['_grads'].double().cpu()
+  rel = lambda a, r: ((a - r).norm() / (r.norm() + 1e-30)).item()
+  for name, b, e in model.modules:
+    d01, d_or = rel(got['1'][b:e], got['0'][b:e]), rel(got['1'][b:e], g_o[b:e])
+    print(f'side stream vs one stream, {name}: {d01:.2e}; side stream vs oracle_bf16: {d_or:.2e}')
+    assert d01 < 1e-4, (name, d01)
+    assert d_or < 0.12, (name, d_or)              # (16 rays, a softplus PropMLP: 7.0e-2 on the simulator; the point here is d01)
 
 
 def test_unsupported_features_fail_loudly():

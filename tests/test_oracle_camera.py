@@ -72,28 +72,23 @@ def test_pose_utilities_match_reference(golden):
 def test_transform_poses_pca_over_several_captures():
   """transform_poses_pca on 12 captures (rings, forward-facing slabs, a near-degenerate line, generic clouds) against the
   reference's own output (tests/golden/make_golden_pca.py executes internal/camera_utils.py:191-227).  The reference's axis
-  signs are whatever LAPACK's general eigen-solver returns; its two fix-ups (right-handed frame, the cameras' mean up
-  vector towards +z) leave a 180-degree turn about z open, so the product's frame (SVD + its own sign rule) may differ from
-  the reference's by exactly that turn, and by nothing else: every capture must match either exactly or after the turn
-  diag(-1, -1, 1), the count of each is printed, and the scale (which does not depend on the signs) must match always.
-  A checkpoint trained in the reference's normalised frame is therefore interchangeable up to that turn only."""
+  signs are whatever LAPACK's general eigen-solver returns, and its two fix-ups (right-handed frame, the cameras' mean up
+  vector towards +z) leave a 180-degree turn about z open; the product asks the same solver (round 4; rounds 1-3 used an SVD
+  with a sign rule of its own and were the turn diag(-1, -1, 1) off on one capture), so every capture must match EXACTLY:
+  a checkpoint or a render path expressed in the reference's normalised frame is interchangeable."""
   import os
   from multinerf_amd import camera_utils as cu
   g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pca_poses.npz'))
   n_sets = len([k for k in g.files if k.startswith('in_')])
   assert n_sets == 12
-  turn = np.diag([-1., -1., 1.])
   same = turned = 0
   for i in range(n_sets):
     p, t = cu.transform_poses_pca(g[f'in_{i}'].copy())
     p_ref, t_ref = g[f'poses_{i}'], g[f'transform_{i}']
     np.testing.assert_allclose(np.abs(p[:, :, 3]).max(), 1.0, rtol=1e-12)
     np.testing.assert_allclose(np.linalg.norm(t[:3, :3], axis=1), np.linalg.norm(t_ref[:3, :3], axis=1), rtol=1e-9)   # scale
-    if np.allclose(p, p_ref, rtol=1e-8, atol=1e-10) and np.allclose(t, t_ref, rtol=1e-8, atol=1e-10):
-      same += 1
-    else:
-      np.testing.assert_allclose(np.einsum('ij,njk->nik', turn, p), p_ref, rtol=1e-8, atol=1e-10, err_msg=f'capture {i}')
-      np.testing.assert_allclose(turn @ t[:3], t_ref[:3], rtol=1e-8, atol=1e-10, err_msg=f'capture {i}')
-      turned += 1
+    np.testing.assert_allclose(p, p_ref, rtol=1e-8, atol=1e-10, err_msg=f'capture {i}')
+    np.testing.assert_allclose(t, t_ref, rtol=1e-8, atol=1e-10, err_msg=f'capture {i}')
+    same += 1
   print(f'transform_poses_pca over {n_sets} captures: {same} identical to the reference, {turned} differ by the 180-degree turn about z')
-  assert same + turned == n_sets
+  assert same == n_sets and turned == 0
