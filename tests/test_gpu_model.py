@@ -348,21 +348,25 @@ def test_side_stream_equals_one_stream_when_both_mlps_share_a_workspace_shape(mo
   st = otrain.init_opt_state(params)
   _, _, _, grads_o = otrain.train_step(params, st, om, on, op, cfg, batch, 0.3, noise=noise, dense_dtype=torch.bfloat16)
   g_o = _flat_grads(model, grads_o).double()
-  got = {}
+  got, first = {}, {}
   for side in ('0', '1'):
     monkeypatch.setenv('MNR_SIDE_STREAM', side)
     state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})
     step = train_utils.create_train_step(model, cfg)
-    for _ in range(2):                                  # (twice: the second call runs with every buffer already allocated)
-      _, stats, _ = step(0, state, batch.map(lambda t: t.cuda()), None, 0.3, 0.0, noise=noise, return_grads=True)
+    # (twice: the second call runs with every buffer already allocated; the optimiser updates the parameters in place, so the
+    # second gradient belongs to the updated parameters, identically in both arms: the oracle is compared with the first)
+    _, stats1, _ = step(0, state, batch.map(lambda t: t.cuda()), None, 0.3, 0.0, noise=noise, return_grads=True)
+    _, stats, _ = step(0, state, batch.map(lambda t: t.cuda()), None, 0.3, 0.0, noise=noise, return_grads=True)
     torch.cuda.synchronize()
     got[side] = stats['_grads'].double().cpu()
+    first[side] = stats1['_grads'].double().cpu()
   rel = lambda a, r: ((a - r).norm() / (r.norm() + 1e-30)).item()
   for name, b, e in model.modules:
-    d01, d_or = rel(got['1'][b:e], got['0'][b:e]), rel(got['1'][b:e], g_o[b:e])
+    d01 = max(rel(got['1'][b:e], got['0'][b:e]), rel(first['1'][b:e], first['0'][b:e]))
+    d_or = rel(first['1'][b:e], g_o[b:e])
     print(f'side stream vs one stream, {name}: {d01:.2e}; side stream vs oracle_bf16: {d_or:.2e}')
     assert d01 < 1e-4, (name, d01)
-    assert d_or < 0.12, (name, d_or)              # (16 rays, a softplus PropMLP: 7.0e-2 on the simulator; the point here is d01)
+    assert d_or < 1.5 * TOL['blender_256']['grad'], (name, d_or)      # (measured on the simulator: 1.6e-2 / 4.3e-3)
 
 
 def test_unsupported_features_fail_loudly():

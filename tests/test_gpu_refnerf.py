@@ -158,6 +158,74 @@ def test_ref_losses_and_weighted_sum(ops):
   np.testing.assert_allclose(ws.cpu().numpy(), (w[..., None] * nrm).sum(1).numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_normals_on_their_own(ops):
+  """The two partial Ref-NeRF mixes of round 4 at kernel level: predicted normals alone (mnr_pred_normals_fwd / _bwd from three
+  columns of the head's fp32 side output into the head's bf16 gradient matrix), density-gradient normals alone
+  (mnr_density_normals_fwd / _bwd on the tangent network's component-major raw_grad), and the orientation loss with only one of the
+  two fields (mnr_ref_losses with normals = NULL / normals_pred = NULL) against the oracle and its autograd
+  (models.py:492,498, ref_utils.py:40-42, train_utils.py:162-178)."""
+  gen = torch.Generator().manual_seed(31)
+  M = 777
+  small = torch.randn((M, 4), generator=gen)
+  small[5, 1:4] = 0.0                                     # a zero vector: l2_normalize clamps the norm (ref_utils.py:41)
+  x = small[:, 1:4].clone().requires_grad_(True)
+  npred_o = -oref.l2_normalize(x)
+  g = torch.randn((M, 3), generator=gen)
+  (npred_o * g).sum().backward()
+  npred = ops.pred_normals_fwd(dev(small), 1)
+  np.testing.assert_allclose(npred.cpu().numpy(), npred_o.detach().numpy(), rtol=1e-5, atol=1e-6)
+  dhb = torch.zeros((M, 16), dtype=torch.bfloat16).cuda()
+  ops.pred_normals_bwd(dev(small), 1, dev(g), dhb, 9)
+  got = dhb.float().cpu()
+  assert (got[:, :9] == 0).all() and (got[:, 12:] == 0).all()
+  np.testing.assert_allclose(got[:, 9:12].numpy(), x.grad.bfloat16().float().numpy(), rtol=1e-2, atol=1e-6)   # (bf16 columns)
+  raw = torch.randn((3, M), generator=gen)
+  raw[:, 7] = 0.0
+  r = raw.clone().requires_grad_(True)
+  nrm_o = -oref.l2_normalize(r.t())
+  (nrm_o * g).sum().backward()
+  nrm = ops.density_normals_fwd(dev(raw))
+  np.testing.assert_allclose(nrm.cpu().numpy(), nrm_o.detach().numpy(), rtol=1e-5, atol=1e-6)
+  g_raw = ops.density_normals_bwd(dev(raw), dev(g))
+  np.testing.assert_allclose(g_raw.cpu().numpy(), r.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+  # the orientation loss with one field only
+  B, Bv, n = 40, 37, 16
+  w = torch.rand((B, n), generator=gen) * 0.05
+  nv = torch.randn((B, n, 3), generator=gen)
+  nv = nv / nv.norm(dim=-1, keepdim=True)
+  v = torch.randn((B, 3), generator=gen)
+  v = v / v.norm(dim=-1, keepdim=True)
+
+  class Obj:
+    pass
+
+  for target, field in (('normals_pred', 'normals_pred'), ('normals', 'normals')):
+    class Cfg:
+      orientation_loss_target = target
+      orientation_coarse_loss_mult, orientation_loss_mult = 0.01, 0.1
+    rays, model = Obj(), Obj()
+    rays.viewdirs, model.num_levels = v[:Bv], 1
+    wv, fv = w[:Bv].clone().requires_grad_(True), nv[:Bv].clone().requires_grad_(True)
+    hist = [{'weights': wv, 'normals': None, 'normals_pred': None}]
+    hist[0][field] = fv
+    lo = otrain.orientation_loss(rays, model, hist, Cfg)
+    lo.backward()
+    stats = torch.zeros(2).cuda()
+    g_w = torch.zeros((B, n)).cuda()
+    is_pred = target == 'normals_pred'
+    g_n, g_np = ops.ref_losses(0.1, 0.0, is_pred, dev(w), None if is_pred else dev(nv.reshape(-1, 3)),
+                               dev(nv.reshape(-1, 3)) if is_pred else None, dev(v), stats, g_w, True, B_valid=Bv)
+    assert (g_n is None) == is_pred and (g_np is None) == (not is_pred)
+    np.testing.assert_allclose(stats.cpu().numpy(), [lo.item(), 0.0], rtol=1e-4, atol=1e-12)
+    np.testing.assert_allclose(g_w.cpu()[:Bv].numpy(), wv.grad.numpy(), rtol=1e-4, atol=1e-9)
+    got_g = (g_np if is_pred else g_n).cpu().reshape(B, n, 3)[:Bv]
+    np.testing.assert_allclose(got_g.numpy(), fv.grad.numpy(), rtol=1e-4, atol=1e-10)
+  # what the reference refuses, the C ABI refuses: the predicted-normal loss needs both fields
+  with pytest.raises(ValueError, match='without density-gradient normals'):
+    ops.ref_losses(0.1, 3e-4, True, dev(w), None, dev(nv.reshape(-1, 3)), dev(v), torch.zeros(2).cuda(), None, False, B_valid=Bv)
+
+
 def test_tangent_features(ops):
   """d(features)/d(mean_c) (forward mode) vs autograd of the oracle's IPE w.r.t. the means."""
   from multinerf_amd import geopoly
