@@ -125,6 +125,9 @@ class MLP:
       # their own (disable_density_normals = False: the tangent network, what configs/llff_raw.gin asks for with the orientation
       # loss); other partial mixes are not.
       bad.append('partial Ref-NeRF feature set ' + str(on) + ' (all of them, predicted normals alone, density normals alone, or none)')
+    if on and self.disable_rgb:
+      # (the two single-field mixes live in the merged head of an MLP with a colour branch)
+      bad.append('normals ' + str(on) + ' on a density-only MLP (disable_rgb)')
     if not self.disable_density_normals and self.warp_fn is not None:
       bad.append('density-gradient normals with a warp_fn')
     if self.is_ref() and self.roughness_activation != 'softplus':
@@ -324,8 +327,9 @@ class Model:
       bad += [f'{name}: {b}' for b in hp.hip_supported()]
     if not self.stop_level_grad:
       bad.append('stop_level_grad=False')
-    if not self.use_viewdirs and (self.nerf_hp.is_ref() or self.prop_hp.is_ref()):
-      bad.append('the Ref-NeRF head without view directions')
+    if not self.use_viewdirs and any(hp.enable_pred_normals or not hp.disable_density_normals
+                                     for hp in (self.nerf_hp, self.prop_hp) if not hp.disable_rgb):
+      bad.append('normals (the Ref-NeRF head or one of its fields) without view directions')
     if self.ray_shape not in ('cone', 'cylinder'):
       raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')
     if self.num_glo_features > 0 and self.single_mlp:

@@ -103,7 +103,7 @@ def test_equal_step_psnr_360_full_width():
   spec = importlib.util.spec_from_file_location('make_golden_psnr', os.path.join(here, 'golden', 'make_golden_psnr.py'))
   G = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(G)
-  seeds = [sd for sd in (G.SEED, G.SEED + 1, G.SEED + 2) if os.path.exists(G.golden_path(sd))]
+  seeds = [sd for sd in range(G.SEED, G.SEED + 5) if os.path.exists(G.golden_path(sd))]
   assert G.SEED in seeds
   cfg = configs.load_preset('360', G.BINDINGS)
   model = models.Model(config=cfg)
@@ -112,13 +112,17 @@ def test_equal_step_psnr_360_full_width():
   om, on, op = helpers.oracle_hparams(model)
   out = os.environ.get('MNR_PSNR_LOG')
   repeats = int(os.environ.get('MNR_PSNR_REPEATS', '3'))
-  all_rows, finals, tails, finals_bf, tails_bf = [], {}, {}, {}, {}
+  all_rows, finals, tails, finals_bf, tails_bf, finals_fb, tails_fb = [], {}, {}, {}, {}, {}, {}
   for seed, rep in [(sd, r) for sd in seeds for r in range(repeats)]:
     ref = json.load(open(G.golden_path(seed)))
     assert ref['steps'] == G.STEPS and ref['rays'] == G.RAYS and ref['seed'] == seed and ref['bindings'] == G.BINDINGS
     # the same protocol through the oracle with the Dense operands rounded to bf16 (round 4: what of the difference is precision)
     ref_bf = json.load(open(G.golden_path(seed, bf16=True))) if os.path.exists(G.golden_path(seed, bf16=True)) else None
     want_bf = {c['step']: c for c in ref_bf['curve']} if ref_bf else {}
+    # ... and with the backward matmuls' incoming gradients rounded as well (oracle.models.BF16_FWD_BWD: every Dense matmul of the
+    # reference's TPU default precision, forward and backward; also what the HIP path stores: dY in bf16)
+    p_fb = G.golden_path(seed, bf16='bf16_fwd_bwd')
+    want_fb = {c['step']: c for c in json.load(open(p_fb))['curve']} if os.path.exists(p_fb) else {}
     flat = model.flat_from_tree(omodels.init_params(om, on, op, seed=seed))
     ev = G.eval_rays(seed)
     ev_rays = ev.rays.map(lambda t: t.cuda())
@@ -135,7 +139,8 @@ def test_equal_step_psnr_360_full_width():
         s = stats.materialize()
         rows.append(dict(seed=seed, replay=rep, step=step, hip_eval_psnr=e, oracle_eval_psnr=want[step]['eval_psnr'], hip_train_loss=s['loss'],
                          oracle_train_loss=want[step]['train_loss'],
-                         oracle_bf16_eval_psnr=want_bf[step]['eval_psnr'] if step in want_bf else None))
+                         oracle_bf16_eval_psnr=want_bf[step]['eval_psnr'] if step in want_bf else None,
+                         oracle_bf16fb_eval_psnr=want_fb[step]['eval_psnr'] if step in want_fb else None))
         print(f'seed {seed} replay {rep} step {step:4d}: eval PSNR hip {e:.3f} oracle {want[step]["eval_psnr"]:.3f} ({e - want[step]["eval_psnr"]:+.3f} dB); '
               f'train loss hip {s["loss"]:.5f} oracle {want[step]["train_loss"]:.5f}')
     first, last = rows[0], rows[-1]
@@ -145,6 +150,9 @@ def test_equal_step_psnr_360_full_width():
     if last['oracle_bf16_eval_psnr'] is not None:
       finals_bf[(seed, rep)] = last['hip_eval_psnr'] - last['oracle_bf16_eval_psnr']
       tails_bf[(seed, rep)] = float(np.mean([r['hip_eval_psnr'] - r['oracle_bf16_eval_psnr'] for r in rows[-3:]]))
+    if last['oracle_bf16fb_eval_psnr'] is not None:
+      finals_fb[(seed, rep)] = last['hip_eval_psnr'] - last['oracle_bf16fb_eval_psnr']
+      tails_fb[(seed, rep)] = float(np.mean([r['hip_eval_psnr'] - r['oracle_bf16fb_eval_psnr'] for r in rows[-3:]]))
     # the mean over the last three checkpoints averages out the step-to-step wobble of either trajectory
     tails[(seed, rep)] = float(np.mean([r['hip_eval_psnr'] - r['oracle_eval_psnr'] for r in rows[-3:]]))
     print(f'equal-step PSNR, 360.gin full width, seed {seed} replay {rep}: final diff {finals[(seed, rep)]:+.3f} dB, mean of the last '
