@@ -89,11 +89,12 @@ def test_equal_step_psnr_360_full_width():
   steps of 256 rays from the oracle's initialisation with the oracle's batches and jitter at every step.  The oracle's
   side ran on the CPU ahead of time (tests/golden/make_golden_psnr.py [--seed S] -> tests/golden/psnr360*.json); here the
   HIP path replays the protocol and must land within 0.1 dB of the oracle's held-out PSNR at equal step count
-  (north_star).  Round 3: THREE seeds (initialisation, batches and jitter all differ), each replayed MNR_PSNR_REPEATS = 3
-  times (the fp32 atomics of the weight gradients make every replay a different trajectory); every run's difference, the
-  seed means, the grand mean and its standard error are printed; asserted: the grand mean of the SIGNED differences (the
-  systematic gap) is consistent with north_star's 0.1 dB at two standard errors and below 0.2 dB outright, no single run further
-  than 0.5 dB off (see the comment at the assertions for the measured noise)."""
+  (north_star).  Up to five seeds (initialisation, batches and jitter all differ), each replayed MNR_PSNR_REPEATS = 3 times
+  (the fp32 atomics of the weight gradients make every replay a different trajectory), against three oracle runs per seed: plain
+  fp32, bf16 forward operands, and bf16 operands in the forward AND the backward matmuls (the reference's TPU default precision);
+  every run's difference, the seed means and the grand means are printed.  Asserted: the grand mean of the SIGNED differences
+  against the reference-precision oracle within 0.1 dB (no error bars subtracted), every seed's mean within 0.15 dB, the grand
+  mean against the fp32 oracle within 0.15 dB, no single run further than 0.5 dB off (see the comment at the assertions)."""
   import importlib.util
   import json
   import os
@@ -179,14 +180,30 @@ def test_equal_step_psnr_360_full_width():
     ob = {sd: round(float(np.mean([finals[k] - finals_bf[k] for k in finals_bf if k[0] == sd])), 3) for sd in seeds}
     print(f'equal-step PSNR against the bf16-EMULATING oracle: final diffs {[round(float(v), 3) for v in vb]} dB; grand mean {float(vb.mean()):+.3f} +- {seb:.3f} dB, '
           f'last-three-checkpoint grand mean {float(tb.mean()):+.3f} dB; oracle_bf16 - oracle_fp32 at step 600 per seed: {ob}')
-  # What is asserted, and why not "every run within 0.1 dB": a 600-step run is chaotic, and the weight gradients are summed
-  # with fp32 atomics in whatever order the workgroups arrive, so ONE seed's difference moves by +-0.07 dB from replay to replay
-  # of the same binary (seed 360 over six replays: +0.108, -0.008, -0.035, +0.150, -0.086, +0.002 dB; seed 362: -0.114, -0.199,
-  # -0.051, -0.151, -0.118, -0.116), and the mean of three single runs by +-0.04: over 13 such triples of round 3 it read between
-  # -0.022 and -0.153 dB, mean -0.073 dB, with this session's kernel changes switched off as well as on (gpurun_out/r3s3 A/B).
-  # That -0.07 dB is the systematic gap between the bf16-input HIP path and the fp32 oracle; nine runs resolve it to +-0.03.
-  # The assertion is the statistical statement those data support: the measured gap is consistent with north_star's 0.1 dB
-  # (two standard errors), and it is below 0.2 dB whatever the noise; a single run is held to 0.5 dB.
-  assert abs(mean) - 2.0 * se <= 0.1 and abs(tmean) - 2.0 * tse <= 0.1, (mean, se, tmean, tse)
-  assert abs(mean) <= 0.2 and abs(tmean) <= 0.2, (mean, tmean)
-  assert float(np.abs(vals).max()) <= 0.5, finals
+  assert finals_fb, 'tests/golden/psnr360_bf16fb*.json missing (make_golden_psnr.py --dense_dtype bf16_fwd_bwd)'
+  vf, tf_ = np.array(list(finals_fb.values())), np.array(list(tails_fb.values()))
+  seeds_fb = sorted({k[0] for k in finals_fb})
+  seed_means_fb = {sd: round(float(np.mean([v for (s_, _), v in finals_fb.items() if s_ == sd])), 3) for sd in seeds_fb}
+  mean_fb, tmean_fb = float(vf.mean()), float(tf_.mean())
+  ofb = {sd: round(float(np.mean([finals[k] - finals_fb[k] for k in finals_fb if k[0] == sd])), 3) for sd in seeds_fb}
+  print(f'equal-step PSNR against the oracle at the reference\'s TPU default precision in BOTH passes (bf16 operands of every Dense matmul, '
+        f'forward and backward): final diffs {[round(float(v), 3) for v in vf]} dB; seed means {seed_means_fb}; grand mean {mean_fb:+.3f} dB, '
+        f'last-three-checkpoint grand mean {tmean_fb:+.3f} dB; that oracle minus the fp32 oracle at step 600 per seed: {ofb}')
+  # What is asserted (round 4).  north_star: "PSNR within 0.1 dB of reference at equal step count".  The reference's Dense layers run
+  # at jax's default precision (internal/models.py: nn.Dense without a precision argument; internal/math.py:21-23 raises it only for
+  # its own matmul helper), which on its TPUs rounds the operands of every matmul, forward AND backward, to bf16.  Round 3 compared
+  # with the fp32 oracle only and found a persistent -0.07 dB (13 triples), which it could not attribute.  Round 4 ran the oracle
+  # at that precision (oracle.models.BF16_FWD_BWD; tests/golden/psnr360_bf16fb*.json) and the gap is the backward rounding: seed
+  # 362, where the HIP path ends 0.18-0.31 dB under the fp32 oracle on every replay, the bf16 forward+backward oracle ends 0.23 dB
+  # under it too (19.947 against 20.180; rounding the forward operands alone: 20.170), and on seeds 360 / 361 all four agree to
+  # +-0.08 dB (profiles/r4e_psnr_s.log, r4g_psnr_s.log).  So:
+  #   * the grand mean of the signed differences against the reference-precision oracle is held to 0.1 dB, PLAINLY (no standard
+  #     errors subtracted; measured +-0.01 dB), and every seed's mean to 0.15 dB;
+  #   * against the plain fp32 oracle the grand mean is held to 0.15 dB (measured -0.08: that IS the precision cost of bf16 matmuls
+  #     on this scene) and reported next to it;
+  #   * one run may be 0.5 dB off (a 600-step run is chaotic and the weight gradients are summed with fp32 atomics in arrival
+  #     order: one seed's difference moves by +-0.05 dB from replay to replay of the same binary).
+  assert abs(mean_fb) <= 0.1 and abs(tmean_fb) <= 0.1, (mean_fb, tmean_fb)
+  assert max(abs(v) for v in seed_means_fb.values()) <= 0.15, seed_means_fb
+  assert abs(mean) <= 0.15 and abs(tmean) <= 0.15, (mean, tmean)
+  assert float(np.abs(vals).max()) <= 0.5 and float(np.abs(vf).max()) <= 0.5, (finals, finals_fb)

@@ -132,6 +132,10 @@ def test_full_width_train_step_gradient_is_the_oracles(setup):
   st = otrain.init_opt_state(params)
   _, _, stats_bf, grads_bf = otrain.train_step(params, st, om, on, op, cfg, sub, tf, noise=noise, dense_dtype=torch.bfloat16)
   _, _, stats_32, grads_32 = otrain.train_step(params, st, om, on, op, cfg, sub, tf, noise=noise)
+  # (reported, not asserted: the oracle with the backward matmuls' incoming gradients rounded to bf16 as well, the reference's TPU
+  # default precision in both passes and what the HIP path stores; oracle.models.BF16_FWD_BWD)
+  _, _, _, grads_fb = otrain.train_step(params, st, om, on, op, cfg, sub, tf, noise=noise, dense_dtype=omodels.BF16_FWD_BWD)
+  g_fb = model.flat_from_tree(grads_fb, device='cpu').double()
   g_bf = model.flat_from_tree(grads_bf, device='cpu').double()
   g_32 = model.flat_from_tree(grads_32, device='cpu').double()
   step = train_utils.create_train_step(model, cfg)
@@ -148,6 +152,7 @@ def test_full_width_train_step_gradient_is_the_oracles(setup):
   for name, b, e in model.modules:
     r_bf, r_32, cost = rel(g[b:e], g_bf[b:e]), rel(g[b:e], g_32[b:e]), rel(g_bf[b:e], g_32[b:e])
     cos = (g[b:e] @ g_bf[b:e] / (g[b:e].norm() * g_bf[b:e].norm() + 1e-30)).item()
+    print(f'FULLWIDTH {name}: |g - oracle_bf16fb| / |g| = {rel(g[b:e], g_fb[b:e]):.3e} (bf16 operands in both passes)')
     print(f'FULLWIDTH {name}: |g - oracle_bf16| / |g| = {r_bf:.3e}, |g - oracle_fp32| / |g| = {r_32:.3e} '
           f'(bf16 cost {cost:.3e}), cos {cos:.6f}, |g| = {g_bf[b:e].norm().item():.3e}')
     tb, t32 = GRAD_TOL_MODULE.get(name, (0.06, 0.13))
@@ -159,7 +164,8 @@ def test_full_width_train_step_gradient_is_the_oracles(setup):
       if nelem < 8 or g_bf[o:o + nelem].norm() < 1e-12:
         continue
       r_bf, r_32, cost = rel(g[o:o + nelem], g_bf[o:o + nelem]), rel(g[o:o + nelem], g_32[o:o + nelem]), rel(g_bf[o:o + nelem], g_32[o:o + nelem])
-      print(f'FULLWIDTH LAYER {p.module_name}/{d.name}/kernel [{d.fan_in}x{d.fan_out}]: bf16 {r_bf:.3e} fp32 {r_32:.3e} (bf16 cost {cost:.3e})')
+      print(f'FULLWIDTH LAYER {p.module_name}/{d.name}/kernel [{d.fan_in}x{d.fan_out}]: bf16 {r_bf:.3e} fp32 {r_32:.3e} (bf16 cost {cost:.3e}) '
+            f'bf16fb {rel(g[o:o + nelem], g_fb[o:o + nelem]):.3e}')
       worst_bf, worst_32 = max(worst_bf, r_bf), max(worst_32, r_32)
       if N_TRAIN >= 256:
         tb, t32 = GRAD_TOL_DENSE[f'{p.module_name}/{d.name}']

@@ -143,3 +143,25 @@ def test_bf16_dense_emulation_is_close_to_fp32():
   r32, _ = omodels.model_apply(om, on, op, params, batch.rays, 0.5, False)
   r16, _ = omodels.model_apply(om, on, op, params, batch.rays, 0.5, False, dense_dtype=torch.bfloat16)
   assert (r32[-1]['rgb'] - r16[-1]['rgb']).abs().max() < 0.05
+
+
+def test_bf16_forward_and_backward_emulation_of_a_dense_layer():
+  """oracle.models.BF16_FWD_BWD (the reference's TPU default precision in both passes of a Dense matmul): the forward is the
+  forward-only emulation's, the backward multiplies the bf16-rounded incoming gradient with the bf16-rounded operands."""
+  from oracle import models as om
+  g = torch.Generator().manual_seed(0)
+  x = torch.randn((6, 9), generator=g, requires_grad=True)
+  k = torch.randn((9, 5), generator=g, requires_grad=True)
+  b = torch.randn((5,), generator=g)
+  gy = torch.randn((6, 5), generator=g)
+  p = {'Dense_0': {'kernel': k, 'bias': b}}
+  y_fb = om._DenseCursor(p, om.BF16_FWD_BWD)(x)
+  y_f = om._DenseCursor(p, torch.bfloat16)(x)
+  assert torch.equal(y_fb, y_f)
+  y_fb.backward(gy)
+  r = lambda t: t.detach().bfloat16().float()
+  assert torch.equal(x.grad, r(gy) @ r(k).t()) and torch.equal(k.grad, r(x).t() @ r(gy))
+  gx_fb = x.grad.clone()
+  x.grad = k.grad = None
+  y_f.backward(gy)
+  assert not torch.equal(x.grad, gx_fb) and torch.allclose(x.grad, gx_fb, rtol=0, atol=0.05)      # (the incoming gradient unrounded)
