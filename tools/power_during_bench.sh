@@ -11,7 +11,7 @@ cd $R
 BP=$!
 : > $OUT/${TAG}_power_raw.txt
 while kill -0 $BP 2>/dev/null; do
-  rocm-smi --showpower --showclocks --csv 2>/dev/null | tail -n 1 >> $OUT/${TAG}_power_raw.txt
+  rocm-smi --showpower --showclocks --csv 2>/dev/null | grep '^card' | tail -n 1 >> $OUT/${TAG}_power_raw.txt
   sleep 0.1
 done
 wait $BP

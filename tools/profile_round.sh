@@ -19,7 +19,7 @@ python $R/tools/prof_summary.py pmc $OUT/${TAG}_pmc_SQ --title "rocprofv3 --pmc 
 rm -rf $OUT/${TAG}_pmc_SQ
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -- python $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_aux > $OUT/${TAG}_pmc_$C.log 2>&1
-  python $R/tools/prof_summary.py pmc $OUT/${TAG}_pmc_$C --title "rocprofv3 --pmc $C ($TAG)" --command "rocprofv3 --kernel-trace --pmc $C -- python bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_aux" --top 12 > $OUT/${TAG}_pmc_$C.md
+  python $R/tools/prof_summary.py pmc $OUT/${TAG}_pmc_$C --title "rocprofv3 --pmc $C ($TAG)" --command "rocprofv3 --kernel-trace --pmc $C -- python bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_aux" --top 40 > $OUT/${TAG}_pmc_$C.md
   rm -rf $OUT/${TAG}_pmc_$C      # raw CSVs are large (kernel names); the summary is what is kept
 done
 rm -rf $OUT/${TAG}_prof

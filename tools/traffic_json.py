@@ -4,13 +4,13 @@
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, HBM section).  The
 number of train steps inside the profiled command is read off the dispatch count of clip_adam_kernel (one per top-level
-module and step: two at 360.gin).
+module and step: two at 360.gin), or given as a fourth argument after the module count.
 """
 import json
 import re
 import sys
 
-MFMA = ('gemm_nt_kernel', 'gemm_tn_kernel', 'gemm_tn_gcol_kernel', 'gemm_nt_wres_kernel', 'mlp_chain_fwd_kernel', 'mlp_chain_bwd_kernel',
+MFMA = ('gemm_nt_kernel', 'gemm_nt_panel_kernel', 'gemm_tn_kernel', 'gemm_tn_gcol_kernel', 'gemm_nt_wres_kernel', 'mlp_chain_fwd_kernel', 'mlp_chain_bwd_kernel',
         'mlp_chain_fwd_ipe_kernel')
 
 
@@ -28,6 +28,10 @@ def main():
   adam = [v for k, v in fetch.items() if 'clip_adam_kernel' in k]
   modules = int(sys.argv[3]) if len(sys.argv) > 3 else 2
   steps = adam[0][0] // modules if adam else None
+  if len(sys.argv) > 4:                      # explicit step count (a summary cut off above clip_adam_kernel)
+    steps = int(sys.argv[4])
+  if steps is None:
+    raise SystemExit('traffic_json.py: clip_adam_kernel is not in the summary: pass <modules> <steps> explicitly')
   f = sum(v[1] for k, v in fetch.items() if any(n in k for n in MFMA))
   w = sum(v[1] for k, v in write.items() if any(n in k for n in MFMA))
   total_f = sum(v[1] for v in fetch.values())
