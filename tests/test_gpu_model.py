@@ -137,6 +137,10 @@ CASES = [
     # off if using orientation loss ... try .01"): the tangent network next to a plain RawNeRF MLP, the orientation loss on `normals`
     ('llff_raw', ['NerfMLP.disable_density_normals = False', 'Config.orientation_loss_mult = 0.01',
                   'Config.orientation_coarse_loss_mult = 0.001', "Config.orientation_loss_target = 'normals'"], 16),
+    # the two single-field mixes in other surroundings: predicted normals next to GLO vectors under the contraction (two MLPs: the
+    # proposal MLP has no normals, so no normal loss can be on, as in the reference), density-gradient normals on a two-MLP preset
+    ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'NerfMLP.enable_pred_normals = True', 'Model.num_glo_features = 4'], 8),
+    ('blender_256', ['NerfMLP.disable_density_normals = False'], 8),
     # 360_glo4.gin: per-camera GLO vectors appended to the view-MLP input (Embed_0 gets gradient)
     ('360', ['NerfMLP.net_width = 256', 'PropMLP.net_width = 128', 'Model.num_glo_features = 4'], 24),
     # a view MLP deep enough to hit its own skip connection (models.py:579): bottleneck gradient joins two paths
