@@ -200,7 +200,7 @@ def test_equal_step_psnr_360_full_width():
   #   * the grand mean of the signed differences against the reference-precision oracle is held to 0.1 dB, PLAINLY (no standard
   #     errors subtracted; measured +0.040 over 15 runs, +0.038 over 25: profiles/r4g_, r4h_psnr360_equal_step.jsonl), and every
   #     seed's mean over its five replays to 0.3 dB (seed 362's replays scatter by +-0.1 dB: its mean read +0.06 and +0.15);
-  #   * against the plain fp32 oracle the grand mean is held to 0.15 dB (measured -0.08: that IS the precision cost of bf16 matmuls
+  #   * against the plain fp32 oracle the grand mean is held to 0.15 dB (measured -0.04 over five seeds, -0.08 over the first three: the precision cost of bf16 matmuls
   #     on this scene) and reported next to it;
   #   * one run may be 0.5 dB off (a 600-step run is chaotic and the weight gradients are summed with fp32 atomics in arrival
   #     order: one seed's difference moves by +-0.05 dB from replay to replay of the same binary).
