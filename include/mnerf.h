@@ -195,6 +195,12 @@ typedef struct {
    * (ld_bits_* are ignored).  Restrictions of c_layout = PANEL: K1 + K2 >= 192, no fp32 side output, no bf16 mask,
    * nb == N, forward layers carry a full bias (n_bias == N), bits_row_mod == 0; A2 and Bt are always row-major. */
   int a1_layout; int c_layout;
+  /* One more output column supplied as a VECTOR: vcol_out[m] = sum_k [A1|A2][m, k] * vcol[k] + *vcol_bias (fp32), next to an
+   * N = 256 result.  The NeRF MLP's density head (internal/models.py:460) next to its 256-wide bottleneck (:527): both read the
+   * last trunk activation, and as column 257 of a merged operand the density would cost a second 256-column tile of MFMAs.
+   * Each of the four waves that share a row block spends one extra MFMA per k-step on it (+12.5 %).  vcol: bf16 [K1 + K2]
+   * (16-byte aligned); needs a1_layout = PANEL, N == 256, K1 + K2 <= 1536, a row-major bf16 result, no fp32 side output. */
+  const uint16_t* vcol; float* vcol_out; const float* vcol_bias;     /* vcol_bias: one device float, or NULL for 0 */
 } mnr_gemm_nt_args;
 #define MNR_LAYOUT_ROWMAJOR 0
 #define MNR_LAYOUT_PANEL 1

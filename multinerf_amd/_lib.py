@@ -64,7 +64,8 @@ class GemmNTArgs(C.Structure):
               ('Cf', vp), ('ldcf', C.c_int), ('f0', C.c_int), ('nf', C.c_int),
               ('mask_bits_out', vp), ('ld_bits_out', C.c_int),
               ('mask_bits_in', vp), ('ld_bits_in', C.c_int),
-              ('bits_row_mod', C.c_int64), ('a1_layout', C.c_int), ('c_layout', C.c_int)]
+              ('bits_row_mod', C.c_int64), ('a1_layout', C.c_int), ('c_layout', C.c_int),
+              ('vcol', vp), ('vcol_out', vp), ('vcol_bias', vp)]
 
 
 class GemmTNArgs(C.Structure):

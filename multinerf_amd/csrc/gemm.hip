@@ -136,12 +136,25 @@ extern "C" int mnr_debug_gemm_timeline(unsigned long long* device_buffer) {
   return MNR_OK;
 }
 
-template <class CFG, bool BITS_IN, bool A1_PANEL = false>
+// VCOL (mnr_gemm_nt_args.vcol): one more output column supplied as a vector, kept in LDS behind everything else for the whole
+// walk: [K1 + K2] bf16 (at most NT_VCOL_MAX_K) followed by 16 bytes of zeros (the fragment of the lanes that hold other columns)
+#define NT_VCOL_MAX_K 1536
+#define NT_VCOL_BYTES (NT_VCOL_MAX_K * 2 + 16)
+
+template <class CFG, bool BITS_IN, bool A1_PANEL = false, bool VCOL = false>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_nt_kernel(mnr_gemm_nt_args p, int fast_epi, long long vtotal) {
   // the wave index lives in an SGPR across the tile loop and the lane index is re-derived per tile (mbcnt): with
   // threadIdx.x itself kept alive across the loop, hipcc spills it and reloads it (behind a vmcnt(0)) at every tile
   const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   unsigned long long* const tl = g_nt_timeline;          // read once: a load per tile is a vmcnt(0) behind the previous tile's stores
+  if constexpr (VCOL) {
+    // the vector goes to LDS once per workgroup (the first tile's prologue barrier publishes it)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    const int t = (int)threadIdx.x, n16 = (p.K1 + p.K2) / 8;
+    if (t < n16) *(u32x4v*)(smem + CFG::LDS_BYTES + t * 16) = *(const u32x4v*)(p.vcol + t * 8);
+    if (t == CFG::THREADS - 1) *(u32x4v*)(smem + CFG::LDS_BYTES + NT_VCOL_MAX_K * 2) = u32x4v{0u, 0u, 0u, 0u};
+  }
   for (int64_t vbid = blockIdx.x; vbid < vtotal; vbid += gridDim.x) {
 #include "gemm_nt_body.inc"
     if (vbid + gridDim.x < vtotal) __syncthreads();      // (persistent launch) this tile's LDS is free for the next one
@@ -184,6 +197,18 @@ static int nt_launch(const mnr_gemm_nt_args* a, int fast_epi, void* stream) {
   }
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
   if constexpr (A1_PANEL) {
+    if (a->vcol) {
+      // one more column as a vector (the density head next to the bottleneck): a flavour of its own, LDS + NT_VCOL_BYTES
+      static unsigned long long attr_set_v = 0;
+      constexpr int lds = CFG::LDS_BYTES + NT_VCOL_BYTES;
+      static_assert(lds <= 160 * 1024, "LDS");
+      if (mnr_attr_needed(&attr_set_v))
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((gemm_nt_kernel<CFG, false, true, true>), dim3((unsigned)grid), dim3(CFG::THREADS), lds, (hipStream_t)stream, *a,
+                         fast_epi, (long long)vtotal);
+      MNR_CHECK_LAUNCH();
+      return MNR_OK;
+    }
     if (mnr_attr_needed(&attr_set))
       (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<CFG, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES);
     hipLaunchKernelGGL((gemm_nt_kernel<CFG, false, true>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES,
@@ -476,11 +501,17 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
   // 16-byte row segments in the epilogue need 8-element-aligned output / mask pitches and bases.
   const int fast_epi = (int)((!a->Cb || (a->ldcb % 8 == 0 && ((uintptr_t)a->Cb % 16) == 0)) &&
                              (!a->mask || (a->ldmask % 8 == 0 && ((uintptr_t)a->mask % 16) == 0)));
+  MNR_CHECK_ARG(!a->vcol || (a->a1_layout == MNR_LAYOUT_PANEL && a->c_layout == MNR_LAYOUT_ROWMAJOR),
+                "mnr_gemm_nt_bf16: vcol goes with a panel-layout A1 and a row-major result");
   if (a->c_layout == MNR_LAYOUT_PANEL) return mnr_gemm_nt_panel_launch(a, stream);
   if (a->a1_layout == MNR_LAYOUT_PANEL) {
     // a panel-layout activation into a row-major result (the merged head behind the trunk): the pipelined tiled kernel
     MNR_CHECK_ARG(a->M % 256 == 0 && a->N % 256 == 0 && a->lda1 == a->K1 && a->K1 % 32 == 0 && !a->mask_bits_in,
                   "mnr_gemm_nt_bf16: a panel-layout A1 needs M, N multiples of 256, lda1 == K1 and a forward epilogue");
+    MNR_CHECK_ARG(!a->vcol || (a->vcol_out && a->N == 256 && a->K1 + a->K2 <= NT_VCOL_MAX_K && !a->Cf && a->Cb && a->nb == a->N &&
+                               (fast_epi & 1) && ((uintptr_t)a->vcol % 16) == 0 && ((uintptr_t)a->vcol_out % 4) == 0),
+                  "mnr_gemm_nt_bf16: vcol needs vcol_out, N == 256, K1 + K2 <= %d, a full-width 16-byte-aligned bf16 result, no fp32 side output",
+                  NT_VCOL_MAX_K);
     return nt_launch<NtBigP, true>(a, fast_epi, stream);
   }
   if (g_nt_wres > 0 && nt_wres_eligible(a, fast_epi)) return nt_wres_launch(a, g_nt_wres, stream);

@@ -39,6 +39,7 @@ import os as _os
 _USE_BITS = _os.environ.get('MNR_RELU_BITS', '1') != '0'   # A/B switch: 1-bit ReLU masks vs re-reading activations
 _USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused per-level Dense chain vs one GEMM per layer
 _FUSED_IPE = _os.environ.get('MNR_FUSED_IPE', '1') != '0'   # A/B switch: rendering builds the proposal levels' IPE features inside the chain kernel
+_HEAD_VCOL = _os.environ.get('MNR_HEAD_VCOL', '1') != '0'  # A/B switch: the density head's forward column as a vector next to the N = 256 bottleneck GEMM (panel trunks)
 _HEAD_GCOL = _os.environ.get('MNR_HEAD_GCOL', '1') != '0'  # A/B switch: the density head's weight gradient as an extra column of the bottleneck's dW GEMM (N = 256, 256x256 tiles) instead of a merged N = 384 GEMM on 128x128 tiles
 # A/B switch: the wide (>= 512) per-layer trunk keeps its activations, gradients and ReLU masks in the panel layout
 # (include/mnerf.h MNR_LAYOUT_PANEL; csrc/gemm_blk.hip): results leave the MFMA accumulators as whole 1-KiB blocks, the K loop
@@ -1071,6 +1072,13 @@ class Model:
         raw_density.copy_(small[:, 0])
         ops.viewdir_enc_fill(R.viewdirs, n, hp.deg_view, VI, bw, plan.ldVI)
         res.update(small=small, npred=ops.pred_normals_fwd(small, 1))
+      elif panel and _HEAD_VCOL and bw == 256 and plan.W <= 1536:
+        # the plain merged head [bottleneck | density] behind a panel-storage trunk: N = 256 and the density column as a VECTOR
+        # (row bw of the merged forward image) instead of a second 256-column tile for one column (mnr_gemm_nt_args.vcol:
+        # one extra MFMA per wave and k-step; bitwise the merged operand's result)
+        ops.gemm_nt(x, Bt[:bw], M=M, N=bw, K1=plan.W, bias=plan.head_bias, n_bias=bw, relu=False, Cb=VI, ldcb=plan.ldVI, nb=bw,
+                    vcol=Bt[bw], vcol_out=raw_density, vcol_bias=plan.head_bias[bw:bw + 1], **lay_a)
+        ops.viewdir_enc_fill(R.viewdirs, n, hp.deg_view, VI, bw, plan.ldVI)
       else:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=bw + 1, relu=False,
                     Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=raw_density, ldcf=1, f0=bw, nf=1, **lay_a)

@@ -315,7 +315,8 @@ def bits_from_tile_order(tile_bits, M, N):
 
 def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, bias=None, n_bias=0,
             relu=False, mask=None, ldmask=0, Cb=None, ldcb=0, nb=0, Cf=None, ldcf=0, f0=0, nf=0,
-            bits_out=None, bits_in=None, bits_row_mod=0, a1_layout=LAYOUT_ROWMAJOR, c_layout=LAYOUT_ROWMAJOR):
+            bits_out=None, bits_in=None, bits_row_mod=0, a1_layout=LAYOUT_ROWMAJOR, c_layout=LAYOUT_ROWMAJOR,
+            vcol=None, vcol_out=None, vcol_bias=None):
   """C[M,N] = epilogue([A1|A2] @ Bt^T).  Pointers may be views with explicit leading dimensions.  a1_layout / c_layout:
   LAYOUT_PANEL for the wide trunk's activations and gradients (include/mnerf.h; the bits are then in tile order)."""
   _chk(A1, bf16, 'A1')
@@ -340,6 +341,12 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
   a.mask_bits_in, a.ld_bits_in = (bits_in.data_ptr(), bits_in.stride(0)) if bits_in is not None else (None, 0)
   a.bits_row_mod = bits_row_mod
   a.a1_layout, a.c_layout = a1_layout, c_layout
+  _chk(vcol, bf16, 'vcol', allow_none=True)
+  _chk(vcol_out, f32, 'vcol_out', allow_none=True)
+  assert (vcol is None) == (vcol_out is None)
+  _chk(vcol_bias, f32, 'vcol_bias', allow_none=True)
+  a.vcol, a.vcol_out = (vcol.data_ptr() if vcol is not None else None), (vcol_out.data_ptr() if vcol_out is not None else None)
+  a.vcol_bias = vcol_bias.data_ptr() if vcol_bias is not None else None
   _e = PROFILE.start()
   L.check(lib().mnr_gemm_nt_bf16(C.byref(a), _stream()))
   PROFILE.stop(_e)

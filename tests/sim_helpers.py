@@ -46,7 +46,7 @@ def ptr(t):
 
 
 def sim_gemm_nt(lib, A1, Bt, A2=None, bias=None, relu=False, mask=None, out_bf16=True, out_f32=None, bits_out=False,
-                bits_in=None, bits_row_mod=0, nb=None, a1_layout=0, c_layout=0):
+                bits_in=None, bits_row_mod=0, nb=None, a1_layout=0, c_layout=0, vcol=None, vcol_bias=None):
   """C = epi([A1|A2] Bt^T) through the simulated mnr_gemm_nt_bf16; returns (Cb, Cf, bits).  a1_layout / c_layout = 1: A1 is
   given / Cb and the bits come back in MNR_LAYOUT_PANEL storage (the bits in tile order, flat)."""
   M, K1 = A1.shape
@@ -76,8 +76,14 @@ def sim_gemm_nt(lib, A1, Bt, A2=None, bias=None, relu=False, mask=None, out_bf16
     a.mask_bits_out, a.ld_bits_out = ptr(bits), bits.stride(0)
   if bits_in is not None:
     a.mask_bits_in, a.ld_bits_in, a.bits_row_mod = ptr(bits_in), (bits_in.stride(0) if bits_in.dim() == 2 else 0), bits_row_mod
+  vout = None
+  if vcol is not None:                                # one more column as a vector -> fp32 [M] (returned in place of Cf)
+    vout = torch.full((M,), float('nan'), dtype=torch.float32)
+    a.vcol, a.vcol_out = ptr(vcol), ptr(vout)
+    if vcol_bias is not None:
+      a.vcol_bias = ptr(vcol_bias)
   sim_check(lib, lib.mnr_gemm_nt_bf16(C.byref(a), None))
-  return Cb, Cf, bits
+  return Cb, (vout if vcol is not None else Cf), bits
 
 
 def sim_gemm_tn(lib, A, B, C_acc, bias_out=None, k_valid=None, n_valid=None, a_layout=0, b_layout=0, gcol=None, gcol_out=None):

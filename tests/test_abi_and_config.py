@@ -24,7 +24,7 @@ def test_library_exports_every_header_symbol():
   # and every exported prototype we bind is declared in the header
   for n in _lib._PROTOS:
     assert n in names
-  assert lib.mnr_abi_version() == 16
+  assert lib.mnr_abi_version() == 17
 
 
 def test_ops_refuse_cpu_tensors():

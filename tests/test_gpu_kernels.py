@@ -598,6 +598,40 @@ def test_gemm_nt_trunk_shapes(ops, K1, K2, bits):
   assert bad == 0, bad
 
 
+@pytest.mark.parametrize('K1,K2', [(1024, 0), (1024, 512), (512, 0)])
+def test_gemm_nt_vector_column_at_the_head_shape(ops, K1, K2):
+  """mnr_gemm_nt_args.vcol at the merged head's shape (M = 65536 rows of a panel-storage trunk activation, N = 256 bottleneck
+  columns + the density column as a vector; also behind a two-segment input): the bf16 result bitwise the plain launch's, the
+  vector column bitwise the fp32 side column of the merged 257-column operand and within fp32 rounding of an fp64 reference."""
+  gen = torch.Generator().manual_seed(61)
+  M = 65536
+  K = K1 + K2
+  X = dev(_bf(torch.relu(torch.randn((M, K1), generator=gen))))
+  X2 = dev(_bf(torch.randn((M, K2), generator=gen))) if K2 else None
+  Bt = _bf(torch.randn((512, K), generator=gen) / math.sqrt(K))
+  Bt[257:] = 0
+  Bt = dev(Bt)
+  bias = dev(torch.randn((257,), generator=gen))
+  Xp = ops.to_panel(X)
+  C0 = torch.zeros((M, 384), dtype=torch.bfloat16).cuda()
+  f0 = torch.zeros((M,), dtype=torch.float32).cuda()
+  ops.gemm_nt(Xp, Bt, M=M, N=512, K1=K1, A2=X2, K2=K2, bias=bias, n_bias=257, Cb=C0, ldcb=384, nb=256, Cf=f0, ldcf=1, f0=256, nf=1,
+              a1_layout=ops.LAYOUT_PANEL)
+  C1 = torch.zeros((M, 384), dtype=torch.bfloat16).cuda()
+  v1 = torch.zeros((M,), dtype=torch.float32).cuda()
+  ops.gemm_nt(Xp, Bt[:256], M=M, N=256, K1=K1, A2=X2, K2=K2, bias=bias, n_bias=256, Cb=C1, ldcb=384, nb=256,
+              vcol=Bt[256], vcol_out=v1, vcol_bias=bias[256:257], a1_layout=ops.LAYOUT_PANEL)
+  torch.cuda.synchronize()
+  assert torch.equal(C1.view(torch.int16), C0.view(torch.int16))
+  assert torch.equal(v1, f0)
+  A = X if X2 is None else torch.cat([X, X2], -1)
+  if A.is_cuda:
+    ref = A.double() @ Bt[256].double() + bias[256].double()
+    err = (v1.double() - ref).abs().max().item()
+    print(f'gemm_nt vcol {M}x256x{K1}+{K2}: max |vector column - fp64| {err:.3e}')
+    assert err < 1e-4 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize('K', [1024, 512])
 def test_gemm_tn_trunk_shapes(ops, K):
   """The trunk's weight-gradient shapes: [1024 (or the 512 padded feature columns), 1024] outputs reduced over 65536

@@ -38,14 +38,14 @@ def _mfma_span(body):
 def test_the_shipped_mfma_kernels_are_all_there(report):
   _, bodies = report
   names = sorted(bodies)
-  assert sum('gemm_nt_kernel' in n for n in names) == 7          # NtBigP (pipelined) / NtBig / NtSmall, with / without bit-mask input; NtBigP reading a panel A1
+  assert sum('gemm_nt_kernel' in n for n in names) == 8          # NtBigP (pipelined) / NtBig / NtSmall, with / without bit-mask input; NtBigP reading a panel A1, the same with a vector column
   assert sum('gemm_nt_panel_kernel' in n for n in names) == 4    # panel result: forward / dX, A1 row-major / panel
   assert sum('gemm_nt_wres_kernel' in n for n in names) == 2
   assert sum('gemm_tn_kernel' in n for n in names) == 5          # TnBig / TnSmall; TnBig with panel A, panel B, both
   assert sum('mlp_chain_fwd_kernel' in n for n in names) == 2 and sum('mlp_chain_bwd_kernel' in n for n in names) == 2   # W = 128 / 256
   assert sum('mlp_chain_fwd_ipe_kernel' in n for n in names) == 2      # the inference chain with the in-kernel IPE producer
   assert sum('gemm_tn_gcol_kernel' in n for n in names) == 2           # TnBig with one more B column from a vector; the same with a panel A
-  assert len(names) == 26, names
+  assert len(names) == 27, names
 
 
 def test_tiled_gemm_k_loops_carry_only_the_hand_counted_vmcnt_waits(report):
@@ -67,14 +67,15 @@ def test_pipelined_nt_loop_spreads_its_dma_between_the_mfmas(report):
   tile's reads)."""
   _, bodies = report
   pipe = {n: b for n, b in bodies.items() if 'gemm_nt_kernel' in n and 'Li32ELi4EE' in n}
-  assert len(pipe) == 3                                          # forward / dX with mask bits / forward from a panel A1
+  assert len(pipe) == 4                                          # forward / dX with mask bits / forward from a panel A1 / + a vector column
   for name, body in pipe.items():
+    vcol = name.endswith('Lb0ELb1ELb1EEv16mnr_gemm_nt_argsix')    # (one extra MFMA per k-step: mnr_gemm_nt_args.vcol)
     code = [l.split(';')[0].rstrip() for l in body]
     w = next(k for k, l in enumerate(code) if 's_waitcnt vmcnt(6)' in l)
     start = max(k for k in range(w) if code[k].startswith('.LBB'))
     end = next(k for k in range(w, len(code)) if code[k].startswith('\ts_cbranch'))
     blk = code[start:end]
-    assert sum('v_mfma' in l for l in blk) == 16, name
+    assert sum('v_mfma' in l for l in blk) == (18 if vcol else 16), name
     assert sum('global_load_lds' in l for l in blk) == 4, name
     assert not any('scratch_' in l for l in blk), name
     ops = [l for l in blk if 'v_mfma' in l or 'global_load_lds' in l]

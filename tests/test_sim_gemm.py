@@ -285,6 +285,34 @@ def test_nt_panel_kernel_forward_and_dx(sim, a1_panel, mode):
   np.testing.assert_allclose(C0.float().numpy(), ref.numpy(), atol=3e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize('mode', MODES)
+def test_nt_vector_column_next_to_a_256_wide_result(sim, mode):
+  """mnr_gemm_nt_args.vcol (the density head next to the bottleneck, models.py:460 / :527): one more output column supplied as a
+  vector, computed by one extra MFMA per wave and k-step on row blocks taken in rotated order.  The 256-wide bf16 result must be
+  bitwise the plain launch's, the vector column bitwise the fp32 side column of the merged 257-column operand (the same products
+  in the same order), with two activation segments, several tiles per workgroup, late DMA and shuffled wave orders."""
+  g = torch.Generator().manual_seed(6)
+  M, K1, K2 = 4096, 192, 64                        # 16 tiles on 8 workgroups: every workgroup walks two
+  X = torch.relu(torch.randn((M, K1), generator=g)).bfloat16()
+  X2 = torch.randn((M, K2), generator=g).bfloat16()
+  Bt = (torch.randn((512, K1 + K2), generator=g) * 0.1).bfloat16()
+  Bt[257:] = 0
+  bias = torch.randn(257, generator=g)
+  sim.mnr_gemm_nt_set_persistent(-8)
+  try:
+    sim.hipsim_reset(*mode)
+    C0, F0, _ = S.sim_gemm_nt(sim, _ops.to_panel(X), Bt, A2=X2, bias=bias, nb=256, out_f32=(256, 1), a1_layout=1)
+    sim.hipsim_reset(*mode)
+    C1, v1, _ = S.sim_gemm_nt(sim, _ops.to_panel(X), Bt[:256].contiguous(), A2=X2, bias=bias[:256].contiguous(), a1_layout=1,
+                              vcol=Bt[256].contiguous(), vcol_bias=bias[256:257].contiguous())
+  finally:
+    sim.mnr_gemm_nt_set_persistent(1)
+  assert torch.equal(C1.view(torch.int16), C0[:, :256].view(torch.int16))
+  assert torch.equal(v1, F0[:, 0])
+  ref = torch.cat([X, X2], 1).float() @ Bt[256].float() + bias[256]
+  np.testing.assert_allclose(v1.numpy(), ref.numpy(), atol=2e-3, rtol=1e-3)
+
+
 @pytest.mark.parametrize('mode', [MODES[1], MODES[3]])
 def test_nt_tiled_kernel_reads_a_panel_activation(sim, mode):
   """The merged head behind a panel-layout trunk: the pipelined tiled kernel with A1 in panel storage, row-major bf16 result
