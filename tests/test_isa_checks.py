@@ -25,6 +25,7 @@ def report():
   mod = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(mod)
   bodies = {}
+  mod.all_digests()                                  # compiles every file once, in parallel; compile_file is cached from here on
   for f in ('gemm.hip', 'gemm_blk.hip', 'fused_mlp.hip'):
     bodies.update({n: b for n, b in mod.all_kernel_bodies(mod.compile_file(f)).items() if any('v_mfma' in l for l in b)})
   return mod, bodies

@@ -285,7 +285,7 @@ def test_nt_panel_kernel_forward_and_dx(sim, a1_panel, mode):
   np.testing.assert_allclose(C0.float().numpy(), ref.numpy(), atol=3e-2, rtol=1e-2)
 
 
-@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('mode', [MODES[1], MODES[3]])
 def test_nt_vector_column_next_to_a_256_wide_result(sim, mode):
   """mnr_gemm_nt_args.vcol (the density head next to the bottleneck, models.py:460 / :527): one more output column supplied as a
   vector, computed by one extra MFMA per wave and k-step on row blocks taken in rotated order.  The 256-wide bf16 result must be

@@ -130,8 +130,13 @@ def mfma_loops(body):
   return loops
 
 
+_ASM_CACHE = {}
+
+
 def compile_file(name):
-  """Device-only assembly text of csrc/<name>."""
+  """Device-only assembly text of csrc/<name> (cached per process: the tests read gemm.hip's three times)."""
+  if name in _ASM_CACHE:
+    return _ASM_CACHE[name]
   tmp = tempfile.mkdtemp(prefix='isa_')
   out = os.path.join(tmp, name + '.s')
   cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '--cuda-device-only', '-S',
@@ -142,6 +147,7 @@ def compile_file(name):
   text = open(out).read()
   import shutil
   shutil.rmtree(tmp, ignore_errors=True)
+  _ASM_CACHE[name] = text
   return text
 
 
@@ -152,8 +158,11 @@ KERNEL_FILES = ('gemm.hip', 'gemm_blk.hip', 'fused_mlp.hip', 'resample.hip', 'fe
 def all_digests():
   """{kernel name: normalized_digest} over every csrc file."""
   out = {}
-  for f in KERNEL_FILES:
-    out.update({n: normalized_digest(b) for n, b in all_kernel_bodies(compile_file(f)).items()})
+  import concurrent.futures
+  with concurrent.futures.ThreadPoolExecutor(max_workers=len(KERNEL_FILES)) as ex:      # (hipcc runs in child processes)
+    texts = list(ex.map(compile_file, KERNEL_FILES))
+  for text in texts:
+    out.update({n: normalized_digest(b) for n, b in all_kernel_bodies(text).items()})
   return out
 
 
