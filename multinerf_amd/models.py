@@ -120,12 +120,14 @@ class MLP:
       bad.append('use_directional_enc without enable_pred_roughness (undefined in the reference: ref_utils.py:147)')
     if self.use_n_dot_v and not self.enable_pred_normals and self.disable_density_normals:
       bad.append('use_n_dot_v without normals (undefined in the reference: models.py:560-563)')
-    if on and not self.is_ref() and on not in (['enable_pred_normals'], ['density normals']):
+    if on and not self.is_ref() and on not in (['enable_pred_normals'], ['density normals'], ['enable_pred_normals', 'density normals']):
       # The Ref-NeRF branch is implemented as one unit (blender_refnerf.gin), plus predicted normals on their own
-      # (enable_pred_normals with disable_density_normals: a Dense(3) head, models.py:494-503) and density-gradient normals on
+      # (enable_pred_normals with disable_density_normals: a Dense(3) head, models.py:494-503), density-gradient normals on
       # their own (disable_density_normals = False: the tangent network, what configs/llff_raw.gin asks for with the orientation
-      # loss); other partial mixes are not.
-      bad.append('partial Ref-NeRF feature set ' + str(on) + ' (all of them, predicted normals alone, density normals alone, or none)')
+      # loss) and the two together (Ref-NeRF's normal regulariser, the predicted-normal loss of train_utils.py:186-203, in front
+      # of a plain view-direction colour); other partial mixes are not.
+      bad.append('partial Ref-NeRF feature set ' + str(on) +
+                 ' (all of them, predicted normals and / or density normals without the reflection colour, or none)')
     if on and self.disable_rgb:
       # (the two single-field mixes live in the merged head of an MLP with a colour branch)
       bad.append('normals ' + str(on) + ' on a density-only MLP (disable_rgb)')
@@ -793,12 +795,17 @@ class Model:
       dnoise = None
       if randomized and hp.density_noise > 0:
         if noise is not None and 'density_noise' in noise:
-          dnoise = noise['density_noise'][i_level].to(dev).reshape(-1, n).float()
+          dnoise = noise['density_noise'][i_level].to(dev).float()
+          dnoise = dnoise.reshape(1, 1).expand(Bp, n) if dnoise.numel() == 1 else dnoise.reshape(-1, n)
           if dnoise.shape[0] != Bp:
             dnoise = torch.cat([dnoise, dnoise[-1:].expand(Bp - dnoise.shape[0], n)], 0)
           dnoise = dnoise.contiguous()
         else:
-          dnoise = torch.randn((Bp, n), generator=gen, device=dev, dtype=f32)
+          # with density-gradient normals the reference draws inside vmap(value_and_grad(predict_density)) (models.py:462-464 under
+          # :478-481) from a key that is closed over, not mapped: every sample of the level gets the SAME value
+          # (tests/golden/make_golden_models.py, case llff_raw_dn)
+          dnoise = (torch.randn((1, 1), generator=gen, device=dev, dtype=f32).expand(Bp, n).contiguous() if plan.tangent
+                    else torch.randn((Bp, n), generator=gen, device=dev, dtype=f32))
       lo, hi = self.bg_intensity_range
       bg = None
       if lo == hi:

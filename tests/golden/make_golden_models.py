@@ -67,6 +67,36 @@ CASES = {
     'llff_raw_train': ('llff_raw', ['NerfMLP.net_width = 32', 'Model.num_prop_samples = 8', 'Model.num_nerf_samples = 8'], 4, True, 0.25),
 }
 
+# Partial Ref-NeRF feature sets (models.py:468-503,512-563,588-602 take every flag on its own; the Ref-NeRF paper's ablations are
+# such sets): blender_refnerf.gin at the sizes above with single flags turned off, and llff_raw.gin with density-gradient normals.
+_RB = ['NerfMLP.net_width = 32', 'NerfMLP.net_width_viewdirs = 16', 'NerfMLP.bottleneck_width = 16', 'Model.num_prop_samples = 7',
+       'Model.num_nerf_samples = 7']
+_NO_PN_LOSS = ['Config.predicted_normal_loss_mult = 0.0', 'Config.predicted_normal_coarse_loss_mult = 0.0']
+_PLAIN_COLOUR = ['NerfMLP.use_directional_enc = False', 'NerfMLP.use_reflections = False', 'NerfMLP.enable_pred_roughness = False',
+                 'NerfMLP.use_diffuse_color = False', 'NerfMLP.use_specular_tint = False', 'NerfMLP.use_n_dot_v = False']
+CASES.update({
+    # predicted normals alone / both normal fields in front of a plain view-direction colour / density-gradient normals alone
+    'refnerf_pn_only': ('blender_refnerf', _RB + _PLAIN_COLOUR + _NO_PN_LOSS + ['NerfMLP.disable_density_normals = True',
+                                                                               'Config.compute_normal_metrics = False'], 3, True, 0.5),
+    'refnerf_pn_dn': ('blender_refnerf', _RB + _PLAIN_COLOUR, 3, True, 0.5),
+    'llff_raw_dn': ('llff_raw', ['NerfMLP.net_width = 32', 'Model.num_prop_samples = 8', 'Model.num_nerf_samples = 8',
+                                 'NerfMLP.disable_density_normals = False', 'Config.orientation_loss_mult = 0.01',
+                                 'Config.orientation_coarse_loss_mult = 0.001', "Config.orientation_loss_target = 'normals'"], 4, True, 0.25),
+    # the complete set minus one flag
+    'refnerf_no_pn': ('blender_refnerf', _RB + _NO_PN_LOSS + ['NerfMLP.enable_pred_normals = False',
+                                                              "Config.orientation_loss_target = 'normals'"], 3, True, 0.5),
+    # (use_reflections = False with the IDE is not a set the reference can run: the IDE of the per-ray view direction [B, 36]
+    # does not broadcast against the per-sample roughness [B, n, 1], ref_utils.py:154; without the IDE it can)
+    'refnerf_no_reflect_no_ide': ('blender_refnerf', _RB + ['NerfMLP.use_reflections = False', 'NerfMLP.use_directional_enc = False'],
+                                  3, True, 0.5),
+    'refnerf_no_ndv': ('blender_refnerf', _RB + ['NerfMLP.use_n_dot_v = False'], 3, False, 0.5),
+    'refnerf_no_ide': ('blender_refnerf', _RB + ['NerfMLP.use_directional_enc = False'], 3, True, 0.5),
+    'refnerf_no_ide_no_rough': ('blender_refnerf', _RB + ['NerfMLP.use_directional_enc = False', 'NerfMLP.enable_pred_roughness = False'],
+                                3, False, 0.5),
+    'refnerf_without_diffuse': ('blender_refnerf', _RB + ['NerfMLP.use_diffuse_color = False'], 3, True, 0.5),
+    'refnerf_no_tint': ('blender_refnerf', _RB + ['NerfMLP.use_specular_tint = False'], 3, False, 0.5),
+})
+
 _CALLABLE_FIELDS = ('raydist_fn', 'warp_fn', 'net_activation', 'density_activation', 'rgb_activation', 'roughness_activation')
 
 
@@ -265,6 +295,7 @@ def install_flax_gin_standins(jax):
 
   jax.value_and_grad = lambda fn, has_aux=False: _ValueAndGrad(fn, has_aux)
   leaf_vmap = jax.vmap
+  rnd_state_ = {'rs': None, 'log': [], 'vmap': None}
 
   def vmap(fn, in_axes=0, out_axes=0):
     if not isinstance(fn, _ValueAndGrad):
@@ -279,14 +310,21 @@ def install_flax_gin_standins(jax):
         scope._counters = dict(snapshot)          # every evaluation creates the same Dense_k again
         return fn.fn(m, covs)
 
-      val, aux = run(means)
-      grad = np.zeros_like(means)
-      h = 1e-30
-      for k in range(means.shape[-1]):
-        e = np.zeros(means.shape[-1])
-        e[k] = 1.0
-        vk, _ = run(_as_cstep(means + 1j * h * e))
-        grad[..., k] = np.asarray(vk).imag / h
+      # a draw inside the vmapped function has the PER-ELEMENT shape and a key that is closed over, not mapped: jax hands every
+      # element of the batch the same value (density noise with density-gradient normals, models.py:462-464 under :478-481),
+      # and value_and_grad evaluates the function once, so the re-evaluations below replay it
+      rnd_state_['vmap'] = {}
+      try:
+        val, aux = run(means)
+        grad = np.zeros_like(means)
+        h = 1e-30
+        for k in range(means.shape[-1]):
+          e = np.zeros(means.shape[-1])
+          e[k] = 1.0
+          vk, _ = run(_as_cstep(means + 1j * h * e))
+          grad[..., k] = np.asarray(vk).imag / h
+      finally:
+        rnd_state_['vmap'] = None
       return (val, aux), grad
 
     return batched
@@ -313,7 +351,7 @@ def install_flax_gin_standins(jax):
 
   # random: opaque keys, one logged stream
   rnd = jax.random
-  state = {'rs': None, 'log': []}
+  state = rnd_state_
 
   class Key:
     pass
@@ -330,6 +368,12 @@ def install_flax_gin_standins(jax):
     return u * (maxval - minval) + minval
 
   def normal(key, shape=()):
+    if state['vmap'] is not None:
+      if id(key) not in state['vmap']:
+        z = state['rs'].standard_normal(tuple(shape)[1:])
+        state['log'].append(('normal', np.asarray(z)))
+        state['vmap'][id(key)] = z
+      return np.broadcast_to(state['vmap'][id(key)], shape)
     z = state['rs'].standard_normal(shape)
     state['log'].append(('normal', z))
     return z
@@ -432,7 +476,7 @@ def run_case(case, rmodels, ref_callables, rnd_state, Key):
     g[f'{case}/loss/stats_{k}'] = np.asarray(v, dtype=np.float64)
   g[f'{case}/loss/interlevel'] = np.asarray(rtrain.interlevel_loss(history, cfg))
   g[f'{case}/loss/distortion'] = np.asarray(rtrain.distortion_loss(history, cfg))
-  if history[-1]['normals'] is not None:
+  if history[-1][cfg.orientation_loss_target] is not None:
     g[f'{case}/loss/orientation'] = np.asarray(rtrain.orientation_loss(rays, model, history, cfg))
   if history[-1]['normals'] is not None and history[-1]['normals_pred'] is not None:
     g[f'{case}/loss/predicted_normal'] = np.asarray(rtrain.predicted_normal_loss(model, history, cfg))
@@ -482,7 +526,7 @@ def run_case(case, rmodels, ref_callables, rnd_state, Key):
       node[parts[-1]] = d
     return out
 
-  uses_inner_cstep = preset == 'blender_refnerf'
+  uses_inner_cstep = history[-1]['normals'] is not None      # (density-gradient normals: the forward pass is a complex step itself)
   for d in range(3):
     V = direction(tree)
     if not uses_inner_cstep:

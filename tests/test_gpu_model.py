@@ -133,6 +133,11 @@ CASES = [
                          'NerfMLP.enable_pred_roughness = False', 'NerfMLP.use_diffuse_color = False', 'NerfMLP.use_specular_tint = False',
                          'NerfMLP.use_n_dot_v = False', 'Config.predicted_normal_loss_mult = 0.0',
                          'Config.predicted_normal_coarse_loss_mult = 0.0', 'Config.compute_normal_metrics = False'], 12),
+    # BOTH normal fields without the reflection colour: Ref-NeRF's normal regulariser (orientation loss on the predicted normals,
+    # predicted-normal loss tying them to the density gradient's, train_utils.py:163-203) in front of a plain view-direction colour
+    ('blender_refnerf', ['NerfMLP.use_directional_enc = False', 'NerfMLP.use_reflections = False',
+                         'NerfMLP.enable_pred_roughness = False', 'NerfMLP.use_diffuse_color = False', 'NerfMLP.use_specular_tint = False',
+                         'NerfMLP.use_n_dot_v = False'], 12),
     # density-gradient normals WITHOUT the rest of the Ref-NeRF head: what configs/llff_raw.gin's own comment asks for ("Turn this
     # off if using orientation loss ... try .01"): the tangent network next to a plain RawNeRF MLP, the orientation loss on `normals`
     ('llff_raw', ['NerfMLP.disable_density_normals = False', 'Config.orientation_loss_mult = 0.01',
