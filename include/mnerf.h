@@ -458,17 +458,29 @@ typedef struct {
   const float* mat;           /* [lmax+1, T] z-polynomial coefficients (ref_utils.py:119-125) */
 } mnr_ide_tables;
 
+/* Which parts of the branch an MLP has (models.py:468-563 takes every flag on its own; a head that is switched off is a zero
+ * column of `small` nobody reads).  What the reference itself cannot run is refused with its own message where it has one:
+ * reflections or n.v without a normal field (models.py:434-435), the IDE without the predicted roughness or on the per-ray
+ * view direction (ref_utils.py:147-154: `kappa_inv` None / [B,36] against [B,n,1]). */
+#define MNR_REF_PRED_NORMALS    1   /* enable_pred_normals: grad_pred columns, normals_to_use = normals_pred (:494-499) */
+#define MNR_REF_DENSITY_NORMALS 2   /* disable_density_normals = False: raw_grad, normals (:478-492) */
+#define MNR_REF_REFLECT         4   /* use_reflections (:540-547); else the view direction is encoded (:549-555) */
+#define MNR_REF_IDE             8   /* use_directional_enc (:436-437); else coord.pos_enc(dir, 0, deg_view, True) (:438-441) */
+#define MNR_REF_N_DOT_V        16   /* use_n_dot_v (:560-563) */
+#define MNR_REF_ROUGHNESS      32   /* enable_pred_roughness (:520-523) */
+
 /* normals = -l2norm(raw_grad), normals_pred = -l2norm(grad_pred), roughness = softplus(raw + bias),
- * refdirs = reflect(-viewdirs, normals_pred), IDE(refdirs, roughness) and n.v written (bf16) into
- * columns [col0, col0 + 2T + 1) of every row of `vi` [M, ldvi]; columns up to col_end zero-filled. */
+ * dir = reflect(-viewdirs, normals_to_use) or viewdirs, IDE(dir, roughness) or pos_enc(dir) and n.v written (bf16) into
+ * columns [col0, col0 + E (+ 1)) of every row of `vi` [M, ldvi], E = 2T or 3 + 6 deg_view; columns up to col_end
+ * zero-filled.  Outputs (and `raw_grad`, `tabs`) of parts that are off may be NULL. */
 int mnr_ref_head_fwd(int64_t M, int n, const float* small, const float* raw_grad, const float* viewdirs,
-                     const mnr_ide_tables* tabs, float roughness_bias, uint16_t* vi, int ldvi, int col0,
-                     int col_end, float* normals_out, float* normals_pred_out, float* roughness_out, void* stream);
+                     const mnr_ide_tables* tabs, int features, int deg_view, float roughness_bias, uint16_t* vi, int ldvi,
+                     int col0, int col_end, float* normals_out, float* normals_pred_out, float* roughness_out, void* stream);
 /* VJP: dvi_a (+ dvi_b, may be NULL) bf16 [M, lddvi] = gradient w.r.t. the view-MLP input; g_npred / g_n
  * [M,3] fp32 from mnr_ref_losses (may be NULL).  Writes bf16 columns [0,col0) (bottleneck = dvi_a + dvi_b),
- * col_gp..+2 and col_rough of dhb [M, lddhb] and g_raw_grad [3,M] fp32. */
+ * col_gp..+2 (predicted normals) and col_rough (roughness) of dhb [M, lddhb] and g_raw_grad [3,M] fp32 (density normals). */
 int mnr_ref_head_bwd(int64_t M, int n, const float* small, const float* raw_grad, const float* viewdirs,
-                     const mnr_ide_tables* tabs, float roughness_bias, const uint16_t* dvi_a,
+                     const mnr_ide_tables* tabs, int features, int deg_view, float roughness_bias, const uint16_t* dvi_a,
                      const uint16_t* dvi_b, int lddvi, int col0, const float* g_npred, const float* g_n,
                      uint16_t* dhb, int lddhb, int col_gp, int col_rough, float* g_raw_grad, void* stream);
 /* dst[:, :cols] = a[:, :cols] + b[:, :cols] (bf16, b may be NULL; dst may alias a): gradient joins of skip concats. */

@@ -181,8 +181,9 @@ _PROTOS = {
     'mnr_exposure_scale': ([i64, vp, vp, vp, vp, vp], i32),
     'mnr_exposure_scale_bwd': ([i64, vp, vp, vp, vp, vp], i32),
     'mnr_render_extras': ([i64, i32, vp, vp, vp, vp, vp], i32),
-    'mnr_ref_head_fwd': ([i64, i32, vp, vp, vp, C.POINTER(IdeTables), f32, vp, i32, i32, i32, vp, vp, vp, vp], i32),
-    'mnr_ref_head_bwd': ([i64, i32, vp, vp, vp, C.POINTER(IdeTables), f32, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp], i32),
+    'mnr_ref_head_fwd': ([i64, i32, vp, vp, vp, C.POINTER(IdeTables), i32, i32, f32, vp, i32, i32, i32, vp, vp, vp, vp], i32),
+    'mnr_ref_head_bwd': ([i64, i32, vp, vp, vp, C.POINTER(IdeTables), i32, i32, f32, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp],
+                         i32),
     'mnr_add_cols_bf16': ([i64, i32, vp, i32, vp, i32, vp, i32, vp], i32),
     'mnr_ref_color_fwd': ([i64, vp, vp, f32, f32, f32, i32, vp, vp], i32),
     'mnr_ref_color_bwd': ([i64, vp, vp, f32, f32, f32, i32, vp, vp, vp, i32, i32, i32, vp], i32),

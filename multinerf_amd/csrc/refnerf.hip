@@ -14,12 +14,15 @@
 //
 // Merged head layout used throughout (columns of the head GEMM output / gradient matrix):
 //   [0, bw) bottleneck | bw density | bw+1..3 grad_pred | bw+4..6 raw diffuse | bw+7..9 raw tint | bw+10 raw roughness
-// `small` = the fp32 side output [M, 11] holding columns bw .. bw+10.
+// `small` = the fp32 side output [M, 11] holding columns bw .. bw+10.  The layout is the same for every feature set
+// (MNR_REF_* bits, models.py:468-563 takes each flag on its own): a head that is switched off is a zero column nobody reads.
 #include "common.h"
 
 #define RF_THREADS 256
 #define RF_MAX_T 36
 #define RF_MAX_L 16
+#define RF_MAX_ENC (2 * RF_MAX_T)       // IDE: 2 T columns; coord.pos_enc of a direction: 3 + 6 deg_view (deg_view <= 11)
+#define RF_PI_2 1.57079632679489661923f
 #define RF_LOG3 1.09861228866810969140f
 
 struct IdeTab {
@@ -102,73 +105,127 @@ __device__ __forceinline__ void rf_ide(const IdeTab& tab, float x, float y, floa
   }
 }
 
+// coord.pos_enc(u, 0, deg, append_identity=True) (coord.py:136-147; models.py:438-441 without the IDE):
+// [u | sin(2^l u) (l-major) | sin(2^l u + pi/2)], and its VJP w.r.t. u.
+__device__ __forceinline__ void rf_posenc(const float* u, int deg, float* out) {
+  int c = 0;
+  for (int i = 0; i < 3; ++i) out[c++] = u[i];
+  for (int l = 0; l < deg; ++l)
+    for (int i = 0; i < 3; ++i) out[c++] = sinf(u[i] * ldexpf(1.0f, l));
+  for (int l = 0; l < deg; ++l)
+    for (int i = 0; i < 3; ++i) out[c++] = sinf(u[i] * ldexpf(1.0f, l) + RF_PI_2);
+}
+
+__device__ __forceinline__ void rf_posenc_bwd(const float* u, int deg, const float* g, float* gu) {
+  for (int i = 0; i < 3; ++i) {
+    float acc = g[i];
+    for (int l = 0; l < deg; ++l) {
+      const float sc = ldexpf(1.0f, l), a = u[i] * sc;
+      acc += sc * (g[3 + 3 * l + i] * cosf(a) + g[3 + 3 * deg + 3 * l + i] * cosf(a + RF_PI_2));
+    }
+    gu[i] = acc;
+  }
+}
+
+__host__ __device__ __forceinline__ int rf_enc_dim(int features, int T, int deg_view) {
+  return (features & MNR_REF_IDE) ? 2 * T : 3 + 6 * deg_view;
+}
+
 // ---------------------------------------------------------------------------
-// Forward: normals, predicted normals, roughness, reflection dirs, IDE, n.v  ->  view-MLP input columns.
+// Forward: normals, predicted normals, roughness, reflection dirs, IDE / pos_enc, n.v  ->  view-MLP input columns.
 
 __global__ __launch_bounds__(RF_THREADS) void ref_head_fwd_kernel(
     int64_t M, int n, const float* __restrict__ small, const float* __restrict__ raw_grad,
-    const float* __restrict__ viewdirs, mnr_ide_tables tabs, float roughness_bias, bf16* __restrict__ vi, int ldvi,
-    int col0, int col_end, float* __restrict__ normals_out, float* __restrict__ npred_out,
+    const float* __restrict__ viewdirs, mnr_ide_tables tabs, int features, int deg_view, float roughness_bias,
+    bf16* __restrict__ vi, int ldvi, int col0, int col_end, float* __restrict__ normals_out, float* __restrict__ npred_out,
     float* __restrict__ rough_out, int vec8) {
   __shared__ IdeTab tab;
-  rf_load_tab(tab, tabs);
+  if (features & MNR_REF_IDE) rf_load_tab(tab, tabs);
   __syncthreads();
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= M) return;
   const int64_t ray = s / n;
   const float v[3] = {viewdirs[ray * 3], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2]};
   const float* sm = small + s * 11;
-  const float gp[3] = {sm[1], sm[2], sm[3]};
-  const float rg[3] = {raw_grad[s], raw_grad[M + s], raw_grad[2 * M + s]};
-  float npred[3], nrm[3], r0, r1;
+  float npred[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f}, r0, r1;
   bool c0, c1;
-  rf_neg_normalize(gp, npred, r0, c0);                          // models.py:498
-  rf_neg_normalize(rg, nrm, r1, c1);                            // models.py:492
-  const float rough = mnr_softplus(sm[10] + roughness_bias);   // models.py:521-523
-  const float ndv = npred[0] * v[0] + npred[1] * v[1] + npred[2] * v[2];
-  // reflect(-v, n) = 2 (n . -v) n - (-v) = v - 2 (n.v) n      (ref_utils.py:22-37, models.py:545)
+  if (features & MNR_REF_PRED_NORMALS) {
+    const float gp[3] = {sm[1], sm[2], sm[3]};
+    rf_neg_normalize(gp, npred, r0, c0);                        // models.py:498
+  }
+  if (features & MNR_REF_DENSITY_NORMALS) {
+    const float rg[3] = {raw_grad[s], raw_grad[M + s], raw_grad[2 * M + s]};
+    rf_neg_normalize(rg, nrm, r1, c1);                          // models.py:492
+  }
+  const float* nu = (features & MNR_REF_PRED_NORMALS) ? npred : nrm;                       // normals_to_use, models.py:499-503
+  const float rough = (features & MNR_REF_ROUGHNESS) ? mnr_softplus(sm[10] + roughness_bias) : 0.0f;   // models.py:521-523
+  const float ndv = nu[0] * v[0] + nu[1] * v[1] + nu[2] * v[2];
+  // reflect(-v, n) = 2 (n . -v) n - (-v) = v - 2 (n.v) n      (ref_utils.py:22-37, models.py:545); else the view direction (:550)
   float u[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) u[i] = v[i] - 2.0f * ndv * npred[i];
-  float ide[2 * RF_MAX_T];
-  rf_ide<false>(tab, u[0], u[1], u[2], rough, ide, nullptr, nullptr, nullptr);
+  for (int i = 0; i < 3; ++i) u[i] = (features & MNR_REF_REFLECT) ? v[i] - 2.0f * ndv * nu[i] : v[i];
+  float enc[RF_MAX_ENC];
+  if (features & MNR_REF_IDE) rf_ide<false>(tab, u[0], u[1], u[2], rough, enc, nullptr, nullptr, nullptr);
+  else rf_posenc(u, deg_view, enc);
+  const int E = rf_enc_dim(features, (features & MNR_REF_IDE) ? tab.T : 0, deg_view);
+  const bool has_ndv = (features & MNR_REF_N_DOT_V) != 0;
   bf16* o = vi + s * ldvi + col0;
-  const int T2 = 2 * tab.T;
   if (vec8) {
-    // [IDE (2T) | n.v | zeros up to col_end] in 16-byte pieces (col0 and col_end are multiples of 8 here)
+    // [encoding (E) | n.v | zeros up to col_end] in 16-byte pieces (col0 and col_end are multiples of 8 here)
     for (int c8 = 0; col0 + c8 * 8 < col_end; ++c8) {
       bf16x8 w;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int i = c8 * 8 + e;
-        w[e] = (bf16)(i < T2 ? ide[i] : (i == T2 ? ndv : 0.0f));      // models.py:560-563 (un-negated viewdirs)
+        w[e] = (bf16)(i < E ? enc[i] : ((i == E && has_ndv) ? ndv : 0.0f));      // models.py:560-563 (un-negated viewdirs)
       }
       *(bf16x8*)(o + c8 * 8) = w;
     }
   } else {
-    for (int i = 0; i < T2; ++i) o[i] = (bf16)ide[i];
-    o[T2] = (bf16)ndv;                                          // models.py:560-563 (un-negated viewdirs)
-    for (int c = col0 + T2 + 1; c < col_end; ++c) vi[s * ldvi + c] = (bf16)0.0f;
+    for (int i = 0; i < E; ++i) o[i] = (bf16)enc[i];
+    if (has_ndv) o[E] = (bf16)ndv;                              // models.py:560-563 (un-negated viewdirs)
+    for (int c = col0 + E + (has_ndv ? 1 : 0); c < col_end; ++c) vi[s * ldvi + c] = (bf16)0.0f;
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    normals_out[s * 3 + i] = nrm[i];
-    npred_out[s * 3 + i] = npred[i];
+    if (features & MNR_REF_DENSITY_NORMALS) normals_out[s * 3 + i] = nrm[i];
+    if (features & MNR_REF_PRED_NORMALS) npred_out[s * 3 + i] = npred[i];
   }
-  rough_out[s] = rough;
+  if (features & MNR_REF_ROUGHNESS) rough_out[s] = rough;
+}
+
+// Which feature sets the reference itself can run (models.py:538-563, ref_utils.py:147-154): the IDE multiplies by the
+// roughness and is evaluated per sample, i.e. on reflection directions; reflections and n.v need a normal field.
+static int rf_check_features(const char* who, int features, const mnr_ide_tables* tabs, int deg_view) {
+  MNR_CHECK_ARG((features & ~(MNR_REF_PRED_NORMALS | MNR_REF_DENSITY_NORMALS | MNR_REF_REFLECT | MNR_REF_IDE | MNR_REF_N_DOT_V |
+                              MNR_REF_ROUGHNESS)) == 0, "%s: unknown feature bits", who);
+  const bool has_normals = (features & (MNR_REF_PRED_NORMALS | MNR_REF_DENSITY_NORMALS)) != 0;
+  MNR_CHECK_ARG(has_normals || !(features & (MNR_REF_REFLECT | MNR_REF_N_DOT_V)), "Normals must be computed for reflection directions.");
+  if (features & MNR_REF_IDE) {
+    MNR_CHECK_ARG((features & MNR_REF_ROUGHNESS) && (features & MNR_REF_REFLECT),
+                  "%s: the IDE needs the predicted roughness and reflection directions (ref_utils.py:147-154)", who);
+    MNR_CHECK_ARG(tabs && tabs->T >= 1 && tabs->T <= RF_MAX_T && tabs->lmax <= RF_MAX_L, "Only deg_view of at most 5 is numerically stable.");
+  } else {
+    MNR_CHECK_ARG(deg_view >= 0 && 3 + 6 * deg_view <= RF_MAX_ENC, "%s: deg_view of the positional encoding out of range", who);
+  }
+  return MNR_OK;
 }
 
 extern "C" int mnr_ref_head_fwd(int64_t M, int n, const float* small, const float* raw_grad, const float* viewdirs,
-                                const mnr_ide_tables* tabs, float roughness_bias, uint16_t* vi, int ldvi, int col0,
-                                int col_end, float* normals_out, float* normals_pred_out, float* roughness_out,
-                                void* stream) {
-  MNR_CHECK_ARG(M > 0 && n > 0 && small && raw_grad && viewdirs && tabs && vi && normals_out && normals_pred_out &&
-                    roughness_out, "mnr_ref_head_fwd: null argument");
-  MNR_CHECK_ARG(tabs->T >= 1 && tabs->T <= RF_MAX_T && tabs->lmax <= RF_MAX_L, "Only deg_view of at most 5 is numerically stable.");
-  MNR_CHECK_ARG(col0 + 2 * tabs->T + 1 <= col_end && col_end <= ldvi, "mnr_ref_head_fwd: columns out of range");
+                                const mnr_ide_tables* tabs, int features, int deg_view, float roughness_bias, uint16_t* vi,
+                                int ldvi, int col0, int col_end, float* normals_out, float* normals_pred_out,
+                                float* roughness_out, void* stream) {
+  MNR_CHECK_ARG(M > 0 && n > 0 && small && viewdirs && vi, "mnr_ref_head_fwd: null argument");
+  if (int rc = rf_check_features("mnr_ref_head_fwd", features, tabs, deg_view)) return rc;
+  MNR_CHECK_ARG(!(features & MNR_REF_DENSITY_NORMALS) || (raw_grad && normals_out), "mnr_ref_head_fwd: density normals without raw_grad / normals_out");
+  MNR_CHECK_ARG(!(features & MNR_REF_PRED_NORMALS) || normals_pred_out, "mnr_ref_head_fwd: predicted normals without normals_pred_out");
+  MNR_CHECK_ARG(!(features & MNR_REF_ROUGHNESS) || roughness_out, "mnr_ref_head_fwd: roughness without roughness_out");
+  const int ncols = rf_enc_dim(features, tabs ? tabs->T : 0, deg_view) + ((features & MNR_REF_N_DOT_V) ? 1 : 0);
+  MNR_CHECK_ARG(col0 + ncols <= col_end && col_end <= ldvi, "mnr_ref_head_fwd: columns out of range");
+  const mnr_ide_tables none = {0, 0, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(ref_head_fwd_kernel, dim3(mnr_cdiv(M, RF_THREADS)), dim3(RF_THREADS), 0, (hipStream_t)stream, M, n,
-                     small, raw_grad, viewdirs, *tabs, roughness_bias, (bf16*)vi, ldvi, col0, col_end, normals_out,
-                     normals_pred_out, roughness_out,
+                     small, raw_grad, viewdirs, (features & MNR_REF_IDE) ? *tabs : none, features, deg_view, roughness_bias,
+                     (bf16*)vi, ldvi, col0, col_end, normals_out, normals_pred_out, roughness_out,
                      (col0 % 8 == 0 && col_end % 8 == 0 && ldvi % 8 == 0 && ((uintptr_t)vi % 16) == 0) ? 1 : 0);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
@@ -182,39 +239,49 @@ extern "C" int mnr_ref_head_fwd(int64_t M, int n, const float* small, const floa
 
 __global__ __launch_bounds__(RF_THREADS) void ref_head_bwd_kernel(
     int64_t M, int n, const float* __restrict__ small, const float* __restrict__ raw_grad,
-    const float* __restrict__ viewdirs, mnr_ide_tables tabs, float roughness_bias, const bf16* __restrict__ dvi_a,
-    const bf16* __restrict__ dvi_b, int lddvi, int col0, const float* __restrict__ g_npred_in,
+    const float* __restrict__ viewdirs, mnr_ide_tables tabs, int features, int deg_view, float roughness_bias,
+    const bf16* __restrict__ dvi_a, const bf16* __restrict__ dvi_b, int lddvi, int col0, const float* __restrict__ g_npred_in,
     const float* __restrict__ g_n_in, bf16* __restrict__ dhb, int lddhb, int col_gp, int col_rough,
     float* __restrict__ g_raw_grad, int vec8) {
   __shared__ IdeTab tab;
-  rf_load_tab(tab, tabs);
+  if (features & MNR_REF_IDE) rf_load_tab(tab, tabs);
   __syncthreads();
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= M) return;
   const int64_t ray = s / n;
   const float v[3] = {viewdirs[ray * 3], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2]};
   const float* sm = small + s * 11;
-  const float gp[3] = {sm[1], sm[2], sm[3]};
-  const float rg[3] = {raw_grad[s], raw_grad[M + s], raw_grad[2 * M + s]};
-  float npred[3], nrm[3], r0, r1;
-  bool c0, c1;
-  rf_neg_normalize(gp, npred, r0, c0);
-  rf_neg_normalize(rg, nrm, r1, c1);
+  float gp[3] = {0.0f, 0.0f, 0.0f}, rg[3] = {0.0f, 0.0f, 0.0f};
+  float npred[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f}, r0 = 1.0f, r1 = 1.0f;
+  bool c0 = true, c1 = true;
+  if (features & MNR_REF_PRED_NORMALS) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gp[i] = sm[1 + i];
+    rf_neg_normalize(gp, npred, r0, c0);
+  }
+  if (features & MNR_REF_DENSITY_NORMALS) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rg[i] = raw_grad[(int64_t)i * M + s];
+    rf_neg_normalize(rg, nrm, r1, c1);
+  }
+  const float* nu = (features & MNR_REF_PRED_NORMALS) ? npred : nrm;
   const float raw_r = sm[10] + roughness_bias;
-  const float rough = mnr_softplus(raw_r);
-  const float ndv = npred[0] * v[0] + npred[1] * v[1] + npred[2] * v[2];
+  const float rough = (features & MNR_REF_ROUGHNESS) ? mnr_softplus(raw_r) : 0.0f;
+  const float ndv = nu[0] * v[0] + nu[1] * v[1] + nu[2] * v[2];
   float u[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) u[i] = v[i] - 2.0f * ndv * npred[i];
-  const int T2 = 2 * tab.T;
-  float g[2 * RF_MAX_T];
+  for (int i = 0; i < 3; ++i) u[i] = (features & MNR_REF_REFLECT) ? v[i] - 2.0f * ndv * nu[i] : v[i];
+  const int E = rf_enc_dim(features, (features & MNR_REF_IDE) ? tab.T : 0, deg_view);
+  const bool has_ndv = (features & MNR_REF_N_DOT_V) != 0;
+  const int ncols = E + (has_ndv ? 1 : 0);
+  float g[RF_MAX_ENC];
   float g_ndv = 0.0f;
   if (vec8) {
-    // the T2 + 1 gradient columns of this sample's row in 16-byte pieces (73 two-byte loads per matrix and thread before:
+    // the gradient columns of this sample's row in 16-byte pieces (73 two-byte loads per matrix and thread before:
     // the kernel was bound by their issue, 5.6 ms per level at 2^21 samples)
     const bf16* pa = dvi_a + s * lddvi + col0;
     const bf16* pb = dvi_b ? dvi_b + s * lddvi + col0 : nullptr;
-    for (int c8 = 0; c8 * 8 <= T2; ++c8) {
+    for (int c8 = 0; c8 * 8 < ncols; ++c8) {
       const bf16x8 a = *(const bf16x8*)(pa + c8 * 8);
       bf16x8 b;
       if (pb) b = *(const bf16x8*)(pb + c8 * 8);
@@ -223,43 +290,49 @@ __global__ __launch_bounds__(RF_THREADS) void ref_head_bwd_kernel(
         const int i = c8 * 8 + e;
         float x = (float)a[e];
         if (pb) x += (float)b[e];
-        if (i < T2) g[i] = x;
-        else if (i == T2) g_ndv = x;
+        if (i < E) g[i] = x;
+        else if (i == E && has_ndv) g_ndv = x;
       }
     }
   } else {
-    for (int i = 0; i < T2; ++i) {
+    for (int i = 0; i < E; ++i) {
       float x = (float)dvi_a[s * lddvi + col0 + i];
       if (dvi_b) x += (float)dvi_b[s * lddvi + col0 + i];
       g[i] = x;
     }
-    g_ndv = (float)dvi_a[s * lddvi + col0 + T2];
-    if (dvi_b) g_ndv += (float)dvi_b[s * lddvi + col0 + T2];
+    if (has_ndv) {
+      g_ndv = (float)dvi_a[s * lddvi + col0 + E];
+      if (dvi_b) g_ndv += (float)dvi_b[s * lddvi + col0 + E];
+    }
   }
   float gu[3] = {0.0f, 0.0f, 0.0f}, gk = 0.0f;
-  rf_ide<true>(tab, u[0], u[1], u[2], rough, nullptr, g, gu, &gk);
-  // u = v - 2 (n.v) n  ->  d/dn
-  float g_np[3];
-  const float gun = gu[0] * npred[0] + gu[1] * npred[1] + gu[2] * npred[2];
+  if (features & MNR_REF_IDE) rf_ide<true>(tab, u[0], u[1], u[2], rough, nullptr, g, gu, &gk);
+  else if (features & MNR_REF_REFLECT) rf_posenc_bwd(u, deg_view, g, gu);        // (of the view direction itself: an input, no gradient)
+  // u = v - 2 (n.v) n  ->  d/dn ; n.v -> d/dn: the gradient of normals_to_use
+  float g_nu[3];
+  const float gun = gu[0] * nu[0] + gu[1] * nu[1] + gu[2] * nu[2];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    g_np[i] = -2.0f * (gun * v[i] + ndv * gu[i]) + g_ndv * v[i];
-    if (g_npred_in) g_np[i] += g_npred_in[s * 3 + i];
+  for (int i = 0; i < 3; ++i)
+    g_nu[i] = ((features & MNR_REF_REFLECT) ? -2.0f * (gun * v[i] + ndv * gu[i]) : 0.0f) + g_ndv * v[i];
+  if (features & MNR_REF_PRED_NORMALS) {
+    float g_np[3], g_gp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g_np[i] = g_nu[i] + (g_npred_in ? g_npred_in[s * 3 + i] : 0.0f);
+    rf_neg_normalize_bwd(gp, r0, c0, g_np, g_gp);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dhb[s * lddhb + col_gp + i] = (bf16)g_gp[i];
   }
-  float g_gp[3];
-  rf_neg_normalize_bwd(gp, r0, c0, g_np, g_gp);
-  const float g_rough_raw = gk * mnr_sigmoid(raw_r);
+  if (features & MNR_REF_ROUGHNESS)       // (without the IDE the roughness is an output only: models.py:521-523, 550)
+    dhb[s * lddhb + col_rough] = (bf16)((features & MNR_REF_IDE) ? gk * mnr_sigmoid(raw_r) : 0.0f);
+  if (features & MNR_REF_DENSITY_NORMALS) {
+    float g_n[3], g_rg[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) dhb[s * lddhb + col_gp + i] = (bf16)g_gp[i];
-  dhb[s * lddhb + col_rough] = (bf16)g_rough_raw;
-  float g_n[3] = {0.0f, 0.0f, 0.0f}, g_rg[3];
-  if (g_n_in) {
+    for (int i = 0; i < 3; ++i)
+      g_n[i] = (g_n_in ? g_n_in[s * 3 + i] : 0.0f) + ((features & MNR_REF_PRED_NORMALS) ? 0.0f : g_nu[i]);
+    rf_neg_normalize_bwd(rg, r1, c1, g_n, g_rg);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) g_n[i] = g_n_in[s * 3 + i];
+    for (int i = 0; i < 3; ++i) g_raw_grad[(int64_t)i * M + s] = g_rg[i];
   }
-  rf_neg_normalize_bwd(rg, r1, c1, g_n, g_rg);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) g_raw_grad[(int64_t)i * M + s] = g_rg[i];
 }
 
 // dhb[:, :cols] = dvi_a[:, :cols] (+ dvi_b[:, :cols]): the bottleneck part of the view-input gradient.
@@ -292,19 +365,26 @@ extern "C" int mnr_add_cols_bf16(int64_t M, int cols, const uint16_t* a, int lda
 }
 
 extern "C" int mnr_ref_head_bwd(int64_t M, int n, const float* small, const float* raw_grad, const float* viewdirs,
-                                const mnr_ide_tables* tabs, float roughness_bias, const uint16_t* dvi_a,
-                                const uint16_t* dvi_b, int lddvi, int col0, const float* g_npred, const float* g_n,
-                                uint16_t* dhb, int lddhb, int col_gp, int col_rough, float* g_raw_grad, void* stream) {
-  MNR_CHECK_ARG(M > 0 && n > 0 && small && raw_grad && viewdirs && tabs && dvi_a && dhb && g_raw_grad,
-                "mnr_ref_head_bwd: null argument");
-  MNR_CHECK_ARG(tabs->T >= 1 && tabs->T <= RF_MAX_T && tabs->lmax <= RF_MAX_L, "Only deg_view of at most 5 is numerically stable.");
-  // 16-byte row pieces when the columns [col0, col0 + 8 ceil((2T + 1) / 8)) are aligned and inside the row
-  const int ncol8 = (2 * tabs->T + 1 + 7) / 8 * 8;
+                                const mnr_ide_tables* tabs, int features, int deg_view, float roughness_bias,
+                                const uint16_t* dvi_a, const uint16_t* dvi_b, int lddvi, int col0, const float* g_npred,
+                                const float* g_n, uint16_t* dhb, int lddhb, int col_gp, int col_rough, float* g_raw_grad,
+                                void* stream) {
+  MNR_CHECK_ARG(M > 0 && n > 0 && small && viewdirs && dvi_a && dhb, "mnr_ref_head_bwd: null argument");
+  if (int rc = rf_check_features("mnr_ref_head_bwd", features, tabs, deg_view)) return rc;
+  MNR_CHECK_ARG(!(features & MNR_REF_DENSITY_NORMALS) || (raw_grad && g_raw_grad), "mnr_ref_head_bwd: density normals without raw_grad / g_raw_grad");
+  MNR_CHECK_ARG((features & MNR_REF_PRED_NORMALS) || !g_npred, "mnr_ref_head_bwd: g_npred without predicted normals");
+  MNR_CHECK_ARG((features & MNR_REF_DENSITY_NORMALS) || !g_n, "mnr_ref_head_bwd: g_n without density-gradient normals");
+  // 16-byte row pieces when the columns [col0, col0 + 8 ceil(ncols / 8)) are aligned and inside the row
+  const int ncols = rf_enc_dim(features, tabs ? tabs->T : 0, deg_view) + ((features & MNR_REF_N_DOT_V) ? 1 : 0);
+  MNR_CHECK_ARG(col0 + ncols <= lddvi, "mnr_ref_head_bwd: columns out of range");
+  const int ncol8 = (ncols + 7) / 8 * 8;
   const int vec8 = (col0 % 8 == 0 && lddvi % 8 == 0 && col0 + ncol8 <= lddvi && ((uintptr_t)dvi_a % 16) == 0 &&
                     (!dvi_b || ((uintptr_t)dvi_b % 16) == 0)) ? 1 : 0;
+  const mnr_ide_tables none = {0, 0, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(ref_head_bwd_kernel, dim3(mnr_cdiv(M, RF_THREADS)), dim3(RF_THREADS), 0, (hipStream_t)stream, M, n,
-                     small, raw_grad, viewdirs, *tabs, roughness_bias, (const bf16*)dvi_a, (const bf16*)dvi_b, lddvi,
-                     col0, g_npred, g_n, (bf16*)dhb, lddhb, col_gp, col_rough, g_raw_grad, vec8);
+                     small, raw_grad, viewdirs, (features & MNR_REF_IDE) ? *tabs : none, features, deg_view, roughness_bias,
+                     (const bf16*)dvi_a, (const bf16*)dvi_b, lddvi, col0, g_npred, g_n, (bf16*)dhb, lddhb, col_gp, col_rough,
+                     g_raw_grad, vec8);
   MNR_CHECK_LAUNCH();
   if (col0 > 0) {
     MNR_CHECK_ARG(col0 % 8 == 0 && lddvi % 8 == 0 && lddhb % 8 == 0, "mnr_ref_head_bwd: bottleneck width / strides must be multiples of 8");

@@ -101,10 +101,18 @@ class MLP:
       raise ValueError('Normals must be computed for reflection directions.')
 
   def is_ref(self):
-    """The complete Ref-NeRF head of configs/blender_refnerf.gin."""
-    return (self.enable_pred_normals and self.use_reflections and self.use_directional_enc and
-            self.enable_pred_roughness and self.use_diffuse_color and self.use_specular_tint and
-            self.use_n_dot_v and not self.disable_density_normals and not self.disable_rgb)
+    """The Ref-NeRF head (models.py:512-563,588-599: reflections, IDE, n.v, roughness, diffuse colour, tint; every flag on its
+    own, blender_refnerf.gin sets all of them): anything beyond the two normal fields, which have lighter paths of their own."""
+    return (not self.disable_rgb) and bool(self.use_reflections or self.use_directional_enc or self.enable_pred_roughness or
+                                           self.use_diffuse_color or self.use_specular_tint or self.use_n_dot_v)
+
+  def ref_features(self):
+    """MNR_REF_* bits of mnr_ref_head_fwd / _bwd (include/mnerf.h)."""
+    from multinerf_amd import ops
+    return ((ops.REF_PRED_NORMALS if self.enable_pred_normals else 0) |
+            (0 if self.disable_density_normals else ops.REF_DENSITY_NORMALS) |
+            (ops.REF_REFLECT if self.use_reflections else 0) | (ops.REF_IDE if self.use_directional_enc else 0) |
+            (ops.REF_N_DOT_V if self.use_n_dot_v else 0) | (ops.REF_ROUGHNESS if self.enable_pred_roughness else 0))
 
   def hip_supported(self):
     """Which reference features the HIP path implements in this round (scope)."""
@@ -118,23 +126,24 @@ class MLP:
       # not a HIP-path restriction: the reference's IDE multiplies by the roughness (ref_utils.py:147: exp(-sigma * kappa_inv)
       # with kappa_inv = None is a TypeError there)
       bad.append('use_directional_enc without enable_pred_roughness (undefined in the reference: ref_utils.py:147)')
+    if self.use_directional_enc and not self.use_reflections and not self.disable_rgb:
+      # the IDE of the per-ray view direction is [B, 2T], the roughness it is attenuated by [B, n, 1] (ref_utils.py:154):
+      # the reference's own broadcast fails (tests/golden/make_golden_models.py)
+      bad.append('use_directional_enc without use_reflections (undefined in the reference: ref_utils.py:154)')
     if self.use_n_dot_v and not self.enable_pred_normals and self.disable_density_normals:
       bad.append('use_n_dot_v without normals (undefined in the reference: models.py:560-563)')
-    if on and not self.is_ref() and on not in (['enable_pred_normals'], ['density normals'], ['enable_pred_normals', 'density normals']):
-      # The Ref-NeRF branch is implemented as one unit (blender_refnerf.gin), plus predicted normals on their own
-      # (enable_pred_normals with disable_density_normals: a Dense(3) head, models.py:494-503), density-gradient normals on
-      # their own (disable_density_normals = False: the tangent network, what configs/llff_raw.gin asks for with the orientation
-      # loss) and the two together (Ref-NeRF's normal regulariser, the predicted-normal loss of train_utils.py:186-203, in front
-      # of a plain view-direction colour); other partial mixes are not.
-      bad.append('partial Ref-NeRF feature set ' + str(on) +
-                 ' (all of them, predicted normals and / or density normals without the reflection colour, or none)')
+    # Every other set of the Ref-NeRF flags runs: the normal fields on their own or together (a Dense(3) head, models.py:494-503;
+    # the tangent network, what configs/llff_raw.gin asks for with the orientation loss), and the Ref-NeRF head with any of its
+    # parts switched off (mnr_ref_head_fwd's feature bits; tests/golden/models.npz holds the reference's outputs for ten such sets).
     if on and self.disable_rgb:
-      # (the two single-field mixes live in the merged head of an MLP with a colour branch)
+      # (the normal fields and the Ref-NeRF head live in the merged head of an MLP with a colour branch)
       bad.append('normals ' + str(on) + ' on a density-only MLP (disable_rgb)')
     if not self.disable_density_normals and self.warp_fn is not None:
       bad.append('density-gradient normals with a warp_fn')
-    if self.is_ref() and self.roughness_activation != 'softplus':
+    if self.enable_pred_roughness and self.roughness_activation != 'softplus':
       bad.append('roughness_activation != softplus')
+    if self.is_ref() and not self.use_directional_enc and self.deg_view > 11:
+      bad.append('deg_view > 11 in the positional encoding of a per-sample direction')
     if self.net_activation not in ('relu', 'softplus', 'silu'):   # what the reference registers (configs.py:29-31)
       bad.append(f'net_activation={self.net_activation}')
     if self.net_activation != 'relu' and not self.disable_density_normals:
@@ -215,10 +224,12 @@ class MLPPlan:
     self.x_concat = concat                     # trunk output carries the features too (depth ending on a skip)
     self.x_width = self.W + (self.F if concat else 0)
     self.density = add(self.x_width, 1)        # models.py:460
-    self.ref = hp.is_ref()
+    self.ref = hp.is_ref() and self.use_viewdirs           # (without view directions the reference skips the branch: models.py:512)
+    self.features = hp.ref_features() if self.ref else 0   # MNR_REF_* bits
     self.pn = hp.enable_pred_normals and not self.ref      # predicted normals without the rest of the Ref-NeRF head
     self.dn = (not hp.disable_density_normals) and not self.ref   # density-gradient normals without it
-    self.tangent = self.ref or self.dn                     # the forward-mode tangent network runs next to the trunk
+    self.tangent = not hp.disable_density_normals          # the forward-mode tangent network runs next to the trunk
+    self.diffuse_on = self.ref and hp.use_diffuse_color    # colour = tone-mapped tinted specular + diffuse (models.py:588-599)
     self.view: List[Tuple[DenseSpec, bool]] = []
     self.bottleneck = None
     self.rgb = None
@@ -263,7 +274,9 @@ class MLPPlan:
         bw = hp.bottleneck_width
         self.head_segs = [(self.bottleneck, 0), (self.density, bw)]
         if self.ref:
-          self.head_segs += [(self.gradpred, bw + 1), (self.diffuse, bw + 4), (self.tint, bw + 7), (self.rough, bw + 10)]
+          # (the same 11 fp32 side columns for every feature set: a head that is switched off is a zero column nobody reads)
+          self.head_segs += [(d, c) for d, c in ((self.gradpred, bw + 1), (self.diffuse, bw + 4), (self.tint, bw + 7),
+                                                 (self.rough, bw + 10)) if d is not None]
         elif self.pn:
           self.head_segs += [(self.gradpred, bw + 1)]
         self.head_cols = bw + (11 if self.ref else 4 if self.pn else 1)
@@ -330,7 +343,7 @@ class Model:
       bad += [f'{name}: {b}' for b in hp.hip_supported()]
     if not self.stop_level_grad:
       bad.append('stop_level_grad=False')
-    if not self.use_viewdirs and any(hp.enable_pred_normals or not hp.disable_density_normals
+    if not self.use_viewdirs and any(hp.enable_pred_normals or not hp.disable_density_normals or hp.is_ref()
                                      for hp in (self.nerf_hp, self.prop_hp) if not hp.disable_rgb):
       bad.append('normals (the Ref-NeRF head or one of its fields) without view directions')
     if self.ray_shape not in ('cone', 'cylinder'):
@@ -503,7 +516,7 @@ class Model:
     if p.has_rgb:
       p.head_bias = torch.zeros(_rup(p.head_cols, 128), dtype=f32, device=self.device)
     if p.ref:
-      p.ide = ops.IdeTablesDev(p.hp.deg_view, self.device)
+      p.ide = ops.IdeTablesDev(p.hp.deg_view, self.device) if p.hp.use_directional_enc else None
 
   def pack_weights(self, flat_params, ipe=False):
     """fp32 master parameters -> bf16 GEMM operands (one launch per MLP; `ipe`: also the group-major layer-0 image of the
@@ -823,10 +836,10 @@ class Model:
         bg = (lo + (hi - lo) * u).contiguous()
       ccfg = ops.composite_cfg(n, opaque_background=self.opaque_background, density_act=hp.density_activation,
                                density_bias=hp.density_bias, density_noise_std=hp.density_noise if dnoise is not None else 0.0,
-                               has_rgb=plan.has_rgb, rgb_act='identity' if plan.ref else hp.rgb_activation,
-                               rgb_premultiplier=1.0 if plan.ref else hp.rgb_premultiplier,
-                               rgb_bias=0.0 if plan.ref else hp.rgb_bias,
-                               rgb_padding=0.0 if plan.ref else hp.rgb_padding, bg_mode=bg_mode, bg_value=bg_value)
+                               has_rgb=plan.has_rgb, rgb_act='identity' if plan.diffuse_on else hp.rgb_activation,
+                               rgb_premultiplier=1.0 if plan.diffuse_on else hp.rgb_premultiplier,
+                               rgb_bias=0.0 if plan.diffuse_on else hp.rgb_bias,
+                               rgb_padding=0.0 if plan.diffuse_on else hp.rgb_padding, bg_mode=bg_mode, bg_value=bg_value)
       raw_density = mlp_out['raw_density'].view(Bp, n)
       raw_rgb = mlp_out['raw_rgb'].view(Bp, n, 3) if plan.has_rgb else None
       density, rgb, weights, rgb_out, acc = ops.composite_fwd(
@@ -845,25 +858,22 @@ class Model:
         rendering['ray_weights'] = weights[:B0][:nvis]
         rendering['ray_rgbs'] = (rgb[:B0][:nvis] if rgb is not None
                                  else torch.zeros((min(nvis, B0), n, 3), dtype=f32, device=dev))
-        if plan.ref:
-          # render.py:187-190: extras composited with the same weights
+        # render.py:187-190: extras composited with the same weights
+        if mlp_out.get('normals') is not None:
           rendering['normals'] = ops.weighted_sum(weights, mlp_out['normals'])[:B0].reshape(lead + (3,))
+        if mlp_out.get('npred') is not None:
           rendering['normals_pred'] = ops.weighted_sum(weights, mlp_out['npred'])[:B0].reshape(lead + (3,))
+        if mlp_out.get('rough') is not None:
           rendering['roughness'] = ops.weighted_sum(weights, mlp_out['rough'])[:B0].reshape(lead + (1,))
-        else:
-          if plan.pn:
-            rendering['normals_pred'] = ops.weighted_sum(weights, mlp_out['npred'])[:B0].reshape(lead + (3,))
-          if plan.dn:
-            rendering['normals'] = ops.weighted_sum(weights, mlp_out['normals'])[:B0].reshape(lead + (3,))
       renderings.append(rendering)
       rgb_hist = rgb[:B0] if rgb is not None else torch.zeros((B0, n, 3), dtype=f32, device=dev)
       ray_history.append(dict(
           density=density[:B0].reshape(lead + (n,)), rgb=rgb_hist.reshape(lead + (n, 3)),
           raw_grad_density=(mlp_out['raw_grad'].t().reshape(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.tangent else None),
-          grad_pred=(mlp_out['small'][:, 1:4].reshape(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if (plan.ref or plan.pn) else None),
+          grad_pred=(mlp_out['small'][:, 1:4].reshape(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if hp.enable_pred_normals else None),
           normals=(mlp_out['normals'].view(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if plan.tangent else None),
-          normals_pred=(mlp_out['npred'].view(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if (plan.ref or plan.pn) else None),
-          roughness=(mlp_out['rough'].view(Bp, n, 1)[:B0].reshape(lead + (n, 1)) if plan.ref else None),
+          normals_pred=(mlp_out['npred'].view(Bp, n, 3)[:B0].reshape(lead + (n, 3)) if hp.enable_pred_normals else None),
+          roughness=(mlp_out['rough'].view(Bp, n, 1)[:B0].reshape(lead + (n, 1)) if mlp_out.get('rough') is not None else None),
           sdist=sdist[:B0].reshape(lead + (n + 1,)), weights=weights[:B0].reshape(lead + (n,)),
           tdist=tdist[:B0].reshape(lead + (n + 1,))))
       if keep_for_backward:
@@ -1066,11 +1076,13 @@ class Model:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=plan.head_bias, n_bias=plan.head_cols, relu=False,
                     Cb=VI, ldcb=plan.ldVI, nb=bw, Cf=small, ldcf=11, f0=bw, nf=11)
         raw_density.copy_(small[:, 0])
-        T_feat, T_acts, raw_grad = self._tangent_forward(plan, tdist, R, M, bits, keep, tag)
+        raw_grad = None
+        if plan.tangent:
+          T_feat, T_acts, raw_grad = self._tangent_forward(plan, tdist, R, M, bits, keep, tag)
+          res.update(T_feat=T_feat, T_acts=T_acts, raw_grad=raw_grad)
         normals, npred, rough = ops.ref_head_fwd(small, raw_grad, R.viewdirs, n, plan.ide, hp.roughness_bias, VI,
-                                                 bw, plan.ldVI)
-        res.update(small=small, T_feat=T_feat, T_acts=T_acts, raw_grad=raw_grad, normals=normals, npred=npred,
-                   rough=rough)
+                                                 bw, plan.ldVI, features=plan.features, deg_view=hp.deg_view)
+        res.update(small=small, normals=normals, npred=npred, rough=rough)
       elif plan.pn:
         # [raw_density | grad_pred] as the fp32 side output; normals_pred = -l2_normalize(grad_pred) (models.py:494-503)
         small = self._buf((tag, 'small_pn'), (M, 4), f32)
@@ -1128,11 +1140,11 @@ class Model:
       ops.gemm_nt(h, self._w(plan, e['f_off'], e['n_pad'], e['f_ld']), M=M, N=e['n_pad'], K1=e['kpad'],
                   bias=flat[d.bias_off:d.bias_off + 3], n_bias=3, relu=False, Cf=raw_rgb, ldcf=3, f0=0, nf=3)
       res.update(VI=VI, vacts=vacts, raw_rgb=raw_rgb)
-      if plan.ref:
-        # models.py:584-602: tinted specular + diffuse, tone-mapped; compositing then sees final colours
+      if plan.diffuse_on:
+        # models.py:584-602: tinted (or halved) specular + diffuse, tone-mapped; compositing then sees final colours
         res['raw_rgb_pre'] = raw_rgb
         res['raw_rgb'] = ops.ref_color_fwd(raw_rgb, res['small'], hp.rgb_premultiplier, hp.rgb_bias, hp.rgb_padding,
-                                           True)
+                                           hp.use_specular_tint)
     else:
       e = plan.packed['density']
       d = plan.density
@@ -1153,7 +1165,7 @@ class Model:
     forward GEMM, dX GEMM and weight-gradient GEMM (with the density column as a vector) all read or write panel storage."""
     if not (_PANEL and _USE_BITS and plan.hp.net_activation == 'relu' and plan.W % 256 == 0 and plan.W >= 512 and M % 256 == 0):
       return False
-    if self._chain_ok(plan) or plan.tangent or plan.pn or not (plan.has_rgb and plan.use_viewdirs):
+    if self._chain_ok(plan) or plan.tangent or plan.pn or plan.ref or not (plan.has_rgb and plan.use_viewdirs):
       return False
     if plan.ldF % 32 != 0 or plan.ldF < 192 or plan.packed['head']['n_pad'] % 256 != 0:
       return False
@@ -1242,7 +1254,8 @@ class Model:
       bw = hp.bottleneck_width
       e = plan.packed['head']
       nh = e['nb_pad']
-      dHB = self._buf(('bwd', slot, 'dHB', nh), (M, nh), bf16, zero=True)   # columns beyond head_cols stay zero
+      # (columns beyond head_cols, and those of Ref-NeRF heads this MLP does not have, stay zero: keyed by module)
+      dHB = self._buf(('bwd', slot, 'dHB', nh, plan.module_name), (M, nh), bf16, zero=True)
       # (the plain merged head [bottleneck | density] of 360.gin: the density column's weight gradient rides in the bottleneck's
       # dW GEMM as a vector, below; it then also leaves the compositing VJP as the fp32 vector that GEMM reads)
       # (for trunks of at least 512 columns: at 256 the merged N = 384 GEMM is six small tiles and the extra column buys nothing,
@@ -1263,10 +1276,10 @@ class Model:
         g_vec = self._buf(('bwd', slot, 'g_den_vec'), (M,), bf16)
         ops.cast_f32_to_bf16(g_den_f32.view(-1), 1, M, 1, g_vec, 1, 0)
         ops.colsum(dHB.view(-1)[bw:], M, 1, gslice(plan.density.bias_off, 1), ld=nh)
-      if plan.ref:
+      if plan.diffuse_on:
         # colour combine VJP: -> d raw specular rgb, and the diffuse / tint columns of the head gradient
         g_raw_rgb = ops.ref_color_bwd(mlp['raw_rgb_pre'], mlp['small'], hp.rgb_premultiplier, hp.rgb_bias,
-                                      hp.rgb_padding, True, g_raw_rgb.contiguous(), dHB, bw + 4, bw + 7)
+                                      hp.rgb_padding, hp.use_specular_tint, g_raw_rgb.contiguous(), dHB, bw + 4, bw + 7)
       # rgb Dense(3): dH, dW, db
       WV = hp.net_width_viewdirs
       vacts = mlp['vacts']
@@ -1342,8 +1355,9 @@ class Model:
       if plan.ref:
         # IDE / reflection / normalisation VJP: fills the bottleneck (dVIa + dVIb), grad_pred and roughness
         # columns of dHB and returns the gradient w.r.t. d raw_density / d mean for the tangent network.
-        g_raw_grad = ops.ref_head_bwd(mlp['small'], mlp['raw_grad'], R.viewdirs, n, plan.ide, hp.roughness_bias,
-                                      dVIa, dVIb, bw, g_npred, g_normals, dHB, bw + 1, bw + 10)
+        g_raw_grad = ops.ref_head_bwd(mlp['small'], mlp.get('raw_grad'), R.viewdirs, n, plan.ide, hp.roughness_bias,
+                                      dVIa, dVIb, bw, g_npred, g_normals, dHB, bw + 1, bw + 10, features=plan.features,
+                                      deg_view=hp.deg_view)
       # merged head: dW, db, dX_last
       e = plan.packed['head']
       if head_gcol:

@@ -704,30 +704,38 @@ class IdeTablesDev:
                          self.mat.data_ptr())
 
 
-def ref_head_fwd(small, raw_grad, viewdirs, n, tabs, roughness_bias, vi, col0, col_end):
-  for x, nm in ((small, 'small'), (raw_grad, 'raw_grad'), (viewdirs, 'viewdirs')):
+# mnr_ref_head_fwd / _bwd feature bits (include/mnerf.h MNR_REF_*)
+REF_PRED_NORMALS, REF_DENSITY_NORMALS, REF_REFLECT, REF_IDE, REF_N_DOT_V, REF_ROUGHNESS = 1, 2, 4, 8, 16, 32
+REF_ALL = 63
+
+
+def ref_head_fwd(small, raw_grad, viewdirs, n, tabs, roughness_bias, vi, col0, col_end, features=REF_ALL, deg_view=0):
+  """-> (normals, normals_pred, roughness); None for the parts `features` switches off."""
+  for x, nm in ((small, 'small'), (viewdirs, 'viewdirs')):
     _chk(x, f32, nm)
+  _chk(raw_grad, f32, 'raw_grad', allow_none=True)
   _chk(vi, bf16, 'vi')
   M = small.shape[0]
   dev = small.device
-  normals = torch.empty((M, 3), dtype=f32, device=dev)
-  npred = torch.empty((M, 3), dtype=f32, device=dev)
-  rough = torch.empty((M,), dtype=f32, device=dev)
-  L.check(lib().mnr_ref_head_fwd(M, n, _ptr(small), _ptr(raw_grad), _ptr(viewdirs), C.byref(tabs.c),
-                                 float(roughness_bias), _ptr(vi), vi.stride(0), col0, col_end, _ptr(normals),
-                                 _ptr(npred), _ptr(rough), _stream()))
+  normals = torch.empty((M, 3), dtype=f32, device=dev) if features & REF_DENSITY_NORMALS else None
+  npred = torch.empty((M, 3), dtype=f32, device=dev) if features & REF_PRED_NORMALS else None
+  rough = torch.empty((M,), dtype=f32, device=dev) if features & REF_ROUGHNESS else None
+  L.check(lib().mnr_ref_head_fwd(M, n, _ptr(small), _ptr(raw_grad), _ptr(viewdirs), C.byref(tabs.c) if tabs is not None else None,
+                                 int(features), int(deg_view), float(roughness_bias), _ptr(vi), vi.stride(0), col0, col_end,
+                                 _ptr(normals), _ptr(npred), _ptr(rough), _stream()))
   return normals, npred, rough
 
 
 def ref_head_bwd(small, raw_grad, viewdirs, n, tabs, roughness_bias, dvi_a, dvi_b, col0, g_npred, g_n, dhb, col_gp,
-                 col_rough):
+                 col_rough, features=REF_ALL, deg_view=0):
+  """-> g_raw_grad [3, M] (None without density-gradient normals)."""
   M = small.shape[0]
   _chk(dvi_a, bf16, 'dvi_a')
   _chk(dvi_b, bf16, 'dvi_b', allow_none=True)
   _chk(dhb, bf16, 'dhb')
-  g_raw_grad = torch.empty((3, M), dtype=f32, device=small.device)
-  L.check(lib().mnr_ref_head_bwd(M, n, _ptr(small), _ptr(raw_grad), _ptr(viewdirs), C.byref(tabs.c),
-                                 float(roughness_bias), _ptr(dvi_a), _ptr(dvi_b), dvi_a.stride(0), col0,
+  g_raw_grad = torch.empty((3, M), dtype=f32, device=small.device) if features & REF_DENSITY_NORMALS else None
+  L.check(lib().mnr_ref_head_bwd(M, n, _ptr(small), _ptr(raw_grad), _ptr(viewdirs), C.byref(tabs.c) if tabs is not None else None,
+                                 int(features), int(deg_view), float(roughness_bias), _ptr(dvi_a), _ptr(dvi_b), dvi_a.stride(0), col0,
                                  _ptr(g_npred), _ptr(g_n), _ptr(dhb), dhb.stride(0), col_gp, col_rough,
                                  _ptr(g_raw_grad), _stream()))
   return g_raw_grad

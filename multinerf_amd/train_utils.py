@@ -316,8 +316,10 @@ class TrainStats(dict):
         'psnrs': -10. / math.log(10.) * np.log(mses),
         'losses': {'data': float(data.sum()), 'interlevel': float(raw[2 * n]), 'distortion': float(raw[2 * n + 1])},
     }
-    if raw[2 * n + 3] != 0 or raw[2 * n + 4] != 0:
+    # (each term under its own multipliers, train_utils.py:281-290)
+    if raw[2 * n + 3] != 0:
       out['losses']['orientation'] = float(raw[2 * n + 3])
+    if raw[2 * n + 4] != 0:
       out['losses']['predicted_normals'] = float(raw[2 * n + 4])
     if raw[4 * n + 5] != 0:
       out['losses']['weight'] = float(raw[4 * n + 5])

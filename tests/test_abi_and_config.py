@@ -24,7 +24,7 @@ def test_library_exports_every_header_symbol():
   # and every exported prototype we bind is declared in the header
   for n in _lib._PROTOS:
     assert n in names
-  assert lib.mnr_abi_version() == 17
+  assert lib.mnr_abi_version() == 18
 
 
 def test_ops_refuse_cpu_tensors():
@@ -93,3 +93,33 @@ def test_presets_equal_reference_gin_files(name):
   configs.load_preset(name)
   assert gin._BINDINGS == ref
   gin.clear_config()
+
+
+def test_every_ref_nerf_feature_set_of_the_goldens_has_a_hip_path():
+  """The sets of Ref-NeRF flags tests/golden/models.npz holds the reference's outputs for (make_golden_models.py CASES) are all
+  accepted by Model.hip_supported(); what the reference itself cannot run is named as such (models.py:434-435,560-563,
+  ref_utils.py:147,154)."""
+  import importlib.util
+  import os
+  from multinerf_amd import configs, models
+  here = os.path.dirname(os.path.abspath(__file__))
+  spec = importlib.util.spec_from_file_location('make_golden_models', os.path.join(here, 'golden', 'make_golden_models.py'))
+  gen = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(gen)
+  assert sum(k.startswith('refnerf_') for k in gen.CASES) >= 9
+  for case, (preset, extra, *_rest) in gen.CASES.items():
+    m = models.Model(config=configs.load_preset(preset, list(extra)))
+    # (the goldens' widths are shrunk to 32 / 16: the only objection the HIP path may have)
+    bad = [b for b in m.hip_supported() if 'multiple of' not in b]
+    assert bad == [], (case, bad)
+    plan = models.MLPPlan(m.nerf_hp, 'NerfMLP_0', m.use_viewdirs, m.num_glo_features, 0)
+    assert plan.ref == m.nerf_hp.is_ref() and plan.tangent == (not m.nerf_hp.disable_density_normals)
+    if plan.ref:
+      assert plan.head_cols == m.nerf_hp.bottleneck_width + 11
+      assert {c0 - m.nerf_hp.bottleneck_width for d, c0 in plan.head_segs[2:]} <= {1, 4, 7, 10}
+  for extra, what in ((['NerfMLP.use_reflections = False'], 'use_directional_enc without use_reflections'),
+                      (['NerfMLP.enable_pred_roughness = False'], 'use_directional_enc without enable_pred_roughness'),
+                      (['NerfMLP.enable_pred_normals = False', 'NerfMLP.disable_density_normals = True', 'NerfMLP.use_reflections = False',
+                        'NerfMLP.use_directional_enc = False'], 'use_n_dot_v without normals')):
+    bad = models.Model(config=configs.load_preset('blender_refnerf', extra)).hip_supported()
+    assert any(what in b and 'undefined in the reference' in b for b in bad), (extra, bad)

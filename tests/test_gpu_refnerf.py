@@ -93,6 +93,102 @@ def test_ref_head_fwd_bwd(ops):
   assert (got[:, :129] == 0).all() and (got[:, 132:138] == 0).all()
 
 
+def _head_ref_features(small, raw_grad, viewdirs_s, rb, F, deg, ops):
+  """models.py:492-563 for a feature set (MNR_REF_* bits): the oracle's leaves composed the way the reference composes them."""
+  npred = -oref.l2_normalize(small[:, 1:4]) if F & ops.REF_PRED_NORMALS else None
+  nrm = -oref.l2_normalize(raw_grad.T) if F & ops.REF_DENSITY_NORMALS else None
+  nu = npred if npred is not None else nrm
+  rough = torch.nn.functional.softplus(small[:, 10] + rb) if F & ops.REF_ROUGHNESS else None
+  d = oref.reflect(-viewdirs_s, nu) if F & ops.REF_REFLECT else viewdirs_s
+  enc = oref.generate_ide_fn(deg)(d, rough[:, None]) if F & ops.REF_IDE else ocoord.pos_enc(d, 0, deg, True)
+  cols = [enc] + ([(nu * viewdirs_s).sum(-1, keepdim=True)] if F & ops.REF_N_DOT_V else [])
+  return nrm, npred, rough, torch.cat(cols, -1)
+
+
+# (predicted normals, density normals, reflect, IDE, n.v, roughness) = bits 1, 2, 4, 8, 16, 32
+@pytest.mark.parametrize('F,deg', [(63, 5), (62, 5), (47, 5), (1 | 2 | 4 | 16, 4), (1 | 2 | 4 | 16 | 32, 4), (1 | 2 | 16 | 32, 4),
+                                   (2 | 4, 3), (32, 4), (1 | 16, 2)])
+def test_ref_head_feature_sets(ops, F, deg):
+  """Every feature set the reference can run (models.py:468-563): the complete head without predicted normals (reflections about
+  the density gradient's normals), without n.v, the positional encoding of the reflection direction with and without a
+  roughness head, the view direction's encoding next to n.v, roughness as an output only ..."""
+  gen = torch.Generator().manual_seed(100 + F)
+  B, n = 9, 16
+  M = B * n
+  small = torch.randn((M, 11), generator=gen)
+  raw_grad = torch.randn((3, M), generator=gen) * 3
+  v = torch.randn((B, 3), generator=gen)
+  v = v / v.norm(dim=-1, keepdim=True)
+  vs = v[:, None, :].expand(B, n, 3).reshape(M, 3)
+  rb = -1.0
+  tabs = ops.IdeTablesDev(deg, 'cuda') if F & ops.REF_IDE else None
+  has_dn, has_pn = bool(F & ops.REF_DENSITY_NORMALS), bool(F & ops.REF_PRED_NORMALS)
+  vi = torch.full((M, 256), 3.0, dtype=torch.bfloat16).cuda()
+  nrm, npred, rough = ops.ref_head_fwd(dev(small), dev(raw_grad) if has_dn else None, dev(v), n, tabs, rb, vi, 128, 256,
+                                       features=F, deg_view=deg)
+  s2, rg2, vs64 = small.double().requires_grad_(True), raw_grad.double().requires_grad_(True), vs.double()
+  nrm_r, npred_r, rough_r, enc_r = _head_ref_features(s2, rg2, vs64, rb, F, deg, ops)
+  for got, want in ((nrm, nrm_r), (npred, npred_r), (rough, rough_r)):
+    assert (got is None) == (want is None)
+    if got is not None:
+      np.testing.assert_allclose(got.cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-6)
+  E = enc_r.shape[1]
+  assert E == (2 * tabs.c.T if F & ops.REF_IDE else 3 + 6 * deg) + (1 if F & ops.REF_N_DOT_V else 0)
+  got_vi = vi.cpu().float()
+  np.testing.assert_allclose(got_vi[:, 128:128 + E].numpy(), enc_r.detach().numpy(), rtol=2**-7, atol=2e-3)
+  assert (got_vi[:, :128] == 3.0).all() and (got_vi[:, 128 + E:] == 0.0).all()
+
+  g_enc = torch.randn((M, E), generator=gen) * 0.1
+  g_np_l = torch.randn((M, 3), generator=gen) * 0.1 if has_pn else None
+  g_n_l = torch.randn((M, 3), generator=gen) * 0.1 if has_dn else None
+  dvi_a = torch.zeros((M, 256), dtype=torch.bfloat16)
+  dvi_a[:, 128:128 + E] = g_enc.to(torch.bfloat16)
+  g_used = dvi_a[:, 128:128 + E].double()
+  obj = (enc_r * g_used).sum()
+  if has_pn:
+    obj = obj + (npred_r * g_np_l.double()).sum()
+  if has_dn:
+    obj = obj + (nrm_r * g_n_l.double()).sum()
+  if obj.requires_grad:
+    obj.backward()
+  dhb = torch.full((M, 256), 7.0, dtype=torch.bfloat16).cuda()
+  g_rg = ops.ref_head_bwd(dev(small), dev(raw_grad) if has_dn else None, dev(v), n, tabs, rb, dev(dvi_a), None, 128,
+                          dev(g_np_l) if has_pn else None, dev(g_n_l) if has_dn else None, dhb, 129, 138, features=F, deg_view=deg)
+  assert (g_rg is None) == (not has_dn)
+  if has_dn:
+    want = rg2.grad.numpy() if rg2.grad is not None else np.zeros((3, M))
+    np.testing.assert_allclose(g_rg.cpu().numpy(), want, rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(want).max())))
+  got = dhb.cpu().float()
+  sg = s2.grad if s2.grad is not None else torch.zeros_like(s2)
+  if has_pn:
+    ref_gp = sg[:, 1:4]
+    np.testing.assert_allclose(got[:, 129:132].numpy(), ref_gp.numpy(), rtol=2e-2, atol=2e-3 * max(ref_gp.abs().max().item(), 1e-6))
+  else:
+    assert (got[:, 129:132] == 7.0).all()                # columns of a head that is off are not touched
+  if F & ops.REF_ROUGHNESS:
+    ref_r = sg[:, 10]
+    np.testing.assert_allclose(got[:, 138].numpy(), ref_r.numpy(), rtol=2e-2, atol=2e-3 * max(ref_r.abs().max().item(), 1e-6))
+    if not F & ops.REF_IDE:
+      assert (got[:, 138] == 0).all()                    # roughness as an output only (models.py:521-523, 550)
+  else:
+    assert (got[:, 138] == 7.0).all()
+  assert (got[:, 132:138] == 7.0).all()
+
+
+def test_ref_head_refuses_what_the_reference_cannot_run(ops):
+  M, n = 32, 16
+  small, v = torch.zeros((M, 11)).cuda(), torch.ones((2, 3)).cuda()
+  vi = torch.zeros((M, 128), dtype=torch.bfloat16).cuda()
+  tabs = ops.IdeTablesDev(5, 'cuda')
+  rg = torch.zeros((3, M)).cuda()
+  with pytest.raises(ValueError, match='Normals must be computed for reflection directions'):
+    ops.ref_head_fwd(small, None, v, n, None, 0.0, vi, 0, 128, features=ops.REF_REFLECT, deg_view=4)
+  with pytest.raises(ValueError, match='IDE needs the predicted roughness and reflection directions'):
+    ops.ref_head_fwd(small, rg, v, n, tabs, 0.0, vi, 0, 128, features=ops.REF_DENSITY_NORMALS | ops.REF_REFLECT | ops.REF_IDE)
+  with pytest.raises(ValueError, match='IDE needs the predicted roughness and reflection directions'):
+    ops.ref_head_fwd(small, rg, v, n, tabs, 0.0, vi, 0, 128, features=ops.REF_DENSITY_NORMALS | ops.REF_ROUGHNESS | ops.REF_IDE)
+
+
 def test_ref_color_fwd_bwd(ops):
   gen = torch.Generator().manual_seed(22)
   M = 999
