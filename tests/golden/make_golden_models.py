@@ -95,6 +95,9 @@ CASES.update({
                                 3, False, 0.5),
     'refnerf_without_diffuse': ('blender_refnerf', _RB + ['NerfMLP.use_diffuse_color = False'], 3, True, 0.5),
     'refnerf_no_tint': ('blender_refnerf', _RB + ['NerfMLP.use_specular_tint = False'], 3, False, 0.5),
+    # the complete head on predicted normals only (no density gradient: no vmap(value_and_grad) in the forward pass)
+    'refnerf_pred_normals_head': ('blender_refnerf', _RB + _NO_PN_LOSS + ['NerfMLP.disable_density_normals = True',
+                                                              'Config.compute_normal_metrics = False'], 3, True, 0.5),
 })
 
 _CALLABLE_FIELDS = ('raydist_fn', 'warp_fn', 'net_activation', 'density_activation', 'rgb_activation', 'roughness_activation')
@@ -526,7 +529,9 @@ def run_case(case, rmodels, ref_callables, rnd_state, Key):
       node[parts[-1]] = d
     return out
 
-  uses_inner_cstep = history[-1]['normals'] is not None      # (density-gradient normals: the forward pass is a complex step itself)
+  # (density-gradient normals: the forward pass is a complex step itself; the IDE computes with complex numbers of its own,
+  # ref_utils.py:140-157: an imaginary perturbation would mix with them)
+  uses_inner_cstep = history[-1]['normals'] is not None or bool(bindings['NerfMLP'].get('use_directional_enc', False))
   for d in range(3):
     V = direction(tree)
     if not uses_inner_cstep:

@@ -164,6 +164,9 @@ CASES = [
     ('blender_refnerf', ['NerfMLP.use_diffuse_color = False'], 8),
     ('blender_refnerf', ['NerfMLP.use_specular_tint = False', 'NerfMLP.enable_pred_roughness = False',
                          'NerfMLP.use_directional_enc = False'], 8),
+    # ... and the complete head on PREDICTED normals only (no density gradient, hence no tangent network and no double backward)
+    ('blender_refnerf', ['NerfMLP.disable_density_normals = True', 'Config.predicted_normal_loss_mult = 0.0',
+                         'Config.predicted_normal_coarse_loss_mult = 0.0', 'Config.compute_normal_metrics = False'], 8),
     # density-gradient normals WITHOUT the rest of the Ref-NeRF head: what configs/llff_raw.gin's own comment asks for ("Turn this
     # off if using orientation loss ... try .01"): the tangent network next to a plain RawNeRF MLP, the orientation loss on `normals`
     ('llff_raw', ['NerfMLP.disable_density_normals = False', 'Config.orientation_loss_mult = 0.01',

@@ -203,8 +203,8 @@ def test_gradient_matches_the_reference_forward_differentiated(case):
         grads[f'{prefix}{k}'] = torch.zeros_like(v) if v.grad is None else v.grad
   collect(params)
   rs = np.random.RandomState(int(GOLD[f'{case}/seed']) + 3)
-  # (the 4-point central difference of the generator where the forward pass is a complex step itself: density-gradient normals)
-  tol = 2e-5 if not on.disable_density_normals else 1e-8
+  # (the 4-point central difference of the generator where the forward pass is a complex step itself, density-gradient normals, or computes with complex numbers, the IDE)
+  tol = 2e-5 if (not on.disable_density_normals or on.use_directional_enc) else 1e-8
   for d in range(3):
     V = _direction(flat, rs)
     got = sum(float((grads[k] * torch.as_tensor(V[k])).sum()) for k in V)
