@@ -108,7 +108,6 @@ class MLP:
 
   def ref_features(self):
     """MNR_REF_* bits of mnr_ref_head_fwd / _bwd (include/mnerf.h)."""
-    from multinerf_amd import ops
     return ((ops.REF_PRED_NORMALS if self.enable_pred_normals else 0) |
             (0 if self.disable_density_normals else ops.REF_DENSITY_NORMALS) |
             (ops.REF_REFLECT if self.use_reflections else 0) | (ops.REF_IDE if self.use_directional_enc else 0) |

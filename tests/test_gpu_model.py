@@ -505,3 +505,20 @@ def test_proposal_levels_backward_as_one_pass_equals_level_by_level(monkeypatch)
     rel = ((g1[b:e].double() - g0[b:e].double()).norm() / (g0[b:e].double().norm() + 1e-30)).item()
     print(f'{mod}: one pass vs level by level: rel {rel:.2e}')
     assert rel < 1e-5, (mod, rel)
+
+
+def test_density_noise_with_density_gradient_normals_is_one_draw_per_level():
+  """models.py:462-464 under :478-481: the reference draws the density noise inside vmap(value_and_grad(predict_density)) from a key
+  that is closed over, so every sample of a level gets the same value (tests/golden/make_golden_models.py, case llff_raw_dn);
+  without density-gradient normals it is one draw per sample."""
+  for extra, one_draw in ((['NerfMLP.disable_density_normals = False'], True), ([], False)):
+    cfg, model, _, params, flat, batch = _setup('llff_raw', extra, 8)
+    gen = torch.Generator(device=flat.device).manual_seed(5)
+    model.apply({'flat': flat}, gen, batch.rays.map(lambda t: t.cuda()), 0.5, False, keep_for_backward=True)
+    for lv in model._saved['levels']:
+      dn = lv['dnoise']
+      assert dn is not None and dn.shape[1] == lv['n']
+      assert bool((dn == dn[0, 0]).all()) == one_draw
+    if one_draw:
+      a, b = (lv['dnoise'][0, 0].item() for lv in model._saved['levels'])
+      assert a != b                                          # (a key per level: models.py:211-212)
