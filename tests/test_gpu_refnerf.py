@@ -189,7 +189,8 @@ def test_ref_head_refuses_what_the_reference_cannot_run(ops):
     ops.ref_head_fwd(small, rg, v, n, tabs, 0.0, vi, 0, 128, features=ops.REF_DENSITY_NORMALS | ops.REF_ROUGHNESS | ops.REF_IDE)
 
 
-def test_ref_color_fwd_bwd(ops):
+@pytest.mark.parametrize('use_tint', [True, False])
+def test_ref_color_fwd_bwd(ops, use_tint):
   gen = torch.Generator().manual_seed(22)
   M = 999
   raw_rgb = torch.randn((M, 3), generator=gen) * 2
@@ -199,18 +200,22 @@ def test_ref_color_fwd_bwd(ops):
   pad = 0.001
   rr, sm = raw_rgb.double().requires_grad_(True), small.double().requires_grad_(True)
   spec = torch.sigmoid(rr)
-  lin = torch.sigmoid(sm[:, 7:10]) * spec + torch.sigmoid(sm[:, 4:7] - math.log(3.0))
+  # (models.py:592-595: the tint, or 0.5 without a tint head)
+  lin = (torch.sigmoid(sm[:, 7:10]) if use_tint else 0.5) * spec + torch.sigmoid(sm[:, 4:7] - math.log(3.0))
   ref = torch.clamp(oimage.linear_to_srgb(lin), 0.0, 1.0) * (1 + 2 * pad) - pad
-  out = ops.ref_color_fwd(dev(raw_rgb), dev(small), 1.0, 0.0, pad, True)
+  out = ops.ref_color_fwd(dev(raw_rgb), dev(small), 1.0, 0.0, pad, use_tint)
   np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-6)
   g = torch.randn((M, 3), generator=gen)
   (ref * g.double()).sum().backward()
   dhb = torch.zeros((M, 256), dtype=torch.bfloat16).cuda()
-  g_rr = ops.ref_color_bwd(dev(raw_rgb), dev(small), 1.0, 0.0, pad, True, dev(g), dhb, 132, 135)
+  g_rr = ops.ref_color_bwd(dev(raw_rgb), dev(small), 1.0, 0.0, pad, use_tint, dev(g), dhb, 132, 135)
   np.testing.assert_allclose(g_rr.cpu().numpy(), rr.grad.numpy(), rtol=2e-4, atol=1e-6)
   got = dhb.cpu().float()
   np.testing.assert_allclose(got[:, 132:135].numpy(), sm.grad[:, 4:7].numpy(), rtol=2**-7, atol=1e-4)
-  np.testing.assert_allclose(got[:, 135:138].numpy(), sm.grad[:, 7:10].numpy(), rtol=2**-7, atol=1e-4)
+  if use_tint:
+    np.testing.assert_allclose(got[:, 135:138].numpy(), sm.grad[:, 7:10].numpy(), rtol=2**-7, atol=1e-4)
+  else:
+    assert (got[:, 135:138] == 0).all()                      # no tint head: its columns are not touched
 
 
 def test_ref_losses_and_weighted_sum(ops):

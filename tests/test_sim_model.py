@@ -37,6 +37,13 @@ CASES = [
     # head, its dX / weight-gradient GEMMs and the trunk's weight-gradient GEMMs), with the skip concat
     ('360', ['NerfMLP.net_width = 512', 'NerfMLP.net_depth = 6', 'PropMLP.net_width = 128', 'PropMLP.net_depth = 2',
              'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 8),
+    # a partial Ref-NeRF feature set (mnr_ref_head_fwd / _bwd's feature bits): reflections about PREDICTED normals only (no
+    # tangent network), the positional encoding of the reflection direction in place of the IDE (roughness an output only),
+    # n.v, diffuse colour without a tint head
+    ('blender_refnerf', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32',
+                         'NerfMLP.disable_density_normals = True', 'NerfMLP.use_directional_enc = False',
+                         'NerfMLP.use_specular_tint = False', 'Config.predicted_normal_loss_mult = 0.0',
+                         'Config.predicted_normal_coarse_loss_mult = 0.0', 'Config.compute_normal_metrics = False'], 4),
 ]
 PANEL_CASE = CASES[3]
 
