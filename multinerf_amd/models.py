@@ -133,7 +133,7 @@ class MLP:
       bad.append('use_n_dot_v without normals (undefined in the reference: models.py:560-563)')
     # Every other set of the Ref-NeRF flags runs: the normal fields on their own or together (a Dense(3) head, models.py:494-503;
     # the tangent network, what configs/llff_raw.gin asks for with the orientation loss), and the Ref-NeRF head with any of its
-    # parts switched off (mnr_ref_head_fwd's feature bits; tests/golden/models.npz holds the reference's outputs for ten such sets).
+    # parts switched off (mnr_ref_head_fwd's feature bits; tests/golden/models.npz holds the reference's outputs for eleven such sets).
     if on and self.disable_rgb:
       # (the normal fields and the Ref-NeRF head live in the merged head of an MLP with a colour branch)
       bad.append('normals ' + str(on) + ' on a density-only MLP (disable_rgb)')
