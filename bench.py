@@ -95,6 +95,15 @@ def main():
   ap.add_argument('--no_aux', action='store_true', help='skip the secondary measurements (4096x192 north-star shape, render)')
   args = ap.parse_args()
 
+  # torch-only preflight in a child process before this process creates a HIP context (multinerf_amd/preflight.py): a box
+  # whose first host -> device copy aborts is then on record as `BOX_FAULT: ...` instead of a core dump of the benchmark
+  pre = None
+  if int(os.environ.get('LOCAL_RANK', '0')) == 0 and os.environ.get('MNR_SKIP_PREFLIGHT') != '1':
+    from multinerf_amd import preflight
+    pre = preflight.check(verbose=False)
+    if not pre['ok']:
+      raise SystemExit('BOX_FAULT: torch-only preflight failed (lines above); libmnerf_hip.so was never loaded')
+
   from multinerf_amd import configs, dist as mdist, models, ops, synthetic, train_utils
   from multinerf_amd import streams as mstreams
 
@@ -314,6 +323,7 @@ def main():
     if aux:
       out['aux'] = aux
     out['library'] = lib_info
+    out['preflight'] = None if pre is None else {'ok': pre['ok'], 'workaround': pre['workaround'], 'versions': pre['versions']}
     out['distributed'] = dist_info
 
   # ---- CPU baseline (rank 0, N=1 only): the oracle on a bounded sample of the same workload (SURVEY 8d protocol:

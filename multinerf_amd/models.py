@@ -1168,6 +1168,10 @@ class Model:
       return False
     if plan.ldF % 32 != 0 or plan.ldF < 192 or plan.packed['head']['n_pad'] % 256 != 0:
       return False
+    if keep and plan.ldF % 256 != 0:
+      # the layer-0 / skip-segment weight gradients are gemm_tn(feat, dY, K = ldF, b_layout = PANEL), and panel operands
+      # need K % 256 == 0 (mnr_gemm_tn_bf16): ldF = 384 / 640 / 896 train on the row-major path (128 x 128 tiles)
+      return False
     return (not keep) or self._head_gcol(plan)
 
   def _glo_table(self, flat):

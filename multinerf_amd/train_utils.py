@@ -297,7 +297,7 @@ def create_train_step(model: models.Model, config, dataset=None):
       out_stats['_grads'] = raw_grads
     if tree_stats:
       # what train_utils.py:304,323-324,334-335 log per summarize_tree key: evaluated lazily in TrainStats.materialize
-      out_stats['_tree'] = dict(ranges=ranges, grads=raw_grads, old=old_flat, new=flat)
+      out_stats['_tree'] = dict(ranges=ranges, grads=raw_grads, old=old_flat, new=flat.clone())   # (a copy: `flat` is updated in place by the next step)
     return new_state, TrainStats(out_stats), rng
 
   return train_step

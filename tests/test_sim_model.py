@@ -208,6 +208,29 @@ def test_panel_trunk_equals_row_major_trunk():
   assert ((a - b).norm() / b.norm()).item() < 1e-5
 
 
+def test_wide_trunk_whose_feature_width_is_not_a_multiple_of_256_trains():
+  """360 + NerfMLP.net_width = 512 + max_deg_point = 8 gives F = 336, ldF = 384.  The panel layout's layer-0 /
+  skip-segment weight gradients need K % 256 == 0, so this trunk must train on the row-major path (`_panel_ok`), as it did before
+  the panel layout existed -- and rendering (keep = False: no weight gradient) may still use panel storage."""
+  name, extra, B = '360', ['NerfMLP.net_width = 512', 'NerfMLP.net_depth = 6', 'NerfMLP.max_deg_point = 8', 'PropMLP.net_width = 128',
+                           'PropMLP.net_depth = 2', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 8
+  with S.simulated_device() as sim:
+    sim.lib.hipsim_reset(0, 0)
+    cfg, model, (om, on, op), params, flat, batch = _setup(name, extra, B)
+    assert model.nerf_plan.ldF == 384
+    noise = helpers.make_noise(model, B)
+    st = otrain.init_opt_state(params)
+    _, _, stats_o, grads_o = otrain.train_step(params, st, om, on, op, cfg, batch, 0.4, noise=noise, dense_dtype=torch.bfloat16)
+    state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+    _, stats, _ = train_utils.create_train_step(model, cfg)(0, state, batch, None, 0.4, 0.0, noise=noise, return_grads=True)
+    sim.check()
+    assert not model._saved['levels'][-1]['mlp'].get('panel')
+    g, g_o = stats['_grads'].double(), model.flat_from_tree(grads_o, device='cpu').double()
+    for mname, b, e in model.modules:
+      if g_o[b:e].norm() > 1e-12:
+        assert ((g[b:e] - g_o[b:e]).norm() / g_o[b:e].norm()).item() < 0.1, mname
+
+
 def test_weight_decay_per_tree_key_and_logging_statistics():
   """Config.weight_decay_mults with summarize_tree keys (train_utils.py:60-68,300-305: a module, a Dense inside one, one kernel)
   and the per-key logging statistics (weight_l2s, grad_norms, grad_maxes, opt_update_norms / _maxes, :304,323-324,332-335)
@@ -236,3 +259,36 @@ def test_weight_decay_per_tree_key_and_logging_statistics():
     with S.simulated_device():
       cfg2, model2, *_ = _setup(name, extra[:3] + ["Config.weight_decay_mults = {'NerfMLP_0/Dense_99': 1.0}"], B)
       train_utils.create_train_step(model2, cfg2)
+
+
+def test_smoke_entry_logic_on_the_simulator(monkeypatch):
+  """__graft_entry__.smoke() (the driver's round-end check: 360.gin forward + one train step's gradient against the oracle) with
+  its own code on the simulator at a reduced width / ray count, the preflight child replaced (no device here)."""
+  import importlib
+  from torch.overrides import TorchFunctionMode
+  from multinerf_amd import preflight
+  entry = importlib.import_module('__graft_entry__')
+  monkeypatch.setattr(preflight, 'check', lambda verbose=True: {'ok': True, 'workaround': None})
+  monkeypatch.setenv('MNR_SMOKE_BINDINGS', 'NerfMLP.net_width = 512;NerfMLP.net_depth = 6;PropMLP.net_width = 128;PropMLP.net_depth = 2;'
+                                           'Model.num_prop_samples = 32;Model.num_nerf_samples = 32')
+  monkeypatch.setenv('MNR_SMOKE_RAYS', '8')
+  monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+  monkeypatch.setattr(torch.cuda, 'set_device', lambda *a: None)
+  monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+
+  def is_cuda(x):
+    return (isinstance(x, str) and x.startswith('cuda')) or (isinstance(x, torch.device) and x.type == 'cuda')
+
+  class CudaIsHost(TorchFunctionMode):
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+      kwargs = dict(kwargs or {})
+      if func is torch.Tensor.cuda:
+        return args[0]
+      if is_cuda(kwargs.get('device')):
+        kwargs['device'] = 'cpu'
+      return func(*tuple('cpu' if is_cuda(a) else a for a in args), **kwargs)
+
+  with S.simulated_device() as sim, CudaIsHost():
+    sim.lib.hipsim_reset(0, 0)
+    entry.smoke()
+    sim.check()

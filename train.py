@@ -70,7 +70,10 @@ def main():
   for step in range(init_step, num_steps + 1):
     batch = next(dataset)
     train_frac = float(np.clip((step - 1) / (config.max_steps - 1), 0, 1))              # train.py:118
-    state, stats, gen = train_pstep(gen, state, batch, cameras, train_frac, 1.0)
+    logging_step = step % config.print_every == 0 or step == num_steps
+    # (the per-key statistics of train_utils.py:304,323-335 -- weight_l2s, grad_norms / maxes, opt_update_norms / maxes -- on the
+    # steps that are logged: they cost two copies of the parameter vector)
+    state, stats, gen = train_pstep(gen, state, batch, cameras, train_frac, 1.0, tree_stats=logging_step)
     stats_buffer.append(stats)
     if step % config.print_every == 0 or step == num_steps:                              # train.py:141-216
       # train.py:150-186: the logged numbers are AVERAGES over the steps since the last print
@@ -90,8 +93,10 @@ def main():
                + ', '.join(f'{k}={v:.5f}' for k, v in s['losses'].items()) + f', {rays_per_sec:.0f} r/s')
         print(msg, flush=True)
         if log:
+          tree = {k: {kk: float(vv) for kk, vv in s[k].items() if kk.count('/') == 0} for k in
+                  ('weight_l2s', 'grad_norms', 'grad_maxes', 'opt_update_norms', 'opt_update_maxes') if isinstance(s.get(k), dict)}
           log.write(json.dumps(dict(step=step, loss=s['loss'], psnr=s['psnr'], lr=lr_fn(step), losses=s['losses'],
-                                    train_rays_per_sec=rays_per_sec)) + '\n')
+                                    train_rays_per_sec=rays_per_sec, **tree)) + '\n')
           log.flush()
       stats_buffer, train_start = [], time.time()
     if config.checkpoint_dir and rank == 0 and (step == 1 or step % config.checkpoint_every == 0):
