@@ -77,6 +77,16 @@ int mnr_resample_level(const mnr_resample_cfg* cfg, int64_t B,
                        const float* near, const float* far,
                        float* sdist_out, float* tdist_out, int32_t* idx_out, void* stream);
 
+/* VJP of mnr_resample_level w.r.t. its incoming step function: Model.stop_level_grad = False (models.py:56,198-201; what
+ * jax differentiates there: stepfun.max_dilate_weights stepfun.py:99-128, the logits models.py:183-185, jax.nn.softmax and
+ * integrate_weights stepfun.py:131-156, math.sorted_interp math.py:108-127, the interval fence-posts stepfun.py:252-262).
+ *  Inputs as the forward call's (same cfg, sdist_prev, w_prev, u_base, jitter: the forward pass is re-run inside);
+ *  g_sdist [B,n+1] = d loss / d sdist_out.  Outputs (overwritten): g_sdist_prev [B,n_prev+1], g_w_prev [B,n_prev]. */
+int mnr_resample_level_bwd(const mnr_resample_cfg* cfg, int64_t B,
+                           const float* sdist_prev, const float* w_prev,
+                           const float* u_base, const float* jitter, const float* g_sdist,
+                           float* g_sdist_prev, float* g_w_prev, void* stream);
+
 /* Leaf: math.sorted_interp(u, cw, t) (math.py:108-127) with the integer index.
  * cw,t [B,nc]; u [B,nu] -> out [B,nu], idx [B,nu] (may be NULL). */
 int mnr_sorted_interp(int64_t B, int nc, int nu, const float* u, const float* cw, const float* t,

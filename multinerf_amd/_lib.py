@@ -143,6 +143,7 @@ _PROTOS = {
     'mnr_abi_version': ([], i32),
     'mnr_device_info': ([i32, C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32], i32),
     'mnr_resample_level': ([C.POINTER(ResampleCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
+    'mnr_resample_level_bwd': ([C.POINTER(ResampleCfg), i64, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_sorted_interp': ([i64, i32, i32, vp, vp, vp, vp, vp, vp], i32),
     'mnr_max_dilate_weights': ([i64, i32, vp, vp, f32, f32, f32, vp, vp, vp, vp], i32),
     'mnr_cast_rays_ipe': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp], i32),

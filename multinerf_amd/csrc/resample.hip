@@ -474,3 +474,406 @@ extern "C" int mnr_max_dilate_weights(int64_t B, int n, const float* t, const fl
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// VJP of the level kernel with respect to the incoming step function (Model.stop_level_grad = False, reference
+// models.py:198-201: the sample positions of a level then carry gradient into the previous level's sdist and weights).
+//
+// Given g_sdist [B, n+1] = d loss / d sdist_out the kernel re-runs the level's forward pass for its rays (the SAME device
+// code in the same order, so the bins every sample fell into are the forward pass's own) and walks it backwards:
+//   fence-posts -> centers (stepfun.py:252-262; the clamped ends pass gradient while inside the domain)
+//   math.sorted_interp (math.py:108-127): c = f0 + off (f1 - f0), off = clip((u - x0) / (x1 - x0), 0, 1): gradient to the two
+//     bracketing fence-posts f0, f1 of the (dilated) histogram and to the two CDF values x0, x1
+//   integrate_weights (stepfun.py:131-150): transposed cumulative sum (suffix sums) behind the min(1, .) clamp
+//   jax.nn.softmax (stepfun.py:156), anneal * log(w + padding) (models.py:183-185; closed bins are constants)
+//   max_dilate_weights (stepfun.py:99-128): renormalisation, pdf <-> weight, the window maximum (gradient to the bin that
+//     attains it), sort + clip (each dilated fence-post is one of t[i], t[i] - d, t[i+1] + d, or a clipped constant)
+// to g_sdist_prev [B, n_prev+1] and g_w_prev [B, n_prev].  The indices (which bin, which maximum, which source of a sorted
+// fence-post) are piecewise constant and carry no gradient, as in the reference's autodiff.  One deliberate deviation: where
+// a bin's weight + padding is exactly 0 its logit is -inf, its softmax weight 0, and autodiff yields 0 * inf = NaN (which the
+// reference's train_step then turns into a zero update through nan_to_num, train_utils.py:326-328); here that product is 0.
+//
+// 16 lanes per ray as in the forward kernel: element-wise passes are split over the lanes, the three scatters / scans
+// (sample -> bracketing bins, suffix sum, window maximum -> bin) run on the ray's first lane (deterministic order).
+
+struct RspBLay {
+  int T, P, W0, TD, WR, BEST, JB, RANK, WN, LG, CW, PASS, CEN, I0, UQ, GC, GTD, GCW, GWK, GWN, GTF, GP, GT, RED, per_ray;
+};
+
+static RspBLay rspb_layout(int np, int n) {
+  RspBLay l;
+  const int m = 3 * np + 1;
+  int o = 0;
+  l.T = o; o += np + 1;
+  l.P = o; o += np;
+  l.W0 = o; o += np;
+  l.TD = o; o += m;
+  l.WR = o; o += m;
+  l.BEST = o; o += m;
+  l.JB = o; o += m;
+  l.RANK = o; o += m;
+  l.WN = o; o += m;
+  l.LG = o; o += m;
+  l.CW = o; o += m;
+  l.PASS = o; o += m;
+  l.CEN = o; o += n;
+  l.I0 = o; o += n;
+  l.UQ = o; o += n;
+  l.GC = o; o += n;
+  l.GTD = o; o += m;
+  l.GCW = o; o += m;
+  l.GWK = o; o += m;
+  l.GWN = o; o += m;
+  l.GTF = o; o += m;
+  l.GP = o; o += np;
+  l.GT = o; o += np + 1;
+  l.RED = o; o += RSP_LPR;
+  l.per_ray = (o + 3) & ~3;
+  return l;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void resample_level_bwd_kernel(
+    mnr_resample_cfg c, int64_t B, RspBLay lay, const float* __restrict__ sdist_prev, const float* __restrict__ w_prev,
+    const float* __restrict__ u_base, const float* __restrict__ jitter, const float* __restrict__ g_sdist,
+    float* __restrict__ g_sdist_prev, float* __restrict__ g_w_prev) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int np = c.n_prev, n = c.n_samples;
+  const float eps2 = MNR_F32_EPS * MNR_F32_EPS;
+  const int64_t ray0 = (int64_t)blockIdx.x * RSP_RPW;
+  const int nrays = (int)min((int64_t)RSP_RPW, B - ray0);
+  for (int e = threadIdx.x; e < RSP_RPW * (np + 1); e += RS_THREADS) {
+    const int r = e / (np + 1), i = e % (np + 1);
+    lds[r * lay.per_ray + lay.T + i] = sdist_prev[(ray0 + min(r, nrays - 1)) * (np + 1) + i];
+  }
+  for (int e = threadIdx.x; e < RSP_RPW * np; e += RS_THREADS) {
+    const int r = e / np, i = e % np;
+    const float wv = w_prev[(ray0 + min(r, nrays - 1)) * np + i];
+    lds[r * lay.per_ray + lay.P + i] = wv;
+    lds[r * lay.per_ray + lay.W0 + i] = wv;
+  }
+  const int g = threadIdx.x / RSP_LPR, l = threadIdx.x % RSP_LPR;
+  const int gr = min(g, nrays - 1);
+  const int64_t ray = ray0 + gr;
+  __syncthreads();
+  float* base = lds + g * lay.per_ray;
+  float* t = base + lay.T;
+  float* p = base + lay.P;
+  const float* w0 = base + lay.W0;
+  float* red = base + lay.RED;
+  float* tdf = base + lay.TD;                          // full dilated fence-posts [3 np + 1]
+  float* wr = base + lay.WR;                           // un-normalised dilated weights [3 np]
+  float* best = base + lay.BEST;
+  int* jb = (int*)(base + lay.JB);
+  int* rank = (int*)(base + lay.RANK);
+  float* wn = base + lay.WN;                           // normalised dilated weights (full) / the incoming weights
+  const int m = 3 * np + 1;
+  float S_total = 1.0f;
+  const float* td;                                     // the histogram being sampled: fence-posts, weights, bins
+  const float* wdn;
+  int nb;
+  if (c.use_dilation) {
+    // ---- forward: rsp_max_dilate with its indices recorded
+    for (int j = l; j < np; j += RSP_LPR) p[j] = p[j] / fmaxf(eps2, t[j + 1] - t[j]);
+    __syncthreads();
+    for (int e = l; e < m; e += RSP_LPR) {
+      float v;
+      int rk;
+      if (e <= np) {
+        v = t[e];
+        rk = e + rsp_count(t, np, -c.dilation, v, true) + rsp_count(t + 1, np, c.dilation, v, false);
+      } else if (e <= 2 * np) {
+        const int j = e - (np + 1);
+        v = t[j] - c.dilation;
+        rk = j + rsp_count(t, np + 1, 0.0f, v, false) + rsp_count(t + 1, np, c.dilation, v, false);
+      } else {
+        const int k = e - (2 * np + 1);
+        v = t[k + 1] + c.dilation;
+        rk = k + rsp_count(t, np + 1, 0.0f, v, true) + rsp_count(t, np, -c.dilation, v, true);
+      }
+      tdf[rk] = fminf(fmaxf(v, c.domain_lo), c.domain_hi);
+      rank[e] = rk;
+    }
+    __syncthreads();
+    const int nw = m - 1;
+    const int ch = (nw + RSP_LPR - 1) / RSP_LPR;
+    const int k0 = min(nw, l * ch), k1 = min(nw, k0 + ch);
+    float csum = 0.0f;
+    if (k0 < k1) {
+      int jhi = rsp_count(t, np, -c.dilation, tdf[k0], true) - 1;
+      int jlo = rsp_count(t + 1, np, c.dilation, tdf[k0], true);
+      for (int k = k0; k < k1; ++k) {
+        const float x = tdf[k];
+        while (jhi + 1 < np && t[jhi + 1] - c.dilation <= x) ++jhi;
+        while (jlo < np && !(t[jlo + 1] + c.dilation > x)) ++jlo;
+        float bst = 0.0f;
+        int jbst = -1;
+        for (int j = jlo; j <= jhi; ++j) {
+          if (p[j] > bst) {
+            bst = p[j];
+            jbst = j;
+          }
+        }
+        best[k] = bst;
+        jb[k] = jbst;
+        const float w = bst * (tdf[k + 1] - x);
+        wr[k] = w;
+        csum += w;
+      }
+    }
+    (void)rsp_chunk_offset(csum, red, l, S_total);
+    const float denom = fmaxf(eps2, S_total);
+    for (int k = k0; k < k1; ++k) wn[k] = wr[k] / denom;
+    __syncthreads();
+    td = tdf + 1;
+    wdn = wn + 1;
+    nb = 3 * np - 2;
+  } else {
+    for (int j = l; j < np; j += RSP_LPR) wn[j] = w0[j];
+    __syncthreads();
+    td = t;
+    wdn = wn;
+    nb = np;
+  }
+  // ---- forward: logits, softmax, CDF (the level kernel's order)
+  float* lg = base + lay.LG;                           // logits, then softmax weights
+  const int ch = (nb + RSP_LPR - 1) / RSP_LPR;
+  const int k0 = min(nb, l * ch), k1 = min(nb, k0 + ch);
+  float mx = -INFINITY;
+  for (int k = k0; k < k1; ++k) {
+    const bool open = td[k + 1] > td[k];
+    const float v = open ? c.anneal * rs_log(wdn[k] + c.resample_padding) : -INFINITY;
+    lg[k] = v;
+    mx = (v != v || mx != mx) ? NAN : fmaxf(mx, v);
+  }
+  __syncthreads();
+  red[l] = mx;
+  __syncthreads();
+  mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < RSP_LPR; ++i) {
+    const float v = red[i];
+    mx = (v != v || mx != mx) ? NAN : fmaxf(mx, v);
+  }
+  float csum = 0.0f;
+  for (int k = k0; k < k1; ++k) {
+    const float e = rs_exp(lg[k] - mx);
+    lg[k] = e;
+    csum += e;
+  }
+  float denom2;
+  (void)rsp_chunk_offset(csum, red, l, denom2);
+  float* cw = base + lay.CW;
+  csum = 0.0f;
+  for (int k = k0; k < k1; ++k) {
+    const float wk = lg[k] / denom2;
+    lg[k] = wk;
+    if (k < nb - 1) csum += wk;
+  }
+  float unused;
+  const float off0 = rsp_chunk_offset(csum, red, l, unused);
+  float* pass_cs = base + lay.PASS;                    // [k + 1] = 1 where min(1, cs[k]) passes gradient
+  float run = 0.0f;
+  for (int k = k0; k < k1 && k < nb - 1; ++k) {
+    run += lg[k];
+    const float cs = off0 + run;
+    cw[k + 1] = (cs != cs) ? cs : fminf(1.0f, cs);
+    pass_cs[k + 1] = (cs <= 1.0f) ? 1.0f : 0.0f;
+  }
+  if (l == 0) {
+    cw[0] = 0.0f;
+    cw[nb] = 1.0f;
+  }
+  __syncthreads();
+  // ---- forward: inverse CDF with the bracketing indices recorded
+  float* centers = base + lay.CEN;
+  int* i0s = (int*)(base + lay.I0);
+  float* uq = base + lay.UQ;                           // the queries u
+  const int chs = (n + RSP_LPR - 1) / RSP_LPR;
+  const int j0 = min(n, l * chs), j1 = min(n, j0 + chs);
+  const float jit1 = (jitter && c.single_jitter) ? jitter[ray] * c.max_jitter : 0.0f;
+  int cur = -2;
+  for (int j = j0; j < j1; ++j) {
+    float u = u_base[j];
+    if (jitter) u = u + (c.single_jitter ? jit1 : jitter[ray * n + j] * c.max_jitter);
+    if (cur == -2) {
+      int lo_i = -1, hi_i = nb + 1;
+      while (hi_i - lo_i > 1) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (cw[mid] <= u) lo_i = mid;
+        else hi_i = mid;
+      }
+      cur = lo_i;
+    }
+    centers[j] = rs_interp_one(u, cw, td, 1, nb + 1, cur);
+    i0s[j] = cur;
+    uq[j] = u;
+  }
+  __syncthreads();
+
+  // ================= backward
+  float* gc = base + lay.GC;
+  float* gtd = base + lay.GTD;                         // d loss / d td (trimmed indexing: the sampled histogram's fence-posts)
+  float* gwn = base + lay.GWN;                         // d loss / d (normalised dilated weights), full indexing when dilated
+  float* gp = base + lay.GP;
+  float* gt = base + lay.GT;
+  const float* gso = g_sdist + ray * (n + 1);
+  // fence-posts -> centers
+  {
+    const float x_first = 2.0f * centers[0] - (centers[1] + centers[0]) / 2.0f;
+    const float x_last = 2.0f * centers[n - 1] - (centers[n - 1] + centers[n - 2]) / 2.0f;
+    const float G0 = (x_first >= c.domain_lo) ? gso[0] : 0.0f;
+    const float Gn = (x_last <= c.domain_hi) ? gso[n] : 0.0f;
+    for (int j = l; j < n; j += RSP_LPR) {
+      float v = 0.0f;
+      if (j >= 1) v += 0.5f * gso[j];
+      if (j + 1 <= n - 1) v += 0.5f * gso[j + 1];
+      if (j == 0) v += 1.5f * G0;
+      if (j == 1) v -= 0.5f * G0;
+      if (j == n - 1) v += 1.5f * Gn;
+      if (j == n - 2) v -= 0.5f * Gn;
+      gc[j] = v;
+    }
+  }
+  for (int k = l; k <= nb; k += RSP_LPR) gtd[k] = 0.0f;
+  __syncthreads();
+  // samples -> bracketing fence-posts and CDF values (first lane of the ray: the samples ascend, so do the bins)
+  float* gcw = base + lay.GCW;                         // d loss / d cw
+  float* gwk = base + lay.GWK;                         // d loss / d softmax weights
+  for (int k = l; k <= nb; k += RSP_LPR) gcw[k] = 0.0f;
+  for (int k = l; k < m; k += RSP_LPR) gwn[k] = 0.0f;
+  __syncthreads();
+  if (l == 0) {
+    for (int j = 0; j < n; ++j) {
+      const int i = i0s[j];
+      const int a = i >= 0 ? i : 0;
+      const int b = i + 1 < nb + 1 ? i + 1 : nb;
+      const float u = uq[j];
+      const float x0 = cw[a], x1 = cw[b], f0 = td[a], f1 = td[b];
+      const float den = x1 - x0;
+      const float raw = (u - x0) / den;
+      const bool fin = (raw == raw) && fabsf(raw) <= 3.4028234664e38f;
+      const float off = mnr_nan0_clip01(raw);
+      const float gcj = gc[j];
+      gtd[a] += gcj * (1.0f - off);
+      gtd[b] += gcj * off;
+      if (fin && raw >= 0.0f && raw <= 1.0f) {
+        const float goff = gcj * (f1 - f0);
+        gcw[a] += goff * (raw - 1.0f) / den;
+        gcw[b] -= goff * raw / den;
+      }
+    }
+    // cw[k+1] = min(1, cs[k]), cs = cumsum(w[:-1]): suffix sums behind the clamp; the last bin's weight gets nothing
+    float suffix = 0.0f;
+    gwk[nb - 1] = 0.0f;
+    for (int k = nb - 2; k >= 0; --k) {
+      suffix += gcw[k + 1] * pass_cs[k + 1];
+      gwk[k] = suffix;
+    }
+  }
+  __syncthreads();
+  // softmax VJP, then the logits' log; lg[] holds the softmax weights
+  float dotp = 0.0f;
+  for (int k = k0; k < k1; ++k) dotp += lg[k] * gwk[k];
+  float dot_total;
+  (void)rsp_chunk_offset(dotp, red, l, dot_total);
+  {
+    float* gdst = c.use_dilation ? gwn + 1 : gwn;
+    for (int k = k0; k < k1; ++k) {
+      const float glog = lg[k] * (gwk[k] - dot_total);
+      const bool open = td[k + 1] > td[k];
+      const float den = wdn[k] + c.resample_padding;
+      gdst[k] = (open && glog != 0.0f) ? glog * c.anneal / den : 0.0f;
+    }
+  }
+  __syncthreads();
+  if (!c.use_dilation) {
+    if (g < nrays) {
+      for (int i = l; i <= np; i += RSP_LPR) g_sdist_prev[ray * (np + 1) + i] = gtd[i];
+      for (int i = l; i < np; i += RSP_LPR) g_w_prev[ray * np + i] = gwn[i];
+    }
+    return;
+  }
+  // ---- max_dilate_weights backwards.  Full indexing from here: gtd_full[r] = gtd[r - 1] for 1 <= r <= m - 2.
+  const int nw = m - 1;
+  {
+    const int chw = (nw + RSP_LPR - 1) / RSP_LPR;
+    const int q0 = min(nw, l * chw), q1 = min(nw, q0 + chw);
+    float d2 = 0.0f;
+    for (int k = q0; k < q1; ++k) d2 += gwn[k] * wn[k];
+    float dot2;
+    (void)rsp_chunk_offset(d2, red, l, dot2);
+    const float denom = fmaxf(eps2, S_total);
+    const bool pass = S_total >= eps2;
+    // g_wr[k] in place of gwn[k]
+    for (int k = q0; k < q1; ++k) gwn[k] = pass ? (gwn[k] - dot2) / denom : gwn[k] / denom;
+  }
+  for (int j = l; j < np; j += RSP_LPR) gp[j] = 0.0f;
+  __syncthreads();
+  // fence-post gradients of the dilated histogram: from the sampling (shifted) and from wr[k] = best[k] (td[k+1] - td[k])
+  float* gtf = base + lay.GTF;                         // [m] full-index d loss / d tdf
+  for (int r = l; r < m; r += RSP_LPR) {
+    float v = (r >= 1 && r <= m - 2) ? gtd[r - 1] : 0.0f;
+    if (r >= 1) v += gwn[r - 1] * best[r - 1];
+    if (r < nw) v -= gwn[r] * best[r];
+    gtf[r] = v;
+  }
+  if (l == 0) {
+    for (int k = 0; k < nw; ++k) {
+      const int j = jb[k];
+      if (j >= 0) gp[j] += gwn[k] * (tdf[k + 1] - tdf[k]);
+    }
+  }
+  __syncthreads();
+  // sort + clip: every source element receives the gradient of the fence-post it became (unless clipped away)
+  for (int i = l; i <= np; i += RSP_LPR) {
+    float v = 0.0f;
+    {
+      const float a = t[i];
+      if (a >= c.domain_lo && a <= c.domain_hi) v += gtf[rank[i]];
+    }
+    if (i < np) {
+      const float bb = t[i] - c.dilation;
+      if (bb >= c.domain_lo && bb <= c.domain_hi) v += gtf[rank[np + 1 + i]];
+    }
+    if (i >= 1) {
+      const float cc = t[i] + c.dilation;
+      if (cc >= c.domain_lo && cc <= c.domain_hi) v += gtf[rank[2 * np + 1 + (i - 1)]];
+    }
+    // pdf = w / max(eps^2, dt): the two bins next to this fence-post
+    if (i < np) {
+      const float dt = t[i + 1] - t[i];
+      if (dt >= eps2) v += gp[i] * p[i] / dt;
+    }
+    if (i >= 1) {
+      const float dt = t[i] - t[i - 1];
+      if (dt >= eps2) v -= gp[i - 1] * p[i - 1] / dt;
+    }
+    gt[i] = v;
+  }
+  __syncthreads();
+  if (g < nrays) {
+    for (int i = l; i <= np; i += RSP_LPR) g_sdist_prev[ray * (np + 1) + i] = gt[i];
+    for (int i = l; i < np; i += RSP_LPR) g_w_prev[ray * np + i] = gp[i] / fmaxf(eps2, t[i + 1] - t[i]);
+  }
+}
+
+extern "C" int mnr_resample_level_bwd(const mnr_resample_cfg* cfg, int64_t B, const float* sdist_prev, const float* w_prev,
+                                      const float* u_base, const float* jitter, const float* g_sdist, float* g_sdist_prev,
+                                      float* g_w_prev, void* stream) {
+  MNR_CHECK_ARG(cfg && B > 0 && sdist_prev && w_prev && u_base && g_sdist && g_sdist_prev && g_w_prev,
+                "mnr_resample_level_bwd: null argument");
+  MNR_CHECK_ARG(cfg->n_samples > 1, "num_samples must be > 1, is %d.", cfg->n_samples);
+  MNR_CHECK_ARG(cfg->n_prev >= 1 && cfg->n_prev <= 1024 && cfg->n_samples <= 1024,
+                "mnr_resample_level_bwd: n_prev=%d / n_samples=%d out of range", cfg->n_prev, cfg->n_samples);
+  const RspBLay lay = rspb_layout(cfg->n_prev, cfg->n_samples);
+  const size_t lds_bytes = (size_t)lay.per_ray * RSP_RPW * 4;
+  MNR_CHECK_ARG(lds_bytes <= 160 * 1024, "mnr_resample_level_bwd: step function too long for LDS");
+  static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
+  if (mnr_attr_needed(&attr_set)) {
+    (void)hipFuncSetAttribute((const void*)resample_level_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  hipLaunchKernelGGL(resample_level_bwd_kernel, dim3(mnr_cdiv(B, RSP_RPW)), dim3(RS_THREADS), lds_bytes, (hipStream_t)stream,
+                     *cfg, B, lay, sdist_prev, w_prev, u_base, jitter, g_sdist, g_sdist_prev, g_w_prev);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}

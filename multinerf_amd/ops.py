@@ -158,6 +158,32 @@ def resample_level(sdist_prev, w_prev, u_base, jitter, near, far, *, n_samples, 
   return (sdist, tdist, idx) if want_idx else (sdist, tdist)
 
 
+def resample_level_bwd(sdist_prev, w_prev, u_base, jitter, g_sdist, *, n_samples, use_dilation, dilation, domain, anneal,
+                       resample_padding, single_jitter, max_jitter, raydist_fn, g_sdist_prev=None, g_w_prev=None):
+  """VJP of `resample_level` w.r.t. (sdist_prev, w_prev) given g_sdist = d loss / d sdist (Model.stop_level_grad = False)."""
+  for t, nm in ((sdist_prev, 'sdist_prev'), (w_prev, 'w_prev'), (u_base, 'u_base'), (g_sdist, 'g_sdist')):
+    _chk(t, f32, nm)
+  _chk(jitter, f32, 'jitter', allow_none=True)
+  B, n_prev = w_prev.shape
+  assert sdist_prev.shape == (B, n_prev + 1) and u_base.numel() == n_samples and g_sdist.shape == (B, n_samples + 1)
+  if jitter is not None:
+    assert jitter.numel() == (B if single_jitter else B * n_samples)
+  cfg = L.ResampleCfg(n_prev, n_samples, int(use_dilation), float(dilation), float(domain[0]),
+                      float(domain[1]), float(anneal), float(resample_padding), int(single_jitter),
+                      float(max_jitter), L.RAYDIST[raydist_fn])
+  dev = w_prev.device
+  if g_sdist_prev is None:
+    g_sdist_prev = torch.empty((B, n_prev + 1), dtype=f32, device=dev)
+  if g_w_prev is None:
+    g_w_prev = torch.empty((B, n_prev), dtype=f32, device=dev)
+  _chk(g_sdist_prev, f32, 'g_sdist_prev')
+  _chk(g_w_prev, f32, 'g_w_prev')
+  assert g_sdist_prev.shape == (B, n_prev + 1) and g_w_prev.shape == (B, n_prev)
+  L.check(lib().mnr_resample_level_bwd(C.byref(cfg), B, _ptr(sdist_prev), _ptr(w_prev), _ptr(u_base), _ptr(jitter),
+                                       _ptr(g_sdist), _ptr(g_sdist_prev), _ptr(g_w_prev), _stream()))
+  return g_sdist_prev, g_w_prev
+
+
 def sorted_interp(u, cw, t):
   for x, nm in ((u, 'u'), (cw, 'cw'), (t, 't')):
     _chk(x, f32, nm)

@@ -190,8 +190,14 @@ def resample_logits(sdist, weights, anneal, resample_padding, differentiable=Fal
   own log in float32 (math.klog: the kernel's, bit for bit).  `differentiable` (Model.stop_level_grad = False, models.py:198-201):
   torch's log on the weights as they are, so that autograd reaches the previous level."""
   if differentiable:
-    w = weights + resample_padding
-    return torch.where(sdist[..., 1:] > sdist[..., :-1], anneal * torch.log(w), torch.full_like(w, -float('inf')))
+    # (closed bins are constants: their weight is replaced by 1 INSIDE the log so that autograd's 0 * d log(0) is 0, not NaN.
+    # A dilated histogram has such bins whenever two fence-posts are clipped to the same domain end, their weight is p * 0 = 0,
+    # and with resample_padding = 0 the reference's own autodiff yields 0 * inf = NaN there, which its train_step then zeroes
+    # with the rest of the gradient (train_utils.py:326-328); the complex-step golden through the reference's code, like this
+    # form and like the HIP kernel, gives the derivative of the function that is actually evaluated.)
+    open_ = sdist[..., 1:] > sdist[..., :-1]
+    w = torch.where(open_, weights + resample_padding, torch.ones_like(weights))
+    return torch.where(open_, anneal * torch.log(w), torch.full_like(w, -float('inf')))
   w = weights.detach() + resample_padding
   lg = rmath.klog(w) if (w.dtype == torch.float32 and _ORDER == 'kernel') else torch.log(w)
   return torch.where(sdist[..., 1:] > sdist[..., :-1], anneal * lg, torch.full_like(w, -float('inf')))
