@@ -137,6 +137,16 @@ int mnr_cast_rays_ipe_tangent(const mnr_ipe_cfg* cfg, int64_t B, int n, const fl
                               const float* origins, const float* directions, const float* radii,
                               const float* basis, uint16_t* feat_out, int ld_feat, void* stream);
 
+/* VJP of mnr_cast_rays_ipe w.r.t. the interval ends (Model.stop_level_grad = False, models.py:198-201: render.cast_rays
+ * render.py:103-127 incl. the conical-frustum / cylinder moments :44-100 and lift_gaussian :21-41, coord.track_linearize(
+ * contract) coord.py:21-60 with the contraction's second derivative, lift_and_diagonalize :129-133, integrated_pos_enc
+ * :102-126).  g_feat_a (and optionally g_feat_b, summed) bf16 [B*n, ld_feat] = d loss / d features;
+ * outputs g_t0, g_t1 fp32 [B*n] = d loss / d (tdist[ray, j], tdist[ray, j+1]) of sample (ray, j). */
+int mnr_cast_rays_ipe_bwd(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist,
+                          const float* origins, const float* directions, const float* radii,
+                          const float* basis, const uint16_t* g_feat_a, const uint16_t* g_feat_b, int ld_feat,
+                          float* g_t0, float* g_t1, void* stream);
+
 /* coord.pos_enc(viewdirs, 0, deg_view, append_identity=True) per ray, written
  * (bf16) into columns [col0, col0+3+6*deg_view) of every one of the ray's n
  * rows of `dst` [B*n, ld]; columns up to col_end are zero-filled
@@ -435,8 +445,31 @@ typedef struct {
   /* loss on the weights: 0 none; 1 interlevel, this level = envelope of (t_ref [B,n_ref+1], w_ref [B,n_ref]);
    * 2 distortion on this level's own histogram.  sdist [B,n+1]: this level's normalised distances.  *wloss_stat += loss */
   int wloss_mode; float wloss_mult; const float* sdist; int n_ref; const float* t_ref; const float* w_ref; float* wloss_stat;
+  /* optional output [B,n] fp32: d loss / d (sigma_i * delta_i), the optical-depth increments of render.py:144-145 -- what
+   * Model.stop_level_grad = False needs to carry the compositing's gradient on to the sample distances (mnr_sdist_bwd) */
+  float* g_x;
 } mnr_level_bwd_args;
 int mnr_level_bwd(const mnr_level_bwd_args* args, void* stream);
+
+/* Model.stop_level_grad = False (models.py:56,198-201): d loss / d sdist [B,n+1] of one level, gathered per fence-post from
+ *   g_x [B,n] (mnr_level_bwd: the optical-depth increments sigma_i * (t_{i+1} - t_i) * |d|, render.py:144-145; needs raw_density
+ *     [B,n] with density_noise / density_noise_std / density_bias / density_act as in mnr_composite_cfg, and dirs [B,3]),
+ *   g_t0, g_t1 [B*n] (mnr_cast_rays_ipe_bwd: the Gaussians' dependence on the interval ends, render.py:103-127),
+ *     both through s_to_t' (coord.py:96-98; raydist_fn, near, far [B], sdist [B,n+1]),
+ *   the distortion loss's own dependence on sdist (stepfun.py:266-276; distortion_mult != 0: weights [B,n], mean over B_valid rays),
+ *   g_sdist_in [B,n+1]: what the NEXT level's resampling sends back (mnr_resample_level_bwd).
+ * Every input group is optional (NULL / 0).  The interlevel loss is piecewise constant in sdist (stepfun.py:64-77). */
+typedef struct {
+  int64_t B, B_valid; int n;
+  const float* sdist; const float* near; const float* far; int raydist_fn;
+  const float* g_x; const float* raw_density; const float* density_noise; float density_noise_std; float density_bias;
+  int density_act; const float* dirs;
+  const float* g_t0; const float* g_t1;
+  float distortion_mult; const float* weights;
+  const float* g_sdist_in;
+  float* g_sdist;
+} mnr_sdist_bwd_args;
+int mnr_sdist_bwd(const mnr_sdist_bwd_args* args, void* stream);
 /* A/B switch: 1 (default) = four lanes per ray where a wave's 16 rays fit LDS, 0 = the lane-per-ray kernel everywhere.
  * Sums are associated differently in the two; both are held to the oracle by the same tolerances. */
 int mnr_level_bwd_set_quad(int on);

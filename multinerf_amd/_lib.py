@@ -125,7 +125,16 @@ class LevelBwdArgs(C.Structure):
               ('data_loss_type', C.c_int), ('charb_padding', C.c_float), ('data_loss_mult', C.c_float),
               ('rgb_out', vp), ('gt', vp), ('lossmult', vp), ('lm_c', C.c_int), ('denom', vp), ('data_stats', vp),
               ('wloss_mode', C.c_int), ('wloss_mult', C.c_float), ('sdist', vp), ('n_ref', C.c_int), ('t_ref', vp),
-              ('w_ref', vp), ('wloss_stat', vp)]
+              ('w_ref', vp), ('wloss_stat', vp), ('g_x', vp)]
+
+
+class SdistBwdArgs(C.Structure):
+  _fields_ = [('B', C.c_int64), ('B_valid', C.c_int64), ('n', C.c_int),
+              ('sdist', vp), ('near', vp), ('far', vp), ('raydist_fn', C.c_int),
+              ('g_x', vp), ('raw_density', vp), ('density_noise', vp), ('density_noise_std', C.c_float),
+              ('density_bias', C.c_float), ('density_act', C.c_int), ('dirs', vp),
+              ('g_t0', vp), ('g_t1', vp), ('distortion_mult', C.c_float), ('weights', vp),
+              ('g_sdist_in', vp), ('g_sdist', vp)]
 
 
 class IdeTables(C.Structure):
@@ -149,6 +158,8 @@ _PROTOS = {
     'mnr_cast_rays_ipe': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp], i32),
     'mnr_cast_rays_ipe_f32': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_cast_rays_ipe_tangent': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, i32, vp], i32),
+    'mnr_cast_rays_ipe_bwd': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp], i32),
+    'mnr_sdist_bwd': ([C.POINTER(SdistBwdArgs), vp], i32),
     'mnr_viewdir_enc_fill': ([i64, i32, vp, i32, vp, i32, i32, i32, vp], i32),
     'mnr_pixels_to_rays': ([i64, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp], i32),
     'mnr_glo_fill': ([i64, i32, i32, vp, vp, i32, vp, i32, i32, vp], i32),

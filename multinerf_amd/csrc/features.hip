@@ -348,3 +348,260 @@ extern "C" int mnr_glo_bwd(int64_t B, int n, int G, const float* g_a, const floa
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// VJP of cast_rays_ipe_kernel with respect to the interval ends (Model.stop_level_grad = False, models.py:198-201: the sample
+// distances then carry gradient, and the features are a function of them through render.cast_rays render.py:103-127,
+// coord.track_linearize(contract) coord.py:21-60, lift_and_diagonalize :129-133 and integrated_pos_enc :102-126).
+//
+// Input: g_feat [M, ld] bf16 = d loss / d features (the dX GEMM of trunk layer 0, plus that of the skip layer's feature
+// segment in g_feat_b).  Output: g_t0 [M], g_t1 [M] = d loss / d (t0, t1) of every sample.
+//
+// Reverse mode down to the per-sample Gaussian, forward mode below it:
+//   phase 1: one thread per sample: the Gaussian (fe_gaussian: the forward pass's own code)
+//   phase 2: one thread per (sample, basis direction k): the features' sin / cos / attenuation once more, and
+//            g_lm[k] = sum_l 2^l (g_sin att cos - g_cos att sin),  g_lv[k] = -1/2 sum_l 4^l (g_sin att sin + g_cos att cos)
+//   phase 3: one thread per sample: g_mean = sum_k g_lm[k] p_k, G = sum_k g_lv[k] p_k p_k^T (9 numbers), then the Gaussian
+//            again on DUAL numbers in (t0, t1) -- the conical-frustum moments, the lift and the contraction with its Jacobian
+//            are differentiated by carrying (value, d/dt0, d/dt1) through the same closed forms (the contraction's second
+//            derivative never has to be written down) -- and g_t = g_mean . d mean/dt + <G, d cov/dt>.
+// The features reach the MLP rounded to bf16; the rounding is treated as the identity (straight through), as autodiff does.
+
+struct FeD2 {
+  float v, a, b;           // value, d/dt0, d/dt1
+};
+__device__ __forceinline__ FeD2 fe_d2(float v) { return FeD2{v, 0.0f, 0.0f}; }
+__device__ __forceinline__ FeD2 operator+(FeD2 x, FeD2 y) { return FeD2{x.v + y.v, x.a + y.a, x.b + y.b}; }
+__device__ __forceinline__ FeD2 operator-(FeD2 x, FeD2 y) { return FeD2{x.v - y.v, x.a - y.a, x.b - y.b}; }
+__device__ __forceinline__ FeD2 operator*(FeD2 x, FeD2 y) { return FeD2{x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b}; }
+__device__ __forceinline__ FeD2 operator*(float s, FeD2 x) { return FeD2{s * x.v, s * x.a, s * x.b}; }
+__device__ __forceinline__ FeD2 operator*(FeD2 x, float s) { return FeD2{s * x.v, s * x.a, s * x.b}; }
+__device__ __forceinline__ FeD2 operator+(FeD2 x, float s) { return FeD2{x.v + s, x.a, x.b}; }
+__device__ __forceinline__ FeD2 operator+(float s, FeD2 x) { return FeD2{x.v + s, x.a, x.b}; }
+__device__ __forceinline__ FeD2 operator-(FeD2 x, float s) { return FeD2{x.v - s, x.a, x.b}; }
+__device__ __forceinline__ FeD2 operator-(float s, FeD2 x) { return FeD2{s - x.v, -x.a, -x.b}; }
+__device__ __forceinline__ FeD2 operator/(FeD2 x, FeD2 y) {
+  const float q = x.v / y.v;
+  return FeD2{q, (x.a - q * y.a) / y.v, (x.b - q * y.b) / y.v};
+}
+__device__ __forceinline__ FeD2 operator/(FeD2 x, float s) { return FeD2{x.v / s, x.a / s, x.b / s}; }
+__device__ __forceinline__ FeD2 fe_sqrt(FeD2 x) {
+  const float r = sqrtf(x.v);
+  return FeD2{r, 0.5f * x.a / r, 0.5f * x.b / r};
+}
+__device__ __forceinline__ FeD2 fe_max_const(float lo, FeD2 x) { return x.v >= lo ? x : fe_d2(lo); }   // max(lo, x)
+
+// fe_gaussian on dual numbers: mean[3], cov[6] (xx, xy, xz, yy, yz, zz) as functions of (t0, t1).
+__device__ __forceinline__ void fe_gaussian_dual(const mnr_ipe_cfg& c, float t0v, float t1v, const float* o, const float* d,
+                                                 float radius, FeD2* mean, FeD2* cov) {
+  const FeD2 t0 = {t0v, 1.0f, 0.0f}, t1 = {t1v, 0.0f, 1.0f};
+  FeD2 t_mean, t_var, r_var;
+  if (c.ray_shape == 0) {
+    const FeD2 mu = (t0 + t1) / 2.0f;
+    const FeD2 hw = (t1 - t0) / 2.0f;
+    const FeD2 denom = fe_max_const(MNR_F32_EPS, 3.0f * (mu * mu) + hw * hw);
+    const FeD2 hw2 = hw * hw, hw4 = hw2 * hw2;
+    t_mean = mu + (2.0f * (mu * hw2)) / denom;
+    t_var = hw2 / 3.0f - ((4.0f / 15.0f) * (hw4 * (12.0f * (mu * mu) - hw2))) / (denom * denom);
+    r_var = (mu * mu) / 4.0f + (5.0f / 12.0f) * hw2 - ((4.0f / 15.0f) * hw4) / denom;
+    r_var = r_var * (radius * radius);
+  } else {
+    t_mean = (t0 + t1) / 2.0f;
+    r_var = fe_d2(radius * radius / 4.0f);
+    t_var = ((t1 - t0) * (t1 - t0)) / 12.0f;
+  }
+  const float dmag = fmaxf(1e-10f, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) mean[i] = o[i] + d[i] * t_mean;
+  if (c.disable_integration) {
+    t_var = fe_d2(0.0f);
+    r_var = fe_d2(0.0f);
+  }
+  const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+  for (int e = 0; e < 6; ++e) {
+    const int i = ii[e], j = jj[e];
+    const float dd = d[i] * d[j];
+    const float null_outer = (i == j ? 1.0f : 0.0f) - d[i] * (d[j] / dmag);
+    cov[e] = t_var * dd + r_var * null_outer;
+  }
+  if (c.warp_contract) {
+    // (the structured form of fe_gaussian: J cov J^T = ku u u^T + r_var (s^2 I + j2x x x^T), mean' = s x)
+    FeD2 m = mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2];
+    m = fe_max_const(MNR_F32_EPS, m);
+    if (!(m.v <= 1.0f)) {
+      const FeD2 sq = fe_sqrt(m);
+      const FeD2 s = (2.0f * sq - 1.0f) / m;
+      const FeD2 cc = (2.0f * (1.0f - sq)) / (m * m);
+      const float oo = o[0] * o[0] + o[1] * o[1] + o[2] * o[2];
+      const float od = o[0] * d[0] + o[1] * d[1] + o[2] * d[2];
+      const FeD2 xd = mean[0] * d[0] + mean[1] * d[1] + mean[2] * d[2];
+      const FeD2 brk = (m - (2.0f * (1.0f - sq)) * (oo + t_mean * od)) / (m * m);
+      FeD2 u[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) u[i] = brk * d[i] + (cc * xd) * o[i];
+      const FeD2 j2x = (2.0f * cc) / sq;
+      const FeD2 ku = t_var - r_var / dmag;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const int i = ii[e], j = jj[e];
+        FeD2 inner = j2x * (mean[i] * mean[j]);
+        if (i == j) inner = inner + s * s;
+        cov[e] = ku * (u[i] * u[j]) + r_var * inner;
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) mean[i] = s * mean[i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_bwd_kernel(
+    mnr_ipe_cfg c, int64_t total, int n, int spb, int pitch, const float* __restrict__ tdist, const float* __restrict__ origins,
+    const float* __restrict__ directions, const float* __restrict__ radii, const float* __restrict__ basis,
+    const bf16* __restrict__ g_feat_a, const bf16* __restrict__ g_feat_b, int ld_feat, float* __restrict__ g_t0,
+    float* __restrict__ g_t1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int K = c.basis_k;
+  const int L = c.max_deg - c.min_deg;
+  const int nfeat = 2 * K * L;
+  // LDS: samples [spb] FeSample | basis [K*3] | g rows [spb][pitch] f32 | per-direction partials [spb][K][2] f32
+  FeSample* gs = (FeSample*)smem;
+  float* bs = (float*)(gs + spb);
+  float* rows = bs + ((K * 3 + 3) & ~3);
+  float* part = rows + (size_t)spb * pitch;
+  const int64_t s0 = (int64_t)blockIdx.x * spb;
+  const int ns = (int)min((int64_t)spb, total - s0);
+  for (int i = threadIdx.x; i < K * 3; i += FE_THREADS) bs[i] = basis[i];
+  if (threadIdx.x < ns) {
+    const int64_t s = s0 + threadIdx.x;
+    const int64_t ray = s / n;
+    const int j = (int)(s % n);
+    const float t0 = tdist[ray * (n + 1) + j], t1 = tdist[ray * (n + 1) + j + 1];
+    float o[3], d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      o[i] = origins[ray * 3 + i];
+      d[i] = directions[ray * 3 + i];
+    }
+    FeSample g;
+    fe_gaussian(c, t0, t1, o, d, radii[ray], g);
+    gs[threadIdx.x] = g;
+  }
+  // the block's gradient rows: 16-byte loads (8 bf16), summed over the two sources, kept as fp32
+  const int cpr = ld_feat >> 3;
+  for (int ch = threadIdx.x; ch < ns * cpr; ch += FE_THREADS) {
+    const int r = ch / cpr, c0 = (ch - r * cpr) << 3;
+    const bf16x8 va = *(const bf16x8*)(g_feat_a + (size_t)(s0 + r) * ld_feat + c0);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)va[i];
+    if (g_feat_b) {
+      const bf16x8 vb = *(const bf16x8*)(g_feat_b + (size_t)(s0 + r) * ld_feat + c0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)vb[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (c0 + i < nfeat) rows[(size_t)r * pitch + c0 + i] = v[i];
+  }
+  __syncthreads();
+  const float inv_k = 1.0f / (float)K;
+  for (int pair = threadIdx.x; pair < ns * K; pair += FE_THREADS) {
+    const int si = (int)(((float)pair + 0.5f) * inv_k);
+    const int k = pair - si * K;
+    const FeSample g = gs[si];
+    const float px = bs[k * 3 + 0], py = bs[k * 3 + 1], pz = bs[k * 3 + 2];
+    const float lm = g.mean[0] * px + g.mean[1] * py + g.mean[2] * pz;
+    const float cx = g.cov[0] * px + g.cov[1] * py + g.cov[2] * pz;
+    const float cy = g.cov[1] * px + g.cov[3] * py + g.cov[4] * pz;
+    const float cz = g.cov[2] * px + g.cov[4] * py + g.cov[5] * pz;
+    const float lv = px * cx + py * cy + pz * cz;
+    const float vscale = -0.5f * 1.44269504088896340736f * lv;
+    const float* grow = rows + (size_t)si * pitch + k;
+    const int half = K * L;
+    float sc = ldexpf(1.0f, c.min_deg);
+    float sn = 0.0f, cs = 1.0f, att = 1.0f;
+    float g_lm = 0.0f, g_lv = 0.0f;
+    for (int l = 0; l < L; ++l) {
+      if ((l & 3) == 0) {
+        fe_sincos_wrapped(fe_wrap_100pi(lm * sc), &sn, &cs);
+        att = exp2f(vscale * sc * sc);
+      }
+      const float fs = att * sn, fc = att * cs;
+      const float gsn = grow[l * K], gcs = grow[half + l * K];
+      g_lm += sc * (gsn * fc - gcs * fs);
+      g_lv += -0.5f * sc * sc * (gsn * fs + gcs * fc);
+      const float s2 = 2.0f * sn * cs;
+      cs = 1.0f - 2.0f * sn * sn;
+      sn = s2;
+      const float a2 = att * att;
+      att = a2 * a2;
+      sc *= 2.0f;
+    }
+    part[(size_t)pair * 2] = g_lm;
+    part[(size_t)pair * 2 + 1] = g_lv;
+  }
+  __syncthreads();
+  if (threadIdx.x < ns) {
+    const int si = threadIdx.x;
+    float gm[3] = {0.0f, 0.0f, 0.0f}, G[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < K; ++k) {
+      const float px = bs[k * 3 + 0], py = bs[k * 3 + 1], pz = bs[k * 3 + 2];
+      const float a = part[(size_t)(si * K + k) * 2], v = part[(size_t)(si * K + k) * 2 + 1];
+      gm[0] += a * px; gm[1] += a * py; gm[2] += a * pz;
+      G[0] += v * px * px; G[1] += v * px * py; G[2] += v * px * pz;
+      G[3] += v * py * py; G[4] += v * py * pz; G[5] += v * pz * pz;
+    }
+    const int64_t s = s0 + si;
+    const int64_t ray = s / n;
+    const int j = (int)(s % n);
+    const float t0 = tdist[ray * (n + 1) + j], t1 = tdist[ray * (n + 1) + j + 1];
+    float o[3], d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      o[i] = origins[ray * 3 + i];
+      d[i] = directions[ray * 3 + i];
+    }
+    FeD2 mean[3], cov[6];
+    fe_gaussian_dual(c, t0, t1, o, d, radii[ray], mean, cov);
+    const float wgt[6] = {1.0f, 2.0f, 2.0f, 1.0f, 2.0f, 1.0f};      // the symmetric matrix's off-diagonal entries count twice
+    float ga = 0.0f, gb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      ga += gm[i] * mean[i].a;
+      gb += gm[i] * mean[i].b;
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      ga += wgt[e] * G[e] * cov[e].a;
+      gb += wgt[e] * G[e] * cov[e].b;
+    }
+    g_t0[s] = ga;
+    g_t1[s] = gb;
+  }
+}
+
+extern "C" int mnr_cast_rays_ipe_bwd(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist, const float* origins,
+                                     const float* directions, const float* radii, const float* basis, const uint16_t* g_feat_a,
+                                     const uint16_t* g_feat_b, int ld_feat, float* g_t0, float* g_t1, void* stream) {
+  MNR_CHECK_ARG(cfg && B > 0 && n > 0 && tdist && origins && directions && radii && basis && g_feat_a && g_t0 && g_t1,
+                "mnr_cast_rays_ipe_bwd: null argument");
+  MNR_CHECK_ARG(cfg->ray_shape == 0 || cfg->ray_shape == 1, "ray_shape must be 'cone' or 'cylinder'");
+  const int K = cfg->basis_k, L = cfg->max_deg - cfg->min_deg;
+  MNR_CHECK_ARG(K >= 1 && K <= 128 && L >= 1 && L <= 32, "mnr_cast_rays_ipe_bwd: basis_k=%d / degrees=%d out of range", K, L);
+  const int nfeat = 2 * K * L;
+  MNR_CHECK_ARG(ld_feat >= nfeat && ld_feat % 8 == 0 && ((uintptr_t)g_feat_a % 16) == 0 && ((uintptr_t)g_feat_b % 16) == 0,
+                "mnr_cast_rays_ipe_bwd: ld_feat=%d must be >= %d and a multiple of 8, rows 16-byte aligned", ld_feat, nfeat);
+  const int pitch = nfeat | 1;                                  // floats; odd: the (sample, direction) threads' column reads spread over the banks
+  int spb = (int)((40 * 1024) / ((size_t)pitch * 4 + (size_t)K * 8));
+  if (spb > 64) spb = 64;
+  spb &= ~3;
+  MNR_CHECK_ARG(spb >= 4, "mnr_cast_rays_ipe_bwd: feature row too long");
+  const size_t lds = (size_t)spb * sizeof(FeSample) + (size_t)((K * 3 + 3) & ~3) * 4 + (size_t)spb * pitch * 4 + (size_t)spb * K * 8;
+  const int64_t total = B * n;
+  hipLaunchKernelGGL(cast_rays_ipe_bwd_kernel, dim3(mnr_cdiv(total, spb)), dim3(FE_THREADS), lds, (hipStream_t)stream, *cfg, total,
+                     n, spb, pitch, tdist, origins, directions, radii, basis, (const bf16*)g_feat_a, (const bf16*)g_feat_b, ld_feat,
+                     g_t0, g_t1);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}

@@ -350,6 +350,7 @@ __global__ __launch_bounds__(CP_THREADS) void level_bwd_kernel(mnr_level_bwd_arg
       if (opaque_last) gx = 0.0f;           // x = +inf is a constant
       suffix += ghat * w;
       l_den[i * S + r] = gx * delta * cp_act_grad(c.density_act, raw, sigma);
+      l_gw[i * S + r] = gx;                 // d loss / d (sigma_i delta_i), for a.g_x (d loss / d w_i is consumed)
       if (i > 0) {
         const float sp = cp_act(c.density_act, l_den[(i - 1) * S + r] + c.density_bias);
         run -= sp * (l_t[i * S + r] - l_t[(i - 1) * S + r]) * dnorm;
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(CP_THREADS) void level_bwd_kernel(mnr_level_bwd_arg
     }
   }
   if (c.has_rgb && a.g_raw_rgb) cp_store_rows(l_rgb, a.g_raw_rgb + ray0 * n * 3, rows, 3 * n, S);
+  if (a.g_x) cp_store_rows(l_gw, a.g_x + ray0 * n, rows, n, S);
 }
 
 // ---------------------------------------------------------------------------
@@ -688,6 +690,7 @@ __global__ __launch_bounds__(CP_THREADS) void level_bwd_quad_kernel(mnr_level_bw
         float gx = ghat * l_tn[i] - after;
         if (c.opaque_background && i == n - 1) gx = 0.0f;      // x = +inf is a constant
         l_den[i] = gx * l_dg[i];
+        l_gh[i] = gx;                              // d loss / d (sigma_i delta_i), for a.g_x (g^_i is consumed)
       }
     }
   }
@@ -729,6 +732,7 @@ __global__ __launch_bounds__(CP_THREADS) void level_bwd_quad_kernel(mnr_level_bw
     }
   }
   if (c.has_rgb && a.g_raw_rgb) store_rows(L.rgb, a.g_raw_rgb + ray0 * n * 3, 3 * n);
+  if (a.g_x) store_rows(L.scr + 2 * n, a.g_x + ray0 * n, n);
 }
 
 // The forward compositing on four lanes per ray (the same quad helpers and LDS plan as level_bwd_quad_kernel): lane q owns the
@@ -1031,6 +1035,103 @@ extern "C" int mnr_exposure_scale_bwd(int64_t B_valid, const float* exposure_val
   MNR_CHECK_ARG(B_valid > 0 && exposure_values && exposure_idx && g_scale && g_offsets, "mnr_exposure_scale_bwd: bad arguments");
   hipLaunchKernelGGL(exposure_scale_bwd_kernel, dim3(mnr_cdiv(B_valid, 256)), dim3(256), 0, (hipStream_t)stream,
                      B_valid, exposure_values, exposure_idx, g_scale, g_offsets);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Model.stop_level_grad = False (models.py:198-201): everything a level's loss says about its own sample distances,
+// gathered per fence-post into d loss / d sdist [B, n+1]:
+//   * the optical-depth increments x_i = sigma_i * (t_{i+1} - t_i) * |d| of render.py:144-145 (g_x from mnr_level_bwd),
+//   * the Gaussians' dependence on the interval ends (g_t0, g_t1 per sample from mnr_cast_rays_ipe_bwd),
+//     both through s_to_t (coord.py:96-98),
+//   * the distortion loss's own dependence on sdist (stepfun.py:266-276; the final level),
+//   * and the gradient that arrives from the NEXT level's resampling (mnr_resample_level_bwd's g_sdist_prev).
+// The interlevel loss is piecewise constant in the distances (stepfun.py:64-77: searchsorted indices) and contributes nothing.
+// One thread per fence-post.
+
+__device__ __forceinline__ float sd_dtds(int fn, float s, float near, float far) {
+  // d/ds of fn_inv(s * fn(far) + (1 - s) * fn(near)), coord.py:63-99
+  float fn_near, fn_far;
+  switch (fn) {
+    case MNR_RAYDIST_RECIPROCAL: fn_near = 1.0f / near; fn_far = 1.0f / far; break;
+    case MNR_RAYDIST_PIECEWISE:
+      fn_near = near < 1.0f ? 0.5f * near : 1.0f - 0.5f / near;
+      fn_far = far < 1.0f ? 0.5f * far : 1.0f - 0.5f / far;
+      break;
+    case MNR_RAYDIST_LOG: fn_near = logf(near); fn_far = logf(far); break;
+    case MNR_RAYDIST_EXP: fn_near = expf(near); fn_far = expf(far); break;
+    case MNR_RAYDIST_SQRT: fn_near = sqrtf(near); fn_far = sqrtf(far); break;
+    case MNR_RAYDIST_SQUARE: fn_near = near * near; fn_far = far * far; break;
+    default: fn_near = near; fn_far = far; break;
+  }
+  const float x = s * fn_far + (1.0f - s) * fn_near;
+  const float dx = fn_far - fn_near;
+  switch (fn) {
+    case MNR_RAYDIST_RECIPROCAL: return -dx / (x * x);
+    case MNR_RAYDIST_PIECEWISE: return x < 0.5f ? 2.0f * dx : 0.5f * dx / ((1.0f - x) * (1.0f - x));
+    case MNR_RAYDIST_LOG: return expf(x) * dx;
+    case MNR_RAYDIST_EXP: return dx / x;
+    case MNR_RAYDIST_SQRT: return 2.0f * x * dx;
+    case MNR_RAYDIST_SQUARE: return 0.5f * dx / sqrtf(x);
+    default: return dx;
+  }
+}
+
+__global__ __launch_bounds__(256) void sdist_bwd_kernel(mnr_sdist_bwd_args a) {
+  const int n = a.n;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.B * (n + 1)) return;
+  const int64_t ray = e / (n + 1);
+  const int k = (int)(e - ray * (n + 1));
+  float gt = 0.0f;
+  if (a.g_x) {
+    const float dx = a.dirs[ray * 3], dy = a.dirs[ray * 3 + 1], dz = a.dirs[ray * 3 + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    auto sigma = [&](int i) {
+      float raw = a.raw_density[ray * n + i] + a.density_bias;
+      if (a.density_noise && a.density_noise_std > 0.0f) raw += a.density_noise_std * a.density_noise[ray * n + i];
+      return cp_act(a.density_act, raw);
+    };
+    if (k >= 1) gt += a.g_x[ray * n + k - 1] * sigma(k - 1) * dnorm;
+    if (k < n) gt -= a.g_x[ray * n + k] * sigma(k) * dnorm;
+  }
+  if (a.g_t0) {
+    if (k < n) gt += a.g_t0[ray * n + k];
+    if (k >= 1) gt += a.g_t1[ray * n + k - 1];
+  }
+  float gs = gt * sd_dtds(a.raydist_fn, a.sdist[e], a.near[ray], a.far[ray]);
+  if (a.distortion_mult != 0.0f && ray < a.B_valid) {
+    // loss = mult / B_valid * [ sum_ij w_i w_j |u_i - u_j| + 1/3 sum_i w_i^2 (s_{i+1} - s_i) ],  u_i = (s_i + s_{i+1}) / 2
+    const float* s = a.sdist + ray * (n + 1);
+    const float* w = a.weights + ray * n;
+    float acc = 0.0f;
+    for (int side = 0; side < 2; ++side) {
+      const int i = k - 1 + side;                  // the two intervals this fence-post bounds
+      if (i < 0 || i >= n) continue;
+      const float ui = (s[i + 1] + s[i]) / 2.0f;
+      float sg = 0.0f;
+      for (int j = 0; j < n; ++j) {
+        const float d = ui - (s[j + 1] + s[j]) / 2.0f;
+        sg += d > 0.0f ? w[j] : (d < 0.0f ? -w[j] : 0.0f);
+      }
+      acc += 0.5f * (2.0f * w[i] * sg);            // d loss / d u_i, half of it to each end
+      acc += (side == 0 ? 1.0f : -1.0f) * w[i] * w[i] / 3.0f;
+    }
+    gs += a.distortion_mult / (float)a.B_valid * acc;
+  }
+  if (a.g_sdist_in) gs += a.g_sdist_in[e];
+  a.g_sdist[e] = gs;
+}
+
+extern "C" int mnr_sdist_bwd(const mnr_sdist_bwd_args* a, void* stream) {
+  MNR_CHECK_ARG(a && a->B > 0 && a->n > 0 && a->sdist && a->near && a->far && a->g_sdist, "mnr_sdist_bwd: null argument");
+  MNR_CHECK_ARG(!a->g_x || (a->raw_density && a->dirs), "mnr_sdist_bwd: g_x needs raw_density and dirs");
+  MNR_CHECK_ARG((a->g_t0 == nullptr) == (a->g_t1 == nullptr), "mnr_sdist_bwd: g_t0 and g_t1 come together");
+  MNR_CHECK_ARG(a->distortion_mult == 0.0f || a->weights, "mnr_sdist_bwd: the distortion term needs the weights");
+  MNR_CHECK_ARG(a->raydist_fn >= 0 && a->raydist_fn <= MNR_RAYDIST_SQUARE, "mnr_sdist_bwd: bad raydist_fn");
+  const int64_t total = a->B * (a->n + 1);
+  hipLaunchKernelGGL(sdist_bwd_kernel, dim3(mnr_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, *a);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }

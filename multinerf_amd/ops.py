@@ -275,6 +275,61 @@ def cast_rays_ipe_tangent(tdist, origins, directions, radii, basis, *, ray_shape
   return out
 
 
+def cast_rays_ipe_bwd(tdist, origins, directions, radii, basis, g_feat_a, g_feat_b=None, *, ray_shape, warp_contract, min_deg,
+                      max_deg, disable_integration=False, g_t0=None, g_t1=None):
+  """VJP of `cast_rays_ipe` w.r.t. the interval ends: g_feat_a (+ g_feat_b) bf16 [B*n, ld] -> (g_t0, g_t1) fp32 [B*n]."""
+  for x, nm in ((tdist, 'tdist'), (origins, 'origins'), (directions, 'directions'), (radii, 'radii'), (basis, 'basis')):
+    _chk(x, f32, nm)
+  _chk(g_feat_a, bf16, 'g_feat_a')
+  _chk(g_feat_b, bf16, 'g_feat_b', allow_none=True)
+  B, n1 = tdist.shape
+  n = n1 - 1
+  ld = g_feat_a.stride(0)
+  assert g_feat_a.shape[0] == B * n and (g_feat_b is None or (g_feat_b.shape[0] == B * n and g_feat_b.stride(0) == ld))
+  cfg = _ipe_cfg(ray_shape, warp_contract, disable_integration, basis, min_deg, max_deg)
+  dev = tdist.device
+  if g_t0 is None:
+    g_t0 = torch.empty((B * n,), dtype=f32, device=dev)
+  if g_t1 is None:
+    g_t1 = torch.empty((B * n,), dtype=f32, device=dev)
+  _chk(g_t0, f32, 'g_t0')
+  _chk(g_t1, f32, 'g_t1')
+  assert g_t0.numel() == B * n and g_t1.numel() == B * n
+  L.check(lib().mnr_cast_rays_ipe_bwd(C.byref(cfg), B, n, _ptr(tdist), _ptr(origins), _ptr(directions), _ptr(radii), _ptr(basis),
+                                      _ptr(g_feat_a), _ptr(g_feat_b), ld, _ptr(g_t0), _ptr(g_t1), _stream()))
+  return g_t0, g_t1
+
+
+def sdist_bwd(sdist, near, far, raydist_fn, *, B_valid=None, g_x=None, raw_density=None, density_noise=None, density_noise_std=0.0,
+              density_bias=0.0, density_act='softplus', dirs=None, g_t0=None, g_t1=None, distortion_mult=0.0, weights=None,
+              g_sdist_in=None, out=None):
+  """d loss / d sdist [B, n+1] of one level (Model.stop_level_grad = False): see mnr_sdist_bwd in include/mnerf.h."""
+  _chk(sdist, f32, 'sdist')
+  B, n1 = sdist.shape
+  n = n1 - 1
+  for x, nm in ((near, 'near'), (far, 'far')):
+    _chk(x, f32, nm)
+  for x, nm in ((g_x, 'g_x'), (raw_density, 'raw_density'), (density_noise, 'density_noise'), (dirs, 'dirs'), (g_t0, 'g_t0'),
+                (g_t1, 'g_t1'), (weights, 'weights'), (g_sdist_in, 'g_sdist_in')):
+    _chk(x, f32, nm, allow_none=True)
+  assert near.numel() == B and far.numel() == B
+  assert g_x is None or (g_x.numel() == B * n and raw_density is not None and raw_density.numel() == B * n and dirs is not None)
+  assert g_sdist_in is None or g_sdist_in.shape == (B, n1)
+  if out is None:
+    out = torch.empty((B, n1), dtype=f32, device=sdist.device)
+  _chk(out, f32, 'out')
+  a = L.SdistBwdArgs()
+  a.B, a.B_valid, a.n = B, (B if B_valid is None else int(B_valid)), n
+  a.sdist, a.near, a.far, a.raydist_fn = _ptr(sdist), _ptr(near), _ptr(far), L.RAYDIST[raydist_fn]
+  a.g_x, a.raw_density, a.density_noise = _ptr(g_x), _ptr(raw_density), _ptr(density_noise)
+  a.density_noise_std, a.density_bias, a.density_act = float(density_noise_std), float(density_bias), L.ACT[density_act]
+  a.dirs, a.g_t0, a.g_t1 = _ptr(dirs), _ptr(g_t0), _ptr(g_t1)
+  a.distortion_mult, a.weights = float(distortion_mult), _ptr(weights)
+  a.g_sdist_in, a.g_sdist = _ptr(g_sdist_in), _ptr(out)
+  L.check(lib().mnr_sdist_bwd(C.byref(a), _stream()))
+  return out
+
+
 def viewdir_enc_fill(viewdirs, n, deg_view, dst, col0, col_end):
   _chk(viewdirs, f32, 'viewdirs')
   _chk(dst, bf16, 'dst')
@@ -623,9 +678,10 @@ def composite_fwd(cfg, raw_density, tdist, dirs, *, raw_rgb=None, density_noise=
 
 def composite_bwd(cfg, raw_density, tdist, dirs, weights, *, raw_rgb=None, density_noise=None, bg=None,
                   exposure_scale=None, g_rgb_out=None, g_weights=None, g_den_bf16=None, ld_bf16=0,
-                  want_f32=True, g_exposure_scale=None, losses=None, g_raw_density_out=None):
+                  want_f32=True, g_exposure_scale=None, losses=None, g_raw_density_out=None, g_x_out=None):
   """Compositing VJP; with `losses` the level's training losses are fused in front of it (mnr_level_bwd):
   g_raw_density_out: optional [B, n] fp32 destination for d loss / d raw_density (else a fresh tensor).
+  g_x_out: optional [B, n] fp32 destination for d loss / d (sigma * delta) (Model.stop_level_grad = False, mnr_sdist_bwd).
   losses = dict(B_valid=..., data=dict(type, charb_padding, mult, rgb_out, gt, lossmult, denom, stats) | None,
                 weights=dict(mode='interlevel'|'distortion', mult, sdist, t_ref, w_ref, stat) | None)."""
   B, n = raw_density.shape
@@ -652,6 +708,10 @@ def composite_bwd(cfg, raw_density, tdist, dirs, weights, *, raw_rgb=None, densi
   a.g_raw_density, a.g_raw_density_bf16, a.ld_bf16 = p(g_raw_density), p(g_den_bf16), ld_bf16
   a.g_raw_rgb, a.g_exposure_scale = p(g_raw_rgb), p(g_exposure_scale)
   a.data_loss_type, a.wloss_mode = -1, 0
+  if g_x_out is not None:
+    _chk(g_x_out, f32, 'g_x_out')
+    assert g_x_out.shape == (B, n) and g_x_out.is_contiguous()
+    a.g_x = p(g_x_out)
   keep = []
   if losses is not None and losses.get('data') is not None:
     d = losses['data']

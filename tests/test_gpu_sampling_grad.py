@@ -106,3 +106,163 @@ def test_resample_level_bwd_is_the_oracles_autograd(B, n_prev, n, use_dil, dil, 
   _rays_close(gs, gs_o, 2e-3, 1e-7, 'g_sdist_prev', max_bad_rays=lim)
   _rays_close(gw, gw_o, 2e-3, 1e-7, 'g_w_prev', max_bad_rays=lim)
   assert torch.isfinite(gs).all() and torch.isfinite(gw).all()
+
+
+# ----------------------------------------------------------------------------- features -> interval ends
+
+
+def _ray_case(B, n, seed, far_samples=False, ndc=False):
+  g = torch.Generator().manual_seed(seed)
+  o = (torch.rand((B, 3), generator=g, dtype=torch.float64) * 2 - 1) * (0.3 if ndc else 1.0)
+  tgt = 0.3 * torch.randn((B, 3), generator=g, dtype=torch.float64)
+  d = tgt - o
+  d = d / d.norm(dim=-1, keepdim=True) * (1.0 + 0.2 * torch.rand((B, 1), generator=g, dtype=torch.float64))
+  radii = (3e-4 + 7e-4 * torch.rand((B, 1), generator=g, dtype=torch.float64)) * (30.0 if ndc else 1.0)
+  c = torch.sort(torch.rand((B, n + 1), generator=g, dtype=torch.float64), dim=-1).values
+  if far_samples:        # reciprocal spacing between 0.2 and 1e3: the contracted region of 360.gin
+    tdist = 1.0 / (c * (1.0 / 1e3) + (1 - c) * (1.0 / 0.2))
+    tdist = torch.flip(tdist, dims=(-1,))
+    tdist = torch.sort(tdist, dim=-1).values
+  else:
+    tdist = (0.0 if ndc else 2.0) + c * (1.0 if ndc else 4.0)
+  return tuple(x.float().double() for x in (o, d, radii, tdist))
+
+
+IPE_CASES = [
+    # (name, ray_shape, contract, basis, min_deg, max_deg, far samples, ndc, disable_integration)
+    ('360', 'cone', True, ('icosahedron', 2), 0, 12, True, False, False),
+    ('360-near', 'cone', True, ('icosahedron', 2), 0, 12, False, False, False),        # samples on both sides of the unit sphere
+    ('blender', 'cone', False, ('octahedron', 1), 0, 16, False, False, False),
+    ('llff_raw', 'cylinder', False, ('octahedron', 1), 0, 16, False, True, False),
+    ('no-integration', 'cone', True, ('icosahedron', 2), 0, 8, True, False, True),
+]
+
+
+@pytest.mark.parametrize('name,ray_shape,contract,basis,min_deg,max_deg,far,ndc,no_int', IPE_CASES)
+def test_cast_rays_ipe_bwd_is_the_oracles_autograd(name, ray_shape, contract, basis, min_deg, max_deg, far, ndc, no_int):
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  from multinerf_amd import geopoly
+  from oracle import coord as ocoord
+  from oracle import render as orender
+  B, n = 24, 16
+  o, d, radii, tdist = _ray_case(B, n, seed=31 + len(name), far_samples=far, ndc=ndc)
+  if name == '360-near':
+    tdist = tdist * 0.5 - 0.6        # t in [0.4, 2.4]: with |o| <= 1.7 the means cross |x| = 1
+    tdist = tdist.float().double()
+  P = torch.as_tensor(geopoly.generate_basis(*basis), dtype=torch.float64)      # [K, 3]
+  K, L = P.shape[0], max_deg - min_deg
+  F = 2 * K * L
+  ld = (F + 127) // 128 * 128
+  gen = torch.Generator().manual_seed(5)
+  gA = torch.randn((B * n, ld), generator=gen).to(torch.bfloat16)
+  gB = torch.randn((B * n, ld), generator=gen).to(torch.bfloat16)
+  # oracle: features(tdist) in float64, loss = <gA + gB, features>
+  t = tdist.clone().requires_grad_(True)
+  means, covs = orender.cast_rays(t, o, d, radii, ray_shape, diag=False)
+  if no_int:
+    covs = torch.zeros_like(covs)
+  if contract:
+    means, covs = ocoord.track_linearize(ocoord.contract, means, covs)
+  lm, lv = ocoord.lift_and_diagonalize(means, covs, P.t())
+  feat = ocoord.integrated_pos_enc(lm, lv, min_deg, max_deg).reshape(B * n, F)
+  gsum = (gA.double() + gB.double())[:, :F]
+  (feat * gsum).sum().backward()
+  want = t.grad
+  f32c = lambda x: dev(x.float().contiguous())
+  g_t0, g_t1 = ops.cast_rays_ipe_bwd(f32c(tdist), f32c(o), f32c(d), f32c(radii.reshape(-1)), f32c(P), dev(gA), dev(gB),
+                                     ray_shape=ray_shape, warp_contract=contract, min_deg=min_deg, max_deg=max_deg,
+                                     disable_integration=no_int)
+  torch.cuda.synchronize()
+  g_t0, g_t1 = g_t0.view(B, n).double().cpu(), g_t1.view(B, n).double().cpu()
+  got = torch.zeros((B, n + 1), dtype=torch.float64)
+  got[:, :n] += g_t0
+  got[:, 1:] += g_t1
+  # fp32 evaluation of sin(mean 2^l): an argument of 2^11 |x| carries 2^11 eps of absolute error, and the gradient adds 504
+  # such terms with random signs: a few 1e-3 of the gradient's scale at degree 12, more at degree 16
+  tol = 2e-3 if max_deg <= 12 else 1.5e-2                                     # (measured 2e-4 / 3e-3)
+  _rays_close(got, want, tol, 1e-6, f'g_tdist [{name}]')
+  # one source only
+  g0, g1 = ops.cast_rays_ipe_bwd(f32c(tdist), f32c(o), f32c(d), f32c(radii.reshape(-1)), f32c(P), dev(gA), None,
+                                 ray_shape=ray_shape, warp_contract=contract, min_deg=min_deg, max_deg=max_deg,
+                                 disable_integration=no_int)
+  t2 = tdist.clone().requires_grad_(True)
+  means, covs = orender.cast_rays(t2, o, d, radii, ray_shape, diag=False)
+  if no_int:
+    covs = torch.zeros_like(covs)
+  if contract:
+    means, covs = ocoord.track_linearize(ocoord.contract, means, covs)
+  lm, lv = ocoord.lift_and_diagonalize(means, covs, P.t())
+  feat = ocoord.integrated_pos_enc(lm, lv, min_deg, max_deg).reshape(B * n, F)
+  (feat * gA.double()[:, :F]).sum().backward()
+  got = torch.zeros((B, n + 1), dtype=torch.float64)
+  got[:, :n] += g0.view(B, n).double().cpu()
+  got[:, 1:] += g1.view(B, n).double().cpu()
+  _rays_close(got, t2.grad, tol, 1e-6, f'g_tdist, one source [{name}]')
+
+
+# ----------------------------------------------------------------------------- compositing / distortion -> sample distances
+
+
+@pytest.mark.parametrize('quad', [1, 0])
+@pytest.mark.parametrize('raydist,opaque,n', [('reciprocal', True, 32), (None, False, 128), ('reciprocal', True, 21), ('piecewise', False, 16)])
+def test_sdist_bwd_with_the_compositing_and_distortion_terms(raydist, opaque, n, quad):
+  """mnr_level_bwd's g_x output + mnr_sdist_bwd against autograd of the oracle's compositing (render.py:130-213) and distortion
+  loss (stepfun.py:266-276) with respect to sdist, through s_to_t."""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  from oracle import coord as ocoord
+  from oracle import render as orender
+  B = 40
+  g = torch.Generator().manual_seed(n)
+  r64 = lambda *s: torch.rand(s, generator=g, dtype=torch.float64).float().double()
+  sdist = torch.sort(r64(B, n + 1), dim=-1).values
+  near = torch.full((B, 1), 0.2 if raydist else 2.0, dtype=torch.float64)
+  far = torch.full((B, 1), 1e3 if raydist == 'reciprocal' else 6.0, dtype=torch.float64)
+  dirs = (torch.randn((B, 3), generator=g, dtype=torch.float64) * 0.7).float().double()
+  raw_den = (torch.randn((B, n), generator=g, dtype=torch.float64) * 2).float().double()
+  raw_rgb = torch.randn((B, n, 3), generator=g, dtype=torch.float64).float().double()
+  g_rgb_out = torch.randn((B, 3), generator=g, dtype=torch.float64).float().double()
+  g_w_up = (0.1 * torch.randn((B, n), generator=g, dtype=torch.float64)).float().double()
+  g_in = torch.randn((B, n + 1), generator=g, dtype=torch.float64).float().double()
+  gt0 = torch.randn((B, n), generator=g, dtype=torch.float64).float().double()
+  gt1 = torch.randn((B, n), generator=g, dtype=torch.float64).float().double()
+  mult = 0.01
+  B_valid = B - 3
+  # ---- oracle
+  s = sdist.clone().requires_grad_(True)
+  _, s_to_t = ocoord.construct_ray_warps(raydist, near, far)
+  tdist = s_to_t(s)
+  density = torch.nn.functional.softplus(raw_den - 1.0)
+  weights = orender.compute_alpha_weights(density, tdist, dirs, opaque_background=opaque)[0]
+  rgb = torch.sigmoid(raw_rgb) * (1 + 2 * 0.001) - 0.001
+  acc = weights.sum(-1)
+  rgb_out = (weights[..., None] * rgb).sum(-2) + torch.clamp(1 - acc, min=0)[..., None] * 1.0
+  loss = (rgb_out * g_rgb_out).sum() + (weights * g_w_up).sum()
+  loss = loss + mult * ostep.lossfun_distortion(s[:B_valid], weights[:B_valid]).mean()
+  loss = loss + (tdist[:, :-1] * gt0).sum() + (tdist[:, 1:] * gt1).sum() + (s * g_in).sum()
+  loss.backward()
+  want = s.grad
+  # ---- kernels
+  f32c = lambda x: dev(x.float().contiguous())
+  ccfg = ops.composite_cfg(n, opaque_background=opaque, density_act='softplus', density_bias=-1.0, density_noise_std=0.0,
+                           has_rgb=True, rgb_act='sigmoid', rgb_premultiplier=1.0, rgb_bias=0.0, rgb_padding=0.001, bg_mode=0,
+                           bg_value=1.0)
+  td32, w32 = f32c(tdist.detach()), f32c(weights.detach())
+  stat = dev(torch.zeros(1))
+  g_x = dev(torch.empty((B, n)))
+  from multinerf_amd import _lib
+  _lib.load().mnr_level_bwd_set_quad(quad)                # both forms of the level kernel write g_x: four lanes per ray / lane per ray
+  try:
+    _run_composite_bwd = lambda: ops.composite_bwd(ccfg, f32c(raw_den), td32, f32c(dirs), w32, raw_rgb=f32c(raw_rgb), g_rgb_out=f32c(g_rgb_out),
+                    g_weights=f32c(g_w_up), g_x_out=g_x,
+                    losses=dict(B_valid=B_valid, data=None, weights=dict(mode='distortion', mult=mult, sdist=f32c(sdist), stat=stat)))
+    _run_composite_bwd()
+  finally:
+    _lib.load().mnr_level_bwd_set_quad(1)
+  got = ops.sdist_bwd(f32c(sdist), f32c(near.reshape(-1)), f32c(far.reshape(-1)), raydist, B_valid=B_valid, g_x=g_x,
+                      raw_density=f32c(raw_den), density_bias=-1.0, density_act='softplus', dirs=f32c(dirs),
+                      g_t0=f32c(gt0.reshape(-1)), g_t1=f32c(gt1.reshape(-1)), distortion_mult=mult, weights=w32,
+                      g_sdist_in=f32c(g_in))
+  torch.cuda.synchronize()
+  _rays_close(got, want, 2e-4, 1e-6, f'g_sdist [{raydist}, n={n}]')
