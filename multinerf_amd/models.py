@@ -340,8 +340,10 @@ class Model:
     bad = []
     for name, hp in (('NerfMLP', self.nerf_hp), ('PropMLP', self.prop_hp)):
       bad += [f'{name}: {b}' for b in hp.hip_supported()]
-    if not self.stop_level_grad:
-      bad.append('stop_level_grad=False')
+    if not self.stop_level_grad and any(not hp.disable_density_normals for hp in (self.nerf_hp, self.prop_hp)):
+      # the density-gradient normals are a function of the sample positions as well (the tangent network's input rows):
+      # their VJP with respect to the interval ends is not built
+      bad.append('stop_level_grad=False with density-gradient normals')
     if not self.use_viewdirs and any(hp.enable_pred_normals or not hp.disable_density_normals or hp.is_ref()
                                      for hp in (self.nerf_hp, self.prop_hp) if not hp.disable_rgb):
       bad.append('normals (the Ref-NeRF head or one of its fields) without view directions')
@@ -444,6 +446,12 @@ class Model:
         bo = alloc(_rup(p.W, 128), _rup(d.fan_out, 64))
         descs.append(L.PackDesc(d.kernel_off, p.W, d.fan_out, bo, _rup(d.fan_out, 64), 0, 0, 0))
         e.update(b_off=bo, b_ld=_rup(d.fan_out, 64))
+      if not self.stop_level_grad and (i == 0 or concat):
+        # stop_level_grad = False: the FEATURES receive gradient (models.py:198-201): backward operand of the feature rows,
+        # kernel rows [0, F) of layer 0 / [W, W + F) of a skip layer, as [ldF][out_pad]
+        bf = alloc(p.ldF, _rup(d.fan_out, 64))
+        descs.append(L.PackDesc(d.kernel_off + (0 if i == 0 else p.W) * d.fan_out, p.F, d.fan_out, bf, _rup(d.fan_out, 64), 0, 0, 0))
+        e.update(bf_off=bf, bf_ld=_rup(d.fan_out, 64))
     assert not p.x_concat, 'net_depth ending on a skip layer is not supported on the HIP path'
     # heads
     if p.has_rgb and p.use_viewdirs:
@@ -649,8 +657,8 @@ class Model:
     """Number of proposal levels whose training buffers are grouped (0 = not grouped): more than one proposal level on
     the fused chain with the shared density-only PropMLP_0."""
     Lg = self.num_levels - 1
-    if not (keep_for_backward and _MERGE_PROPS and Lg >= 2 and not self.single_mlp):
-      return 0
+    if not (keep_for_backward and _MERGE_PROPS and Lg >= 2 and not self.single_mlp and self.stop_level_grad):
+      return 0                                         # (stop_level_grad = False: the levels' backward passes run one after the other)
     plan = self.prop_plan
     return Lg if (self._chain_ok(plan) and not plan.has_rgb) else 0
 
@@ -770,10 +778,11 @@ class Model:
       else:
         pad = 1 / (2 * n)
         u_base = self._const(('u_det', i_level), (n, pad, eps), lambda: torch.linspace(pad, 1. - pad - eps, n, dtype=f32).to(dev))
-      sdist, tdist = ops.resample_level(
-          sdist, weights, u_base, jitter, near, far, n_samples=n, use_dilation=use_dilation, dilation=dilation,
-          domain=(init_s_near, init_s_far), anneal=anneal, resample_padding=self.resample_padding,
-          single_jitter=self.single_jitter, max_jitter=max_jitter, raydist_fn=self.raydist_fn)
+      rs_kw = dict(n_samples=n, use_dilation=use_dilation, dilation=dilation, domain=(init_s_near, init_s_far), anneal=anneal,
+                   resample_padding=self.resample_padding, single_jitter=self.single_jitter, max_jitter=max_jitter,
+                   raydist_fn=self.raydist_fn)
+      rs_in = (sdist, weights, u_base, jitter)           # (kept for mnr_resample_level_bwd when stop_level_grad is off)
+      sdist, tdist = ops.resample_level(sdist, weights, u_base, jitter, near, far, **rs_kw)
 
       # --- featurise + MLP
       M = Bp * n
@@ -878,7 +887,8 @@ class Model:
       if keep_for_backward:
         saved.append(dict(level=i_level, is_prop=is_prop, n=n, plan=plan, M=M, tag=tag, feat=feat, mlp=mlp_out, group=group,
                           ccfg=ccfg, raw_density=raw_density, raw_rgb=raw_rgb, dnoise=dnoise, bg=bg,
-                          tdist=tdist, sdist=sdist, weights=weights, rgb_out=rgb_out, expo=expo))
+                          tdist=tdist, sdist=sdist, weights=weights, rgb_out=rgb_out, expo=expo, rs_kw=rs_kw, rs_in=rs_in,
+                          near=near, far=far, radii=radii))
 
     if compute_extras:
       # models.py:299-310: proposal levels show the final level's average colour.
@@ -1178,11 +1188,15 @@ class Model:
     G = self.num_glo_features
     return flat[self.glo_off:self.glo_off + self.num_glo_embeddings * G].view(self.num_glo_embeddings, G)
 
-  def backward_level(self, lv, flat, grads, g_rgb_out, g_weights, g_expo=None, g_normals=None, g_npred=None, losses=None):
+  def backward_level(self, lv, flat, grads, g_rgb_out, g_weights, g_expo=None, g_normals=None, g_npred=None, losses=None,
+                     g_x_out=None, g_feat_out=None):
     """VJP of one level w.r.t. the parameters: compositing -> heads -> trunk.
     grads: flat fp32 gradient vector (accumulated into).  g_normals / g_npred [M,3]: from the Ref-NeRF
     normal losses (train_utils.py:162-197).  losses: this level's data / interlevel / distortion losses, evaluated
-    and differentiated inside the compositing VJP's launch (ops.composite_bwd)."""
+    and differentiated inside the compositing VJP's launch (ops.composite_bwd).
+    stop_level_grad = False (models.py:198-201): g_x_out [B, n] receives d loss / d (sigma * delta) of the compositing, and
+    the list g_feat_out the bf16 [M, ldF] matrices whose sum is d loss / d features (one per trunk layer that reads the
+    features: layer 0 and the skip layer)."""
     plan: MLPPlan = lv['plan']
     hp = plan.hp
     M, n, tag = lv['M'], lv['n'], lv['tag']
@@ -1232,12 +1246,23 @@ class Model:
         return dict(bits_in=mlp['bits'][i])
       return dict(mask=acts[i], ldmask=W)
 
+    def feat_grad(i, dy, dy_panel=False):
+      """d loss / d features through trunk layer i (0 or a skip layer): dY_i @ kernel_i[feature rows]^T -> bf16 [M, ldF]."""
+      if g_feat_out is None:
+        return
+      e_ = plan.packed[('trunk', i)]
+      out = self._buf(('bwd', slot, 'g_feat', len(g_feat_out)), (M, plan.ldF), bf16)
+      ops.gemm_nt(dy, self._w(plan, e_['bf_off'], plan.ldF, e_['bf_ld']), M=M, N=plan.ldF, K1=e_['bf_ld'], Cb=out,
+                  ldcb=plan.ldF, nb=plan.ldF, **(dict(a1_layout=PAN) if dy_panel else {}))
+      g_feat_out.append(out)
+
     g_raw_grad = None
     if plan.has_rgb and not plan.use_viewdirs:
       g_raw_density, g_rgb = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], raw_rgb=lv['raw_rgb'],
           density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights, want_f32=True,
-          exposure_scale=lv['expo'], g_exposure_scale=g_expo if lv['expo'] is not None else None, losses=losses)
+          exposure_scale=lv['expo'], g_exposure_scale=g_expo if lv['expo'] is not None else None, losses=losses,
+          g_x_out=g_x_out)
       # the 4-column head [density | rgb]: dX into the trunk, dW / db scattered to the two Dense layers
       g4 = self._buf(('bwd', slot, 'g4'), (M, 4), f32)
       g4[:, 0].copy_(g_raw_density.view(M))
@@ -1269,7 +1294,7 @@ class Model:
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], raw_rgb=lv['raw_rgb'],
           density_noise=lv['dnoise'], bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights,
           g_den_bf16=dHB.view(-1)[bw:], ld_bf16=nh, want_f32=head_gcol, exposure_scale=lv['expo'],
-          g_exposure_scale=g_expo if lv['expo'] is not None else None, losses=losses)
+          g_exposure_scale=g_expo if lv['expo'] is not None else None, losses=losses, g_x_out=g_x_out)
       g_raw_rgb = g_rgb.view(M, 3)
       if head_gcol:
         # the density column of dHB once more as a contiguous bf16 vector, and the density bias gradient from the strided column
@@ -1387,7 +1412,7 @@ class Model:
     else:
       g_raw_density, _ = ops.composite_bwd(
           lv['ccfg'], lv['raw_density'], lv['tdist'], R.directions, lv['weights'], density_noise=lv['dnoise'],
-          bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights, want_f32=True, losses=losses)
+          bg=lv['bg'], g_rgb_out=g_rgb_out, g_weights=g_weights, want_f32=True, losses=losses, g_x_out=g_x_out)
       d = plan.density
       if mlp.get('chain'):
         # fused dX chain: head dW / db from the last activation, then every dY_i in one launch; dW_i = x_{i-1}^T dY_i below
@@ -1408,6 +1433,8 @@ class Model:
           if concat:
             ops.gemm_tn(feat, dYs[i], gslice(dl.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
                         lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
+          if i == 0 or concat:
+            feat_grad(i, dYs[i])
         return
       ops.small_head_bwd(x_last, W, g_raw_density.view(M, 1), flat[d.kernel_off:d.kernel_off + W].view(W, 1),
                          M=M, K=W, Cn=1, dX=dA, lddx=W, relu_mask=relu,
@@ -1430,6 +1457,8 @@ class Model:
         if concat:
           ops.gemm_tn(feat, dYs[i], gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
                       lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
+        if i == 0 or concat:
+          feat_grad(i, dYs[i])
       return
     # trunk: per layer its dW (independent of the dX chain: on the dW stream when that switch is on), then the dX GEMM the
     # next layer waits for
@@ -1446,6 +1475,8 @@ class Model:
         if concat:
           ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
                       lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W, **tn_b)
+      if i == 0 or concat:
+        feat_grad(i, dy, dy_panel=panel)
       if i > 0:
         Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
         other = dy_buf(i - 1)

@@ -189,7 +189,7 @@ def create_train_step(model: models.Model, config, dataset=None):
     # their all-reduce runs under the proposal levels' backward (~1/5 of the step) instead of after it.
     order = list(range(nlev))
     early = []                                                         # [(begin, end, handle)]
-    overlap = mdist.world_size() > 1 and nlev > 1 and not model.single_mlp
+    overlap = mdist.world_size() > 1 and nlev > 1 and not model.single_mlp and model.stop_level_grad
     if overlap:
       order = [nlev - 1] + order[:-1]
 
@@ -226,9 +226,56 @@ def create_train_step(model: models.Model, config, dataset=None):
         for li in lis:
           level_backward(li)
 
+    def levels_backward_through_the_sampling():
+      """Model.stop_level_grad = False (models.py:198-201): the levels are no longer independent.  Last level first; each
+      level's loss gradient with respect to its own sample distances (the compositing's optical-depth increments, the
+      Gaussians' interval ends behind the features, the distortion loss, and what the next level sent back) goes through
+      the VJP of the level's resampling into the previous level's distances and weights (oracle/models.py:487-496; the
+      reference differentiates stepfun.sample_intervals, max_dilate_weights and the logits of models.py:183-185)."""
+      g_s_next = None
+      for li in reversed(range(nlev)):
+        lv = levels[li]
+        plan = lv['plan']
+        Bp_, n_ = lv['sdist'].shape[0], lv['n']
+        through = li >= 1                                # level 0 resamples a constant histogram: nothing upstream of it
+        g_x = model._buf(('train', 'g_x', li), (Bp_, n_), f32) if through else None
+        g_feat = [] if through else None
+        model.backward_level(lv, flat, grads, None, g_w[li], g_expo, g_nrm[li], g_npr[li],
+                             losses=dict(B_valid=B0, data=data_spec[li], weights=w_spec[li]), g_x_out=g_x, g_feat_out=g_feat)
+        if not through:
+          break
+        while len(g_feat) > 2:                           # more than one skip layer: fold the extra matrices into the first
+          extra = g_feat.pop()
+          ops.add_cols_bf16(g_feat[0], extra, g_feat[0], plan.ldF)
+        hp = plan.hp
+        g_t0, g_t1 = ops.cast_rays_ipe_bwd(
+            lv['tdist'], R.origins, R.directions, lv['radii'], plan.basis_dev, g_feat[0], g_feat[1] if len(g_feat) > 1 else None,
+            ray_shape=model.ray_shape, warp_contract=(hp.warp_fn == 'contract'), min_deg=hp.min_deg_point,
+            max_deg=hp.max_deg_point, disable_integration=model.disable_integration,
+            g_t0=model._buf(('train', 'g_t0', li), (Bp_ * n_,), f32), g_t1=model._buf(('train', 'g_t1', li), (Bp_ * n_,), f32))
+        ccfg = lv['ccfg']
+        fine = li == nlev - 1
+        g_s = ops.sdist_bwd(
+            lv['sdist'], lv['near'], lv['far'], model.raydist_fn, B_valid=B0, g_x=g_x, raw_density=lv['raw_density'],
+            density_noise=lv['dnoise'], density_noise_std=ccfg.density_noise_std, density_bias=hp.density_bias,
+            density_act=hp.density_activation, dirs=R.directions, g_t0=g_t0, g_t1=g_t1,
+            distortion_mult=(config.distortion_loss_mult if fine else 0.0), weights=lv['weights'], g_sdist_in=g_s_next,
+            out=model._buf(('train', 'g_sdist', li), (Bp_, n_ + 1), f32))
+        sd_prev, w_prev, u_base, jitter = lv['rs_in']
+        g_s_next, g_w_prev = ops.resample_level_bwd(
+            sd_prev, w_prev, u_base, jitter, g_s, **lv['rs_kw'],
+            g_sdist_prev=model._buf(('train', 'g_sdist_prev', li), tuple(sd_prev.shape), f32),
+            g_w_prev=model._buf(('train', 'g_w_prev', li), tuple(w_prev.shape), f32))
+        if g_w[li - 1] is None:
+          g_w[li - 1] = g_w_prev
+        else:
+          g_w[li - 1].add_(g_w_prev)
+
     bs = backward_streams(dev)
     prop_lis = list(range(nlev - 1))
-    if bs is None:
+    if not model.stop_level_grad:
+      levels_backward_through_the_sampling()
+    elif bs is None:
       if order[0] == nlev - 1:
         level_backward(nlev - 1)
         props_backward(prop_lis)

@@ -24,7 +24,7 @@ def test_library_exports_every_header_symbol():
   # and every exported prototype we bind is declared in the header
   for n in _lib._PROTOS:
     assert n in names
-  assert lib.mnr_abi_version() == 18
+  assert lib.mnr_abi_version() == 19
 
 
 def test_ops_refuse_cpu_tensors():
@@ -110,8 +110,8 @@ def test_every_ref_nerf_feature_set_of_the_goldens_has_a_hip_path():
   for case, (preset, extra, *_rest) in gen.CASES.items():
     m = models.Model(config=configs.load_preset(preset, list(extra)))
     # (the goldens' widths are shrunk to 32 / 16: the only objection the HIP path may have)
-    # (... and the one golden that pins the ORACLE for a switch the HIP path does not have yet)
-    bad = [b for b in m.hip_supported() if 'multiple of' not in b and not (case == 'blender_sampling_grad' and b == 'stop_level_grad=False')]
+    # (`blender_sampling_grad`: Model.stop_level_grad = False is on the HIP path since round 5)
+    bad = [b for b in m.hip_supported() if 'multiple of' not in b]
     assert bad == [], (case, bad)
     plan = models.MLPPlan(m.nerf_hp, 'NerfMLP_0', m.use_viewdirs, m.num_glo_features, 0)
     assert plan.ref == m.nerf_hp.is_ref() and plan.tangent == (not m.nerf_hp.disable_density_normals)
