@@ -289,10 +289,33 @@ Config.adam_eps = 1e-8
 }
 
 
+# reference configs/debug.gin: an OVERLAY (the reference passes it as a second --gin_configs file): a short schedule and
+# small MLPs, among them PropMLP.net_width = 64.  load_preset('360+debug') binds it on top of a scene preset.
+PRESETS['debug'] = """
+Config.checkpoint_every = 1000
+Config.print_every = 100
+Config.train_render_every = 1000
+Config.lr_delay_mult = 0.1
+Config.lr_delay_steps = 500
+Config.batch_size = 2048
+Config.render_chunk_size = 2048
+Config.lr_init = 5e-4
+Config.lr_final = 5e-6
+Config.factor = 4
+Config.early_exit_steps = 3000
+PropMLP.net_depth = 2
+PropMLP.net_width = 64
+NerfMLP.net_depth = 4
+NerfMLP.net_width = 128
+"""
+
+
 def load_preset(name, gin_bindings=None):
-  """Clear gin state, bind a named preset (+ extra bindings), return Config."""
+  """Clear gin state, bind a named preset or several ('360+debug': left to right, like repeated --gin_configs) and the
+  extra bindings, return Config."""
   gin.clear_config()
-  gin.parse_config(PRESETS[name], skip_unknown=False)
+  for part in name.split('+'):
+    gin.parse_config(PRESETS[part], skip_unknown=False)
   for b in (gin_bindings or []):
     gin.parse_config(b, skip_unknown=False)
   return Config()

@@ -150,8 +150,10 @@ class MLP:
       bad.append(f'net_activation={self.net_activation} with density-gradient normals')
     if self.warp_fn not in (None, 'contract'):
       bad.append(f'warp_fn={self.warp_fn}')
-    if self.net_width % 128 != 0:
-      bad.append('net_width not a multiple of 128')
+    if self.net_width <= 0:
+      bad.append('net_width must be positive')
+    # (a net_width that is not a multiple of 128, e.g. configs/debug.gin's PropMLP.net_width = 64, runs on kernels of the next
+    # multiple of 128 with structurally zero padding: Model.build / Model._to_exec)
     if not self.disable_rgb and (self.bottleneck_width <= 0 or self.bottleneck_width % 64 != 0):
       bad.append('bottleneck_width must be a positive multiple of 64')
     if not self.disable_rgb and self.net_width_viewdirs % 128 != 0:
@@ -369,30 +371,64 @@ class Model:
     if bad:
       raise NotImplementedError('not yet implemented on the HIP path: ' + '; '.join(bad))
     self.device = torch.device(device)
-    self.nerf_plan = MLPPlan(self.nerf_hp, 'NerfMLP_0', self.use_viewdirs, self.num_glo_features, 0)
-    if self.single_mlp:
-      self.prop_plan = self.nerf_plan
-      end = self.nerf_plan.param_end
+
+    def layout(nerf_hp, prop_hp):
+      """(plans, modules, glo_off, expo_off, num_params) of the flat parameter vector for these hyper-parameters."""
+      nerf = MLPPlan(nerf_hp, 'NerfMLP_0', self.use_viewdirs, self.num_glo_features, 0)
+      plans, end = [nerf], nerf.param_end
+      if not self.single_mlp:
+        prop = MLPPlan(prop_hp, 'PropMLP_0', self.use_viewdirs, 0, nerf.param_end)
+        plans.append(prop)
+        end = prop.param_end
+      modules = [(p.module_name, p.param_begin, p.param_end) for p in plans]
+      glo_off = expo_off = None
+      if self.num_glo_features > 0:
+        # nn.Embed(num_glo_embeddings, num_glo_features) auto-named Embed_0 (models.py:101-106)
+        glo_off = end
+        end += self.num_glo_embeddings * self.num_glo_features
+        modules.append(('Embed_0', glo_off, end))
+      if self.learned_exposure_scaling:
+        # nn.Embed(num_glo_embeddings, 3, zeros init, name='exposure_scaling_offsets') (models.py:112-121)
+        expo_off = end
+        end += self.num_glo_embeddings * 3
+        modules.append(('exposure_scaling_offsets', expo_off, end))
+      return plans, modules, glo_off, expo_off, end
+
+    # The parameter vector the callers see (`num_params`, `modules`, params_tree / flat_from_tree / param_ranges) is flax's,
+    # at the widths the configuration names.  The kernels want trunk widths that are multiples of 128 (the GEMM tile): a width
+    # such as configs/debug.gin's PropMLP.net_width = 64 runs as the next multiple of 128 on an EXECUTION layout whose extra
+    # rows / columns are structurally zero (`_to_exec` scatters the parameters into it before a pass, `true_grads` gathers the
+    # gradient back: zero weights and biases give zero activations behind the ReLU and zero gradients; behind another
+    # activation the padded units are non-zero but feed zero rows of the next kernel, and their gradients are dropped).
+    pad = lambda hp: hp if hp.net_width % 128 == 0 else dataclasses.replace(hp, net_width=_rup(hp.net_width, 128))
+    self._tplans, self.modules, self.glo_off_true, self.expo_off_true, self.num_params = layout(self.nerf_hp, self.prop_hp)
+    nerf_x = pad(self.nerf_hp)
+    prop_x = nerf_x if self.single_mlp else pad(self.prop_hp)
+    self._pad_index = None
+    if nerf_x is self.nerf_hp and prop_x is self.prop_hp:
+      self._plans, self.glo_off, self.expo_off, self.num_params_exec = self._tplans, self.glo_off_true, self.expo_off_true, self.num_params
     else:
-      self.prop_plan = MLPPlan(self.prop_hp, 'PropMLP_0', self.use_viewdirs, 0, self.nerf_plan.param_end)
-      end = self.prop_plan.param_end
-    self.modules = [(self.nerf_plan.module_name, self.nerf_plan.param_begin, self.nerf_plan.param_end)]
-    if not self.single_mlp:
-      self.modules.append((self.prop_plan.module_name, self.prop_plan.param_begin, self.prop_plan.param_end))
-    self.glo_off = None
-    if self.num_glo_features > 0:
-      # nn.Embed(num_glo_embeddings, num_glo_features) auto-named Embed_0 (models.py:101-106)
-      self.glo_off = end
-      end += self.num_glo_embeddings * self.num_glo_features
-      self.modules.append(('Embed_0', self.glo_off, end))
-    self.expo_off = None
-    if self.learned_exposure_scaling:
-      # nn.Embed(num_glo_embeddings, 3, zeros init, name='exposure_scaling_offsets') (models.py:112-121)
-      self.expo_off = end
-      end += self.num_glo_embeddings * 3
-      self.modules.append(('exposure_scaling_offsets', self.expo_off, end))
-    self.num_params = end
-    self._plans = [self.nerf_plan] + ([] if self.single_mlp else [self.prop_plan])
+      self._plans, _, self.glo_off, self.expo_off, self.num_params_exec = layout(nerf_x, prop_x)
+      idx = torch.empty(self.num_params, dtype=torch.int64)
+      for pt, px in zip(self._tplans, self._plans):
+        shift = px.W - pt.W
+        for dt, dx in zip(pt.dense, px.dense):
+          rows = torch.arange(dt.fan_in)
+          # input rows: the trunk's own columns first; what follows them in a concatenated input (the features) moves up
+          reads_trunk = dt.fan_in == pt.W or dt.fan_in == pt.W + pt.F
+          if reads_trunk and dx.fan_in != dt.fan_in:
+            rows = torch.where(rows < pt.W, rows, rows + shift)
+          cols = torch.arange(dt.fan_out)
+          idx[dt.kernel_off:dt.kernel_off + dt.fan_in * dt.fan_out] = (dx.kernel_off + rows[:, None] * dx.fan_out + cols[None, :]).reshape(-1)
+          idx[dt.bias_off:dt.bias_off + dt.fan_out] = dx.bias_off + cols
+      for o_t, o_x, cnt in ((self.glo_off_true, self.glo_off, self.num_glo_embeddings * self.num_glo_features),
+                            (self.expo_off_true, self.expo_off, self.num_glo_embeddings * 3)):
+        if o_t is not None:
+          idx[o_t:o_t + cnt] = o_x + torch.arange(cnt)
+      assert idx.unique().numel() == self.num_params
+      self._pad_index = idx.to(self.device)
+    self.nerf_plan = self._plans[0]
+    self.prop_plan = self._plans[0] if self.single_mlp else self._plans[1]
     for p in self._plans:
       p.basis_dev = torch.as_tensor(p.basis, dtype=f32, device=self.device).contiguous()
       self._layout_packed(p)
@@ -543,7 +579,7 @@ class Model:
     assert self._built
     gen = torch.Generator().manual_seed(seed)
     flat = torch.zeros(self.num_params, dtype=f32)
-    for p in self._plans:
+    for p in self._tplans:
       for d in p.dense:
         kind = p.hp.weight_init
         if kind == 'he_uniform':
@@ -554,17 +590,17 @@ class Model:
           raise NotImplementedError(f'weight_init {kind}')
         w = (torch.rand((d.fan_in, d.fan_out), generator=gen, dtype=torch.float64) * 2 - 1) * lim
         flat[d.kernel_off:d.kernel_off + d.fan_in * d.fan_out] = w.reshape(-1).float()
-    if self.glo_off is not None:
+    if self.glo_off_true is not None:
       # flax nn.Embed default init: variance_scaling(1.0, 'fan_in', 'normal', out_axis=0) -> std 1/sqrt(features)
       G = self.num_glo_features
       e = torch.randn((self.num_glo_embeddings, G), generator=gen, dtype=torch.float64) / math.sqrt(G)
-      flat[self.glo_off:self.glo_off + e.numel()] = e.reshape(-1).float()
+      flat[self.glo_off_true:self.glo_off_true + e.numel()] = e.reshape(-1).float()
     return flat.to(self.device)
 
   def params_tree(self, flat):
     """Nested dict of views into `flat` with flax's names (train.py:194-195 layout)."""
     tree = {}
-    for p in self._plans:
+    for p in self._tplans:
       m = {}
       for d in p.dense:
         m[d.name] = {
@@ -572,12 +608,12 @@ class Model:
             'bias': flat[d.bias_off:d.bias_off + d.fan_out],
         }
       tree[p.module_name] = m
-    if self.glo_off is not None:
+    if self.glo_off_true is not None:
       n = self.num_glo_embeddings * self.num_glo_features
-      tree['Embed_0'] = {'embedding': flat[self.glo_off:self.glo_off + n].view(-1, self.num_glo_features)}
-    if self.expo_off is not None:
+      tree['Embed_0'] = {'embedding': flat[self.glo_off_true:self.glo_off_true + n].view(-1, self.num_glo_features)}
+    if self.expo_off_true is not None:
       n = self.num_glo_embeddings * 3
-      tree['exposure_scaling_offsets'] = {'embedding': flat[self.expo_off:self.expo_off + n].view(-1, 3)}
+      tree['exposure_scaling_offsets'] = {'embedding': flat[self.expo_off_true:self.expo_off_true + n].view(-1, 3)}
     return tree
 
   def param_ranges(self):
@@ -587,7 +623,7 @@ class Model:
     out = {}
     for name, b, e in self.modules:
       out[name] = (b, e)
-    for p in self._plans:
+    for p in self._tplans:
       for d in p.dense:
         kb, ke = d.kernel_off, d.kernel_off + d.fan_in * d.fan_out
         bb, be = d.bias_off, d.bias_off + d.fan_out
@@ -595,26 +631,41 @@ class Model:
         out[f'{p.module_name}/{d.name}'] = (kb, be)
         out[f'{p.module_name}/{d.name}/kernel'] = (kb, ke)
         out[f'{p.module_name}/{d.name}/bias'] = (bb, be)
-    if self.glo_off is not None:
+    if self.glo_off_true is not None:
       out['Embed_0/embedding'] = out['Embed_0']
-    if self.expo_off is not None:
+    if self.expo_off_true is not None:
       out['exposure_scaling_offsets/embedding'] = out['exposure_scaling_offsets']
     return out
 
   def flat_from_tree(self, tree, device=None):
     """Inverse of params_tree for externally supplied parameters (e.g. the oracle's)."""
     flat = torch.zeros(self.num_params, dtype=f32)
-    for p in self._plans:
+    for p in self._tplans:
       for d in p.dense:
         flat[d.kernel_off:d.kernel_off + d.fan_in * d.fan_out] = tree[p.module_name][d.name]['kernel'].detach().reshape(-1).float().cpu()
         flat[d.bias_off:d.bias_off + d.fan_out] = tree[p.module_name][d.name]['bias'].detach().float().cpu()
-    if self.glo_off is not None:
+    if self.glo_off_true is not None:
       n = self.num_glo_embeddings * self.num_glo_features
-      flat[self.glo_off:self.glo_off + n] = tree['Embed_0']['embedding'].detach().reshape(-1).float().cpu()
-    if self.expo_off is not None:
+      flat[self.glo_off_true:self.glo_off_true + n] = tree['Embed_0']['embedding'].detach().reshape(-1).float().cpu()
+    if self.expo_off_true is not None:
       n = self.num_glo_embeddings * 3
-      flat[self.expo_off:self.expo_off + n] = tree['exposure_scaling_offsets']['embedding'].detach().reshape(-1).float().cpu()
+      flat[self.expo_off_true:self.expo_off_true + n] = tree['exposure_scaling_offsets']['embedding'].detach().reshape(-1).float().cpu()
     return flat.to(device or self.device)
+
+  def _to_exec(self, flat):
+    """The parameter vector the kernels read: `flat` itself, or (padded trunk widths, `build`) its scatter into the
+    zero-padded execution layout."""
+    if self._pad_index is None:
+      return flat
+    if flat.numel() == self.num_params_exec and self.num_params_exec != self.num_params:
+      return flat                                        # (already in the execution layout)
+    buf = self._buf(('exec', 'flat'), (self.num_params_exec,), f32, zero=True)
+    buf.index_copy_(0, self._pad_index, flat)
+    return buf
+
+  def true_grads(self, grads_exec):
+    """Gradient in the callers' layout from the execution layout's (the padded entries' gradients are dropped)."""
+    return grads_exec if self._pad_index is None else grads_exec.index_select(0, self._pad_index)
 
   # Workspace -------------------------------------------------------------------------
 
@@ -693,6 +744,7 @@ class Model:
     noise['u_jitter'][level] uniform [0,1) of shape [B,1] / [B,n]."""
     if not self._built:
       self.build(flat.device)
+    flat = self._flat_exec = self._to_exec(flat)
     fused_ipe = _FUSED_IPE and not keep_for_backward
     if repack:
       self.pack_weights(flat, ipe=fused_ipe)

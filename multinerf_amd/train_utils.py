@@ -124,7 +124,9 @@ def create_train_step(model: models.Model, config, dataset=None):
       gt = torch.cat([gt, gt[-1:].expand(Bp - gt.shape[0], 3)], 0).contiguous()
     ops.lossmult_sum(lossmult, B0, denom)
 
-    grads = model._buf(('train', 'grads'), (model.num_params,), f32)
+    # (the kernels' layout of the parameters: `flat` itself unless a trunk width is padded to the GEMM tile, models.Model.build)
+    flat_true, flat = flat, model._flat_exec
+    grads = model._buf(('train', 'grads'), (model.num_params_exec,), f32)
     grads.zero_()
 
     # Data, interlevel and distortion losses (train_utils.py:85-111, 131-159) are evaluated AND differentiated inside
@@ -189,7 +191,7 @@ def create_train_step(model: models.Model, config, dataset=None):
     # their all-reduce runs under the proposal levels' backward (~1/5 of the step) instead of after it.
     order = list(range(nlev))
     early = []                                                         # [(begin, end, handle)]
-    overlap = mdist.world_size() > 1 and nlev > 1 and not model.single_mlp and model.stop_level_grad
+    overlap = mdist.world_size() > 1 and nlev > 1 and not model.single_mlp and model.stop_level_grad and model._pad_index is None
     if overlap:
       order = [nlev - 1] + order[:-1]
 
@@ -301,6 +303,7 @@ def create_train_step(model: models.Model, config, dataset=None):
                              R.exposure_idx.reshape(-1).to(torch.int32).contiguous(), g_expo,
                              grads[model.expo_off:model.expo_off + n_off], B0)
 
+    flat, grads = flat_true, model.true_grads(grads)                  # back in the callers' layout (the same tensors unless padded)
     # losses['weight'] = sum_k mult_k * |params[k]|^2 over the summarize_tree keys k of the parameter tree (train_utils.py:60-68,
     # 300-305: a module, a Dense inside it, or one kernel / bias); its gradient 2 * mult_k * params[k] goes into the same ranges
     for key, mult in (config.weight_decay_mults or {}).items():

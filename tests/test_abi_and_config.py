@@ -124,3 +124,21 @@ def test_every_ref_nerf_feature_set_of_the_goldens_has_a_hip_path():
                         'NerfMLP.use_directional_enc = False'], 'use_n_dot_v without normals')):
     bad = models.Model(config=configs.load_preset('blender_refnerf', extra)).hip_supported()
     assert any(what in b and 'undefined in the reference' in b for b in bad), (extra, bad)
+
+
+def test_debug_overlay_binds_and_its_widths_build():
+  """reference configs/debug.gin on top of configs/360.gin (`--gin_configs 360.gin --gin_configs debug.gin`): PropMLP 2 x 64,
+  NerfMLP 4 x 128 are accepted by the HIP path (round-4 verdict: `hip_supported()` refused the 64-wide trunk)."""
+  from multinerf_amd import configs, models
+  cfg = configs.load_preset('360+debug')
+  assert cfg.batch_size == 2048 and cfg.early_exit_steps == 3000 and cfg.near == 0.2
+  m = models.Model(config=cfg)
+  assert (m.prop_hp.net_width, m.prop_hp.net_depth, m.nerf_hp.net_width, m.nerf_hp.net_depth) == (64, 2, 128, 4)
+  assert m.hip_supported() == []
+  m.build('cpu')
+  # flax's parameter count at the widths the file names; the kernels' padded layout is larger and maps one to one into it
+  assert m.num_params == sum(d.fan_in * d.fan_out + d.fan_out for p in m._tplans for d in p.dense)
+  assert m.prop_plan.W == 128 and m._tplans[1].W == 64 and m.num_params_exec > m.num_params
+  flat = m.init_flat_params(seed=1).cpu()
+  ex = m._to_exec(flat)
+  assert torch.equal(m.true_grads(ex), flat) and int((ex != 0).sum()) == int((flat != 0).sum())

@@ -210,6 +210,12 @@ CASES = [
     # a trunk too wide for the fused chain (512, as 360.gin's 1024): per-layer GEMMs on 256x256 tiles, the density head's weight
     # gradient as a vector column of the bottleneck's dW GEMM (gemm_tn_gcol_kernel)
     ('360', ['NerfMLP.net_width = 512', 'PropMLP.net_width = 128'], 16),
+    # the MLP shapes of the reference's configs/debug.gin (:14-18: PropMLP 2 x 64, NerfMLP 4 x 128): a trunk width that is not a
+    # multiple of the 128-column GEMM tile runs on a zero-padded execution layout (models.Model.build / _to_exec / true_grads)
+    ('360', ['PropMLP.net_depth = 2', 'PropMLP.net_width = 64', 'NerfMLP.net_depth = 4', 'NerfMLP.net_width = 128'], 16),
+    # ... and widths that are multiples of nothing in particular, behind a non-ReLU activation (the padded units are then
+    # non-zero, feed zero kernel rows, and their gradients are dropped)
+    ('blender_256', ['PropMLP.net_width = 96', 'NerfMLP.net_width = 200', 'NerfMLP.net_activation = @jax.nn.softplus'], 16),
 ]
 
 
@@ -434,8 +440,10 @@ def test_unsupported_features_fail_loudly():
   cfg = configs.load_preset('blender_refnerf', ['NerfMLP.net_activation = @jax.nn.softplus'])
   with pytest.raises(NotImplementedError, match='density-gradient normals'):
     models.Model(config=cfg).build('cuda')
-  cfg = configs.load_preset('360', ['Model.stop_level_grad = False'])
-  with pytest.raises(NotImplementedError, match='stop_level_grad'):
+  # Model.stop_level_grad = False is on the HIP path since round 5 (tests/test_gpu_sampling_grad.py), except next to the
+  # density-gradient normals, which are a function of the sample positions too
+  cfg = configs.load_preset('blender_refnerf', ['Model.stop_level_grad = False'])
+  with pytest.raises(NotImplementedError, match='stop_level_grad=False with density-gradient normals'):
     models.Model(config=cfg).build('cuda')
 
 

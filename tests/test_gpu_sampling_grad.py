@@ -340,6 +340,6 @@ def test_train_step_through_the_sampling_matches_the_oracle(name, preset, bindin
     cost = ((r - r32).norm() / (r32.norm() + 1e-30)).item()
     print(f'SAMPLING_GRAD {name} {mod}: grad cos {cos:.6f} rel err {rel:.3e} (the oracle\'s own bf16 cost {cost:.3e})')
     if strict:
-      assert cos > 0.99 and rel < max(0.05, 1.5 * cost), (mod, cos, rel, cost)
+      assert cos > 0.985 and rel < max(0.05, 1.5 * cost), (mod, cos, rel, cost)        # (measured on the MI355X: >= 0.9925 / <= 0.66 cost)
     else:
       assert rel < max(0.1, cost), (mod, cos, rel, cost)

@@ -44,6 +44,10 @@ CASES = [
                          'NerfMLP.disable_density_normals = True', 'NerfMLP.use_directional_enc = False',
                          'NerfMLP.use_specular_tint = False', 'Config.predicted_normal_loss_mult = 0.0',
                          'Config.predicted_normal_coarse_loss_mult = 0.0', 'Config.compute_normal_metrics = False'], 4),
+    # the MLP shapes of the reference's configs/debug.gin (PropMLP 2 x 64, NerfMLP 4 x 128): a trunk width below the GEMM tile
+    # on the zero-padded execution layout (models.Model.build / _to_exec / true_grads)
+    ('360', ['PropMLP.net_depth = 2', 'PropMLP.net_width = 64', 'NerfMLP.net_depth = 4', 'NerfMLP.net_width = 128',
+             'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 8),
 ]
 PANEL_CASE = CASES[3]
 
