@@ -131,8 +131,9 @@ int mnr_cast_rays_ipe_f32(const mnr_ipe_cfg* cfg, int64_t B, int n, const float*
                           const float* basis, float* feat_out, void* stream);
 
 /* Tangent features for the density-gradient normals (models.py:478-492 via forward mode):
- * row c*B*n + s of feat_out (bf16 [3*B*n, ld_feat]) = d(IPE features of sample s)/d(mean_c), c = x,y,z.
- * Only valid without a warp (the covariance then does not depend on the mean). */
+ * row c*B*n + s of feat_out (bf16 [3*B*n, ld_feat]) = d(IPE features of sample s)/d(mean_c), c = x,y,z, mean = the Gaussian's
+ * mean as predict_density receives it (models.py:441-446: BEFORE warp_fn; with cfg->warp_contract the rows carry the
+ * contraction's Jacobian and, through J cov J^T with the covariance held fixed, its derivative). */
 int mnr_cast_rays_ipe_tangent(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist,
                               const float* origins, const float* directions, const float* radii,
                               const float* basis, uint16_t* feat_out, int ld_feat, void* stream);
@@ -221,32 +222,15 @@ typedef struct {
    * Each of the four waves that share a row block spends one extra MFMA per k-step on it (+12.5 %).  vcol: bf16 [K1 + K2]
    * (16-byte aligned); needs a1_layout = PANEL, N == 256, K1 + K2 <= 1536, a row-major bf16 result, no fp32 side output. */
   const uint16_t* vcol; float* vcol_out; const float* vcol_bias;     /* vcol_bias: one device float, or NULL for 0 */
+  /* c_layout = PANEL: 1 = walk the M-tiles in descending order (the caller alternates it between consecutive layers: a layer
+   * then starts with the rows the previous one wrote last).  Performance only; results do not depend on it. */
+  int walk_descending;
 } mnr_gemm_nt_args;
 #define MNR_LAYOUT_ROWMAJOR 0
 #define MNR_LAYOUT_PANEL 1
 
 /* C[M,N] = epilogue([A1|A2] * Bt^T). */
 int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* args, void* stream);
-/* Profiling hook: device buffer of 16 uint64 per workgroup (s_memtime at entry, K-loop start, K-loop end, exit;
- * s_memrealtime at entry, exit; XCC_ID<<32|HW_ID; unused; epilogue pass stamps) written by
- * every following mnr_gemm_nt_bf16 / mnr_gemm_tn_bf16 launch (TN: [7] = steps << 32 | does-bias); NULL switches it off. */
-int mnr_debug_gemm_timeline(unsigned long long* device_buffer);
-/* A/B switch: 0 = one workgroup per output tile; n > 0 (default 1) = persistent launches, n workgroups per CU walk the
- * tiles; n < 0 = at most -n workgroups in total. */
-/* A/B switch: 1 (default) = the 256x256 tiles use the hand-pipelined K loop (BK = 32 x 4 stages, LDS-DMA issued between the
-   MFMAs), 0 = the two-stage BK = 64 loop.  Bitwise equal results. */
-int mnr_gemm_nt_set_pipelined(int on);
-int mnr_gemm_nt_set_persistent(int wgs_per_cu);
-/* A/B switch: 1 (default) = eligible short-K launches (N = 256, K1 <= 256, K2 = 0, full-width bf16 output, no fp32 side
- * output, no bf16 mask) go to the weights-resident persistent kernel (weights in registers, one workgroup per CU walking
- * the M tiles); n > 1 = the same with at most n workgroups; 0 = off. */
-int mnr_gemm_nt_set_wres(int max_wgs);
-/* Test hook of the panel-result kernel (c_layout = MNR_LAYOUT_PANEL, csrc/gemm_blk.hip): at most n persistent workgroups
- * (every workgroup then walks several tiles at small sizes); 0 (default) = one per CU. */
-int mnr_gemm_nt_panel_set_max_wgs(int n);
-/* A/B switch of the same kernel: 1 (default) = consecutive launches walk the M-tiles in alternating directions (a layer starts
- * with the rows the previous layer wrote last); 0 = always ascending.  Resets the direction of the next launch to ascending. */
-int mnr_gemm_nt_panel_set_alternate(int on);
 
 /* ---- Fused Dense chain (csrc/fused_mlp.hip): the trunk of internal/models.py:441-465 (Dense + ReLU layers, optionally
  * one skip concat of the input features, :458-459) and, for a density-only MLP, its Dense(1) head (:460) as ONE
@@ -290,9 +274,6 @@ typedef struct {
   const float* origins; const float* directions; const float* radii; const float* basis;   /* as mnr_cast_rays_ipe */
 } mnr_chain_ipe_args;
 int mnr_mlp_chain_fwd_ipe(const mnr_mlp_chain_fwd_args* chain, const mnr_chain_ipe_args* ipe, void* stream);
-/* A/B switch of both chain kernels: 1 (default) = a layer's copy-out (activation / gradient rows, mask bits) is issued from
- * inside the NEXT layer's MFMA pass, behind that pass's last weight request; 0 = in front of the pass.  Bitwise equal. */
-int mnr_mlp_chain_set_deferred(int on);
 
 typedef struct {
   int64_t M; int W; int depth;
@@ -308,9 +289,6 @@ typedef struct {
                                  and dY[depth-1] must be NULL */
 } mnr_mlp_chain_bwd_args;
 int mnr_mlp_chain_bwd(const mnr_mlp_chain_bwd_args* args, void* stream);
-/* Profiling hook: device buffer of 32 uint64 per workgroup, stamped (s_memtime per phase of the workgroup's second tile,
- * see csrc/fused_mlp.hip) by every following mnr_mlp_chain_fwd / _bwd launch; NULL switches it off. */
-int mnr_debug_chain_timeline(unsigned long long* device_buffer);
 
 typedef struct {
   const uint16_t* A; int lda; int K;   /* A [M, lda] bf16, K columns used, K multiple of 128 */
@@ -470,9 +448,6 @@ typedef struct {
   float* g_sdist;
 } mnr_sdist_bwd_args;
 int mnr_sdist_bwd(const mnr_sdist_bwd_args* args, void* stream);
-/* A/B switch: 1 (default) = four lanes per ray where a wave's 16 rays fit LDS, 0 = the lane-per-ray kernel everywhere.
- * Sums are associated differently in the two; both are held to the oracle by the same tolerances. */
-int mnr_level_bwd_set_quad(int on);
 
 /* RawNeRF exposure (replaces models.py:257-267).  out[b,c] = exposure_values[b] *
  * (1 + [idx[b] > 0] * offsets[idx[b], c]); offsets = the 'exposure_scaling_offsets' embedding

@@ -65,7 +65,7 @@ class GemmNTArgs(C.Structure):
               ('mask_bits_out', vp), ('ld_bits_out', C.c_int),
               ('mask_bits_in', vp), ('ld_bits_in', C.c_int),
               ('bits_row_mod', C.c_int64), ('a1_layout', C.c_int), ('c_layout', C.c_int),
-              ('vcol', vp), ('vcol_out', vp), ('vcol_bias', vp)]
+              ('vcol', vp), ('vcol_out', vp), ('vcol_bias', vp), ('walk_descending', C.c_int)]
 
 
 class GemmTNArgs(C.Structure):
@@ -165,19 +165,10 @@ _PROTOS = {
     'mnr_glo_fill': ([i64, i32, i32, vp, vp, i32, vp, i32, i32, vp], i32),
     'mnr_glo_bwd': ([i64, i32, i32, vp, vp, vp, i32, vp, vp], i32),
     'mnr_gemm_nt_bf16': ([C.POINTER(GemmNTArgs), vp], i32),
-    'mnr_debug_gemm_timeline': ([vp], i32),
-    'mnr_gemm_nt_set_persistent': ([i32], i32),
-    'mnr_level_bwd_set_quad': ([i32], i32),
-    'mnr_gemm_nt_set_pipelined': ([i32], i32),
-    'mnr_gemm_nt_set_wres': ([i32], i32),
-    'mnr_gemm_nt_panel_set_max_wgs': ([i32], i32),
-    'mnr_gemm_nt_panel_set_alternate': ([i32], i32),
     'mnr_gemm_tn_bf16': ([C.POINTER(GemmTNArgs), vp], i32),
     'mnr_mlp_chain_fwd': ([C.POINTER(MlpChainFwdArgs), vp], i32),
     'mnr_mlp_chain_bwd': ([C.POINTER(MlpChainBwdArgs), vp], i32),
     'mnr_mlp_chain_fwd_ipe': ([C.POINTER(MlpChainFwdArgs), C.POINTER(ChainIpeArgs), vp], i32),
-    'mnr_debug_chain_timeline': ([vp], i32),
-    'mnr_mlp_chain_set_deferred': ([i32], i32),
     'mnr_colsum_bf16': ([vp, i32, i64, i32, vp, vp], i32),
     'mnr_pack_weights_bf16': ([vp, vp, i32, i32, vp, vp], i32),
     'mnr_scatter_add_f32': ([vp, i32, i32, i32, i32, i32, vp, i32, vp], i32),
@@ -217,12 +208,25 @@ _PROTOS = {
     'mnr_clip_adam': ([C.POINTER(AdamCfg), i64, i64, vp, vp, vp, vp, vp, vp], i32),
 }
 
+# include/mnerf_debug.h: development / test hooks (process-global A/B switches, small-grid test hooks, timelines).  The
+# package never calls them; tests/ and tools/ reach them through debug().
+_DEBUG_PROTOS = {
+    'mnr_debug_gemm_timeline': ([vp], i32),
+    'mnr_gemm_nt_set_persistent': ([i32], i32),
+    'mnr_level_bwd_set_quad': ([i32], i32),
+    'mnr_gemm_nt_set_pipelined': ([i32], i32),
+    'mnr_gemm_nt_set_wres': ([i32], i32),
+    'mnr_gemm_nt_panel_set_max_wgs': ([i32], i32),
+    'mnr_debug_chain_timeline': ([vp], i32),
+    'mnr_mlp_chain_set_deferred': ([i32], i32),
+}
+
 _lib = None
 
 
-def header_symbols():
-  """Every function name include/mnerf.h declares."""
-  with open(HEADER_PATH) as f:
+def header_symbols(path=None):
+  """Every function name include/mnerf.h (or the header at `path`) declares."""
+  with open(path or HEADER_PATH) as f:
     text = f.read()
   text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
   return sorted(set(re.findall(r'\b(mnr_[a-z0-9_]+)\s*\(', text)))
@@ -248,6 +252,19 @@ def load():
     fn.argtypes = argtypes
     fn.restype = restype
   _lib = lib
+  return lib
+
+
+DEBUG_HEADER_PATH = os.path.join(os.path.dirname(HEADER_PATH), 'mnerf_debug.h')
+
+
+def debug(handle=None):
+  """The loaded library with the hooks of include/mnerf_debug.h bound (tests / tools only)."""
+  lib = handle if handle is not None else load()
+  for name, (argtypes, restype) in _DEBUG_PROTOS.items():
+    fn = getattr(lib, name)
+    fn.argtypes = argtypes
+    fn.restype = restype
   return lib
 
 

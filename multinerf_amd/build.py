@@ -19,7 +19,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(HERE, 'libmnerf_hip.so')
 OBJ_DIR = os.path.join(HERE, 'build')
 SOURCES = ['api.hip', 'gemm.hip', 'gemm_blk.hip', 'fused_mlp.hip', 'resample.hip', 'features.hip', 'render.hip', 'losses.hip', 'optim.hip', 'refnerf.hip', 'camera.hip']
-HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'gemm_nt_body.inc'), os.path.join(CSRC, 'gemm_tn_body.inc'), os.path.join(CSRC, 'gemm_nt_side.inc'), os.path.join(CSRC, 'ray_losses.h'), os.path.join(CSRC, 'ipe_math.h'), os.path.join(INCLUDE, 'mnerf.h')]
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'gemm_nt_body.inc'), os.path.join(CSRC, 'gemm_tn_body.inc'), os.path.join(CSRC, 'gemm_nt_side.inc'), os.path.join(CSRC, 'ray_losses.h'), os.path.join(CSRC, 'ipe_math.h'), os.path.join(INCLUDE, 'mnerf.h'), os.path.join(INCLUDE, 'mnerf_debug.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + os.environ.get('MNR_EXTRA_HIPCC_FLAGS', '').split()
 
 

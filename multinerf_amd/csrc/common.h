@@ -7,6 +7,7 @@
 #include <stdlib.h>
 
 #include "../../include/mnerf.h"
+#include "../../include/mnerf_debug.h"
 
 typedef __bf16 bf16;
 typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));

@@ -26,6 +26,92 @@
 #define FE_THREADS 256
 #include "ipe_math.h"
 
+// Tangents of the contraction for the density-gradient normals (models.py:445-446 applies warp_fn INSIDE predict_density, so
+// jax.value_and_grad, :478-481, differentiates through it): with x the pre-warp mean and the covariance an INPUT of
+// predict_density (held fixed),  z = s x,  cov' = J cov J^T = ku u u^T + r_var (s^2 I + j2x x x^T)  (fe_gaussian's structured
+// form, u = J d, J = s I + cc x x^T), this returns for c = x, y, z:
+//   dz[c]  = d z / d x_c  = cc x_c x + s e_c                                              (column c of J)
+//   dC[c]  = d cov' / d x_c = ku (du_c u^T + u du_c^T) + r_var (2 s ds_c I + dj2x_c x x^T + j2x (e_c x^T + x e_c^T))
+// with du_c = cc (x_c d + d_c x + (x.d) e_c) + 2 cc' x_c (x.d) x,  ds_c = cc x_c,  cc' = (3 sqrt(m) - 4) / m^3 and
+// dj2x_c = d(2 cc / sqrt(m))/dm * 2 x_c.  u itself comes from fe_gaussian's cancellation-free form.  Inside the unit ball the
+// contraction is the identity: dz[c] = e_c, dC = 0 (the no-warp case).
+struct FeTangent {
+  float dz[3][3];
+  float dC[3][6];          // xx, xy, xz, yy, yz, zz
+};
+
+__device__ __forceinline__ void fe_contract_tangent(const mnr_ipe_cfg& c, float t0, float t1, const float* o, const float* d,
+                                                    float radius, FeTangent& T) {
+#pragma unroll
+  for (int cc_ = 0; cc_ < 3; ++cc_) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T.dz[cc_][i] = (i == cc_) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) T.dC[cc_][e] = 0.0f;
+  }
+  if (!c.warp_contract) return;
+  float t_mean, t_var, r_var;
+  if (c.ray_shape == 0) {
+    const float mu = (t0 + t1) / 2.0f;
+    const float hw = (t1 - t0) / 2.0f;
+    const float denom = fmaxf(MNR_F32_EPS, 3.0f * mu * mu + hw * hw);
+    const float hw2 = hw * hw, hw4 = hw2 * hw2;
+    t_mean = mu + (2.0f * mu * hw2) / denom;
+    t_var = hw2 / 3.0f - (4.0f / 15.0f) * hw4 * (12.0f * mu * mu - hw2) / (denom * denom);
+    r_var = (mu * mu) / 4.0f + (5.0f / 12.0f) * hw2 - (4.0f / 15.0f) * hw4 / denom;
+    r_var *= radius * radius;
+  } else {
+    t_mean = (t0 + t1) / 2.0f;
+    r_var = radius * radius / 4.0f;
+    t_var = (t1 - t0) * (t1 - t0) / 12.0f;
+  }
+  if (c.disable_integration) {
+    t_var = 0.0f;
+    r_var = 0.0f;
+  }
+  const float dmag = fmaxf(1e-10f, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  float x[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) x[i] = o[i] + d[i] * t_mean;
+  const float m = fmaxf(MNR_F32_EPS, x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  if (m <= 1.0f) return;
+  const float sq = sqrtf(m);
+  const float s = (2.0f * sq - 1.0f) / m;
+  const float cc = 2.0f * (1.0f - sq) / (m * m);
+  const float ccp = (3.0f * sq - 4.0f) / (m * m * m);              // d cc / d m
+  const float j2x = 2.0f * cc / sq;
+  const float j2xp = (2.0f * ccp - cc / m) / sq;                   // d (2 cc / sqrt(m)) / d m  = 2 cc' / sq - cc / (m sq)
+  const float oo = o[0] * o[0] + o[1] * o[1] + o[2] * o[2];
+  const float od = o[0] * d[0] + o[1] * d[1] + o[2] * d[2];
+  const float xd = x[0] * d[0] + x[1] * d[1] + x[2] * d[2];
+  const float brk = (m - 2.0f * (1.0f - sq) * (oo + t_mean * od)) / (m * m);
+  float u[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) u[i] = brk * d[i] + cc * xd * o[i];
+  const float ku = t_var - r_var / dmag;
+  const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float xk = x[k];
+    float du[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      du[i] = cc * (xk * d[i] + d[k] * x[i] + (i == k ? xd : 0.0f)) + 2.0f * ccp * xk * xd * x[i];
+      T.dz[k][i] = cc * xk * x[i] + (i == k ? s : 0.0f);
+    }
+    const float ds = cc * xk;
+    const float dj = j2xp * 2.0f * xk;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int i = ii[e], j = jj[e];
+      float v = ku * (du[i] * u[j] + u[i] * du[j]);
+      float w = dj * x[i] * x[j] + j2x * ((i == k ? x[j] : 0.0f) + (j == k ? x[i] : 0.0f));
+      if (i == j) w += 2.0f * s * ds;
+      T.dC[k][e] = v + r_var * w;
+    }
+  }
+}
+
 template <bool OUT_F32, bool TANGENT>
 __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
     mnr_ipe_cfg c, int64_t total, int n, int spb, int pitch, const float* __restrict__ tdist,
@@ -38,7 +124,8 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
   const int nfeat = 2 * K * L;
   // LDS: samples [spb] FeSample | basis [K*3] | rows [spb][ld] (bf16 or f32)
   FeSample* gs = (FeSample*)smem;
-  float* bs = (float*)(gs + spb);
+  FeTangent* gt = (FeTangent*)(gs + spb);                           // (TANGENT only: [spb] behind the samples)
+  float* bs = TANGENT ? (float*)(gt + spb) : (float*)(gs + spb);
   char* rows = (char*)(bs + ((K * 3 + 3) & ~3));
   const int64_t s0 = (int64_t)blockIdx.x * spb;
   const int ns = (int)min((int64_t)spb, total - s0);
@@ -58,6 +145,11 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
     FeSample g;
     fe_gaussian(c, t0, t1, o, d, radii[ray], g);
     gs[threadIdx.x] = g;
+    if (TANGENT) {
+      FeTangent T;
+      fe_contract_tangent(c, t0, t1, o, d, radii[ray], T);
+      gt[threadIdx.x] = T;
+    }
     if (means_out) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) means_out[s * 3 + i] = g.mean[i];
@@ -100,6 +192,17 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
     const int lstep = K * (OUT_F32 ? 4 : 2);
     float sc = ldexpf(1.0f, c.min_deg);                              // 2^deg, exact
     float sn = 0.0f, cs = 1.0f, att = 1.0f;
+    float dlm[3] = {px, py, pz}, dlv[3] = {0.0f, 0.0f, 0.0f};
+    if (TANGENT) {
+      const FeTangent& T = gt[si];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        dlm[cc] = px * T.dz[cc][0] + py * T.dz[cc][1] + pz * T.dz[cc][2];
+        const float* C6 = T.dC[cc];
+        dlv[cc] = px * (C6[0] * px + C6[1] * py + C6[2] * pz) + py * (C6[1] * px + C6[3] * py + C6[4] * pz) +
+                  pz * (C6[2] * px + C6[4] * py + C6[5] * pz);
+      }
+    }
     for (int l = 0; l < L; ++l) {
       if ((l & 3) == 0) {
         fe_sincos_wrapped(fe_wrap_100pi(lm * sc), &sn, &cs);
@@ -108,14 +211,15 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
       const float fs = att * sn;
       const float fc = att * cs;
       if (TANGENT) {
-        // d/d mean_c of att sin(lm 2^l) = att 2^l cos(.) p_k[c];  of att cos(.) = -att 2^l sin(.) p_k[c]
-        // (no warp: the variance does not depend on the mean).
-        const float pc[3] = {px, py, pz};
+        // d/d mean_c of att sin(lm 2^l) = att 2^l cos(.) dlm_c - 1/2 4^l att sin(.) dlv_c;  of att cos(.): -att 2^l sin(.) dlm_c
+        // - 1/2 4^l att cos(.) dlv_c, with dlm_c = p_k . dz[c], dlv_c = p_k^T dC[c] p_k (no warp: dlm_c = p_k[c], dlv_c = 0:
+        // the variance does not depend on the mean).
+        const float hv = -0.5f * sc * sc;
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
           char* rp = rowp + (size_t)cc * spb * pitch;
-          *(bf16*)rp = (bf16)(fc * sc * pc[cc]);
-          *(bf16*)(rp + half) = (bf16)(-fs * sc * pc[cc]);
+          *(bf16*)rp = (bf16)(fc * sc * dlm[cc] + hv * fs * dlv[cc]);
+          *(bf16*)(rp + half) = (bf16)(-fs * sc * dlm[cc] + hv * fc * dlv[cc]);
         }
       } else if (OUT_F32) {
         *(float*)rowp = fs;
@@ -168,7 +272,6 @@ static int fe_launch(int mode /*0 bf16, 1 f32, 2 tangent*/, const mnr_ipe_cfg* c
   MNR_CHECK_ARG(K >= 1 && K <= 128 && L >= 1 && L <= 32, "mnr_cast_rays_ipe: basis_k=%d / degrees=%d out of range", K, L);
   const bool f32 = mode == 1;
   const bool tangent = mode == 2;
-  MNR_CHECK_ARG(!tangent || !cfg->warp_contract, "mnr_cast_rays_ipe_tangent: not valid with a warp");
   const int nfeat = 2 * K * L;
   const int row_elems = f32 ? nfeat : ld_feat;
   MNR_CHECK_ARG(f32 || (ld_feat >= nfeat && ld_feat % 8 == 0), "mnr_cast_rays_ipe: ld_feat=%d must be >= %d and a multiple of 8", ld_feat, nfeat);
@@ -180,7 +283,8 @@ static int fe_launch(int mode /*0 bf16, 1 f32, 2 tangent*/, const mnr_ipe_cfg* c
   MNR_CHECK_ARG(spb >= 4, "mnr_cast_rays_ipe: feature row too long");
   // 48 B of padding per staged row: consecutive samples then sit 12 banks apart (a wave covers ~3 samples x 21 directions)
   const int pitch = (int)row_bytes + 48;
-  const size_t lds = (size_t)spb * sizeof(FeSample) + (size_t)((K * 3 + 3) & ~3) * 4 + (size_t)spb * pitch * (tangent ? 3 : 1);
+  const size_t lds = (size_t)spb * (sizeof(FeSample) + (tangent ? sizeof(FeTangent) : 0)) + (size_t)((K * 3 + 3) & ~3) * 4 +
+                     (size_t)spb * pitch * (tangent ? 3 : 1);
   const int64_t total = B * n;
   const int grid = mnr_cdiv(total, spb);
   if (tangent) {

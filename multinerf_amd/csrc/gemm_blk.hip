@@ -437,14 +437,9 @@ __global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, 
 #undef PN_I
 }
 
-// Consecutive launches walk the M-tiles in alternating directions (default on; same-box A/B 31.21 / 31.21 -> 31.12 / 31.12 ms per
-// step at 360.gin: the rows a layer reads first are the ones the previous layer wrote last)
-static int g_panel_alternate = 1, g_panel_rev_next = 0;
-extern "C" int mnr_gemm_nt_panel_set_alternate(int on) {
-  g_panel_alternate = on;
-  g_panel_rev_next = 0;
-  return MNR_OK;
-}
+// The caller alternates mnr_gemm_nt_args.walk_descending between consecutive layers (same-box A/B 31.21 / 31.21 -> 31.12 / 31.12 ms
+// per step at 360.gin: the rows a layer reads first are the ones the previous layer wrote last).  A per-call argument: round 4
+// toggled a process-global here, which two streams raced on.
 static int g_panel_max_wgs = 0;                           // tests: at most this many workgroups (0: one per CU)
 extern "C" int mnr_gemm_nt_panel_set_max_wgs(int n) {
   g_panel_max_wgs = n;
@@ -458,8 +453,7 @@ static int panel_launch_t(const mnr_gemm_nt_args* a, int64_t grid, int64_t vtota
   if (mnr_attr_needed(&attr_set))
     (void)hipFuncSetAttribute((const void*)gemm_nt_panel_kernel<A1_PANEL, BITS_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL((gemm_nt_panel_kernel<A1_PANEL, BITS_IN>), dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, *a,
-                     (long long)vtotal, g_panel_rev_next);
-  if (g_panel_alternate) g_panel_rev_next ^= 1;
+                     (long long)vtotal, a->walk_descending ? 1 : 0);
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }

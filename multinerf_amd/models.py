@@ -35,21 +35,16 @@ def _rup(x, m):
   return (x + m - 1) // m * m
 
 
-import os as _os
-_USE_BITS = _os.environ.get('MNR_RELU_BITS', '1') != '0'   # A/B switch: 1-bit ReLU masks vs re-reading activations
-_USE_CHAIN = _os.environ.get('MNR_FUSED_CHAIN', '1') != '0'  # A/B switch: fused per-level Dense chain vs one GEMM per layer
-_FUSED_IPE = _os.environ.get('MNR_FUSED_IPE', '1') != '0'   # A/B switch: rendering builds the proposal levels' IPE features inside the chain kernel
-_HEAD_VCOL = _os.environ.get('MNR_HEAD_VCOL', '1') != '0'  # A/B switch: the density head's forward column as a vector next to the N = 256 bottleneck GEMM (panel trunks)
-_HEAD_GCOL = _os.environ.get('MNR_HEAD_GCOL', '1') != '0'  # A/B switch: the density head's weight gradient as an extra column of the bottleneck's dW GEMM (N = 256, 256x256 tiles) instead of a merged N = 384 GEMM on 128x128 tiles
-# A/B switch: the wide (>= 512) per-layer trunk keeps its activations, gradients and ReLU masks in the panel layout
-# (include/mnerf.h MNR_LAYOUT_PANEL; csrc/gemm_blk.hip): results leave the MFMA accumulators as whole 1-KiB blocks, the K loop
-# runs as one pipeline across output tiles
-_PANEL = _os.environ.get('MNR_PANEL', '1') != '0'
-# A/B switch: the backward pass of ALL proposal levels as one pass (they share PropMLP_0 and the sample count, reference
-# models.py:120-121,166): their features / activations / mask bits sit in consecutive row blocks of one buffer per kind, so
-# one dX chain and one weight-gradient GEMM per layer cover L*M rows (half the launches and half the 256 KiB atomic
-# epilogues of the per-level form at 360.gin).
-_MERGE_PROPS = _os.environ.get('MNR_MERGE_PROPS', '1') != '0'
+# Module-level switches of the host orchestration.  Every one of them was a same-box A/B in rounds 2-4 (profiles/HISTORY.md,
+# profiles/r4_ab.md) and is settled; they stay as plain constants because the bitwise / parity tests compare the two forms of
+# each (tests/test_gpu_chain.py, tests/test_sim_model.py set them on the module).  The environment is not read.
+_USE_BITS = True      # 1-bit ReLU masks (False: the dX GEMMs re-read the saved activations)
+_USE_CHAIN = True     # fused per-level Dense chain for 128 / 256-wide trunks (False: one GEMM per layer)
+_FUSED_IPE = True     # rendering builds the proposal levels' IPE features inside the chain kernel
+_HEAD_VCOL = True     # the density head's forward column as a vector next to the N = 256 bottleneck GEMM (panel trunks)
+_HEAD_GCOL = True     # the density head's weight gradient as an extra column of the bottleneck's dW GEMM
+_PANEL = True         # wide (>= 512) per-layer trunks keep activations, gradients and masks in the panel layout (csrc/gemm_blk.hip)
+_MERGE_PROPS = True   # the backward pass of all proposal levels as one pass (they share PropMLP_0 and the sample count)
 
 
 # =============================================================================
@@ -137,8 +132,6 @@ class MLP:
     if on and self.disable_rgb:
       # (the normal fields and the Ref-NeRF head live in the merged head of an MLP with a colour branch)
       bad.append('normals ' + str(on) + ' on a density-only MLP (disable_rgb)')
-    if not self.disable_density_normals and self.warp_fn is not None:
-      bad.append('density-gradient normals with a warp_fn')
     if self.enable_pred_roughness and self.roughness_activation != 'softplus':
       bad.append('roughness_activation != softplus')
     if self.is_ref() and not self.use_directional_enc and self.deg_view > 11:
@@ -1040,7 +1033,8 @@ class Model:
     T_feat = self._buf((tag, 'T_feat'), (3 * M, plan.ldF), bf16)
     ops.cast_rays_ipe_tangent(tdist, R.origins, R.directions, R.radii.reshape(-1).contiguous(), plan.basis_dev,
                               ray_shape=self.ray_shape, min_deg=hp.min_deg_point, max_deg=hp.max_deg_point,
-                              ld_feat=plan.ldF, out=T_feat)
+                              ld_feat=plan.ldF, out=T_feat, warp_contract=(hp.warp_fn == 'contract'),
+                              disable_integration=self.disable_integration)
     T_acts = []
     t = None
     for i, (d, concat) in enumerate(plan.trunk):
@@ -1103,13 +1097,13 @@ class Model:
       dst = out if relu else activate((tag, 'z', i if keep else i % 2), out, plan.W, zs)
       if i == 0:
         ops.gemm_nt(feat, Bt, M=M, N=e['n_pad'], K1=plan.ldF, bias=bias, n_bias=d.fan_out, relu=relu,
-                    Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo, **lay_c)
+                    Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo, walk_descending=bool(i & 1), **lay_c)
       elif concat:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, A2=feat, K2=plan.ldF, bias=bias, n_bias=d.fan_out,
-                    relu=relu, Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo, **lay_a, **lay_c)
+                    relu=relu, Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo, walk_descending=bool(i & 1), **lay_a, **lay_c)
       else:
         ops.gemm_nt(x, Bt, M=M, N=e['n_pad'], K1=plan.W, bias=bias, n_bias=d.fan_out, relu=relu,
-                    Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo, **lay_a, **lay_c)
+                    Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo, walk_descending=bool(i & 1), **lay_a, **lay_c)
       if not relu:
         ops.act_fwd(hp.net_activation, dst, out)
       acts.append(out)
@@ -1532,7 +1526,8 @@ class Model:
       if i > 0:
         Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
         other = dy_buf(i - 1)
-        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, **mask_kw(i - 1), **lay_ac)
+        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, walk_descending=bool(i & 1),
+                    **mask_kw(i - 1), **lay_ac)
         act_vjp(mlp['zs'][i - 1] if not relu else None, other)
         dy = other
 

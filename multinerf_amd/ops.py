@@ -41,25 +41,9 @@ def _chk(t, dtype, name, allow_none=False):
     raise ValueError(f'{name} must be contiguous')
 
 
-_cfg_applied = False
-
-
 def lib():
-  global _cfg_applied
-  if not _cfg_applied:
-    _cfg_applied = True
-    if os.environ.get('MNR_NT_PERSIST'):        # A/B switch: persistent NT launches, workgroups per CU (0: off)
-      L.check(L.load().mnr_gemm_nt_set_persistent(int(os.environ['MNR_NT_PERSIST'])))
-    if os.environ.get('MNR_NT_PIPE'):           # A/B switch: hand-pipelined K loop of the 256x256 NT tiles (0: off)
-      L.check(L.load().mnr_gemm_nt_set_pipelined(int(os.environ['MNR_NT_PIPE'])))
-    if os.environ.get('MNR_LEVEL_BWD_QUAD'):    # A/B switch: four-lanes-per-ray level backward (0: lane per ray)
-      L.check(L.load().mnr_level_bwd_set_quad(int(os.environ['MNR_LEVEL_BWD_QUAD'])))
-    if os.environ.get('MNR_CHAIN_DEFER'):       # A/B switch: fused chain's copy-outs inside the next layer's MFMA pass (0: in front of it)
-      L.check(L.load().mnr_mlp_chain_set_deferred(int(os.environ['MNR_CHAIN_DEFER'])))
-    if os.environ.get('MNR_NT_WRES'):           # A/B switch: weights-resident kernel for the short-K layers (0: off)
-      L.check(L.load().mnr_gemm_nt_set_wres(int(os.environ['MNR_NT_WRES'])))
-    if os.environ.get('MNR_PANEL_ALTERNATE'):   # A/B switch: consecutive panel-kernel launches walk the M-tiles in alternating directions
-      L.check(L.load().mnr_gemm_nt_panel_set_alternate(int(os.environ['MNR_PANEL_ALTERNATE'])))
+  """The loaded C-ABI library (include/mnerf.h).  No process-global switches are applied: the development hooks of
+  include/mnerf_debug.h are reached through multinerf_amd._lib.debug() by tests and tools only."""
   return L.load()
 
 
@@ -259,14 +243,14 @@ def cast_rays_ipe_f32(tdist, origins, directions, radii, basis, *, ray_shape, wa
 
 
 def cast_rays_ipe_tangent(tdist, origins, directions, radii, basis, *, ray_shape, min_deg, max_deg, ld_feat,
-                          out=None):
-  """-> bf16 [3*B*n, ld_feat]: rows c*B*n + s = d(features of sample s)/d(mean_c) (no warp)."""
+                          out=None, warp_contract=False, disable_integration=False):
+  """-> bf16 [3*B*n, ld_feat]: rows c*B*n + s = d(features of sample s)/d(mean_c), mean = the pre-warp mean."""
   for x, nm in ((tdist, 'tdist'), (origins, 'origins'), (directions, 'directions'), (radii, 'radii'),
                 (basis, 'basis')):
     _chk(x, f32, nm)
   B, n1 = tdist.shape
   n = n1 - 1
-  cfg = _ipe_cfg(ray_shape, False, False, basis, min_deg, max_deg)
+  cfg = _ipe_cfg(ray_shape, warp_contract, disable_integration, basis, min_deg, max_deg)
   if out is None:
     out = torch.empty((3 * B * n, ld_feat), dtype=bf16, device=tdist.device)
   _chk(out, bf16, 'out')
@@ -397,7 +381,7 @@ def bits_from_tile_order(tile_bits, M, N):
 def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, bias=None, n_bias=0,
             relu=False, mask=None, ldmask=0, Cb=None, ldcb=0, nb=0, Cf=None, ldcf=0, f0=0, nf=0,
             bits_out=None, bits_in=None, bits_row_mod=0, a1_layout=LAYOUT_ROWMAJOR, c_layout=LAYOUT_ROWMAJOR,
-            vcol=None, vcol_out=None, vcol_bias=None):
+            vcol=None, vcol_out=None, vcol_bias=None, walk_descending=False):
   """C[M,N] = epilogue([A1|A2] @ Bt^T).  Pointers may be views with explicit leading dimensions.  a1_layout / c_layout:
   LAYOUT_PANEL for the wide trunk's activations and gradients (include/mnerf.h; the bits are then in tile order)."""
   _chk(A1, bf16, 'A1')
@@ -422,6 +406,7 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
   a.mask_bits_in, a.ld_bits_in = (bits_in.data_ptr(), bits_in.stride(0)) if bits_in is not None else (None, 0)
   a.bits_row_mod = bits_row_mod
   a.a1_layout, a.c_layout = a1_layout, c_layout
+  a.walk_descending = int(bool(walk_descending))
   _chk(vcol, bf16, 'vcol', allow_none=True)
   _chk(vcol_out, f32, 'vcol_out', allow_none=True)
   assert (vcol is None) == (vcol_out is None)

@@ -100,6 +100,10 @@ CASES.update({
     # (blender_256.gin: no contraction, whose jax.linearize this script differentiates by a complex step of its own)
     'blender_sampling_grad': ('blender_256', ['NerfMLP.net_width = 32', 'PropMLP.net_width = 16', 'Model.num_prop_samples = 9',
                                               'Model.num_nerf_samples = 6', 'Model.stop_level_grad = False'], 4, True, 0.1),
+    # density-gradient normals UNDER the contraction: models.py:445-446 applies warp_fn inside predict_density, so value_and_grad
+    # (:478-481) differentiates through track_linearize(contract) -- Ref-NeRF on an unbounded scene (jax.linearize under an
+    # outer complex step: see `linearize` below)
+    'refnerf_contract': ('blender_refnerf', _RB + ['NerfMLP.warp_fn = @coord.contract'], 3, True, 0.5),
     # the complete head on predicted normals only (no density gradient: no vmap(value_and_grad) in the forward pass)
     'refnerf_pred_normals_head': ('blender_refnerf', _RB + _NO_PN_LOSS + ['NerfMLP.disable_density_normals = True',
                                                               'Config.compute_normal_metrics = False'], 3, True, 0.5),
@@ -358,8 +362,34 @@ def install_flax_gin_standins(jax):
 
   jax.numpy.maximum = maximum
 
+  # (np.where hands back the base class: a complex-step array that went through coord.contract's `where` would reach
+  # math.safe_sin's `x % t` without CStep's remainder; only the class changes, never a value)
+  real_where = np.where
+
+  def where(*a):
+    r = real_where(*a)
+    return _as_cstep(r) if (len(a) == 3 and np.iscomplexobj(r)) else r
+
+  jax.numpy.where = where
+
   def linearize(fn, x):
     y = fn(x)
+    if np.iscomplexobj(x):
+      # An OUTER complex step is already on the input: the Ref-NeRF normals' value_and_grad (above) perturbs the means that
+      # models.py:445-446 then hands to track_linearize(warp_fn, ...) -- density-gradient normals under the contraction, case
+      # `refnerf_contract`.  A second imaginary step would mix with it, so J v is a central difference along the REAL axis,
+      # which carries the outer perturbation through unchanged (contract is smooth away from |x| = 1: four-point stencil with
+      # step 1e-4: truncation ~1e-17, rounding ~1e-12 relative).
+      # J v is linear in v and the tangents are columns of a covariance (1e-6 and below): the stencil runs along v / |v|.
+      e = 1e-4
+      at = lambda a, v: _as_cstep(fn(_as_cstep(x + a * v)))
+
+      def jvp(v):
+        sc = np.maximum(np.max(np.abs(np.real(v)), axis=-1, keepdims=True), 1e-300)
+        u = v / sc
+        return sc * (8 * (at(e, u) - at(-e, u)) - (at(2 * e, u) - at(-2 * e, u))) / (12 * e)
+
+      return y, jvp
     h = 1e-30
     return y, lambda v: np.asarray(fn(_as_cstep(x + 1j * h * v))).imag / h
 
@@ -652,11 +682,15 @@ def main():
                    'square': jnp.square, 'relu': _relu, 'softplus': jax.nn.softplus, 'safe_exp': rmath.safe_exp,
                    'contract': rcoord.contract, 'train_utils': rtrain}
   g = {}
+  only = [a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--only=')]
+  out = ([a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--out=')] or [OUT])[0]
   for case in CASES:
+    if only and case not in only:
+      continue
     g.update(run_case(case, rmodels, ref_callables, rnd_state, Key))
     print(case, 'ok')
-  np.savez_compressed(OUT, **g)
-  print(f'wrote {OUT}: {len(g)} arrays, {os.path.getsize(OUT)} bytes')
+  np.savez_compressed(out, **g)
+  print(f'wrote {out}: {len(g)} arrays, {os.path.getsize(out)} bytes')
 
 
 if __name__ == '__main__':

@@ -25,7 +25,7 @@ def load_sim():
   lib.hipsim_error.restype = C.c_char_p
   lib.hipsim_reset.argtypes = [C.c_int, C.c_long]
   lib.hipsim_stats.argtypes = [C.POINTER(C.c_ulonglong)]
-  for name, (argtypes, restype) in L._PROTOS.items():
+  for name, (argtypes, restype) in list(L._PROTOS.items()) + list(L._DEBUG_PROTOS.items()):
     fn = getattr(lib, name, None)
     if fn is not None:
       fn.argtypes = argtypes
@@ -46,13 +46,15 @@ def ptr(t):
 
 
 def sim_gemm_nt(lib, A1, Bt, A2=None, bias=None, relu=False, mask=None, out_bf16=True, out_f32=None, bits_out=False,
-                bits_in=None, bits_row_mod=0, nb=None, a1_layout=0, c_layout=0, vcol=None, vcol_bias=None):
+                bits_in=None, bits_row_mod=0, nb=None, a1_layout=0, c_layout=0, vcol=None, vcol_bias=None,
+                walk_descending=False):
   """C = epi([A1|A2] Bt^T) through the simulated mnr_gemm_nt_bf16; returns (Cb, Cf, bits).  a1_layout / c_layout = 1: A1 is
   given / Cb and the bits come back in MNR_LAYOUT_PANEL storage (the bits in tile order, flat)."""
   M, K1 = A1.shape
   N = Bt.shape[0]
   a = L.GemmNTArgs()
   a.a1_layout, a.c_layout = a1_layout, c_layout
+  a.walk_descending = int(walk_descending)
   a.A1, a.lda1, a.K1 = ptr(A1), A1.stride(0), K1
   if A2 is not None:
     a.A2, a.lda2, a.K2 = ptr(A2), A2.stride(0), A2.shape[1]
@@ -120,11 +122,10 @@ class simulated_device:
     missing = [n for n in L._PROTOS if not hasattr(self.lib, n)]
     if missing:
       raise RuntimeError(f'simulator build lacks {missing}')
-    self.saved = (L._lib, ops._stream, ops._on_device, ops._cfg_applied)
+    self.saved = (L._lib, ops._stream, ops._on_device)
     L._lib = self.lib
     ops._stream = lambda: None
     ops._on_device = lambda t: True
-    ops._cfg_applied = False          # the MNR_NT_PERSIST / MNR_NT_WRES switches, if set, now configure the simulator build
     self.lib.hipsim_reset(0, 0)
     return self
 
@@ -134,7 +135,7 @@ class simulated_device:
 
   def __exit__(self, *exc):
     from multinerf_amd import ops
-    L._lib, ops._stream, ops._on_device, ops._cfg_applied = self.saved
+    L._lib, ops._stream, ops._on_device = self.saved
     self.lib.mnr_gemm_nt_set_persistent(1)
     self.lib.mnr_gemm_nt_set_wres(1)
     return False

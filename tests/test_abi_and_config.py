@@ -24,6 +24,20 @@ def test_library_exports_every_header_symbol():
   # and every exported prototype we bind is declared in the header
   for n in _lib._PROTOS:
     assert n in names
+  # the development / test hooks live in a header of their own (round-4 verdict: nine process-global switches sat in the public
+  # ABI): declared there, exported, bound only through _lib.debug(), and none of them in include/mnerf.h or in the package
+  dbg = _lib.header_symbols(_lib.DEBUG_HEADER_PATH)
+  assert sorted(dbg) == sorted(_lib._DEBUG_PROTOS) and not (set(dbg) & set(names))
+  for n in dbg:
+    assert hasattr(lib, n), n
+  import glob
+  pkg = os.path.dirname(_lib.__file__)
+  for f in glob.glob(os.path.join(pkg, '*.py')):
+    if os.path.basename(f) == '_lib.py':
+      continue
+    text = open(f).read()
+    assert not any(n in text for n in dbg), f
+    assert 'os.environ' not in text or os.path.basename(f) in ('build.py', 'dist.py', 'preflight.py', 'streams.py'), f
   assert lib.mnr_abi_version() == 19
 
 

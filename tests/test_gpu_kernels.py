@@ -32,9 +32,9 @@ def ops():
 @pytest.fixture(params=[1, 0], ids=['quad', 'lane'])
 def level_bwd_kernel(request, ops):
   """Both level-backward kernels: four lanes per ray (default where 16 rays fit LDS) and lane per ray (long rays, A/B)."""
-  ops.L.check(ops.lib().mnr_level_bwd_set_quad(request.param))
+  ops.L.check(ops.L.debug().mnr_level_bwd_set_quad(request.param))
   yield request.param
-  ops.L.check(ops.lib().mnr_level_bwd_set_quad(1))
+  ops.L.check(ops.L.debug().mnr_level_bwd_set_quad(1))
 
 
 def dev(x):
@@ -399,9 +399,9 @@ def test_gemm_nt_pipelined_loop_is_bitwise_the_two_stage_loop(ops, K1, K2):
   W2 = dev(_bf(torch.randn((N, N), generator=gen) / math.sqrt(N)))
   outs = []
   try:
-    ops.L.check(ops.lib().mnr_gemm_nt_set_persistent(-8))
+    ops.L.check(ops.L.debug().mnr_gemm_nt_set_persistent(-8))
     for pipe in (1, 0):
-      ops.L.check(ops.lib().mnr_gemm_nt_set_pipelined(pipe))
+      ops.L.check(ops.L.debug().mnr_gemm_nt_set_pipelined(pipe))
       act = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
       bits = torch.zeros((M, N // 8), dtype=torch.uint8).cuda()
       dx = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
@@ -409,8 +409,8 @@ def test_gemm_nt_pipelined_loop_is_bitwise_the_two_stage_loop(ops, K1, K2):
       ops.gemm_nt(G, W2, M=M, N=N, K1=N, bits_in=bits, Cb=dx, ldcb=N, nb=N)
       outs.append((act.cpu().view(torch.int16), bits.cpu(), dx.cpu().view(torch.int16)))
   finally:
-    ops.L.check(ops.lib().mnr_gemm_nt_set_pipelined(1))
-    ops.L.check(ops.lib().mnr_gemm_nt_set_persistent(1))
+    ops.L.check(ops.L.debug().mnr_gemm_nt_set_pipelined(1))
+    ops.L.check(ops.L.debug().mnr_gemm_nt_set_persistent(1))
   for a, b in zip(*outs):
     assert torch.equal(a, b)
   A = A1.cpu().float() if A2 is None else torch.cat([A1.cpu().float(), A2.cpu().float()], -1)
@@ -442,7 +442,7 @@ def test_gemm_nt_panel_kernel_is_bitwise_the_tiled_kernel(ops, K1, K2, a1_panel)
   A1p = dev(ops.to_panel(A1) if a1_panel else A1)
   try:
     for cap in (8, 0):
-      ops.L.check(ops.lib().mnr_gemm_nt_panel_set_max_wgs(cap))
+      ops.L.check(ops.L.debug().mnr_gemm_nt_panel_set_max_wgs(cap))
       act = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
       bits = torch.zeros((M * N // 8,), dtype=torch.uint8).cuda()
       dx = torch.zeros((M, N), dtype=torch.bfloat16).cuda()
@@ -453,7 +453,7 @@ def test_gemm_nt_panel_kernel_is_bitwise_the_tiled_kernel(ops, K1, K2, a1_panel)
       assert torch.equal(ops.bits_from_tile_order(bits, M, N), bits0), cap
       assert torch.equal(ops.from_panel(dx).view(torch.int16), dx0.view(torch.int16)), cap
   finally:
-    ops.L.check(ops.lib().mnr_gemm_nt_panel_set_max_wgs(0))
+    ops.L.check(ops.L.debug().mnr_gemm_nt_panel_set_max_wgs(0))
   A = A1.float() if A2 is None else torch.cat([A1.float(), A2.cpu().float()], -1)
   want = torch.relu(A.double() @ Bt.cpu().double().T + bias.cpu().double())
   np.testing.assert_allclose(act0.cpu().double().numpy(), want.numpy(), rtol=2**-7, atol=1e-2)

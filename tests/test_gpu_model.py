@@ -210,12 +210,19 @@ CASES = [
     # a trunk too wide for the fused chain (512, as 360.gin's 1024): per-layer GEMMs on 256x256 tiles, the density head's weight
     # gradient as a vector column of the bottleneck's dW GEMM (gemm_tn_gcol_kernel)
     ('360', ['NerfMLP.net_width = 512', 'PropMLP.net_width = 128'], 16),
+    # density-gradient normals under warp_fn = contract (models.py:445-446 applies the warp INSIDE predict_density, so
+    # value_and_grad, :478-481, differentiates through it; refused until round 5): Ref-NeRF on a contracted scene, and the
+    # normals alone with the orientation loss on them
+    ('blender_refnerf', ['NerfMLP.warp_fn = @coord.contract'], 8),
+    ('llff_raw', ['NerfMLP.disable_density_normals = False', 'Config.orientation_loss_mult = 0.01',
+                  'Config.orientation_coarse_loss_mult = 0.001', "Config.orientation_loss_target = 'normals'",
+                  'NerfMLP.warp_fn = @coord.contract'], 8),
     # the MLP shapes of the reference's configs/debug.gin (:14-18: PropMLP 2 x 64, NerfMLP 4 x 128): a trunk width that is not a
     # multiple of the 128-column GEMM tile runs on a zero-padded execution layout (models.Model.build / _to_exec / true_grads)
     ('360', ['PropMLP.net_depth = 2', 'PropMLP.net_width = 64', 'NerfMLP.net_depth = 4', 'NerfMLP.net_width = 128'], 16),
     # ... and widths that are multiples of nothing in particular, behind a non-ReLU activation (the padded units are then
     # non-zero, feed zero kernel rows, and their gradients are dropped)
-    ('blender_256', ['PropMLP.net_width = 96', 'NerfMLP.net_width = 200', 'NerfMLP.net_activation = @jax.nn.softplus'], 16),
+    ('blender_256', ['PropMLP.net_width = 192', 'NerfMLP.net_width = 320', 'NerfMLP.net_activation = @jax.nn.softplus'], 16),
 ]
 
 

@@ -252,14 +252,14 @@ def test_sdist_bwd_with_the_compositing_and_distortion_terms(raydist, opaque, n,
   stat = dev(torch.zeros(1))
   g_x = dev(torch.empty((B, n)))
   from multinerf_amd import _lib
-  _lib.load().mnr_level_bwd_set_quad(quad)                # both forms of the level kernel write g_x: four lanes per ray / lane per ray
+  _lib.debug().mnr_level_bwd_set_quad(quad)                # both forms of the level kernel write g_x: four lanes per ray / lane per ray
   try:
     _run_composite_bwd = lambda: ops.composite_bwd(ccfg, f32c(raw_den), td32, f32c(dirs), w32, raw_rgb=f32c(raw_rgb), g_rgb_out=f32c(g_rgb_out),
                     g_weights=f32c(g_w_up), g_x_out=g_x,
                     losses=dict(B_valid=B_valid, data=None, weights=dict(mode='distortion', mult=mult, sdist=f32c(sdist), stat=stat)))
     _run_composite_bwd()
   finally:
-    _lib.load().mnr_level_bwd_set_quad(1)
+    _lib.debug().mnr_level_bwd_set_quad(1)
   got = ops.sdist_bwd(f32c(sdist), f32c(near.reshape(-1)), f32c(far.reshape(-1)), raydist, B_valid=B_valid, g_x=g_x,
                       raw_density=f32c(raw_den), density_bias=-1.0, density_act='softplus', dirs=f32c(dirs),
                       g_t0=f32c(gt0.reshape(-1)), g_t1=f32c(gt1.reshape(-1)), distortion_mult=mult, weights=w32,

@@ -26,6 +26,11 @@ _spec = importlib.util.spec_from_file_location('make_golden_models', os.path.joi
 _gen = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_gen)
 CASES = _gen.CASES
+# Cases whose reference-side generator has a finite difference INSIDE the forward pass: density-gradient normals under the
+# contraction (`refnerf_contract`: jax.linearize under the outer complex step of value_and_grad is a four-point real-axis stencil,
+# tests/golden/make_golden_models.py `linearize`), whose 1e-12 error the sixteen IPE degrees' attenuation exp(-4^l var / 2)
+# amplifies: measured 6e-9 relative in raw_grad_density, held to 5e-8.  Everything else is exact to rounding and held to 1e-9.
+NESTED_FD = ('refnerf_contract',)
 GOLD = np.load(os.path.join(HERE, 'golden', 'models.npz'))
 
 
@@ -86,6 +91,8 @@ def test_model_apply_matches_the_reference_source(case):
   rend, hist = omodels.model_apply(om, on, op, params, rays, float(GOLD[f'{case}/train_frac']), True, zero_glo=False, noise=noise)
   assert len(rend) == m.num_levels
   tol = dict(rtol=1e-9, atol=1e-11)
+  if case in NESTED_FD:
+    tol = dict(rtol=5e-8, atol=1e-10)
   checked = 0
   for lvl in range(m.num_levels):
     for group, got in (('rendering', rend[lvl]), ('history', hist[lvl])):
@@ -125,6 +132,8 @@ def test_loss_terms_match_the_reference_source(case):
                       alphas=torch.as_tensor(b['alphas']), normals=torch.as_tensor(b['normals']))
   want = _sub(f'{case}/loss/')
   tol = dict(rtol=1e-9, atol=1e-12)
+  if case in NESTED_FD:
+    tol = dict(rtol=5e-8, atol=1e-10)
   loss, stats = otrain.compute_data_loss(batch, rend, rays, cfg)
   np.testing.assert_allclose(float(loss.detach()), want["data"], **tol)
   assert {f'stats_{k}' for k in stats} == {k for k in want if k.startswith('stats_')}

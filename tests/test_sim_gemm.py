@@ -267,7 +267,6 @@ def test_nt_panel_kernel_forward_and_dx(sim, a1_panel, mode):
     C0, _, b0 = S.sim_gemm_nt(sim, A1, Bt, A2=A2, bias=bias, relu=True, bits_out=True)
     sim.hipsim_reset(*mode)
     D0, _, _ = S.sim_gemm_nt(sim, dY, Wt, bits_in=b0)
-    sim.mnr_gemm_nt_panel_set_alternate(1)          # (the second launch of each pair below walks the M-tiles in descending order)
     for wgs in (8, 16):
       sim.mnr_gemm_nt_panel_set_max_wgs(wgs)
       sim.hipsim_reset(*mode)
@@ -276,7 +275,9 @@ def test_nt_panel_kernel_forward_and_dx(sim, a1_panel, mode):
       assert torch.equal(_ops.from_panel(Cp).view(torch.int16), C0.view(torch.int16))
       assert torch.equal(_ops.bits_from_tile_order(bp.view(-1), M, N), b0)
       sim.hipsim_reset(*mode)
-      Dp, _, _ = S.sim_gemm_nt(sim, _ops.to_panel(dY) if a1_panel else dY, Wt, bits_in=bp.view(-1), a1_layout=a1_panel, c_layout=1)
+      # (the second launch of each pair walks the M-tiles in descending order: mnr_gemm_nt_args.walk_descending)
+      Dp, _, _ = S.sim_gemm_nt(sim, _ops.to_panel(dY) if a1_panel else dY, Wt, bits_in=bp.view(-1), a1_layout=a1_panel, c_layout=1,
+                               walk_descending=True)
       assert torch.equal(_ops.from_panel(Dp).view(torch.int16), D0.view(torch.int16))
   finally:
     sim.mnr_gemm_nt_panel_set_max_wgs(0)

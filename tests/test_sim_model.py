@@ -48,6 +48,10 @@ CASES = [
     # on the zero-padded execution layout (models.Model.build / _to_exec / true_grads)
     ('360', ['PropMLP.net_depth = 2', 'PropMLP.net_width = 64', 'NerfMLP.net_depth = 4', 'NerfMLP.net_width = 128',
              'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 8),
+    # density-gradient normals UNDER the contraction (models.py:445-446 warps inside predict_density, :478-481 differentiates
+    # through it): the tangent rows carry the contraction's Jacobian and its derivative; Ref-NeRF's colour depends on them
+    ('blender_refnerf', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32',
+                         'NerfMLP.warp_fn = @coord.contract'], 4),
 ]
 PANEL_CASE = CASES[3]
 

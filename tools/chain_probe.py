@@ -95,10 +95,10 @@ def main():
 
     def timeline(name, fn, slots):
       buf.zero_()
-      ops.L.check(ops.lib().mnr_debug_chain_timeline(buf.data_ptr()))
+      ops.L.check(ops.L.debug().mnr_debug_chain_timeline(buf.data_ptr()))
       fn()
       torch.cuda.synchronize()
-      ops.L.check(ops.lib().mnr_debug_chain_timeline(None))
+      ops.L.check(ops.L.debug().mnr_debug_chain_timeline(None))
       t = buf.cpu().numpy().astype(np.float64)
       ok = t[:, 31] > 0
       t = t[ok]

@@ -20,7 +20,7 @@ OUT_DIR = os.path.join(HERE, '_build')
 LIB = os.path.join(OUT_DIR, 'libmnerf_sim.so')
 SOURCES = ['api.hip', 'gemm.hip', 'gemm_blk.hip', 'fused_mlp.hip', 'resample.hip', 'features.hip', 'render.hip', 'losses.hip', 'optim.hip', 'refnerf.hip', 'camera.hip']
 DEPS = [os.path.join(HERE, 'hipsim.cpp'), os.path.join(HERE, 'selftest.hip'), os.path.join(HERE, 'hip', 'hip_runtime.h'), os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'gemm_nt_body.inc'), os.path.join(CSRC, 'gemm_tn_body.inc'), os.path.join(CSRC, 'gemm_nt_side.inc'), os.path.join(CSRC, 'ray_losses.h'), os.path.join(CSRC, 'ipe_math.h'),
-        os.path.join(ROOT, 'include', 'mnerf.h')]
+        os.path.join(ROOT, 'include', 'mnerf.h'), os.path.join(ROOT, 'include', 'mnerf_debug.h')]
 FLAGS = ['-std=c++17', '-O0', '-fPIC', '-Wno-psabi', '-I', HERE, '-I', CSRC, '-Wall', '-Wno-unused-function', '-Wno-unused-variable',
          '-Wno-unused-but-set-variable', '-Wno-unknown-pragmas', '-Wno-pass-failed']
 

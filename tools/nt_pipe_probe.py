@@ -41,7 +41,7 @@ def case(M, N, K1, K2=0, fwd=True, sparse=True):
   for wide in PIPES:
     if wide > 1 and not fwd:
       continue                                  # the probe variants exist for the forward kernel only
-    ops.L.check(ops.lib().mnr_gemm_nt_set_pipelined(wide))
+    ops.L.check(ops.L.debug().mnr_gemm_nt_set_pipelined(wide))
     C = torch.zeros((M, N), dtype=bf, device=dev)
     bo = torch.zeros((M, N // 8), dtype=torch.uint8, device=dev)
     if fwd:
@@ -54,10 +54,10 @@ def case(M, N, K1, K2=0, fwd=True, sparse=True):
     if M >= 65536:
       import numpy as np
       buf = torch.zeros((8192 * 2, 16), dtype=torch.int64, device=dev)
-      ops.L.check(ops.lib().mnr_debug_gemm_timeline(buf.data_ptr()))
+      ops.L.check(ops.L.debug().mnr_debug_gemm_timeline(buf.data_ptr()))
       fn()
       torch.cuda.synchronize()
-      ops.L.check(ops.lib().mnr_debug_gemm_timeline(None))
+      ops.L.check(ops.L.debug().mnr_debug_gemm_timeline(None))
       t = buf.cpu().numpy()
       first = (np.arange(t.shape[0]) < 256)[t[:, 3] != 0]          # a workgroup's first tile: no epilogue stores in front of its fill
       full = t[t[:, 3] != 0].astype(np.float64)
@@ -73,7 +73,7 @@ def case(M, N, K1, K2=0, fwd=True, sparse=True):
     if w != 0 and 0 in outs:
       same = torch.equal(outs[0][0], outs[w][0]) and torch.equal(outs[0][1], outs[w][1])
       print(f'   pipe={w}: ' + ('bitwise equal' if same else 'MISMATCH'), flush=True)
-  ops.L.check(ops.lib().mnr_gemm_nt_set_pipelined(1))
+  ops.L.check(ops.L.debug().mnr_gemm_nt_set_pipelined(1))
 
 
 if os.environ.get('PIPES') and not os.environ.get('ALL_CASES'):

@@ -85,12 +85,12 @@ if os.environ.get('TIMING_ONLY'):         # probe builds (MNR_LIB_PATH, -DPN_DBG
   case(524288, 1024, 1024, a1_panel=False, a_rows=1)
   sys.exit(0)
 if os.environ.get('SMALL'):
-  ops.L.check(ops.lib().mnr_gemm_nt_panel_set_max_wgs(8))
+  ops.L.check(ops.L.debug().mnr_gemm_nt_panel_set_max_wgs(8))
   for a1p in (True, False):
     ok &= case(4096, 512, 256, 0, True, a1p, reps=2)
     ok &= case(4096, 512, 192, 64, True, a1p, reps=2)
     ok &= case(2304, 256, 320, 0, False, a1p, reps=2)
-  ops.L.check(ops.lib().mnr_gemm_nt_panel_set_max_wgs(0))
+  ops.L.check(ops.L.debug().mnr_gemm_nt_panel_set_max_wgs(0))
 ok &= case(524288, 1024, 1024)
 ok &= case(524288, 1024, 1024, fwd=False)
 ok &= case(524288, 1024, 512, a1_panel=False)

@@ -33,7 +33,7 @@ def case(M, N, K1, K2=0, fwd=True):
   bits = torch.randint(0, 256, (M, N // 8), generator=g, device=dev, dtype=torch.uint8)
   outs = {}
   for persist in (0, 1, 0, 1):
-    ops.L.check(ops.lib().mnr_gemm_nt_set_persistent(persist))
+    ops.L.check(ops.L.debug().mnr_gemm_nt_set_persistent(persist))
     C = torch.zeros((M, N), dtype=bf, device=dev)
     bo = torch.zeros((M, N // 8), dtype=torch.uint8, device=dev)
     if fwd:
@@ -49,7 +49,7 @@ def case(M, N, K1, K2=0, fwd=True):
     print(f'M={M} N={N} K={K1}+{K2} {"fwd" if fwd else "dX "} persist={persist}: {us:8.1f} us  {2.0 * M * N * (K1 + K2) / us / 1e6:7.1f} TF/s', flush=True)
   same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
   print('   bitwise equal' if same else '   MISMATCH', flush=True)
-  ops.L.check(ops.lib().mnr_gemm_nt_set_persistent(0))
+  ops.L.check(ops.L.debug().mnr_gemm_nt_set_persistent(0))
 
 
 case(524288, 1024, 1024)

@@ -81,11 +81,11 @@ def main():
         f'  chain with in-kernel IPE {t_fused * 1e3:7.1f} us')
   # timeline of the fused kernel (second tile of every workgroup)
   tl = torch.zeros((256 * 32,), dtype=torch.int64, device=dev)
-  L.check(ops.lib().mnr_debug_chain_timeline(tl.data_ptr()))
+  L.check(ops.L.debug().mnr_debug_chain_timeline(tl.data_ptr()))
   ops.mlp_chain_fwd_ipe(tdist, R.origins, R.directions, radii, plan.basis_dev, ipe_layers, M=M, W=W, w_head=w_head, b_head=b_head,
                         head_out=out, **kw)
   torch.cuda.synchronize()
-  L.check(ops.lib().mnr_debug_chain_timeline(None))
+  L.check(ops.L.debug().mnr_debug_chain_timeline(None))
   t = tl.cpu().view(256, 32).double()
   t = t[t[:, 0] > 0]
   D = len(plan.trunk)

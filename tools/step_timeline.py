@@ -56,10 +56,10 @@ for key, idx in want.items():
     n[0] += 1
     if on:
       buf.zero_()
-      ops.L.check(ops.lib().mnr_debug_gemm_timeline(buf.data_ptr()))
+      ops.L.check(ops.L.debug().mnr_debug_gemm_timeline(buf.data_ptr()))
     r = orig(*a, **k)
     if on:
-      ops.L.check(ops.lib().mnr_debug_gemm_timeline(None))
+      ops.L.check(ops.L.debug().mnr_debug_gemm_timeline(None))
     return r
 
   ops.gemm_nt = hooked
@@ -112,10 +112,10 @@ for key, idx in want.items():
     n[0] += 1
     if on:
       buf.zero_()
-      ops.L.check(ops.lib().mnr_debug_gemm_timeline(buf.data_ptr()))
+      ops.L.check(ops.L.debug().mnr_debug_gemm_timeline(buf.data_ptr()))
     r = orig_tn(*a, **k)
     if on:
-      ops.L.check(ops.lib().mnr_debug_gemm_timeline(None))
+      ops.L.check(ops.L.debug().mnr_debug_gemm_timeline(None))
     return r
 
   ops.gemm_tn = hooked_tn
