@@ -33,7 +33,8 @@
 // and 3 behind an epilogue also leave its stores outstanding (a RACE: timing only), 6 = every second store, 7 / 8 = every M-tile
 // reads the A1 rows of M-tile (m & 7) / (m & 63): one 512-KiB tile per XCD (L2-resident, not L1) / 32 MiB in all (Infinity-Cache-
 // resident): what an A operand that does not come from HBM is worth; 9 / 10 = (m & 511) / (m & 1023): 256 / 512 MiB, re-read 4 / 2
-// times a launch (past the Infinity Cache, still few pages); 11 / 12 = (m & 127) / (m & 255): 64 / 128 MiB.  0 in the product.
+// times a launch (past the Infinity Cache, still few pages); 11 / 12 = (m & 127) / (m & 255): 64 / 128 MiB; 13 / 14 = 1/6 / 1/3
+// fewer LDS fragment reads (read_frags).  0 in the product.
 #ifndef PN_DBG
 #define PN_DBG 0
 #endif
@@ -176,7 +177,12 @@ __global__ __launch_bounds__(512) void gemm_nt_panel_kernel(mnr_gemm_nt_args p, 
   auto read_frags = [&](const char* st, int ks, bf16x8 (&A)[MI], bf16x8 (&Bf)[NJ]) {
     const int ko = ((ks * 2 + kh) ^ sw) << 4;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) A[i] = *(const bf16x8*)(st + a_lane + ko + i * 32 * ROWB);
+    for (int i = 0; i < MI; ++i) {
+      // (probe builds 13 / 14: one / two of the four A-fragment reads of a k-step are skipped, the registers of another row block
+      // reused -- wrong values, timing only: what the launch costs with 1/6 / 1/3 fewer LDS fragment reads per MFMA)
+      if ((PN_DBG == 13 && i == 3) || (PN_DBG == 14 && i >= 2)) A[i] = A[i - 2 + (PN_DBG == 13 ? 1 : 0)];
+      else A[i] = *(const bf16x8*)(st + a_lane + ko + i * 32 * ROWB);
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) Bf[j] = *(const bf16x8*)(st + b_lane + ko + j * 32 * ROWB);
   };

@@ -222,7 +222,7 @@ CASES = [
     ('360', ['PropMLP.net_depth = 2', 'PropMLP.net_width = 64', 'NerfMLP.net_depth = 4', 'NerfMLP.net_width = 128'], 16),
     # ... and widths that are multiples of nothing in particular, behind a non-ReLU activation (the padded units are then
     # non-zero, feed zero kernel rows, and their gradients are dropped)
-    ('blender_256', ['PropMLP.net_width = 192', 'NerfMLP.net_width = 320', 'NerfMLP.net_activation = @jax.nn.softplus'], 16),
+    ('blender_256', ['PropMLP.net_width = 192', 'PropMLP.net_activation = @jax.nn.softplus', 'NerfMLP.net_width = 320'], 16),
 ]
 
 
