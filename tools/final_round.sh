@@ -10,6 +10,7 @@ python3 -c 'import sys; sys.path.insert(0,"."); import __graft_entry__ as e; e.s
 tail -3 $OUT/${TAG}_driver_pytest.log; tail -4 $OUT/${TAG}_driver_smoke.log
 bash tools/profile_round.sh $TAG
 export TMPDIR=/tmp
+export MNR_SKIP_PREFLIGHT=1   # (rocprofv3 follows the preflight child, and its --stats database then holds that process only)
 cd /tmp
 MNR_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_serial_prof -- python $R/bench.py --steps 5 --warmup 2 --no_cpu_baseline --no_aux > $OUT/${TAG}_serial_prof.log 2>&1
 python $R/tools/prof_summary.py stats $OUT/${TAG}_serial_prof --title "rocprofv3 --kernel-trace --stats ($TAG, one stream)" --command "MNR_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no_cpu_baseline --no_aux" > $OUT/${TAG}_serial_kernel_stats.md

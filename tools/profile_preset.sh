@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 cd $R
 timeout 900 python bench.py "$@" > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -- python $R/bench.py "$@" --steps 5 --warmup 2 --no_cpu_baseline --no_aux > $OUT/${TAG}_prof.log 2>&1
+MNR_SKIP_PREFLIGHT=1 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -- python $R/bench.py "$@" --steps 5 --warmup 2 --no_cpu_baseline --no_aux > $OUT/${TAG}_prof.log 2>&1
 python $R/tools/prof_summary.py stats $OUT/${TAG}_prof --title "rocprofv3 --kernel-trace --stats ($TAG)" --command "rocprofv3 --kernel-trace --stats -- python bench.py $* --steps 5 --warmup 2 --no_cpu_baseline --no_aux" > $OUT/${TAG}_kernel_stats.md
 rm -rf $OUT/${TAG}_prof
 cut -c1-400 $OUT/${TAG}_bench.json

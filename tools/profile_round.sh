@@ -8,6 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
+export MNR_SKIP_PREFLIGHT=1   # (rocprofv3 follows the preflight child, and its --stats database then holds that process only)
 cd $R
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 CMD="python bench.py --steps 5 --warmup 2 --no_cpu_baseline --no_aux"
