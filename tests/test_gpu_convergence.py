@@ -33,11 +33,16 @@ def _psnr(model_rgb, gt):
   return -10.0 / math.log(10.0) * math.log(mse)        # image.mse_to_psnr, image.py:28-30
 
 
-def test_equal_step_psnr_matches_oracle():
+@pytest.mark.parametrize('extra', [[], ['Model.stop_level_grad = False', 'Model.resample_padding = 0.01']],
+                         ids=['stop_level_grad', 'through_the_sampling'])
+def test_equal_step_psnr_matches_oracle(extra):
+  """`through_the_sampling`: the same protocol with Model.stop_level_grad = False (models.py:198-201; resample_padding 0.01 as
+  blender_refnerf.gin sets it: with 0 a closed dilated bin makes the REFERENCE's gradient NaN): 150 steps in
+  which every step's gradient went through the sampling VJPs must train as the oracle's do."""
   if not torch.cuda.is_available():
     pytest.skip('no GPU')
   torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
-  cfg = configs.load_preset('blender_256', BINDINGS)
+  cfg = configs.load_preset('blender_256', BINDINGS + extra)
   model = models.Model(config=cfg)
   model.build('cuda')
   om, on, op = helpers.oracle_hparams(model)

@@ -220,7 +220,7 @@ CASES = [
     # the MLP shapes of the reference's configs/debug.gin (:14-18: PropMLP 2 x 64, NerfMLP 4 x 128): a trunk width that is not a
     # multiple of the 128-column GEMM tile runs on a zero-padded execution layout (models.Model.build / _to_exec / true_grads)
     ('360', ['PropMLP.net_depth = 2', 'PropMLP.net_width = 64', 'NerfMLP.net_depth = 4', 'NerfMLP.net_width = 128'], 16),
-    # ... and widths that are multiples of nothing in particular, behind a non-ReLU activation (the padded units are then
+    # ... and widths that are multiples of 64 only, the proposal MLP behind a non-ReLU activation (its padded units are then
     # non-zero, feed zero kernel rows, and their gradients are dropped)
     ('blender_256', ['PropMLP.net_width = 192', 'PropMLP.net_activation = @jax.nn.softplus', 'NerfMLP.net_width = 320'], 16),
 ]
