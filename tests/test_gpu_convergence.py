@@ -99,7 +99,7 @@ def test_equal_step_psnr_360_full_width():
   fp32, bf16 forward operands, and bf16 operands in the forward AND the backward matmuls (the reference's TPU default precision);
   every run's difference, the seed means and the grand means are printed.  Asserted: the grand mean of the SIGNED differences
   against the reference-precision oracle within 0.1 dB (no error bars subtracted), every seed's mean within 0.3 dB, the grand
-  mean against the fp32 oracle within 0.15 dB, no single run further than 0.5 dB off (see the comment at the assertions)."""
+  mean against the fp32 oracle within 0.1 dB at two standard errors, no single run further than 0.5 dB off (see the comment at the assertions)."""
   import importlib.util
   import json
   import os
@@ -206,11 +206,13 @@ def test_equal_step_psnr_360_full_width():
   #     errors subtracted; measured +0.040 over 15 runs, +0.038 over 25: profiles/r4g_, r4h_psnr360_equal_step.jsonl), and every
   #     seed's mean over its replays (eight since the end of round 4: the grand means' standard error drops from 0.016 to 0.013 dB, and
   #     the last-three-checkpoint mean has read +0.059 / +0.067) to 0.3 dB (seed 362's replays scatter by +-0.1 dB: its mean read +0.06 and +0.15);
-  #   * against the plain fp32 oracle the grand mean is held to 0.15 dB (measured -0.04 over five seeds, -0.08 over the first three: the precision cost of bf16 matmuls
-  #     on this scene) and reported next to it;
+  #   * against the plain fp32 oracle the grand mean is held to 0.1 dB at two standard errors (measured -0.053 +- 0.013 over five seeds x
+  #     eight replays, -0.08 over the first three seeds: the precision cost of bf16 matmuls on this scene) and reported next to it;
   #   * one run may be 0.5 dB off (a 600-step run is chaotic and the weight gradients are summed with fp32 atomics in arrival
   #     order: one seed's difference moves by +-0.05 dB from replay to replay of the same binary).
   assert abs(mean_fb) <= 0.1 and abs(tmean_fb) <= 0.1, (mean_fb, tmean_fb)
   assert max(abs(v) for v in seed_means_fb.values()) <= 0.3, seed_means_fb
-  assert abs(mean) <= 0.15 and abs(tmean) <= 0.15, (mean, tmean)
+  # (the fp32-oracle gate at its earlier strength: within 0.1 dB at two standard errors; with fewer than five seeds
+  # x eight replays the standard error is what it is)
+  assert abs(mean) <= 0.1 + 2 * se and abs(tmean) <= 0.1 + 2 * tse, (mean, se, tmean, tse)
   assert float(np.abs(vals).max()) <= 0.5 and float(np.abs(vf).max()) <= 0.5, (finals, finals_fb)
