@@ -46,3 +46,11 @@ def test_in_kernel_ipe_chain_passes_on_the_simulator():
   mnr_mlp_chain_fwd, leaf level and through Model.__call__ (tests/test_gpu_chain.py, ~25 s of simulator time)."""
   tail = _child(['tests/test_gpu_chain.py', '-k', 'in_kernel_ipe'], 900)
   assert ' passed' in tail and 'failed' not in tail and 'skipped' not in tail, tail
+
+
+def test_sampling_gradient_kernels_pass_on_the_simulator():
+  """Model.stop_level_grad = False (round 5): mnr_resample_level_bwd, mnr_cast_rays_ipe_bwd, mnr_sdist_bwd + the level kernels'
+  g_x output against the oracle's autograd, and the composed train steps (at the simulator's reduced widths), with the code of
+  tests/test_gpu_sampling_grad.py unchanged."""
+  tail = _child(['tests/test_gpu_sampling_grad.py'], 1500)
+  assert ' passed' in tail and 'failed' not in tail and 'skipped' not in tail, tail
