@@ -340,6 +340,14 @@ int mnr_cast_f32_to_bf16(const float* src, int ld_src, int64_t M, int n, uint16_
  * kind: 1 = softplus, 2 = silu; arithmetic in fp32, one bf16 rounding. */
 int mnr_act_fwd_bf16(int kind, int64_t n, const uint16_t* z, uint16_t* a, void* stream);
 int mnr_act_bwd_bf16(int kind, int64_t n, const uint16_t* z, uint16_t* d, void* stream);
+/* The same activations inside the forward-mode tangent network of the density-gradient normals (models.py:478-492: with a
+ * non-ReLU net_activation jax differentiates through act' as well).  z [n = M*W] the layer's primal pre-activation, U [3n] its
+ * tangent pre-activation (rows c*M + s = direction c of sample s):
+ *   mnr_act_tangent_fwd_bf16: T[3n] = act'(z) * U;
+ *   mnr_act_tangent_bwd_bf16: G[3n] (d loss / d T) becomes G * act'(z) in place, and extra[n] = sum_c G_c * U_c * act''(z) =
+ *   d loss / d z through act', to be added to the primal backward pass's gradient of that layer. */
+int mnr_act_tangent_fwd_bf16(int kind, int64_t n, const uint16_t* z, const uint16_t* U, uint16_t* T, void* stream);
+int mnr_act_tangent_bwd_bf16(int kind, int64_t n, const uint16_t* z, const uint16_t* U, uint16_t* G, uint16_t* extra, void* stream);
 
 /* X[m, c] += scale * noise[m, c] (fp32 add, one bf16 rounding) for the first `cols` columns of the bf16 matrix X [M, ld]:
  * the bottleneck noise of models.py:530-533 (`bottleneck += bottleneck_noise * random.normal(...)`) on the

@@ -174,6 +174,8 @@ _PROTOS = {
     'mnr_scatter_add_f32': ([vp, i32, i32, i32, i32, i32, vp, i32, vp], i32),
     'mnr_act_fwd_bf16': ([i32, i64, vp, vp, vp], i32),
     'mnr_act_bwd_bf16': ([i32, i64, vp, vp, vp], i32),
+    'mnr_act_tangent_fwd_bf16': ([i32, i64, vp, vp, vp, vp], i32),
+    'mnr_act_tangent_bwd_bf16': ([i32, i64, vp, vp, vp, vp, vp], i32),
     'mnr_add_noise_bf16': ([i64, i32, vp, i32, vp, f32, vp], i32),
     'mnr_cast_f32_to_bf16': ([vp, i32, i64, i32, vp, i32, i32, vp], i32),
     'mnr_small_head_bwd': ([i64, i32, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i64, vp, i64, vp], i32),

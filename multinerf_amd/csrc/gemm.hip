@@ -820,6 +820,80 @@ extern "C" int mnr_act_fwd_bf16(int kind, int64_t n, const uint16_t* z, uint16_t
   return act_launch(false, kind, n, z, a, stream);
 }
 
+// The tangent network of the density-gradient normals (models.py:478-492 in forward mode) behind a non-ReLU
+// activation.  With z [M, W] the primal pre-activation of a layer and U [3 M, W] the tangent pre-activation (rows c * M + s =
+// direction c of sample s):
+//   forward : T = act'(z) * U
+//   backward: given G = d loss / d T:  S = G * act'(z)  (in place: what the weight-gradient and dX GEMMs take), and the term a
+//             ReLU network does not have,  extra[s] = sum_c G[c M + s] * U[c M + s] * act''(z[s])  = d loss / d z through act',
+//             which joins the PRIMAL backward pass's gradient of that layer (autodiff's second-order term of the "double backward").
+__device__ __forceinline__ float mnr_act_deriv2(int kind, float z) {
+  const float sg = mnr_sigmoid(z);
+  const float d = sg * (1.0f - sg);
+  if (kind == 1) return d;                                         // softplus'' = sigmoid'
+  return d * (2.0f + z * (1.0f - 2.0f * sg));                      // silu'' = sigmoid' (2 + z (1 - 2 sigmoid))
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void act_tangent_kernel(int kind, int64_t chunks, const bf16* __restrict__ z, const bf16* __restrict__ U,
+                                                          bf16* __restrict__ io, bf16* __restrict__ extra) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < chunks; e += (int64_t)gridDim.x * blockDim.x) {
+    const bf16x8 zv = *(const bf16x8*)(z + e * 8);
+    float d1[8], d2[8], acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      d1[i] = mnr_act_deriv(kind, (float)zv[i]);
+      d2[i] = BWD ? mnr_act_deriv2(kind, (float)zv[i]) : 0.0f;
+      acc[i] = 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int64_t o = (c * chunks + e) * 8;
+      const bf16x8 u = *(const bf16x8*)(U + o);
+      bf16x8 v;
+      if constexpr (BWD) {
+        const bf16x8 g = *(const bf16x8*)(io + o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[i] += (float)g[i] * (float)u[i] * d2[i];
+          v[i] = (bf16)((float)g[i] * d1[i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (bf16)((float)u[i] * d1[i]);
+      }
+      *(bf16x8*)(io + o) = v;
+    }
+    if constexpr (BWD) {
+      bf16x8 x;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = (bf16)acc[i];
+      *(bf16x8*)(extra + e * 8) = x;
+    }
+  }
+}
+
+static int act_tangent_launch(bool bwd, int kind, int64_t n, const uint16_t* z, const uint16_t* U, uint16_t* io, uint16_t* extra, void* stream) {
+  MNR_CHECK_ARG((kind == 1 || kind == 2) && z && U && io && (!bwd || extra) && n > 0 && n % 8 == 0 && ((uintptr_t)z % 16) == 0 &&
+                    ((uintptr_t)U % 16) == 0 && ((uintptr_t)io % 16) == 0 && ((uintptr_t)extra % 16) == 0,
+                "mnr_act_tangent_*_bf16: kind 1 (softplus) / 2 (silu), n = M * W a multiple of 8, 16-byte-aligned pointers");
+  const int64_t chunks = n / 8;
+  const int64_t want = (chunks + 255) / 256;
+  const int grid = (int)(want > 16384 ? 16384 : want);
+  if (bwd) hipLaunchKernelGGL(act_tangent_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, kind, chunks, (const bf16*)z, (const bf16*)U, (bf16*)io, (bf16*)extra);
+  else hipLaunchKernelGGL(act_tangent_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, kind, chunks, (const bf16*)z, (const bf16*)U, (bf16*)io, (bf16*)extra);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}
+
+extern "C" int mnr_act_tangent_fwd_bf16(int kind, int64_t n, const uint16_t* z, const uint16_t* U, uint16_t* T, void* stream) {
+  return act_tangent_launch(false, kind, n, z, U, T, nullptr, stream);
+}
+
+extern "C" int mnr_act_tangent_bwd_bf16(int kind, int64_t n, const uint16_t* z, const uint16_t* U, uint16_t* G, uint16_t* extra, void* stream) {
+  return act_tangent_launch(true, kind, n, z, U, G, extra, stream);
+}
+
 extern "C" int mnr_act_bwd_bf16(int kind, int64_t n, const uint16_t* z, uint16_t* d, void* stream) {
   return act_launch(true, kind, n, z, d, stream);
 }

@@ -138,9 +138,6 @@ class MLP:
       bad.append('deg_view > 11 in the positional encoding of a per-sample direction')
     if self.net_activation not in ('relu', 'softplus', 'silu'):   # what the reference registers (configs.py:29-31)
       bad.append(f'net_activation={self.net_activation}')
-    if self.net_activation != 'relu' and not self.disable_density_normals:
-      # the forward-mode tangent network of the density-gradient normals is built on ReLU's piecewise linearity
-      bad.append(f'net_activation={self.net_activation} with density-gradient normals')
     if self.warp_fn not in (None, 'contract'):
       bad.append(f'warp_fn={self.warp_fn}')
     if self.net_width <= 0:
@@ -1025,7 +1022,7 @@ class Model:
                           head_out=raw_density)
     return dict(acts=[], bits=[], raw_density=raw_density, chain=True)
 
-  def _tangent_forward(self, plan: MLPPlan, tdist, R, M, bits, keep, tag):
+  def _tangent_forward(self, plan: MLPPlan, tdist, R, M, bits, keep, tag, zs=None):
     """Density-gradient normals by forward mode (models.py:473-492 without a second autodiff pass): the three
     tangent feature rows d features / d mean_c of every sample run through the trunk as 3 * M extra GEMM rows whose ReLU is the
     primal layer's 1-bit mask; the density column of the last layer gives raw_grad [3, M]."""
@@ -1035,27 +1032,33 @@ class Model:
                               ray_shape=self.ray_shape, min_deg=hp.min_deg_point, max_deg=hp.max_deg_point,
                               ld_feat=plan.ldF, out=T_feat, warp_contract=(hp.warp_fn == 'contract'),
                               disable_integration=self.disable_integration)
-    T_acts = []
+    T_acts, T_pre = [], []
     t = None
+    relu = hp.net_activation == 'relu'
     for i, (d, concat) in enumerate(plan.trunk):
       e2 = plan.packed[('trunk', i)]
       tout = self._buf((tag, 'T_act', i if keep else i % 2), (3 * M, plan.W), bf16)
       Bt2 = self._w(plan, e2['f_off'], e2['n_pad'], e2['f_ld'])
+      # ReLU: T_i = mask_i * (T_{i-1} W_i), the mask applied in the GEMM's epilogue.  Any other activation: the GEMM leaves the
+      # tangent pre-activation U_i (kept for the backward pass's act'' term), then T_i = act'(z_i) * U_i
+      mk = dict(bits_in=bits[i], bits_row_mod=M) if relu else {}
+      dst = tout if relu else self._buf((tag, 'T_pre', i if keep else i % 2), (3 * M, plan.W), bf16)
       if i == 0:
-        ops.gemm_nt(T_feat, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.ldF, bits_in=bits[i], bits_row_mod=M,
-                    Cb=tout, ldcb=plan.W, nb=plan.W)
+        ops.gemm_nt(T_feat, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.ldF, Cb=dst, ldcb=plan.W, nb=plan.W, **mk)
       elif concat:
-        ops.gemm_nt(t, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.W, A2=T_feat, K2=plan.ldF, bits_in=bits[i],
-                    bits_row_mod=M, Cb=tout, ldcb=plan.W, nb=plan.W)
+        ops.gemm_nt(t, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.W, A2=T_feat, K2=plan.ldF, Cb=dst, ldcb=plan.W, nb=plan.W, **mk)
       else:
-        ops.gemm_nt(t, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.W, bits_in=bits[i], bits_row_mod=M,
-                    Cb=tout, ldcb=plan.W, nb=plan.W)
+        ops.gemm_nt(t, Bt2, M=3 * M, N=e2['n_pad'], K1=plan.W, Cb=dst, ldcb=plan.W, nb=plan.W, **mk)
+      if not relu:
+        ops.act_tangent_fwd(hp.net_activation, zs[i], dst, tout)
+        T_pre.append(dst)
       T_acts.append(tout)
       t = tout
     raw_grad = self._buf((tag, 'raw_grad'), (3, M), f32)
     ed = plan.packed['density']
     ops.gemm_nt(t, self._w(plan, ed['f_off'], ed['n_pad'], ed['f_ld']), M=3 * M, N=ed['n_pad'], K1=plan.W,
                 Cf=raw_grad, ldcf=1, f0=0, nf=1)
+    self._T_pre = T_pre                                   # (non-ReLU activations: the tangent pre-activations, for _tangent_backward)
     return T_feat, T_acts, raw_grad
 
   def _mlp_forward(self, plan: MLPPlan, flat, feat, M, n, R, tag, keep, tdist=None, bnoise=None, group=None):
@@ -1094,7 +1097,7 @@ class Model:
       Bt = self._w(plan, e['f_off'], e['n_pad'], e['f_ld'])
       bias = flat[d.bias_off:d.bias_off + d.fan_out]
       # non-ReLU activations: the GEMM stores the pre-activation, a second kernel applies softplus / silu
-      dst = out if relu else activate((tag, 'z', i if keep else i % 2), out, plan.W, zs)
+      dst = out if relu else activate((tag, 'z', i if (keep or plan.tangent) else i % 2), out, plan.W, zs)
       if i == 0:
         ops.gemm_nt(feat, Bt, M=M, N=e['n_pad'], K1=plan.ldF, bias=bias, n_bias=d.fan_out, relu=relu,
                     Cb=dst, ldcb=plan.W, nb=plan.W, bits_out=bo, walk_descending=bool(i & 1), **lay_c)
@@ -1133,8 +1136,8 @@ class Model:
         raw_density.copy_(small[:, 0])
         raw_grad = None
         if plan.tangent:
-          T_feat, T_acts, raw_grad = self._tangent_forward(plan, tdist, R, M, bits, keep, tag)
-          res.update(T_feat=T_feat, T_acts=T_acts, raw_grad=raw_grad)
+          T_feat, T_acts, raw_grad = self._tangent_forward(plan, tdist, R, M, bits, keep, tag, zs=zs)
+          res.update(T_feat=T_feat, T_acts=T_acts, raw_grad=raw_grad, T_pre=self._T_pre)
         normals, npred, rough = ops.ref_head_fwd(small, raw_grad, R.viewdirs, n, plan.ide, hp.roughness_bias, VI,
                                                  bw, plan.ldVI, features=plan.features, deg_view=hp.deg_view)
         res.update(small=small, normals=normals, npred=npred, rough=rough)
@@ -1160,8 +1163,8 @@ class Model:
       if plan.dn:
         # density-gradient normals without the rest of the Ref-NeRF head (models.py:478-492): for the renderings and the
         # orientation loss; they do not enter the colour
-        T_feat, T_acts, raw_grad = self._tangent_forward(plan, tdist, R, M, bits, keep, tag)
-        res.update(T_feat=T_feat, T_acts=T_acts, raw_grad=raw_grad, normals=ops.density_normals_fwd(raw_grad))
+        T_feat, T_acts, raw_grad = self._tangent_forward(plan, tdist, R, M, bits, keep, tag, zs=zs)
+        res.update(T_feat=T_feat, T_acts=T_acts, raw_grad=raw_grad, normals=ops.density_normals_fwd(raw_grad), T_pre=self._T_pre)
       if plan.glo > 0:
         ops.glo_fill(self._glo_table(flat), self._glo_cam, M // n, n, VI, plan.glo_col)
       if bnoise is not None:
@@ -1487,8 +1490,9 @@ class Model:
                          dW=gslice(d.kernel_off, W), db=gslice(d.bias_off, 1))
       act_vjp(mlp['zs'][-1] if not relu else None, dA)
     feat = lv['feat']
+    t_extras = None
     if g_raw_grad is not None:
-      self._tangent_backward(plan, flat, grads, mlp, feat, M, g_raw_grad, slot)
+      t_extras = self._tangent_backward(plan, flat, grads, mlp, feat, M, g_raw_grad, slot)
     if mlp.get('chain_trunk'):
       # fused dX chain from the dY_last the head GEMMs left in dA; then dW_i = [x_{i-1} | feat]^T dY_i per layer
       dYs = [self._buf(('bwd', slot, 'dYc', W, i), (M, W), bf16) for i in range(D - 1)] + [None]
@@ -1512,6 +1516,8 @@ class Model:
     for i in reversed(range(len(plan.trunk))):
       d, concat = plan.trunk[i]
       e = plan.packed[('trunk', i)]
+      if t_extras is not None:
+        ops.add_cols_bf16(dy, t_extras[i], dy, W)        # the tangent network's act'' term of this layer's pre-activation
       if i == 0:
         ops.gemm_tn(feat, dy, gslice(d.kernel_off, plan.F * W), M=M, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
                     ldc=W, k_valid=plan.F, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_b)
@@ -1585,14 +1591,20 @@ class Model:
     gA = self._buf(('bwd', slot, 'gTA', W), (M3, W), bf16)
     gB = self._buf(('bwd', slot, 'gTB', W), (M3, W), bf16)
     d = plan.density
+    relu = plan.hp.net_activation == 'relu'
+    # Non-ReLU activations: T_l = act'(z_l) * U_l depends on the primal pre-activation too; the term
+    # d loss / d z_l = sum_c G_l * U_l * act''(z_l) comes back as `extras[l]` and joins the primal backward pass (backward_level)
+    extras = None if relu else [self._buf(('bwd', slot, 'T_extra', W, i), (M, W), bf16) for i in range(len(plan.trunk))]
     # G_last = bits_last * (g_raw_grad[:, None] w_density^T);  dW_density += T_last^T g_raw_grad
     ops.small_head_bwd(T_acts[-1], W, g_raw_grad.view(M3, 1), flat[d.kernel_off:d.kernel_off + W].view(W, 1),
                        M=M3, K=W, Cn=1, dX=gA, lddx=W, relu_mask=False, dW=gslice(d.kernel_off, W), db=None,
-                       bits=bits[-1], bits_row_mod=M)
+                       bits=bits[-1] if relu else None, bits_row_mod=M if relu else 0)
     gy, other = gA, gB
     for i in reversed(range(len(plan.trunk))):
       d, concat = plan.trunk[i]
       e = plan.packed[('trunk', i)]
+      if not relu:
+        ops.act_tangent_bwd(plan.hp.net_activation, mlp['zs'][i], mlp['T_pre'][i], gy, extras[i])     # gy: d loss / d T_i -> d loss / d U_i
       if i == 0:
         ops.gemm_tn(T_feat, gy, gslice(d.kernel_off, plan.F * W), M=M3, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
                     ldc=W, k_valid=plan.F, n_valid=W)
@@ -1602,9 +1614,10 @@ class Model:
           ops.gemm_tn(T_feat, gy, gslice(d.kernel_off + W * W, plan.F * W), M=M3, K=plan.ldF, N=W,
                       lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
         Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
-        ops.gemm_nt(gy, Bw, M=M3, N=_rup(W, 128), K1=e['b_ld'], bits_in=bits[i - 1], bits_row_mod=M,
-                    Cb=other, ldcb=W, nb=W)
+        ops.gemm_nt(gy, Bw, M=M3, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W,
+                    **(dict(bits_in=bits[i - 1], bits_row_mod=M) if relu else {}))
         gy, other = other, gy
+    return extras
 
 
 # =============================================================================

@@ -591,6 +591,22 @@ def act_bwd(kind, z, d):
   L.check(lib().mnr_act_bwd_bf16(L.NET_ACT[kind], z.numel(), _ptr(z), _ptr(d), _stream()))
 
 
+def act_tangent_fwd(kind, z, U, T):
+  """T = act'(z) * U: the tangent network of the density-gradient normals behind a non-ReLU activation; z [M, W], U, T [3M, W]."""
+  for x, nm in ((z, 'z'), (U, 'U'), (T, 'T')):
+    _chk(x, bf16, nm)
+  assert U.shape == T.shape and U.numel() == 3 * z.numel()
+  L.check(lib().mnr_act_tangent_fwd_bf16(L.NET_ACT[kind], z.numel(), _ptr(z), _ptr(U), _ptr(T), _stream()))
+
+
+def act_tangent_bwd(kind, z, U, G, extra):
+  """G (d loss / d T, [3M, W]) *= act'(z) in place; extra [M, W] = sum_c G_c * U_c * act''(z) (joins the primal gradient of z)."""
+  for x, nm in ((z, 'z'), (U, 'U'), (G, 'G'), (extra, 'extra')):
+    _chk(x, bf16, nm)
+  assert U.shape == G.shape and U.numel() == 3 * z.numel() and extra.shape == z.shape
+  L.check(lib().mnr_act_tangent_bwd_bf16(L.NET_ACT[kind], z.numel(), _ptr(z), _ptr(U), _ptr(G), _ptr(extra), _stream()))
+
+
 def add_noise_bf16(X, cols, noise, scale):
   """X[:, :cols] += scale * noise (fp32 add, one bf16 rounding); X bf16 [M, ld], noise fp32 [M, cols]."""
   _chk(noise, f32, 'noise')

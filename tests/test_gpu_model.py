@@ -123,6 +123,11 @@ def _tols(name, extra):
     # |kernel - oracle_bf16| 0.114, |oracle_bf16 - oracle_fp32| 0.082, |kernel - oracle_fp32| 0.133, cosine 0.9936; every Dense
     # layer within 2x its own bf16 cost (the per-layer check below)
     t['grad'], t32['grad'], t['cos'] = 0.17, 0.2, 0.99
+  if 'Config.data_loss_mult = 0.0' in extra:
+    # normal losses ONLY: the whole gradient reaches the trunk through the tangent network, the same two bf16 evaluations of an
+    # ill-conditioned quantity as the case above.  Measured on the simulator: |kernel - oracle_bf16| 0.086 where
+    # |oracle_bf16 - oracle_fp32| is 0.110, |kernel - oracle_fp32| 0.056, cosine 0.9963
+    t['grad'], t32['grad'], t['cos'] = 0.17, 0.2, 0.99
   if any('net_activation' in b for b in extra):
     for d in (t, t32):
       for k in ('sdist', 'weights', 'rgb'):
@@ -217,6 +222,14 @@ CASES = [
     ('llff_raw', ['NerfMLP.disable_density_normals = False', 'Config.orientation_loss_mult = 0.01',
                   'Config.orientation_coarse_loss_mult = 0.001', "Config.orientation_loss_target = 'normals'",
                   'NerfMLP.warp_fn = @coord.contract'], 8),
+    # density-gradient normals behind a non-ReLU activation (refused until round 5): the tangent network's act' factors and the
+    # act'' term its backward pass hands to the primal one; the whole Ref-NeRF head with silu, and softplus with normal losses only
+    # (where that term is half of the gradient: tests/test_sim_model.py)
+    ('blender_refnerf', ['NerfMLP.net_activation = @jax.nn.silu'], 8),
+    ('blender_refnerf', ['NerfMLP.net_activation = @jax.nn.softplus', 'Config.data_loss_mult = 0.0', 'Config.data_coarse_loss_mult = 0.0',
+                         'Config.orientation_loss_mult = 1.0', 'Config.orientation_coarse_loss_mult = 1.0',
+                         "Config.orientation_loss_target = 'normals'", 'Config.predicted_normal_loss_mult = 1.0',
+                         'Config.predicted_normal_coarse_loss_mult = 1.0'], 8),
     # the MLP shapes of the reference's configs/debug.gin (:14-18: PropMLP 2 x 64, NerfMLP 4 x 128): a trunk width that is not a
     # multiple of the 128-column GEMM tile runs on a zero-padded execution layout (models.Model.build / _to_exec / true_grads)
     ('360', ['PropMLP.net_depth = 2', 'PropMLP.net_width = 64', 'NerfMLP.net_depth = 4', 'NerfMLP.net_width = 128'], 16),
@@ -443,9 +456,6 @@ def test_unsupported_features_fail_loudly():
     models.Model(config=cfg).build('cuda')
   cfg = configs.load_preset('360', ['NerfMLP.net_activation = "tanh"'])       # not an activation the reference registers
   with pytest.raises(NotImplementedError, match='net_activation'):
-    models.Model(config=cfg).build('cuda')
-  cfg = configs.load_preset('blender_refnerf', ['NerfMLP.net_activation = @jax.nn.softplus'])
-  with pytest.raises(NotImplementedError, match='density-gradient normals'):
     models.Model(config=cfg).build('cuda')
   # Model.stop_level_grad = False is on the HIP path since round 5 (tests/test_gpu_sampling_grad.py), except next to the
   # density-gradient normals, which are a function of the sample positions too
