@@ -93,6 +93,7 @@ def main():
                   help='before the benchmark: all-reduce / all-gather known patterns over the process group, assert the results '
                        'and time a 36 MB fp32 all-reduce (first contact with RCCL must not be the first bug)')
   ap.add_argument('--no_aux', action='store_true', help='skip the secondary measurements (4096x192 north-star shape, render)')
+  ap.add_argument('--pair_dxdw', type=int, default=-1, help='A/B: models._PAIR_DXDW (1 on, 0 off; default: the module\'s own setting)')
   args = ap.parse_args()
 
   # torch-only preflight in a child process before this process creates a HIP context (multinerf_amd/preflight.py): a box
@@ -107,6 +108,8 @@ def main():
   from multinerf_amd import configs, dist as mdist, models, ops, synthetic, train_utils
   from multinerf_amd import streams as mstreams
 
+  if args.pair_dxdw >= 0:
+    models._PAIR_DXDW = bool(args.pair_dxdw)
   mdist.init_from_env()
   rank, world = mdist.rank(), mdist.world_size()
   if world != args.gpus:
@@ -288,6 +291,7 @@ def main():
             'train_frac': train_frac,
             'params': model.num_params, 'workspace_GiB': round(model.workspace_bytes() / 2 ** 30, 2),
             'backward_streams': mstreams.describe_env() if not model.single_mlp else {'side_stream': False},
+            'pair_dxdw': bool(models._PAIR_DXDW),
             'algorithmic_train_mflop_per_ray': train_flops / 1e6,
             'algorithmic_fwd_mflop_per_ray': fwd_flops / 1e6,
             'whole_step_tflops_per_gpu': train_flops * B / (ms_per_step * 1e-3) / 1e12,

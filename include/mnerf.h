@@ -225,6 +225,7 @@ typedef struct {
   /* c_layout = PANEL: 1 = walk the M-tiles in descending order (the caller alternates it between consecutive layers: a layer
    * then starts with the rows the previous one wrote last).  Performance only; results do not depend on it. */
   int walk_descending;
+  int max_wgs;                 /* c_layout = PANEL: > 0 caps the persistent grid (a paired launch shares the chip, see mnr_gemm_tn_args) */
 } mnr_gemm_nt_args;
 #define MNR_LAYOUT_ROWMAJOR 0
 #define MNR_LAYOUT_PANEL 1
@@ -305,6 +306,11 @@ typedef struct {
                                           widening N from 256 to 384 */
   int a_layout, b_layout;              /* MNR_LAYOUT_* of A and B (PANEL: lda == K resp. ldb == N of the whole matrix, K and N
                                           multiples of 256; the 256 x 256 output tile only) */
+  /* Pairing with the dX GEMM that reads the same B (= dY) matrix (Model backward, one layer): m_interleave = 1 hands the
+   * M-splits the 256-row M-tiles block-cyclically (split s takes M-tiles s, s + splits, ...) so that every split walks M from
+   * top to bottom at the pace of a persistent NT launch running next to it; max_wgs > 0 caps the grid (the two launches then
+   * share the chip).  Performance only. */
+  int m_interleave, max_wgs;
 } mnr_gemm_tn_args;
 
 /* Weight gradient: C += A^T B (fp32 atomics; C must be initialised by the caller). */

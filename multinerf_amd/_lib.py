@@ -65,7 +65,7 @@ class GemmNTArgs(C.Structure):
               ('mask_bits_out', vp), ('ld_bits_out', C.c_int),
               ('mask_bits_in', vp), ('ld_bits_in', C.c_int),
               ('bits_row_mod', C.c_int64), ('a1_layout', C.c_int), ('c_layout', C.c_int),
-              ('vcol', vp), ('vcol_out', vp), ('vcol_bias', vp), ('walk_descending', C.c_int)]
+              ('vcol', vp), ('vcol_out', vp), ('vcol_bias', vp), ('walk_descending', C.c_int), ('max_wgs', C.c_int)]
 
 
 class GemmTNArgs(C.Structure):
@@ -74,7 +74,7 @@ class GemmTNArgs(C.Structure):
               ('M', C.c_int64), ('C', vp), ('ldc', C.c_int),
               ('k_valid', C.c_int), ('n_valid', C.c_int),
               ('bias_out', vp), ('bias_n_valid', C.c_int), ('gcol', vp), ('gcol_out', vp),
-              ('a_layout', C.c_int), ('b_layout', C.c_int)]
+              ('a_layout', C.c_int), ('b_layout', C.c_int), ('m_interleave', C.c_int), ('max_wgs', C.c_int)]
 
 
 CHAIN_MAX_DEPTH = 8

@@ -597,6 +597,11 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   // (every workgroup ends with an atomic epilogue of its whole fp32 tile: a split must be long enough to pay for it)
   constexpr int min_steps = 4;
   while (splits > unit && (total_steps + splits - 1) / splits < min_steps) splits -= unit;
+  if (a->m_interleave) {
+    // block-cyclic M-tiles: every split gets the same whole number of 256-row M-tiles (4 steps of 64 rows)
+    MNR_CHECK_ARG(total_steps % (4 * splits) == 0, "mnr_gemm_tn_bf16: m_interleave needs M / 256 = %d to be a multiple of the %d splits",
+                  total_steps / 4, splits);
+  }
   const int steps_per_split = (total_steps + splits - 1) / splits;
   const int64_t grid = (int64_t)splits * tiles;
   // LDS: a panel operand's stage image carries 128 bytes of padding per 1-KiB block (gemm_tn_body.inc)
@@ -630,7 +635,7 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
   // one workgroup per CU: every workgroup ends with a 256 KiB fp32 atomic epilogue (21-88k cycles, bound by the
   // L2's atomic rate, tools/step_timeline.py), so a second round of workgroups only adds epilogues:
   // 512 -> 256 workgroups = 398k -> 407k rays/s end to end, 1024: 390k; 128 / 512 re-measured in round 3 (profiles/HISTORY.md).
-  const int tn_target = mnr_cu_count();
+  const int tn_target = (a->max_wgs > 0 && a->max_wgs < mnr_cu_count()) ? a->max_wgs : mnr_cu_count();
   MNR_CHECK_ARG(!a->gcol || (a->gcol_out && a->K % 256 == 0 && a->N % 256 == 0 && ((uintptr_t)a->gcol % 32) == 0),
                 "mnr_gemm_tn_bf16: gcol needs gcol_out, K and N multiples of 256 and a 32-byte-aligned vector");
   const bool ap = a->a_layout == MNR_LAYOUT_PANEL, bp = a->b_layout == MNR_LAYOUT_PANEL;

@@ -490,6 +490,7 @@ int mnr_gemm_nt_panel_launch(const mnr_gemm_nt_args* a, void* stream) {
   const int64_t vtotal = (mt + 7) / 8 * 8 * nt;
   MNR_CHECK_ARG(vtotal < (1ll << 31), "mnr_gemm_nt_bf16: grid too large");
   int64_t cap = g_panel_max_wgs > 0 ? g_panel_max_wgs : mnr_cu_count();
+  if (a->max_wgs > 0 && a->max_wgs < cap) cap = a->max_wgs;
   cap = cap / 8 * 8;
   if (cap < 8) cap = 8;
   const int64_t grid = vtotal < cap ? vtotal : cap;

@@ -45,6 +45,11 @@ _HEAD_VCOL = True     # the density head's forward column as a vector next to th
 _HEAD_GCOL = True     # the density head's weight gradient as an extra column of the bottleneck's dW GEMM
 _PANEL = True         # wide (>= 512) per-layer trunks keep activations, gradients and masks in the panel layout (csrc/gemm_blk.hip)
 _MERGE_PROPS = True   # the backward pass of all proposal levels as one pass (they share PropMLP_0 and the sample count)
+# A panel-storage trunk layer's dW and dX GEMMs read the same dY matrix: side by side on two streams with half the chip each, the
+# dW kernel's M-splits block-cyclic (mnr_gemm_tn_args.m_interleave), so that both walk M from top to bottom and part of the second
+# reads of dY is served by the Infinity Cache instead of HBM: 532.4 / 533.8 k -> 538.1 / 538.1 k rays/s on one box, gradients equal
+# up to the atomics' order (profiles/r5_ab.md (d); pacing the two launches against each other returned nothing and is gone)
+_PAIR_DXDW = True
 
 
 # =============================================================================
@@ -1513,11 +1518,45 @@ class Model:
     # trunk: per layer its dW (independent of the dX chain: on the dW stream when that switch is on), then the dX GEMM the
     # next layer waits for
     dy = dA
+    pair = bool(_PAIR_DXDW and panel and self.device.type == 'cuda' and (M // 256) % 8 == 0)
+    if pair:
+      cur_s = torch.cuda.current_stream(self.device)
+      if getattr(self, '_dw_stream', None) is None:
+        self._dw_stream = torch.cuda.Stream(device=self.device)
+        self._half_cus = max(8, torch.cuda.get_device_properties(self.device).multi_processor_count // 2 // 8 * 8)
+      dw_done = None
     for i in reversed(range(len(plan.trunk))):
       d, concat = plan.trunk[i]
       e = plan.packed[('trunk', i)]
       if t_extras is not None:
         ops.add_cols_bf16(dy, t_extras[i], dy, W)        # the tangent network's act'' term of this layer's pre-activation
+      if pair and i > 0:
+        # dW_i on the side stream, dX_i on this one, half the chip each, both ascending through M
+        ready = torch.cuda.Event()
+        ready.record(cur_s)
+        self._dw_stream.wait_event(ready)
+        with torch.cuda.stream(self._dw_stream):
+          ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W,
+                      bias_out=gslice(d.bias_off, W), bias_n_valid=W, m_interleave=True, max_wgs=self._half_cus, **tn_a, **tn_b)
+          if concat:
+            ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
+                        lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W, **tn_b)
+          done = torch.cuda.Event()
+          done.record(self._dw_stream)
+        if concat:
+          feat_grad(i, dy, dy_panel=panel)
+        if dw_done is not None:
+          cur_s.wait_event(dw_done)                      # dX_i overwrites the buffer dW_{i+1} read its dY from
+        Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
+        other = dy_buf(i - 1)
+        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, max_wgs=self._half_cus,
+                    **mask_kw(i - 1), **lay_ac)
+        dw_done = done
+        dy = other
+        continue
+      if pair and dw_done is not None:
+        cur_s.wait_event(dw_done)
+        dw_done = None
       if i == 0:
         ops.gemm_tn(feat, dy, gslice(d.kernel_off, plan.F * W), M=M, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
                     ldc=W, k_valid=plan.F, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_b)

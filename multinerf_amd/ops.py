@@ -381,7 +381,7 @@ def bits_from_tile_order(tile_bits, M, N):
 def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, bias=None, n_bias=0,
             relu=False, mask=None, ldmask=0, Cb=None, ldcb=0, nb=0, Cf=None, ldcf=0, f0=0, nf=0,
             bits_out=None, bits_in=None, bits_row_mod=0, a1_layout=LAYOUT_ROWMAJOR, c_layout=LAYOUT_ROWMAJOR,
-            vcol=None, vcol_out=None, vcol_bias=None, walk_descending=False):
+            vcol=None, vcol_out=None, vcol_bias=None, walk_descending=False, max_wgs=0):
   """C[M,N] = epilogue([A1|A2] @ Bt^T).  Pointers may be views with explicit leading dimensions.  a1_layout / c_layout:
   LAYOUT_PANEL for the wide trunk's activations and gradients (include/mnerf.h; the bits are then in tile order)."""
   _chk(A1, bf16, 'A1')
@@ -407,6 +407,7 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
   a.bits_row_mod = bits_row_mod
   a.a1_layout, a.c_layout = a1_layout, c_layout
   a.walk_descending = int(bool(walk_descending))
+  a.max_wgs = int(max_wgs)
   _chk(vcol, bf16, 'vcol', allow_none=True)
   _chk(vcol_out, f32, 'vcol_out', allow_none=True)
   assert (vcol is None) == (vcol_out is None)
@@ -419,7 +420,8 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
 
 
 def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, n_valid=None, bias_out=None,
-            bias_n_valid=0, gcol=None, gcol_out=None, a_layout=LAYOUT_ROWMAJOR, b_layout=LAYOUT_ROWMAJOR):
+            bias_n_valid=0, gcol=None, gcol_out=None, a_layout=LAYOUT_ROWMAJOR, b_layout=LAYOUT_ROWMAJOR, m_interleave=False,
+            max_wgs=0):
   """Cout[k,n] += sum_m A[m,k] B[m,n]; optionally bias_out[n] += sum_m B[m,n] (fused bias gradient) and
   gcol_out[k] += sum_m A[m,k] gcol[m] (one more column of B given as a contiguous bf16 vector [M])."""
   _chk(bias_out, f32, 'bias_out', allow_none=True)
@@ -441,6 +443,7 @@ def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, 
   a.gcol = gcol.data_ptr() if gcol is not None else None
   a.gcol_out = gcol_out.data_ptr() if gcol_out is not None else None
   a.a_layout, a.b_layout = a_layout, b_layout
+  a.m_interleave, a.max_wgs = int(bool(m_interleave)), int(max_wgs)
   _e = PROFILE.start()
   L.check(lib().mnr_gemm_tn_bf16(C.byref(a), _stream()))
   PROFILE.stop(_e)

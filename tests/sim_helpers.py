@@ -88,13 +88,15 @@ def sim_gemm_nt(lib, A1, Bt, A2=None, bias=None, relu=False, mask=None, out_bf16
   return Cb, (vout if vcol is not None else Cf), bits
 
 
-def sim_gemm_tn(lib, A, B, C_acc, bias_out=None, k_valid=None, n_valid=None, a_layout=0, b_layout=0, gcol=None, gcol_out=None):
+def sim_gemm_tn(lib, A, B, C_acc, bias_out=None, k_valid=None, n_valid=None, a_layout=0, b_layout=0, gcol=None, gcol_out=None,
+                m_interleave=False, max_wgs=0):
   """C_acc[K,N] += A^T B (and bias_out += column sums of B) through the simulated mnr_gemm_tn_bf16.  a_layout / b_layout = 1:
   the operand is given in MNR_LAYOUT_PANEL storage; gcol [M] bf16 / gcol_out [K] fp32: the extra column of B."""
   M, K = A.shape
   N = B.shape[1]
   a = L.GemmTNArgs()
   a.a_layout, a.b_layout = a_layout, b_layout
+  a.m_interleave, a.max_wgs = int(m_interleave), int(max_wgs)
   if gcol is not None:
     a.gcol, a.gcol_out = ptr(gcol), ptr(gcol_out)
   a.A, a.lda, a.K = ptr(A), A.stride(0), K

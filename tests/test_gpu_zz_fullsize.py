@@ -241,3 +241,32 @@ def test_full_batch_gradient_is_the_mean_of_its_quarters(setup):
   lr = float(train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})[1](0))
   assert (new - flat0).abs().max().item() <= 1.01 * lr + 1e-7          # (+ fp32 rounding of the parameters)
   helpers.assert_adam_matches_oracle(model, cfg, flat.float().cpu(), g_full.float(), None, state2)
+
+
+def test_paired_dx_dw_equals_one_after_the_other(setup):
+  """models._PAIR_DXDW (a trunk layer's dW and dX GEMMs side by side on two streams with half the chip each, the dW kernel's
+  M-splits block-cyclic, profiles/r5_ab.md (d)) against the sequential order: the same gradient up to the order of the
+  weight-gradient atomics, on 2048 rays of configs/360.gin at full width."""
+  from multinerf_amd import models as M_
+  cfg, model, _, params, flat, batch = setup
+  n = min(2048, B_FULL)
+  sub = _dev(batch.map(lambda t: t[:n]))
+  noise = {k: {lv: t.cuda() for lv, t in d.items()} for k, d in helpers.make_noise(model, n).items()}
+  step = train_utils.create_train_step(model, cfg)
+  gs = {}
+  old = M_._PAIR_DXDW
+  try:
+    for on in (True, False, True):
+      M_._PAIR_DXDW = on
+      state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})
+      _, stats, _ = step(0, state, sub, None, 0.4, 0.0, noise=noise, return_grads=True)
+      torch.cuda.synchronize()
+      g = stats['_grads'].double().cpu()
+      if on in gs:
+        print(f'paired twice: |dg| / |g| = {((g - gs[on]).norm() / g.norm()).item():.2e} (the atomics\' order)')
+      gs.setdefault(on, g)
+  finally:
+    M_._PAIR_DXDW = old
+  rel = ((gs[True] - gs[False]).norm() / gs[False].norm()).item()
+  print(f'paired vs one after the other: |dg| / |g| = {rel:.2e}')
+  assert torch.isfinite(gs[True]).all() and rel < 1e-5

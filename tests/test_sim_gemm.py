@@ -357,3 +357,29 @@ def test_tn_panel_operands(sim, ap, bp, mode):
   if gcol is not None:
     np.testing.assert_allclose(g1.numpy(), (A.float().T @ gcol.float()).numpy(), atol=2e-3, rtol=1e-4)
     np.testing.assert_allclose(g1.numpy(), g0.numpy(), atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize('layouts', [(0, 0), (1, 1), (1, 0)])
+def test_tn_block_cyclic_m_splits(sim, layouts):
+  """mnr_gemm_tn_args.m_interleave / max_wgs (the dW launch of a paired dX + dW, models._PAIR_DXDW): the M-splits take the
+  256-row M-tiles block-cyclically instead of contiguously -- the same sums over rows in another order; row-major and panel
+  operands, the bias gradient and the extra column along."""
+  ap, bp = layouts
+  g = torch.Generator().manual_seed(11)
+  M, K, N = 4096, 256, 512
+  A = torch.randn((M, K), generator=g).bfloat16()
+  B = torch.randn((M, N), generator=g).bfloat16()
+  gcol = torch.randn(M, generator=g).bfloat16() if (ap, bp) == (1, 0) else None
+  ref, refb = A.float().T @ B.float(), B.float().sum(0)
+  sim.hipsim_reset(1, 3)
+  for il, cap in ((False, 0), (True, 8), (True, 16)):
+    C, b = torch.zeros((K, N)), torch.zeros(N)
+    gout = torch.zeros(K) if gcol is not None else None
+    S.sim_gemm_tn(sim, _ops.to_panel(A) if ap else A, _ops.to_panel(B) if bp else B, C, bias_out=b, a_layout=ap, b_layout=bp,
+                  gcol=gcol, gcol_out=gout, m_interleave=il, max_wgs=cap)
+    np.testing.assert_allclose(C.numpy(), ref.numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(b.numpy(), refb.numpy(), rtol=1e-5, atol=1e-3)
+    if gcol is not None:
+      np.testing.assert_allclose(gout.numpy(), (A.float().T @ gcol.float()).numpy(), rtol=1e-4, atol=1e-2)
+  with pytest.raises(RuntimeError, match='m_interleave needs'):
+    S.sim_gemm_tn(sim, A[:768], B[:768], torch.zeros((K, N)), m_interleave=True, max_wgs=16)     # 3 M-tiles on 8 splits
