@@ -311,6 +311,14 @@ typedef struct {
    * top to bottom at the pace of a persistent NT launch running next to it; max_wgs > 0 caps the grid (the two launches then
    * share the chip).  Performance only. */
   int m_interleave, max_wgs;
+  /* B given by its factors instead of as a matrix (then B may be NULL; row-major A, K and N multiples of 256):
+   *   B[m, n] = bit n of rank1_bits[m, :] ? bf16(rank1_g[m] * rank1_w[n]) : 0
+   * the gradient w.r.t. the LAST hidden layer's pre-activation of an MLP whose only head is Dense(1) (the proposal MLP,
+   * models.py:460: dY_last = relu'(z_last) * (g_density (x) w_density)), value for value what mnr_mlp_chain_bwd computes and would
+   * otherwise have to store for this launch to read back (M x N x 2 bytes each way).  rank1_g: fp32 [M] (4-byte aligned),
+   * rank1_w: fp32 [N] (16-byte aligned), rank1_bits: the forward pass's 1-bit ReLU masks, row-major, bit (n & 7) of byte
+   * [m * ld_rank1_bits + n / 8] (4-byte aligned, ld_rank1_bits a multiple of 4). */
+  const float* rank1_g; const float* rank1_w; const uint8_t* rank1_bits; int ld_rank1_bits;
 } mnr_gemm_tn_args;
 
 /* Weight gradient: C += A^T B (fp32 atomics; C must be initialised by the caller). */

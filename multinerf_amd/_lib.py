@@ -74,7 +74,8 @@ class GemmTNArgs(C.Structure):
               ('M', C.c_int64), ('C', vp), ('ldc', C.c_int),
               ('k_valid', C.c_int), ('n_valid', C.c_int),
               ('bias_out', vp), ('bias_n_valid', C.c_int), ('gcol', vp), ('gcol_out', vp),
-              ('a_layout', C.c_int), ('b_layout', C.c_int), ('m_interleave', C.c_int), ('max_wgs', C.c_int)]
+              ('a_layout', C.c_int), ('b_layout', C.c_int), ('m_interleave', C.c_int), ('max_wgs', C.c_int),
+              ('rank1_g', vp), ('rank1_w', vp), ('rank1_bits', vp), ('ld_rank1_bits', C.c_int)]
 
 
 CHAIN_MAX_DEPTH = 8

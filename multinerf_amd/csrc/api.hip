@@ -16,7 +16,7 @@ void mnr_set_error(const char* fmt, ...) {
 
 extern "C" const char* mnr_last_error(void) { return g_err; }
 
-extern "C" int mnr_abi_version(void) { return 19; }
+extern "C" int mnr_abi_version(void) { return 20; }
 
 extern "C" int mnr_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch_name,
                                int arch_name_len) {

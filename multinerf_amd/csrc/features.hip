@@ -165,9 +165,12 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
 
   const int row_elems = OUT_F32 ? nfeat : ld_feat;
   // `pitch`: bytes between staged rows in LDS (row bytes + padding: with 1-KiB rows every sample of a wave hits the same banks).
-  // The kernel streams its feature rows out at ≈3.9 TB/s (1 GB per 64-sample proposal level in 0.27 ms), the write rate HBM
-  // sustains: the arithmetic only has to stay under that (round 2 cut it from ≈470 to ≈340 instructions per (sample,
-  // direction) without changing the time), so the inner loop is short rather than clever:
+  // The kernel streams its feature rows out at 3.0-3.9 TB/s (1 GB per 64-sample proposal level in 0.27-0.36 ms).  That is NOT the
+  // write rate HBM sustains (a plain fill writes 6.9 TB/s, profiles/r5k_write_rate.txt): without its write-out the kernel takes 246 of
+  // its 357 us, without the encoding loop 191 (profiles/r5m_ipe_probe.txt): the two phases of a block barely overlap with the
+  // other blocks of its CU.  Round 2 cut the loop from ≈470 to ≈340 instructions per (sample, direction) without changing the
+  // time; round 5's two-directions-per-thread loop on v_pk_mul_f32 (1.7x fewer instructions, same bits) was 5-9 % SLOWER
+  // (profiles/r5n_probe.txt) and is not here.  The inner loop is short rather than clever:
   // an anchor every 4th degree = one sin / cos of the wrapped argument (math.safe_sin's wrap at float32(100 pi),
   // math.py:26-28; fe_sincos_wrapped) and one hardware exp2 for the attenuation; the 3 degrees behind it by the double-angle
   // recurrence (sin 2x = 2 sin x cos x, cos 2x = 1 - 2 sin^2 x; cf. stable_pos_enc in the reference's tests/coord_test.py:34-43)
@@ -175,7 +178,11 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
   // cos is the reference's sin(x + pi/2).  sin and cos feature of a (degree, direction) leave as one packed bf16 pair.
   // TANGENT: three rows per sample (d/d mean_x, d/d mean_y, d/d mean_z), staged as [c][sample][ld].
   const float inv_k = 1.0f / (float)K;
+#if defined(FE_DBG) && FE_DBG == 1                      // timing probe (tools/ipe_probe.py): no encoding (rows are whatever LDS holds)
+  for (int pair = threadIdx.x; pair < 0; pair += FE_THREADS) {
+#else
   for (int pair = threadIdx.x; pair < ns * K; pair += FE_THREADS) {
+#endif
     const int si = (int)(((float)pair + 0.5f) * inv_k);       // pair / K, exact for pair < 2^20
     const int k = pair - si * K;
     const FeSample g = gs[si];
@@ -255,7 +262,11 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
   for (int cc = 0; cc < (TANGENT ? 3 : 1); ++cc) {
     char* dst = (char*)feat_out + ((size_t)cc * total + s0) * row_bytes;
     const char* src = rows + (size_t)cc * spb * pitch;
+#if defined(FE_DBG) && FE_DBG == 2                      // timing probe: no write-out (one chunk per block keeps the encoding alive)
+    for (int ch = threadIdx.x; ch < 1; ch += FE_THREADS) {
+#else
     for (int ch = threadIdx.x; ch < ns * cpr; ch += FE_THREADS) {
+#endif
       const int r = ch / cpr, o = (ch - r * cpr) << 4;
       *(uint4*)(dst + (size_t)r * row_bytes + o) = *(const uint4*)(src + (size_t)r * pitch + o);
     }

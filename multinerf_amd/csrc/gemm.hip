@@ -572,7 +572,7 @@ static inline int mnr_gcd(int a, int b) {
 
 template <class CFG, bool A_PANEL = false, bool B_PANEL = false>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
-  constexpr bool GCOL = false;
+  constexpr bool GCOL = false, RANK1 = false;
 #include "gemm_tn_body.inc"
 }
 
@@ -580,11 +580,19 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_kernel(mnr_gemm_tn_args 
 // weight-gradient GEMMs without it keep their registers and schedule.
 template <class CFG, bool A_PANEL = false, bool B_PANEL = false>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_tn_gcol_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
-  constexpr bool GCOL = true;
+  constexpr bool GCOL = true, RANK1 = false;
 #include "gemm_tn_body.inc"
 }
 
-template <class CFG, bool G = false, bool AP = false, bool BP = false>
+// B built inside the kernel from its rank-1 factors and the ReLU mask bits (mnr_gemm_tn_args.rank1_*): the proposal MLP's last dY
+// is never stored (1 GB written by mlp_chain_bwd and 1 GB read back here per step of 360.gin).
+template <class CFG>
+__global__ __launch_bounds__(CFG::THREADS) void gemm_tn_rank1_kernel(mnr_gemm_tn_args p, int splits, int steps_per_split) {
+  constexpr bool GCOL = false, RANK1 = true, A_PANEL = false, B_PANEL = false;
+#include "gemm_tn_body.inc"
+}
+
+template <class CFG, bool G = false, bool AP = false, bool BP = false, bool R1 = false>
 static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   const int tiles = (a->K / CFG::BKO) * (a->N / CFG::BNO);
   const int total_steps = (int)(a->M / TN_BM);
@@ -605,14 +613,19 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   const int steps_per_split = (total_steps + splits - 1) / splits;
   const int64_t grid = (int64_t)splits * tiles;
   // LDS: a panel operand's stage image carries 128 bytes of padding per 1-KiB block (gemm_tn_body.inc)
-  constexpr int lds = CFG::STAGES * ((AP ? (CFG::BKO / 16) * 1152 : CFG::A_BYTES) + (BP ? (CFG::BNO / 16) * 1152 : CFG::B_BYTES));
+  constexpr int lds = CFG::STAGES * ((AP ? (CFG::BKO / 16) * 1152 : CFG::A_BYTES) + (BP ? (CFG::BNO / 16) * 1152 : CFG::B_BYTES)) +
+                      (R1 ? CFG::STAGES * 1280 + 128 : 0);      // (rank1: the ring of factor slots + the mask table, gemm_tn_body.inc)
   static_assert(lds <= 160 * 1024, "LDS");
   static unsigned long long attr_set = 0;                 // per device (mnr_attr_needed)
   if (mnr_attr_needed(&attr_set)) {
-    if constexpr (G) (void)hipFuncSetAttribute((const void*)gemm_tn_gcol_kernel<CFG, AP, BP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if constexpr (R1) (void)hipFuncSetAttribute((const void*)gemm_tn_rank1_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else if constexpr (G) (void)hipFuncSetAttribute((const void*)gemm_tn_gcol_kernel<CFG, AP, BP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     else (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<CFG, AP, BP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
-  if constexpr (G)
+  if constexpr (R1)
+    hipLaunchKernelGGL((gemm_tn_rank1_kernel<CFG>), dim3((unsigned)grid), dim3(CFG::THREADS), lds, (hipStream_t)stream, *a, splits,
+                       steps_per_split);
+  else if constexpr (G)
     hipLaunchKernelGGL((gemm_tn_gcol_kernel<CFG, AP, BP>), dim3((unsigned)grid), dim3(CFG::THREADS), lds, (hipStream_t)stream,
                        *a, splits, steps_per_split);
   else
@@ -627,7 +640,8 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
   MNR_CHECK_ARG(a->M > 0 && a->M % TN_BM == 0, "mnr_gemm_tn_bf16: M=%lld must be a positive multiple of 64", (long long)a->M);
   MNR_CHECK_ARG(a->K > 0 && a->K % 128 == 0 && a->N > 0 && a->N % 128 == 0,
                 "mnr_gemm_tn_bf16: K=%d, N=%d must be multiples of 128", a->K, a->N);
-  MNR_CHECK_ARG(a->A && a->B && a->C, "mnr_gemm_tn_bf16: null operand");
+  const bool rank1 = a->rank1_g != nullptr;
+  MNR_CHECK_ARG(a->A && (a->B || rank1) && a->C, "mnr_gemm_tn_bf16: null operand");
   MNR_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0, "mnr_gemm_tn_bf16: lda/ldb must be multiples of 8");
   // The 256x256 tile halves operand traffic per MFMA and issues 4x the atomics per workgroup: it is used whenever K and N are
   // multiples of 256 (the 128x128 tile for the 256-wide layers measured slower in round 3, profiles/HISTORY.md).
@@ -639,6 +653,14 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
   MNR_CHECK_ARG(!a->gcol || (a->gcol_out && a->K % 256 == 0 && a->N % 256 == 0 && ((uintptr_t)a->gcol % 32) == 0),
                 "mnr_gemm_tn_bf16: gcol needs gcol_out, K and N multiples of 256 and a 32-byte-aligned vector");
   const bool ap = a->a_layout == MNR_LAYOUT_PANEL, bp = a->b_layout == MNR_LAYOUT_PANEL;
+  if (rank1) {
+    MNR_CHECK_ARG(!a->B && !a->gcol && a->a_layout == MNR_LAYOUT_ROWMAJOR && a->b_layout == MNR_LAYOUT_ROWMAJOR && big,
+                  "mnr_gemm_tn_bf16: rank1 goes with B == NULL, no gcol, row-major A, K and N multiples of 256");
+    MNR_CHECK_ARG(a->rank1_w && a->rank1_bits && ((uintptr_t)a->rank1_g % 4) == 0 && ((uintptr_t)a->rank1_w % 16) == 0 &&
+                      ((uintptr_t)a->rank1_bits % 4) == 0 && a->ld_rank1_bits % 4 == 0 && a->ld_rank1_bits * 8 >= a->N,
+                  "mnr_gemm_tn_bf16: rank1 needs g (fp32 [M]), w (fp32 [N], 16-byte aligned) and mask rows of >= N bits with a pitch that is a multiple of 4");
+    return tn_launch<TnBig, false, false, false, true>(a, tn_target, stream);
+  }
   MNR_CHECK_ARG((ap || a->a_layout == MNR_LAYOUT_ROWMAJOR) && (bp || a->b_layout == MNR_LAYOUT_ROWMAJOR), "mnr_gemm_tn_bf16: unknown layout");
   if (ap || bp) {
     // panel operands: the 256 x 256 tile only (the 1024-wide trunk's weight gradients)

@@ -35,6 +35,15 @@ def _rup(x, m):
   return (x + m - 1) // m * m
 
 
+def _rank1_last(plan, D, W, feature_gradient):
+  """Whether the last hidden layer's dY = relu'(z) * (g (x) w_density) of a Dense(1)-headed chain (the proposal MLP, reference
+  models.py:457-460) can stay unstored: its weight-gradient GEMM then builds it from the factors (`mnr_gemm_tn_args.rank1_*`).  Not
+  when another reader needs the matrix (a skip concat's second GEMM, the feature gradient of a one-layer trunk)."""
+  concat_last = bool(plan.trunk[D - 1][1])
+  k_in = plan.ldF if D == 1 else W
+  return bool(_RANK1_LAST and W % 256 == 0 and k_in % 256 == 0 and not concat_last and not (feature_gradient and D == 1))
+
+
 # Module-level switches of the host orchestration.  Every one of them was a same-box A/B in rounds 2-4 (profiles/HISTORY.md,
 # profiles/r4_ab.md) and is settled; they stay as plain constants because the bitwise / parity tests compare the two forms of
 # each (tests/test_gpu_chain.py, tests/test_sim_model.py set them on the module).  The environment is not read.
@@ -45,6 +54,7 @@ _HEAD_VCOL = True     # the density head's forward column as a vector next to th
 _HEAD_GCOL = True     # the density head's weight gradient as an extra column of the bottleneck's dW GEMM
 _PANEL = True         # wide (>= 512) per-layer trunks keep activations, gradients and masks in the panel layout (csrc/gemm_blk.hip)
 _MERGE_PROPS = True   # the backward pass of all proposal levels as one pass (they share PropMLP_0 and the sample count)
+_RANK1_LAST = True    # the proposal MLP's last dY built inside its weight-gradient GEMM from (g, w_density, mask bits) instead of stored
 # A panel-storage trunk layer's dW and dX GEMMs read the same dY matrix: side by side on two streams with half the chip each, the
 # dW kernel's M-splits block-cyclic (mnr_gemm_tn_args.m_interleave), so that both walk M from top to bottom and part of the second
 # reads of dY is served by the Infinity Cache instead of HBM: 532.4 / 533.8 k -> 538.1 / 538.1 k rays/s on one box, gradients equal
@@ -1475,7 +1485,10 @@ class Model:
                            relu_mask=False, dW=gslice(d.kernel_off, W), db=gslice(d.bias_off, 1))
         D = len(plan.trunk)
         # (keyed by level: the proposal levels' backward passes may run side by side on streams of their own)
-        dYs = [self._buf(('bwd', slot, 'dYc', W, i, lv['level']), (M, W), bf16) for i in range(D)]
+        # (the last dY = mask * (g (x) w_head) is not stored when its only reader, the last layer's weight-gradient GEMM, can
+        # build it from the factors: `_rank1_last`)
+        r1 = _rank1_last(plan, D, W, g_feat_out is not None)
+        dYs = [None if (r1 and i == D - 1) else self._buf(('bwd', slot, 'dYc', W, i, lv['level']), (M, W), bf16) for i in range(D)]
         Bws = [None] + [self._w(plan, plan.packed[('trunk', i)]['b_off'], _rup(W, 128), plan.packed[('trunk', i)]['b_ld'])
                         for i in range(1, D)]
         ops.mlp_chain_bwd(g_raw_density.view(M), w_head, mlp['bits'], Bws, dYs, M=M, W=W)
@@ -1483,7 +1496,8 @@ class Model:
         for i, (dl, concat) in enumerate(plan.trunk):
           inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
           ops.gemm_tn(inp, dYs[i], gslice(dl.kernel_off, kv * W), M=M, K=in_w, N=W, lda=in_w, ldb=W, ldc=W,
-                      k_valid=kv, n_valid=W, bias_out=gslice(dl.bias_off, W), bias_n_valid=W)
+                      k_valid=kv, n_valid=W, bias_out=gslice(dl.bias_off, W), bias_n_valid=W,
+                      rank1=(g_raw_density.view(M), w_head, mlp['bits'][i]) if dYs[i] is None else None)
           if concat:
             ops.gemm_tn(feat, dYs[i], gslice(dl.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
                         lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
@@ -1603,14 +1617,16 @@ class Model:
     w_head = flat[d.kernel_off:d.kernel_off + W]
     ops.small_head_bwd(acts[-1], W, g_all.view(Mall, 1), w_head.view(W, 1), M=Mall, K=W, Cn=1, dX=None,
                        relu_mask=False, dW=grads[d.kernel_off:d.kernel_off + W], db=grads[d.bias_off:d.bias_off + 1])
-    dYs = [self._buf(('bwd', 'dYc', W, i, 'props'), (Mall, W), bf16) for i in range(D)]
+    r1 = _rank1_last(plan, D, W, False)
+    dYs = [None if (r1 and i == D - 1) else self._buf(('bwd', 'dYc', W, i, 'props'), (Mall, W), bf16) for i in range(D)]
     Bws = [None] + [self._w(plan, plan.packed[('trunk', i)]['b_off'], _rup(W, 128), plan.packed[('trunk', i)]['b_ld'])
                     for i in range(1, D)]
     ops.mlp_chain_bwd(g_all, w_head, bits, Bws, dYs, M=Mall, W=W)
     for i, (dl, concat) in enumerate(plan.trunk):
       inp, in_w, kv = (feat, plan.ldF, plan.F) if i == 0 else (acts[i - 1], W, W)
       ops.gemm_tn(inp, dYs[i], grads[dl.kernel_off:dl.kernel_off + kv * W], M=Mall, K=in_w, N=W, lda=in_w, ldb=W,
-                  ldc=W, k_valid=kv, n_valid=W, bias_out=grads[dl.bias_off:dl.bias_off + W], bias_n_valid=W)
+                  ldc=W, k_valid=kv, n_valid=W, bias_out=grads[dl.bias_off:dl.bias_off + W], bias_n_valid=W,
+                  rank1=(g_all, w_head, bits[i]) if dYs[i] is None else None)
       if concat:
         o = dl.kernel_off + W * W
         ops.gemm_tn(feat, dYs[i], grads[o:o + plan.F * W], M=Mall, K=plan.ldF, N=W, lda=plan.ldF, ldb=W, ldc=W,

@@ -421,19 +421,31 @@ def gemm_nt(A1, Bt, *, M, N, K1, A2=None, K2=0, lda1=None, lda2=None, ldb=None, 
 
 def gemm_tn(A, B, Cout, *, M, K, N, lda=None, ldb=None, ldc=None, k_valid=None, n_valid=None, bias_out=None,
             bias_n_valid=0, gcol=None, gcol_out=None, a_layout=LAYOUT_ROWMAJOR, b_layout=LAYOUT_ROWMAJOR, m_interleave=False,
-            max_wgs=0):
+            max_wgs=0, rank1=None):
   """Cout[k,n] += sum_m A[m,k] B[m,n]; optionally bias_out[n] += sum_m B[m,n] (fused bias gradient) and
-  gcol_out[k] += sum_m A[m,k] gcol[m] (one more column of B given as a contiguous bf16 vector [M])."""
+  gcol_out[k] += sum_m A[m,k] gcol[m] (one more column of B given as a contiguous bf16 vector [M]).
+  rank1 = (g [M] fp32, w [N] fp32, bits [M, N / 8] uint8) with B = None: B[m,n] = bit ? bf16(g[m] w[n]) : 0 is built inside
+  the kernel (the proposal MLP's last dY, mnr_gemm_tn_args.rank1_*)."""
   _chk(bias_out, f32, 'bias_out', allow_none=True)
   _chk(gcol, bf16, 'gcol', allow_none=True)
   _chk(gcol_out, f32, 'gcol_out', allow_none=True)
   assert (gcol is None) == (gcol_out is None) and (gcol is None or (gcol.numel() == M and gcol.is_contiguous()))
   _chk(A, bf16, 'A')
-  _chk(B, bf16, 'B')
+  _chk(B, bf16, 'B', allow_none=rank1 is not None)
   _chk(Cout, f32, 'C')
   a = L.GemmTNArgs()
   a.A, a.lda, a.K = A.data_ptr(), lda if lda else A.stride(0), K
-  a.B, a.ldb, a.N = B.data_ptr(), ldb if ldb else B.stride(0), N
+  if rank1 is not None:
+    g, w, bits = rank1
+    _chk(g, f32, 'rank1 g')
+    _chk(w, f32, 'rank1 w')
+    _chk(bits, torch.uint8, 'rank1 bits')
+    assert B is None and g.numel() == M and g.is_contiguous() and w.numel() >= N and w.is_contiguous()
+    assert bits.dim() == 2 and bits.shape[0] == M and bits.shape[1] * 8 >= N and bits.stride(1) == 1
+    a.B, a.ldb, a.N = None, N, N
+    a.rank1_g, a.rank1_w, a.rank1_bits, a.ld_rank1_bits = g.data_ptr(), w.data_ptr(), bits.data_ptr(), bits.stride(0)
+  else:
+    a.B, a.ldb, a.N = B.data_ptr(), ldb if ldb else B.stride(0), N
   a.M = M
   a.C, a.ldc = Cout.data_ptr(), ldc if ldc else Cout.stride(0)
   a.k_valid = K if k_valid is None else k_valid

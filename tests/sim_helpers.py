@@ -89,18 +89,23 @@ def sim_gemm_nt(lib, A1, Bt, A2=None, bias=None, relu=False, mask=None, out_bf16
 
 
 def sim_gemm_tn(lib, A, B, C_acc, bias_out=None, k_valid=None, n_valid=None, a_layout=0, b_layout=0, gcol=None, gcol_out=None,
-                m_interleave=False, max_wgs=0):
+                m_interleave=False, max_wgs=0, rank1=None):
   """C_acc[K,N] += A^T B (and bias_out += column sums of B) through the simulated mnr_gemm_tn_bf16.  a_layout / b_layout = 1:
-  the operand is given in MNR_LAYOUT_PANEL storage; gcol [M] bf16 / gcol_out [K] fp32: the extra column of B."""
+  the operand is given in MNR_LAYOUT_PANEL storage; gcol [M] bf16 / gcol_out [K] fp32: the extra column of B.
+  rank1 = (g [M] fp32, w [N] fp32, bits [M, >= N / 8] uint8) with B = None: B is built inside the kernel."""
   M, K = A.shape
-  N = B.shape[1]
+  N = B.shape[1] if rank1 is None else rank1[1].numel()
   a = L.GemmTNArgs()
   a.a_layout, a.b_layout = a_layout, b_layout
   a.m_interleave, a.max_wgs = int(m_interleave), int(max_wgs)
   if gcol is not None:
     a.gcol, a.gcol_out = ptr(gcol), ptr(gcol_out)
   a.A, a.lda, a.K = ptr(A), A.stride(0), K
-  a.B, a.ldb, a.N = ptr(B), B.stride(0), N
+  if rank1 is None:
+    a.B, a.ldb, a.N = ptr(B), B.stride(0), N
+  else:
+    a.B, a.ldb, a.N = None, N, N
+    a.rank1_g, a.rank1_w, a.rank1_bits, a.ld_rank1_bits = ptr(rank1[0]), ptr(rank1[1]), ptr(rank1[2]), rank1[2].stride(0)
   a.M, a.C, a.ldc = M, ptr(C_acc), C_acc.stride(0)
   a.k_valid = K if k_valid is None else k_valid
   a.n_valid = N if n_valid is None else n_valid

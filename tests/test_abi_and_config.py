@@ -38,7 +38,7 @@ def test_library_exports_every_header_symbol():
     text = open(f).read()
     assert not any(n in text for n in dbg), f
     assert 'os.environ' not in text or os.path.basename(f) in ('build.py', 'dist.py', 'preflight.py', 'streams.py'), f
-  assert lib.mnr_abi_version() == 19
+  assert lib.mnr_abi_version() == 20
 
 
 def test_ops_refuse_cpu_tensors():

@@ -206,7 +206,11 @@ def _rays(gen, B):
 
 @pytest.mark.parametrize('shape,contract,basis_name,maxdeg', [('cone', True, ('icosahedron', 2), 12),
                                                               ('cone', False, ('octahedron', 1), 16),
-                                                              ('cylinder', False, ('octahedron', 1), 16)])
+                                                              ('cylinder', False, ('octahedron', 1), 16),
+                                                              # an even number of directions (6) and a wide one (46: three passes of the
+                                                              # bf16 kernel's (sample, direction pair) loop)
+                                                              ('cone', True, ('icosahedron', 1), 10),
+                                                              ('cone', False, ('icosahedron', 3), 4)])
 def test_cast_rays_ipe(ops, shape, contract, basis_name, maxdeg):
   from multinerf_amd import geopoly
   gen = torch.Generator().manual_seed(4)
@@ -561,6 +565,38 @@ def test_gemm_tn_extra_column(ops, M, K, N, ldb):
   assert (gg[kv:] == 3).all()
   with pytest.raises(ValueError, match='gcol'):
     ops.gemm_tn(dev(A), dev(Bfull), Cout, M=M, K=K, N=128, ldb=ldb, gcol=dev(_bf(g)), gcol_out=gout)
+
+
+@pytest.mark.parametrize('M,K,N,pitch', [(16384, 256, 256, 32), (8192 + 64, 512, 512, 80), (128, 256, 256, 32),
+                                         pytest.param(1 << 20, 256, 256, 32, id='proposal_level_rows')])
+def test_gemm_tn_rank1_b_operand(ops, M, K, N, pitch):
+  """mnr_gemm_tn_args.rank1_*: B[m, n] = bit ? bf16(g[m] w[n]) : 0 built in LDS from the factors (the proposal MLP's last dY,
+  models.py:457-460: relu'(z) * (g_density (x) w_density)), against fp64 of the same bf16 matrix and against the launch that
+  reads it stored (same image, same order inside a workgroup: equal up to the order of the fp32 atomics); the fused bias
+  gradient and the k_valid / n_valid window; two n-tiles and a mask pitch wider than the tile, a single 64-row step, and the
+  360.gin proposal level's own row count."""
+  gen = torch.Generator().manual_seed(29)
+  A = dev(_bf(torch.randn((M, K), generator=gen)))
+  g = dev(0.1 * torch.randn((M,), generator=gen))
+  w = dev(torch.randn((N,), generator=gen))
+  bits = dev(torch.randint(0, 256, (M, pitch), generator=gen, dtype=torch.uint8))
+  bit = ((bits[:, :N // 8, None].int() >> torch.arange(8, device=bits.device)) & 1).reshape(M, N).bool()
+  Bm = torch.where(bit, g[:, None] * w[None, :], torch.zeros((), device=g.device)).bfloat16()
+  ref = A.double().T @ Bm.double()
+  kv, nv = K - 8, N - 3
+  C0, b0 = torch.ones((K, N), dtype=torch.float32).cuda(), torch.zeros((N,)).cuda()
+  C1, b1 = torch.ones((K, N), dtype=torch.float32).cuda(), torch.zeros((N,)).cuda()
+  ops.gemm_tn(A, Bm, C0, M=M, K=K, N=N, k_valid=kv, n_valid=nv, bias_out=b0, bias_n_valid=N)
+  ops.gemm_tn(A, None, C1, M=M, K=K, N=N, k_valid=kv, n_valid=nv, bias_out=b1, bias_n_valid=N, rank1=(g, w, bits))
+  got = C1.double()
+  np.testing.assert_allclose(got[:kv, :nv].cpu().numpy(), (ref + 1)[:kv, :nv].cpu().numpy(), rtol=1e-4, atol=1e-4 * math.sqrt(M))
+  assert (got[kv:] == 1).all() and (got[:, nv:] == 1).all()
+  np.testing.assert_allclose(b1.double().cpu().numpy(), Bm.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4 * math.sqrt(M))
+  rel = ((C1 - C0).double().norm() / (C0 - 1).double().norm()).item()
+  print(f'rank1 vs stored B at M = {M}: |dC| / |C| = {rel:.2e}')
+  assert rel < 1e-6
+  with pytest.raises(ValueError, match='rank1'):
+    ops.gemm_tn(A, None, C1, M=M, K=K, N=N, rank1=(g, w, bits), gcol=dev(_bf(torch.zeros(M))), gcol_out=torch.zeros((K,)).cuda())
 
 
 @pytest.mark.parametrize('K1,K2,bits', [(1024, 0, False), (1024, 512, False), (1024, 0, True)])

@@ -270,3 +270,28 @@ def test_paired_dx_dw_equals_one_after_the_other(setup):
   rel = ((gs[True] - gs[False]).norm() / gs[False].norm()).item()
   print(f'paired vs one after the other: |dg| / |g| = {rel:.2e}')
   assert torch.isfinite(gs[True]).all() and rel < 1e-5
+
+
+def test_last_proposal_dy_built_in_its_weight_gradient_gemm_equals_the_stored_one(setup):
+  """models._RANK1_LAST (the proposal MLP's last dY never stored: `mnr_gemm_tn_args.rank1_*`) against the stored matrix: the same
+  gradient up to the order of the weight-gradient atomics, on 2048 rays of configs/360.gin at full width."""
+  from multinerf_amd import models as M_
+  cfg, model, _, params, flat, batch = setup
+  n = min(2048, B_FULL)
+  sub = _dev(batch.map(lambda t: t[:n]))
+  noise = {k: {lv: t.cuda() for lv, t in d.items()} for k, d in helpers.make_noise(model, n).items()}
+  step = train_utils.create_train_step(model, cfg)
+  gs = {}
+  old = M_._RANK1_LAST
+  try:
+    for on in (True, False):
+      M_._RANK1_LAST = on
+      state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone().cuda(), 'params': None})
+      _, stats, _ = step(0, state, sub, None, 0.4, 0.0, noise=noise, return_grads=True)
+      torch.cuda.synchronize()
+      gs[on] = stats['_grads'].double().cpu()
+  finally:
+    M_._RANK1_LAST = old
+  rel = ((gs[True] - gs[False]).norm() / gs[False].norm()).item()
+  print(f'last proposal dY built in the kernel vs stored: |dg| / |g| = {rel:.2e}')
+  assert torch.isfinite(gs[True]).all() and rel < 1e-5

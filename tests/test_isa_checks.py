@@ -46,7 +46,8 @@ def test_the_shipped_mfma_kernels_are_all_there(report):
   assert sum('mlp_chain_fwd_kernel' in n for n in names) == 2 and sum('mlp_chain_bwd_kernel' in n for n in names) == 2   # W = 128 / 256
   assert sum('mlp_chain_fwd_ipe_kernel' in n for n in names) == 2      # the inference chain with the in-kernel IPE producer
   assert sum('gemm_tn_gcol_kernel' in n for n in names) == 2           # TnBig with one more B column from a vector; the same with a panel A
-  assert len(names) == 27, names
+  assert sum('gemm_tn_rank1_kernel' in n for n in names) == 1          # TnBig with B built in LDS from its rank-1 factors and mask bits
+  assert len(names) == 28, names
 
 
 def test_tiled_gemm_k_loops_carry_only_the_hand_counted_vmcnt_waits(report):

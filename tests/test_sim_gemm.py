@@ -383,3 +383,26 @@ def test_tn_block_cyclic_m_splits(sim, layouts):
       np.testing.assert_allclose(gout.numpy(), (A.float().T @ gcol.float()).numpy(), rtol=1e-4, atol=1e-2)
   with pytest.raises(RuntimeError, match='m_interleave needs'):
     S.sim_gemm_tn(sim, A[:768], B[:768], torch.zeros((K, N)), m_interleave=True, max_wgs=16)     # 3 M-tiles on 8 splits
+
+
+@pytest.mark.parametrize('late_dma', [0, 1])
+def test_tn_rank1_b_operand_built_in_the_kernel(sim, late_dma):
+  """mnr_gemm_tn_args.rank1_*: B[m, n] = bit ? bf16(g[m] w[n]) : 0 expanded in LDS from the factors (the proposal MLP's last dY,
+  models.py:460 behind the ReLU of :457) must give what the stored matrix gives, value for value: same B image, same order of
+  the sums.  Several splits, two n-tiles, K = 512 (two k-tiles share an n-tile), splits of 1-3 M-tiles (the prologue / tail
+  variants of the stage loop), the DMA data arriving as late as the counted waits allow."""
+  g = torch.Generator().manual_seed(23)
+  for M, K, N, cap in ((2048, 256, 256, 0), (1536, 512, 512, 16), (256, 256, 256, 8), (4096, 256, 256, 8)):
+    A = torch.randn((M, K), generator=g).bfloat16()
+    gh = torch.randn(M, generator=g) * 0.1
+    w = torch.randn(N, generator=g)
+    bits = torch.randint(0, 256, (M, N // 8 + 4), generator=g, dtype=torch.uint8)            # (a pitch wider than the tile)
+    bit = ((bits[:, :N // 8, None].int() >> torch.arange(8)) & 1).reshape(M, N).bool()
+    B = torch.where(bit, gh[:, None] * w[None, :], torch.zeros(())).bfloat16()
+    sim.hipsim_reset(late_dma, 5)
+    C0, b0 = torch.zeros((K, N)), torch.zeros(N)
+    S.sim_gemm_tn(sim, A, B, C0, bias_out=b0, max_wgs=cap, m_interleave=(M == 4096))
+    C1, b1 = torch.zeros((K, N)), torch.zeros(N)
+    S.sim_gemm_tn(sim, A, None, C1, bias_out=b1, max_wgs=cap, m_interleave=(M == 4096), rank1=(gh, w, bits))
+    np.testing.assert_allclose(C0.numpy(), (A.float().T @ B.float()).numpy(), rtol=1e-5, atol=2e-3)
+    assert torch.equal(C1, C0) and torch.equal(b1, b0), (M, K, N, (C1 - C0).abs().max().item())

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from multinerf_amd import configs, models, train_utils
+from multinerf_amd import configs, models, ops, train_utils
 from oracle import models as omodels
 from oracle import train_utils as otrain
 from tests import helpers
@@ -186,6 +186,35 @@ def test_proposal_levels_backward_as_one_pass_equals_level_by_level():
     rel = ((a - r).norm() / (r.norm() + 1e-30)).item()
     print(f'{mod}: merged vs per-level rel {rel:.2e}')
     assert rel < 1e-5, (mod, rel)
+
+
+RANK1_CASE = ('360', ['NerfMLP.net_width = 128', 'NerfMLP.net_depth = 2', 'PropMLP.net_width = 256', 'PropMLP.net_depth = 3',
+                      'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32'], 8)
+
+
+@pytest.mark.parametrize('extra', [[], ['Model.stop_level_grad = False']])
+def test_last_proposal_dy_built_inside_its_weight_gradient_gemm(extra, monkeypatch):
+  """models._RANK1_LAST: a 256-wide proposal MLP's last dY = relu'(z) * (g (x) w_density) is not stored by the dX chain; the last
+  layer's weight-gradient GEMM builds it from (g, w_density, mask bits) (`mnr_gemm_tn_args.rank1_*`).  Same values, same order of
+  the sums: the gradient of a train step must come out bit for bit, through `backward_prop_levels` (both proposal levels in one
+  pass) and through `backward_level` (level by level: the sampling gradient's path)."""
+  from multinerf_amd import models as M_
+  out = {}
+  with S.simulated_device() as sim:
+    sim.lib.hipsim_reset(1, 3)
+    for on in (True, False):
+      monkeypatch.setattr(M_, '_RANK1_LAST', on)
+      calls = []
+      real = ops.gemm_tn
+      monkeypatch.setattr(ops, 'gemm_tn', lambda *a, **k: (calls.append(k.get('rank1') is not None), real(*a, **k))[1])
+      model, g, st = _grads_of_one_step(RANK1_CASE[0], RANK1_CASE[1] + extra, RANK1_CASE[2], merge=True)
+      monkeypatch.setattr(ops, 'gemm_tn', real)
+      sim.check()
+      assert (model._props_group(True) == 2) == (not extra)
+      assert sum(calls) == ((1 if not extra else 2) if on else 0), calls
+      out[on] = (g, st['loss'])
+  assert out[True][1] == out[False][1]
+  assert torch.equal(out[True][0], out[False][0]), (out[True][0] - out[False][0]).abs().max().item()
 
 
 def test_density_only_mlp_with_a_skip_concat_on_the_fused_chain():
