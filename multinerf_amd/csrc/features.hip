@@ -23,7 +23,12 @@
 // explicit fmaf calls are fused in all).
 #pragma clang fp contract(off)
 
+#ifndef FE_THREADS                                     // (probe builds: -DFE_THREADS=... -DFE_STAGE_BYTES=..., tools/ipe_probe.py)
 #define FE_THREADS 256
+#endif
+#ifndef FE_STAGE_BYTES
+#define FE_STAGE_BYTES (32 * 1024)                      // feature rows a block stages in LDS
+#endif
 #include "ipe_math.h"
 
 // Tangents of the contraction for the density-gradient normals (models.py:445-446 applies warp_fn INSIDE predict_density, so
@@ -143,7 +148,12 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
       d[i] = directions[ray * 3 + i];
     }
     FeSample g;
+#if defined(FE_DBG) && FE_DBG == 3                      // timing probe: no Gaussian arithmetic
+    g.mean[0] = t0 + o[0], g.mean[1] = t1 + o[1], g.mean[2] = d[2] + radii[ray];
+    for (int i = 0; i < 6; ++i) g.cov[i] = 1e-3f * d[i % 3];
+#else
     fe_gaussian(c, t0, t1, o, d, radii[ray], g);
+#endif
     gs[threadIdx.x] = g;
     if (TANGENT) {
       FeTangent T;
@@ -234,8 +244,12 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
       } else {
         const f32x2 pr = {fs, fc};
         const bf16x2 pb = __builtin_convertvector(pr, bf16x2);       // one v_cvt_pk_bf16_f32
+#if defined(FE_DBG) && FE_DBG == 4                      // timing probe: one LDS store per (sample, direction) instead of 2 L
+        if (l == L - 1) *(bf16x2*)(rows + (size_t)si * pitch + (size_t)k * 4) = pb;
+#else
         *(bf16*)rowp = pb[0];
         *(bf16*)(rowp + half) = pb[1];
+#endif
       }
       rowp += lstep;
       const float s2 = 2.0f * sn * cs;
@@ -288,7 +302,7 @@ static int fe_launch(int mode /*0 bf16, 1 f32, 2 tangent*/, const mnr_ipe_cfg* c
   MNR_CHECK_ARG(f32 || (ld_feat >= nfeat && ld_feat % 8 == 0), "mnr_cast_rays_ipe: ld_feat=%d must be >= %d and a multiple of 8", ld_feat, nfeat);
   MNR_CHECK_ARG(!f32 || nfeat % 4 == 0, "mnr_cast_rays_ipe_f32: feature count must be a multiple of 4");
   const size_t row_bytes = (size_t)row_elems * (f32 ? 4 : 2);
-  int spb = (int)((32 * 1024) / (row_bytes * (tangent ? 3 : 1)));
+  int spb = (int)(FE_STAGE_BYTES / (row_bytes * (tangent ? 3 : 1)));
   if (spb > FE_THREADS) spb = FE_THREADS;
   spb &= ~3;                       // keeps the row buffer 16-byte aligned behind the FeSample array
   MNR_CHECK_ARG(spb >= 4, "mnr_cast_rays_ipe: feature row too long");
