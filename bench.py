@@ -303,7 +303,7 @@ def main():
         },
         'roofline': {
             'bound': 'mfma',
-            'kernel': 'gemm_nt_kernel + gemm_nt_wres_kernel + gemm_tn_kernel + gemm_tn_gcol_kernel + mlp_chain_fwd/bwd_kernel (bf16 MFMA 32x32x16)',
+            'kernel': 'gemm_nt_kernel + gemm_nt_panel_kernel + gemm_nt_wres_kernel + gemm_tn_kernel + gemm_tn_gcol_kernel + gemm_tn_rank1_kernel + mlp_chain_fwd/bwd_kernel (bf16 MFMA 32x32x16)',
             'achieved': achieved_tflops,
             'peak': 2500.0,
             'unit': 'TFLOP/s',

@@ -10,7 +10,7 @@ import json
 import re
 import sys
 
-MFMA = ('gemm_nt_kernel', 'gemm_nt_panel_kernel', 'gemm_tn_kernel', 'gemm_tn_gcol_kernel', 'gemm_nt_wres_kernel', 'mlp_chain_fwd_kernel', 'mlp_chain_bwd_kernel',
+MFMA = ('gemm_nt_kernel', 'gemm_nt_panel_kernel', 'gemm_tn_kernel', 'gemm_tn_gcol_kernel', 'gemm_tn_rank1_kernel', 'gemm_nt_wres_kernel', 'mlp_chain_fwd_kernel', 'mlp_chain_bwd_kernel',
         'mlp_chain_fwd_ipe_kernel')
 
 
