@@ -31,6 +31,10 @@ int mnr_gemm_nt_panel_set_max_wgs(int n);
  * inside the NEXT layer's MFMA pass, behind that pass's last weight request; 0 = in front of the pass.  Bitwise equal. */
 int mnr_mlp_chain_set_deferred(int on);
 
+/* Test hook of the chain kernels: at most n persistent workgroups (every workgroup then walks several tiles at small sizes);
+ * 0 (default) = one per CU. */
+int mnr_mlp_chain_set_max_wgs(int n);
+
 /* Profiling hook: device buffer of 32 uint64 per workgroup, stamped (s_memtime per phase of the workgroup's second tile,
  * see csrc/fused_mlp.hip) by every following mnr_mlp_chain_fwd / _bwd launch; NULL switches it off. */
 int mnr_debug_chain_timeline(unsigned long long* device_buffer);

@@ -222,6 +222,7 @@ _DEBUG_PROTOS = {
     'mnr_gemm_nt_panel_set_max_wgs': ([i32], i32),
     'mnr_debug_chain_timeline': ([vp], i32),
     'mnr_mlp_chain_set_deferred': ([i32], i32),
+    'mnr_mlp_chain_set_max_wgs': ([i32], i32),
 }
 
 _lib = None

@@ -620,8 +620,16 @@ extern "C" int mnr_mlp_chain_set_deferred(int on) {
   return MNR_OK;
 }
 
+// Test hook (include/mnerf_debug.h): at most n persistent workgroups, so that small sizes walk several tiles per workgroup.
+static int g_fm_max_wgs = 0;
+extern "C" int mnr_mlp_chain_set_max_wgs(int n) {
+  g_fm_max_wgs = n > 0 ? n : 0;
+  return MNR_OK;
+}
+
 static int fm_grid(int64_t tiles) {
-  const int cus = mnr_cu_count();
+  int cus = mnr_cu_count();
+  if (g_fm_max_wgs > 0 && g_fm_max_wgs < cus) cus = g_fm_max_wgs;
   return (int)(tiles < cus ? tiles : cus);
 }
 

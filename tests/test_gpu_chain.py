@@ -279,3 +279,43 @@ def test_render_with_in_kernel_ipe_equals_feature_matrix_path(monkeypatch):
     np.testing.assert_allclose(x.numpy(), y.numpy(), atol=1e-3)
   np.testing.assert_allclose(rgb_a.numpy(), rgb_b.numpy(), atol=5e-3)
   np.testing.assert_allclose(dm_a.numpy(), dm_b.numpy(), rtol=2e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize('W,K0,depth,tiles', [(128, 128, 2, 20), (256, 64, 3, 12)])
+def test_chain_small_grids_change_no_bit(W, K0, depth, tiles):
+  """The chain kernels' persistent loop at sizes the simulator finishes: with at most n workgroups (mnr_mlp_chain_set_max_wgs,
+  include/mnerf_debug.h) every workgroup walks several tiles, and that must not change one bit of the forward pass (activations,
+  masks, head) or of the dX chain."""
+  ops = models.ops
+  dbg = ops.L.debug()
+  M = tiles * 256
+  g = torch.Generator().manual_seed(11)
+  bf = torch.bfloat16
+  feat = (torch.rand((M, K0), generator=g) * 2 - 1).to(bf).cuda()
+  layers = [(((torch.rand((W, K0 if i == 0 else W), generator=g) * 2 - 1) * (6.0 / (K0 if i == 0 else W)) ** 0.5).to(bf).cuda(),
+             (0.05 * torch.randn((W,), generator=g)).cuda()) for i in range(depth)]
+  wh = ((torch.rand((W,), generator=g) * 2 - 1) * 0.15).to(bf).cuda()
+  bh = torch.full((1,), 0.01).cuda()
+  gh = (torch.randn((M,), generator=g) * 0.01).cuda()
+  Bw = [None] + [layers[i][0].t().contiguous() for i in range(1, depth)]
+
+  def run():
+    out = torch.empty((M,), device='cuda')
+    acts = [torch.empty((M, W), dtype=bf, device='cuda') for _ in range(depth)]
+    bits = [torch.empty((M, W // 8), dtype=torch.uint8, device='cuda') for _ in range(depth)]
+    dY = [torch.empty((M, W), dtype=bf, device='cuda') for _ in range(depth)]
+    ops.mlp_chain_fwd(feat, K0, layers, M=M, W=W, w_head=wh, b_head=bh, head_out=out, acts=acts, bits=bits)
+    ops.mlp_chain_bwd(gh, wh.float(), bits, Bw, dY, M=M, W=W)
+    torch.cuda.synchronize()
+    return [out.cpu()] + [a.cpu().view(torch.int16) for a in acts] + [b.cpu() for b in bits] + [d.cpu().view(torch.int16) for d in dY]
+
+  ref = run()
+  assert ref[1].float().abs().max().item() > 0                                      # (not a comparison of zeros)
+  try:
+    for max_wgs in (24, 5, 1):
+      ops.L.check(dbg.mnr_mlp_chain_set_max_wgs(max_wgs))
+      got = run()
+      for i, (x, y) in enumerate(zip(ref, got)):
+        assert torch.equal(x, y), f'max_wgs {max_wgs}: output {i} differs'
+  finally:
+    ops.L.check(dbg.mnr_mlp_chain_set_max_wgs(0))

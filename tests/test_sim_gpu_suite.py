@@ -43,8 +43,9 @@ def test_kernel_level_gpu_tests_pass_on_the_simulator():
 
 def test_in_kernel_ipe_chain_passes_on_the_simulator():
   """The inference chain with the in-kernel IPE producer (mnr_mlp_chain_fwd_ipe) against mnr_cast_rays_ipe +
-  mnr_mlp_chain_fwd, leaf level and through Model.__call__ (tests/test_gpu_chain.py, ~25 s of simulator time)."""
-  tail = _child(['tests/test_gpu_chain.py', '-k', 'in_kernel_ipe'], 900)
+  mnr_mlp_chain_fwd, leaf level and through Model.__call__ (tests/test_gpu_chain.py, ~25 s of simulator time); the chain
+  kernels' persistent loops over several tiles per workgroup, bit for bit (~60 s)."""
+  tail = _child(['tests/test_gpu_chain.py', '-k', 'in_kernel_ipe or small_grids'], 900)
   assert ' passed' in tail and 'failed' not in tail and 'skipped' not in tail, tail
 
 
