@@ -16,7 +16,10 @@
 //
 // HBM traffic per level and direction is what training has to keep for dW anyway: the bf16 activations / gradients
 // (written once, straight from the LDS tile in full 2W-byte rows, 1-bit ReLU masks alongside); nothing is read back
-// between layers.  Inference (acts = bits = NULL) writes only the head output.
+// between layers.  Inference (acts = bits = NULL) writes only the head output.  The rows leave with NONTEMPORAL stores
+// (global_store_dwordx4 ... nt): nothing on the chip reads them again before they have left every cache, and without the
+// hint they push the lines the next tile's feature stream and the following launches want out of the L2 / Infinity Cache:
+// forward chain -2 to -4 %, backward chain -5 %, blender_256 / llff_raw steps -2 to -3 % (profiles/r5_ab.md (i)).
 //
 // LDS tile format (shared with gemm.hip's NT kernel): a [256 rows][W] bf16 activation is W/64 K-tiles of
 // [256][64] = 32 KiB, row pitch 128 B, 16-byte slot s of row r stored at slot position s ^ ((r >> 1) & 7).
@@ -214,7 +217,7 @@ __device__ __forceinline__ void fm_layer_mfma(const char* X, const bf16* __restr
             mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xAA, 0xf, 0xf, false) << 16;    // quad_perm [2,2,2,2]
             if ((ch & 3) == 0) *(unsigned*)(bits + (r + (int64_t)u * C::ROW_STEP) * (W / 8) + ch) = mb;
           }
-          if constexpr ((DEFER & 1) != 0) *(u32x4*)(dst + (r + (int64_t)u * C::ROW_STEP) * W + ch * 8) = cpw[u];
+          if constexpr ((DEFER & 1) != 0) __builtin_nontemporal_store(cpw[u], (u32x4*)(dst + (r + (int64_t)u * C::ROW_STEP) * W + ch * 8));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -374,7 +377,7 @@ __device__ __forceinline__ void fm_copy_out(const char* X, int tid_, int64_t m0,
         mb |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xAA, 0xf, 0xf, false) << 16;    // quad_perm [2,2,2,2]
         if ((ch & 3) == 0) *(unsigned*)(bits + bo + (int64_t)u * C::ROW_STEP * (W / 8)) = mb;
       }
-      if constexpr (DST) *(u32x4*)(dst + e0 + (int64_t)u * C::ROW_STEP * W) = w[u];
+      if constexpr (DST) __builtin_nontemporal_store(w[u], (u32x4*)(dst + e0 + (int64_t)u * C::ROW_STEP * W));
       if constexpr (HEAD) {
         const bf16x8 v = __builtin_bit_cast(bf16x8, w[u]);
         float s = 0.0f;

@@ -112,6 +112,7 @@ def main():
 
     fwd_slots = [1] + [x for li in range(D) for x in (2 + 3 * li, 3 + 3 * li, 4 + 3 * li)]
     timeline('fwd train', lambda: ops.mlp_chain_fwd(feat, K0, layers, M=M, W=W, w_head=wh, b_head=bh, head_out=out, acts=acts, bits=bits), fwd_slots)
+    timeline('fwd train, no masks', lambda: ops.mlp_chain_fwd(feat, K0, layers, M=M, W=W, w_head=wh, b_head=bh, head_out=out, acts=acts), fwd_slots)
     timeline('fwd inference', lambda: ops.mlp_chain_fwd(feat, K0, layers, M=M, W=W, w_head=wh, b_head=bh, head_out=out), fwd_slots)
     bwd_slots = [1] + [x for li in range(D - 1, 0, -1) for x in (2 + 3 * li, 3 + 3 * li, 4 + 3 * li)]
     timeline('bwd chain', lambda: ops.mlp_chain_bwd(gh, whf, bits, Bw, dY, M=M, W=W), bwd_slots)
