@@ -281,30 +281,32 @@ def test_render_with_in_kernel_ipe_equals_feature_matrix_path(monkeypatch):
   np.testing.assert_allclose(dm_a.numpy(), dm_b.numpy(), rtol=2e-2, atol=1e-3)
 
 
-@pytest.mark.parametrize('W,K0,depth,tiles', [(128, 128, 2, 20), (256, 64, 3, 12)])
-def test_chain_small_grids_change_no_bit(W, K0, depth, tiles):
+@pytest.mark.parametrize('W,K0,depth,tiles,skip', [(128, 128, 2, 20, 0), (256, 64, 3, 12, 0), (128, 64, 3, 10, 2)])
+def test_chain_small_grids_change_no_bit(W, K0, depth, tiles, skip):
   """The chain kernels' persistent loop at sizes the simulator finishes: with at most n workgroups (mnr_mlp_chain_set_max_wgs,
   include/mnerf_debug.h) every workgroup walks several tiles, and that must not change one bit of the forward pass (activations,
-  masks, head) or of the dX chain."""
+  masks, head) or of the dX chain.  skip > 0: that layer reads [x | features] (models.py:458-459), the feature segment streamed
+  a second time per tile."""
   ops = models.ops
   dbg = ops.L.debug()
   M = tiles * 256
   g = torch.Generator().manual_seed(11)
   bf = torch.bfloat16
   feat = (torch.rand((M, K0), generator=g) * 2 - 1).to(bf).cuda()
-  layers = [(((torch.rand((W, K0 if i == 0 else W), generator=g) * 2 - 1) * (6.0 / (K0 if i == 0 else W)) ** 0.5).to(bf).cuda(),
+  fan_in = lambda i: K0 if i == 0 else (W + K0 if i == skip else W)
+  layers = [(((torch.rand((W, fan_in(i)), generator=g) * 2 - 1) * (6.0 / fan_in(i)) ** 0.5).to(bf).cuda(),
              (0.05 * torch.randn((W,), generator=g)).cuda()) for i in range(depth)]
   wh = ((torch.rand((W,), generator=g) * 2 - 1) * 0.15).to(bf).cuda()
   bh = torch.full((1,), 0.01).cuda()
   gh = (torch.randn((M,), generator=g) * 0.01).cuda()
-  Bw = [None] + [layers[i][0].t().contiguous() for i in range(1, depth)]
+  Bw = [None] + [layers[i][0][:, :W].t().contiguous() for i in range(1, depth)]     # (the dX chain runs over the x segment)
 
   def run():
     out = torch.empty((M,), device='cuda')
     acts = [torch.empty((M, W), dtype=bf, device='cuda') for _ in range(depth)]
     bits = [torch.empty((M, W // 8), dtype=torch.uint8, device='cuda') for _ in range(depth)]
     dY = [torch.empty((M, W), dtype=bf, device='cuda') for _ in range(depth)]
-    ops.mlp_chain_fwd(feat, K0, layers, M=M, W=W, w_head=wh, b_head=bh, head_out=out, acts=acts, bits=bits)
+    ops.mlp_chain_fwd(feat, K0, layers, M=M, W=W, w_head=wh, b_head=bh, head_out=out, acts=acts, bits=bits, skip_layer=skip)
     ops.mlp_chain_bwd(gh, wh.float(), bits, Bw, dY, M=M, W=W)
     torch.cuda.synchronize()
     return [out.cpu()] + [a.cpu().view(torch.int16) for a in acts] + [b.cpu() for b in bits] + [d.cpu().view(torch.int16) for d in dY]
