@@ -11,7 +11,12 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 # MNR_LIB_PATH: load another build of the same ABI (same-box A/B of two kernel versions; never a different implementation)
 LIB_PATH = os.environ.get('MNR_LIB_PATH') or os.path.join(HERE, 'libmnerf_hip.so')
+# The fp32-Dense DEBUG build (multinerf_amd/build.py, csrc/common.h MNR_DENSE_F32): the same kernel sources with float storage and
+# plain fp32 Dense layers, loaded on demand for Model(dense_precision='fp32') and active inside `dense_f32()` only.
+LIB_F32_PATH = os.path.join(HERE, 'libmnerf_hip_f32.so')
 HEADER_PATH = os.path.join(os.path.dirname(HERE), 'include', 'mnerf.h')
+# entry points of the layout-specific MFMA files that the fp32 build does not have (the host never calls them in that mode)
+F32_ABSENT = ('mnr_mlp_chain_fwd', 'mnr_mlp_chain_fwd_ipe', 'mnr_mlp_chain_bwd')
 
 
 def describe():
@@ -236,27 +241,64 @@ def header_symbols(path=None):
   return sorted(set(re.findall(r'\b(mnr_[a-z0-9_]+)\s*\(', text)))
 
 
-def load():
-  """Load libmnerf_hip.so; raises (never falls back) when it is unavailable."""
-  global _lib
-  if _lib is not None:
-    return _lib
-  if not os.path.exists(LIB_PATH):
+def _bind(path, absent=()):
+  if not os.path.exists(path):
     raise RuntimeError(
-        f'{LIB_PATH} is missing: the HIP extension has not been built. Run '
+        f'{path} is missing: the HIP extension has not been built. Run '
         '`python -m multinerf_amd.build` (needs hipcc, ROCm >= 7.0). There is no CPU fallback.')
   # torch must load ITS HIP runtime first: libmnerf_hip.so then binds to that same libamdhip64
   # instead of pulling a second copy from /opt/rocm (two runtimes in one process cannot share the device).
   import torch  # noqa: F401
-  lib = C.CDLL(LIB_PATH)
+  lib = C.CDLL(path)
   lib.mnr_last_error.restype = C.c_char_p
   lib.mnr_last_error.argtypes = []
   for name, (argtypes, restype) in _PROTOS.items():
+    if name in absent:
+      continue
     fn = getattr(lib, name)      # AttributeError if the symbol is missing
     fn.argtypes = argtypes
     fn.restype = restype
-  _lib = lib
   return lib
+
+
+_lib_f32 = None
+_f32_depth = 0                    # > 0: inside dense_f32(): load() hands out the fp32-Dense debug build
+
+
+def load():
+  """Load libmnerf_hip.so (inside `dense_f32()`: libmnerf_hip_f32.so); raises (never falls back) when it is unavailable."""
+  global _lib, _lib_f32
+  if _f32_depth > 0:
+    if _lib_f32 is None:
+      _lib_f32 = _bind(LIB_F32_PATH, F32_ABSENT)
+    return _lib_f32
+  if _lib is None:
+    _lib = _bind(LIB_PATH)
+  return _lib
+
+
+def f32_active():
+  return _f32_depth > 0
+
+
+class dense_f32:
+  """Context: the C-ABI calls inside go to the fp32-Dense debug build, and what include/mnerf.h calls a bf16 matrix (uint16_t*)
+  is a float matrix.  Re-entrant; `on=False` makes it a no-op (so that callers can write `with model.library():`)."""
+
+  def __init__(self, on=True):
+    self.on = bool(on)
+
+  def __enter__(self):
+    global _f32_depth
+    if self.on:
+      _f32_depth += 1
+    return self
+
+  def __exit__(self, *exc):
+    global _f32_depth
+    if self.on:
+      _f32_depth -= 1
+    return False
 
 
 DEBUG_HEADER_PATH = os.path.join(os.path.dirname(HEADER_PATH), 'mnerf_debug.h')

@@ -5,6 +5,11 @@
 
 The shared library is written IN-TREE (multinerf_amd/libmnerf_hip.so) so that it
 travels with the source snapshot to the GPU box; it is git-ignored.
+
+A second library, libmnerf_hip_f32.so, is the fp32-Dense DEBUG build (`Model(dense_precision='fp32')`): the same kernel
+sources compiled with -DMNR_DENSE_F32 (activation / gradient / packed-weight storage float instead of bf16, csrc/common.h)
+and csrc/dense_f32.inc in place of the MFMA GEMMs; the layout-specific MFMA files (gemm_blk.hip, fused_mlp.hip) are not part
+of it.  It exists for parity against the plain fp32 oracle and is never on bench.py's path.
 """
 
 import concurrent.futures
@@ -17,9 +22,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(HERE, 'libmnerf_hip.so')
+LIB_F32 = os.path.join(HERE, 'libmnerf_hip_f32.so')
 OBJ_DIR = os.path.join(HERE, 'build')
 SOURCES = ['api.hip', 'gemm.hip', 'gemm_blk.hip', 'fused_mlp.hip', 'resample.hip', 'features.hip', 'render.hip', 'losses.hip', 'optim.hip', 'refnerf.hip', 'camera.hip']
-HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'gemm_nt_body.inc'), os.path.join(CSRC, 'gemm_tn_body.inc'), os.path.join(CSRC, 'gemm_nt_side.inc'), os.path.join(CSRC, 'ray_losses.h'), os.path.join(CSRC, 'ipe_math.h'), os.path.join(INCLUDE, 'mnerf.h'), os.path.join(INCLUDE, 'mnerf_debug.h')]
+SOURCES_F32 = [s for s in SOURCES if s not in ('gemm_blk.hip', 'fused_mlp.hip')]
+F32_DEFINES = ['-DMNR_DENSE_F32=1']
+HEADERS = [os.path.join(CSRC, 'dense_f32.inc'), os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'gemm_nt_body.inc'), os.path.join(CSRC, 'gemm_tn_body.inc'), os.path.join(CSRC, 'gemm_nt_side.inc'), os.path.join(CSRC, 'ray_losses.h'), os.path.join(CSRC, 'ipe_math.h'), os.path.join(INCLUDE, 'mnerf.h'), os.path.join(INCLUDE, 'mnerf_debug.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + os.environ.get('MNR_EXTRA_HIPCC_FLAGS', '').split()
 
 
@@ -40,38 +48,45 @@ def _digest():
 
 
 def is_stale():
-  stamp = LIB + '.stamp'
-  if not (os.path.exists(LIB) and os.path.exists(stamp)):
-    return True
-  with open(stamp) as f:
-    return f.read().strip() != _digest()
+  d = _digest()
+  for lib in (LIB, LIB_F32):
+    stamp = lib + '.stamp'
+    if not (os.path.exists(lib) and os.path.exists(stamp)):
+      return True
+    with open(stamp) as f:
+      if f.read().strip() != d:
+        return True
+  return False
 
 
 def build(force=False, verbose=True):
-  """Compile every HIP translation unit for gfx950 and link the C-ABI library."""
+  """Compile every HIP translation unit for gfx950 and link the C-ABI library (and the fp32-Dense debug build next to it)."""
   if not force and not is_stale():
     return LIB
   os.makedirs(OBJ_DIR, exist_ok=True)
   hipcc = _hipcc()
 
-  def compile_one(src):
-    obj = os.path.join(OBJ_DIR, src.replace('.hip', '.o'))
-    cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+  def compile_one(job):
+    src, f32 = job
+    obj = os.path.join(OBJ_DIR, src.replace('.hip', '_f32.o' if f32 else '.o'))
+    cmd = [hipcc] + FLAGS + (F32_DEFINES if f32 else []) + ['-c', os.path.join(CSRC, src), '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-      raise RuntimeError(f'hipcc failed on {src}:\n{r.stdout}\n{r.stderr}')
+      raise RuntimeError(f'hipcc failed on {src}{" (fp32 build)" if f32 else ""}:\n{r.stdout}\n{r.stderr}')
     return obj
 
-  with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-    objs = list(ex.map(compile_one, SOURCES))
-  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
-  r = subprocess.run(cmd, capture_output=True, text=True)
-  if r.returncode != 0:
-    raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
-  with open(LIB + '.stamp', 'w') as f:
-    f.write(_digest())
-  if verbose:
-    print(f'built {LIB} ({os.path.getsize(LIB)} bytes)')
+  jobs = [(s, False) for s in SOURCES] + [(s, True) for s in SOURCES_F32]
+  with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(jobs), 2 * (os.cpu_count() or 4))) as ex:
+    objs = list(ex.map(compile_one, jobs))
+  for lib, mine in ((LIB, objs[:len(SOURCES)]), (LIB_F32, objs[len(SOURCES):])):
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + mine
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+    with open(lib + '.stamp', 'w') as f:
+      f.write(_digest())
+    if verbose:
+      print(f'built {lib} ({os.path.getsize(lib)} bytes)')
   return LIB
 
 

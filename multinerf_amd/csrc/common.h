@@ -9,7 +9,16 @@
 #include "../../include/mnerf.h"
 #include "../../include/mnerf_debug.h"
 
+// `bf16` is the STORAGE type of every activation / gradient / packed-weight matrix the Dense layers read or write.  The product
+// library is built with it as __bf16 (the MFMA operand type).  The fp32-Dense debug build (multinerf_amd/build.py: libmnerf_hip_f32.so,
+// -DMNR_DENSE_F32: Model(dense_precision='fp32'), SURVEY.md section 7 hard parts 2 / 10) compiles the SAME kernel sources with the
+// storage type float and csrc/dense_f32.inc in place of the MFMA GEMMs, so that parity against the plain fp32 oracle can be held
+// at ~1e-4 instead of at the bf16 rounding of the operands; a uint16_t* in include/mnerf.h is a float* there.
+#ifdef MNR_DENSE_F32
+typedef float bf16;
+#else
 typedef __bf16 bf16;
+#endif
 typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));

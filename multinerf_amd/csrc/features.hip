@@ -204,9 +204,9 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
     const float cz = g.cov[2] * px + g.cov[4] * py + g.cov[5] * pz;
     const float lv = px * cx + py * cy + pz * cz;
     const float vscale = -0.5f * 1.44269504088896340736f * lv;       // exp(-v/2) = exp2(vscale * 4^deg)
-    char* rowp = rows + (size_t)si * pitch + (size_t)k * (OUT_F32 ? 4 : 2);       // column k of the sample's row (row 0 of 3 if TANGENT)
-    const int half = K * L * (OUT_F32 ? 4 : 2);                      // byte offset of the cos half of the row
-    const int lstep = K * (OUT_F32 ? 4 : 2);
+    char* rowp = rows + (size_t)si * pitch + (size_t)k * (OUT_F32 ? 4 : (int)sizeof(bf16));       // column k of the sample's row (row 0 of 3 if TANGENT)
+    const int half = K * L * (OUT_F32 ? 4 : (int)sizeof(bf16));                      // byte offset of the cos half of the row
+    const int lstep = K * (OUT_F32 ? 4 : (int)sizeof(bf16));
     float sc = ldexpf(1.0f, c.min_deg);                              // 2^deg, exact
     float sn = 0.0f, cs = 1.0f, att = 1.0f;
     float dlm[3] = {px, py, pz}, dlv[3] = {0.0f, 0.0f, 0.0f};
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_kernel(
   }
   __syncthreads();
   // Coalesced write-out: the block's rows are contiguous in HBM (16 B per lane); in LDS they are `pitch` apart.
-  const int row_bytes = row_elems * (OUT_F32 ? 4 : 2);
+  const int row_bytes = row_elems * (OUT_F32 ? 4 : (int)sizeof(bf16));
   const int cpr = row_bytes >> 4;                         // 16-B chunks per row (row_bytes is a multiple of 16)
   for (int cc = 0; cc < (TANGENT ? 3 : 1); ++cc) {
     char* dst = (char*)feat_out + ((size_t)cc * total + s0) * row_bytes;
@@ -301,7 +301,7 @@ static int fe_launch(int mode /*0 bf16, 1 f32, 2 tangent*/, const mnr_ipe_cfg* c
   const int row_elems = f32 ? nfeat : ld_feat;
   MNR_CHECK_ARG(f32 || (ld_feat >= nfeat && ld_feat % 8 == 0), "mnr_cast_rays_ipe: ld_feat=%d must be >= %d and a multiple of 8", ld_feat, nfeat);
   MNR_CHECK_ARG(!f32 || nfeat % 4 == 0, "mnr_cast_rays_ipe_f32: feature count must be a multiple of 4");
-  const size_t row_bytes = (size_t)row_elems * (f32 ? 4 : 2);
+  const size_t row_bytes = (size_t)row_elems * (f32 ? 4 : sizeof(bf16));
   int spb = (int)(FE_STAGE_BYTES / (row_bytes * (tangent ? 3 : 1)));
   if (spb > FE_THREADS) spb = FE_THREADS;
   spb &= ~3;                       // keeps the row buffer 16-byte aligned behind the FeSample array

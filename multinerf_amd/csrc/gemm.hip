@@ -30,6 +30,11 @@
 
 #include "common.h"
 
+#ifdef MNR_DENSE_F32
+// fp32-Dense debug build (common.h): the two Dense entry points on plain fp32 FMAs; everything below the #endif is shared.
+#include "dense_f32.inc"
+#else
+
 // ---------------------------------------------------------------------------
 // NT kernel.
 //
@@ -679,6 +684,8 @@ extern "C" int mnr_gemm_tn_bf16(const mnr_gemm_tn_args* a, void* stream) {
   if (big) return tn_launch<TnBig>(a, tn_target, stream);
   return tn_launch<TnSmall>(a, 3 * mnr_cu_count(), stream);         // (the 64-KiB tile: up to three workgroups per CU)
 }
+
+#endif  // MNR_DENSE_F32
 
 // ---------------------------------------------------------------------------
 // Bias gradient: out[n] += sum_m X[m,n].

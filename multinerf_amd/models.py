@@ -35,6 +35,17 @@ def _rup(x, m):
   return (x + m - 1) // m * m
 
 
+def _in_library(fn):
+  """Run a Model method inside the model's library context (`Model.library`: a no-op for the product)."""
+  import functools
+
+  @functools.wraps(fn)
+  def wrapped(self, *a, **kw):
+    with self.library():
+      return fn(self, *a, **kw)
+  return wrapped
+
+
 def _rank1_last(plan, D, W, feature_gradient):
   """Whether the last hidden layer's dY = relu'(z) * (g (x) w_density) of a Dense(1)-headed chain (the proposal MLP, reference
   models.py:457-460) can stay unstored: its weight-gradient GEMM then builds it from the factors (`mnr_gemm_tn_args.rank1_*`).  Not
@@ -335,6 +346,12 @@ class Model:
   resample_padding: float = 0.0
   use_gpu_resampling: bool = False
   opaque_background: bool = False
+  # Not a reference field.  'bf16' (the product): Dense layers bf16 x bf16 -> fp32 on the MFMA units, activations and their
+  # gradients stored in bf16 (the reference's TPU default precision).  'fp32' (DEBUG, parity only): the reference's jax-cpu
+  # precision (flax Dense in fp32, models.py:436-437, math.py:21-23): the same host code and the same kernel sources from the
+  # fp32-Dense build libmnerf_hip_f32.so (float storage, plain-FMA Dense layers, csrc/dense_f32.inc); per-layer GEMMs only (no
+  # fused chain, no panel storage, no vector columns: those are MFMA layouts).  Never benchmarked.
+  dense_precision: str = 'bf16'
 
   # ------------------------------------------------------------------ construction
 
@@ -342,6 +359,17 @@ class Model:
     self.nerf_hp = NerfMLP()
     self.prop_hp = self.nerf_hp if self.single_mlp else PropMLP()
     self._built = False
+    if self.dense_precision not in ('bf16', 'fp32'):
+      raise ValueError("dense_precision must be 'bf16' or 'fp32'")
+    self._f32 = self.dense_precision == 'fp32'
+
+  def _adt_is_f32(self):
+    return self._f32
+
+  def library(self):
+    """Context in which this model's C-ABI calls run: a no-op for the product, the fp32-Dense debug build for
+    dense_precision = 'fp32' (multinerf_amd/_lib.py: dense_f32)."""
+    return L.dense_f32(self._f32)
 
   def hip_supported(self):
     bad = []
@@ -560,12 +588,13 @@ class Model:
     arr = (L.PackDesc * len(descs))(*descs)
     p.pack_descs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
     p.pack_max_elems = max(d.rows_in * d.cols_out for d in descs)
-    p.wbf = torch.zeros(off, dtype=bf16, device=self.device)     # padding stays zero forever
+    p.wbf = torch.zeros(off, dtype=f32 if self._f32 else bf16, device=self.device)     # padding stays zero forever
     if p.has_rgb:
       p.head_bias = torch.zeros(_rup(p.head_cols, 128), dtype=f32, device=self.device)
     if p.ref:
       p.ide = ops.IdeTablesDev(p.hp.deg_view, self.device) if p.hp.use_directional_enc else None
 
+  @_in_library
   def pack_weights(self, flat_params, ipe=False):
     """fp32 master parameters -> bf16 GEMM operands (one launch per MLP; `ipe`: also the group-major layer-0 image of the
     chain with the in-kernel IPE producer)."""
@@ -675,6 +704,8 @@ class Model:
   # Workspace -------------------------------------------------------------------------
 
   def _buf(self, key, shape, dtype, zero=False):
+    if dtype is bf16 and self._f32:
+      dtype = f32                                   # (dense_precision = 'fp32': the Dense layers' matrices are stored in fp32)
     k = (key, tuple(shape), dtype)
     t = self._ws.get(k)
     if t is None:
@@ -743,6 +774,7 @@ class Model:
       prod *= n
     return out
 
+  @_in_library
   def _forward(self, flat, rng, rays, train_frac, compute_extras, zero_glo=True, noise=None,
                keep_for_backward=False, repack=True):
     """The level loop of models.py:147-297.  `noise` (parity tests) overrides `rng`:
@@ -963,13 +995,12 @@ class Model:
     """A [rows, ld] view into the packed bf16 operand buffer."""
     return plan.wbf[off:off + rows * ld].view(rows, ld)
 
-  @staticmethod
-  def _chain_ok(plan: MLPPlan):
+  def _chain_ok(self, plan: MLPPlan):
     """The fused per-level kernels (csrc/fused_mlp.hip) cover a trunk of width 128 / 256, depth <= 8, with at most one
     skip concat: the proposal MLP of every config (with its Dense(1) head inside the kernel) and the 256-wide NeRF
     trunks of blender_256 / llff_raw / blender_refnerf (heads stay per-layer GEMMs on the trunk's output)."""
     skips = [i for i, (_, c) in enumerate(plan.trunk) if c]
-    if not (_USE_CHAIN and _USE_BITS and plan.hp.net_activation == 'relu' and plan.W in (128, 256) and
+    if not (_USE_CHAIN and not self._f32 and _USE_BITS and plan.hp.net_activation == 'relu' and plan.W in (128, 256) and
             1 <= len(plan.trunk) <= L.CHAIN_MAX_DEPTH and
             len(skips) <= 1 and not plan.x_concat):
       return False
@@ -1013,11 +1044,10 @@ class Model:
                       skip_layer=skip)
     return dict(acts=acts or [], bits=bits or [], raw_density=raw_density, chain=True)
 
-  @classmethod
-  def _ipe_chain_ok(cls, plan: MLPPlan):
+  def _ipe_chain_ok(self, plan: MLPPlan):
     """A density-only MLP on the fused chain without a skip concat (the proposal MLP of every BASELINE config), with an
     encoding the in-kernel producer covers (groups of four degrees, at most 24 basis directions)."""
-    return cls._chain_ok(plan) and 'trunk0_ipe' in plan.packed
+    return self._chain_ok(plan) and 'trunk0_ipe' in plan.packed
 
   def _chain_forward_ipe(self, plan: MLPPlan, flat, tdist, R, radii, M, tag):
     """models.py:441-465 for a density-only MLP AND its featurisation (render.cast_rays + integrated_pos_enc,
@@ -1229,14 +1259,14 @@ class Model:
   def _head_gcol(self, plan: MLPPlan):
     """The merged head's weight gradient as the bottleneck's 256-column GEMM plus the density column as a vector (backward_level)."""
     W, bw = plan.W, plan.hp.bottleneck_width
-    return bool(_HEAD_GCOL and plan.has_rgb and plan.use_viewdirs and not plan.ref and len(plan.head_segs) == 2 and
+    return bool(_HEAD_GCOL and not self._f32 and plan.has_rgb and plan.use_viewdirs and not plan.ref and len(plan.head_segs) == 2 and
                 bw % 256 == 0 and W % 256 == 0 and W >= 512)
 
   def _panel_ok(self, plan: MLPPlan, M, keep):
     """True when this level's per-layer trunk runs in the panel layout: a ReLU trunk of width >= 512 (a multiple of 256: the
     narrower ones take the fused chain / weights-resident kernels) under the plain merged head of models.py:494-585, whose
     forward GEMM, dX GEMM and weight-gradient GEMM (with the density column as a vector) all read or write panel storage."""
-    if not (_PANEL and _USE_BITS and plan.hp.net_activation == 'relu' and plan.W % 256 == 0 and plan.W >= 512 and M % 256 == 0):
+    if not (_PANEL and not self._f32 and _USE_BITS and plan.hp.net_activation == 'relu' and plan.W % 256 == 0 and plan.W >= 512 and M % 256 == 0):
       return False
     if self._chain_ok(plan) or plan.tangent or plan.pn or plan.ref or not (plan.has_rgb and plan.use_viewdirs):
       return False
@@ -1252,6 +1282,7 @@ class Model:
     G = self.num_glo_features
     return flat[self.glo_off:self.glo_off + self.num_glo_embeddings * G].view(self.num_glo_embeddings, G)
 
+  @_in_library
   def backward_level(self, lv, flat, grads, g_rgb_out, g_weights, g_expo=None, g_normals=None, g_npred=None, losses=None,
                      g_x_out=None, g_feat_out=None):
     """VJP of one level w.r.t. the parameters: compositing -> heads -> trunk.
@@ -1590,6 +1621,7 @@ class Model:
         act_vjp(mlp['zs'][i - 1] if not relu else None, other)
         dy = other
 
+  @_in_library
   def backward_prop_levels(self, lvs, flat, grads, g_weights, losses):
     """`backward_level` for ALL proposal levels in one pass (grouped buffers, `_props_group`): each level's compositing
     VJP (with its losses) writes its slice of one head-gradient vector, then ONE head VJP, ONE dX chain and ONE

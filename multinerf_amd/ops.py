@@ -28,7 +28,15 @@ def _on_device(t):
   return t.is_cuda
 
 
+def act_dtype():
+  """Storage type of the Dense layers' activation / gradient / packed-weight matrices: bf16, or fp32 inside
+  `_lib.dense_f32()` (the fp32-Dense debug build, Model(dense_precision='fp32'))."""
+  return f32 if L.f32_active() else bf16
+
+
 def _chk(t, dtype, name, allow_none=False):
+  if dtype is bf16 and L.f32_active():
+    dtype = f32
   if t is None:
     if allow_none:
       return
@@ -212,7 +220,7 @@ def cast_rays_ipe(tdist, origins, directions, radii, basis, *, ray_shape, warp_c
   cfg = _ipe_cfg(ray_shape, warp_contract, disable_integration, basis, min_deg, max_deg)
   dev = tdist.device
   if out is None:
-    out = torch.empty((B * n, ld_feat), dtype=bf16, device=dev)
+    out = torch.empty((B * n, ld_feat), dtype=act_dtype(), device=dev)
   _chk(out, bf16, 'out')
   assert out.shape == (B * n, ld_feat)
   means = covs = None
@@ -252,7 +260,7 @@ def cast_rays_ipe_tangent(tdist, origins, directions, radii, basis, *, ray_shape
   n = n1 - 1
   cfg = _ipe_cfg(ray_shape, warp_contract, disable_integration, basis, min_deg, max_deg)
   if out is None:
-    out = torch.empty((3 * B * n, ld_feat), dtype=bf16, device=tdist.device)
+    out = torch.empty((3 * B * n, ld_feat), dtype=act_dtype(), device=tdist.device)
   _chk(out, bf16, 'out')
   L.check(lib().mnr_cast_rays_ipe_tangent(C.byref(cfg), B, n, _ptr(tdist), _ptr(origins), _ptr(directions),
                                           _ptr(radii), _ptr(basis), _ptr(out), ld_feat, _stream()))
@@ -625,8 +633,8 @@ def act_tangent_bwd(kind, z, U, G, extra):
 def add_noise_bf16(X, cols, noise, scale):
   """X[:, :cols] += scale * noise (fp32 add, one bf16 rounding); X bf16 [M, ld], noise fp32 [M, cols]."""
   _chk(noise, f32, 'noise')
-  if X.dtype != bf16 or not _on_device(X):
-    raise ValueError('X must be a bf16 device tensor')
+  if X.dtype != act_dtype() or not _on_device(X):
+    raise ValueError(f'X must be a {act_dtype()} device tensor')
   M = X.shape[0]
   assert noise.shape == (M, cols)
   L.check(lib().mnr_add_noise_bf16(M, cols, _ptr(X), X.stride(0), _ptr(noise), float(scale), _stream()))
@@ -846,8 +854,8 @@ def ref_head_bwd(small, raw_grad, viewdirs, n, tabs, roughness_bias, dvi_a, dvi_
 def add_cols_bf16(a, b, dst, cols):
   """dst[:, :cols] = a[:, :cols] + b[:, :cols] (row strides taken from the tensors)."""
   for x, nm in ((a, 'a'), (dst, 'dst')):
-    if x.dtype != bf16 or not _on_device(x):
-      raise ValueError(f'{nm} must be a bf16 device tensor')
+    if x.dtype != act_dtype() or not _on_device(x):
+      raise ValueError(f'{nm} must be a {act_dtype()} device tensor')
   M = a.shape[0]
   L.check(lib().mnr_add_cols_bf16(M, cols, _ptr(a), a.stride(0), _ptr(b), b.stride(0) if b is not None else 0,
                                   _ptr(dst), dst.stride(0), _stream()))

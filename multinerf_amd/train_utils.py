@@ -96,6 +96,10 @@ def create_train_step(model: models.Model, config, dataset=None):
 
   def train_step(rng, state: TrainState, batch, cameras, train_frac, loss_threshold, noise=None,
                  return_grads=False, tree_stats=False):
+    with model.library():          # (a no-op for the product; Model.dense_precision = 'fp32': the fp32-Dense debug build)
+      return train_step_impl(rng, state, batch, cameras, train_frac, loss_threshold, noise, return_grads, tree_stats)
+
+  def train_step_impl(rng, state: TrainState, batch, cameras, train_frac, loss_threshold, noise, return_grads, tree_stats):
     flat = state.params['flat']
     dev = flat.device
     rays = batch.rays

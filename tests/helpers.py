@@ -51,3 +51,42 @@ def assert_adam_matches_oracle(model, cfg, flat0, raw_grad, opt0, state2, what='
   print(f'{what}Adam vs oracle on the kernel gradient: mu rel {e_mu:.2e} (abs / max {e_mu_abs:.2e}), nu rel {e_nu:.2e}, |update err| / lr {upd_err:.2e} (lr {lr:.3e})')
   assert e_mu < 2e-3 and e_mu_abs < 1e-6 and e_nu < 2e-4 and upd_err < 1e-3, (e_mu, e_mu_abs, e_nu, upd_err)
   return state2.mu.detach().clone(), state2.nu.detach().clone(), state2.step
+
+
+def to_float64(x):
+  """A pytree (dict / list / tuple / the package's dataclasses) with every floating tensor upcast to float64."""
+  if torch.is_tensor(x):
+    return x.detach().double() if x.is_floating_point() else x
+  if isinstance(x, dict):
+    return {k: to_float64(v) for k, v in x.items()}
+  if dataclasses.is_dataclass(x) and not isinstance(x, type):
+    return dataclasses.replace(x, **{f.name: to_float64(getattr(x, f.name)) for f in dataclasses.fields(x)})
+  if isinstance(x, (list, tuple)):
+    return type(x)(to_float64(v) for v in x)
+  return x
+
+
+def flat_from_tree_f64(model, tree):
+  """models.Model.flat_from_tree without its cast to float32 (the float64 oracle's gradient as one vector)."""
+  flat = torch.zeros(model.num_params, dtype=torch.float64)
+  views = model.params_tree(flat)
+  for mname, mod in views.items():
+    for dname, d in mod.items():
+      if isinstance(d, dict):
+        for k, v in d.items():
+          v.copy_(tree[mname][dname][k].detach().double().reshape(v.shape))
+      else:
+        d.copy_(tree[mname][dname].detach().double().reshape(d.shape))
+  return flat
+
+
+def oracle_train_step_f64(params, om, on, op, cfg, batch, train_frac, noise):
+  """oracle.train_utils.train_step evaluated in float64 on the SAME float32 inputs (parameters, rays, noise upcast): the
+  reference arithmetic without rounding, what the fp32-Dense debug mode (models.Model.dense_precision = 'fp32') is held
+  against.  (The oracle is pinned to the reference's own code in float64: tests/test_oracle_models_golden.py.)
+  -> (stats, gradient tree)."""
+  from oracle import train_utils as otrain
+  p64 = to_float64(params)
+  _, _, stats, grads = otrain.train_step(p64, otrain.init_opt_state(p64), om, on, op, cfg, to_float64(batch), train_frac,
+                                         noise=to_float64(noise))
+  return stats, grads

@@ -10,17 +10,19 @@ from multinerf_amd import _lib as L
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _sim = None
+_sim_f32 = None
 
 
-def load_sim():
-  """Build (if stale) and load libmnerf_sim.so; binds every prototype of multinerf_amd._lib it exports."""
-  global _sim
-  if _sim is not None:
-    return _sim
+def load_sim(f32=False):
+  """Build (if stale) and load libmnerf_sim.so (f32: libmnerf_sim_f32.so, the fp32-Dense debug build); binds every prototype of
+  multinerf_amd._lib it exports."""
+  global _sim, _sim_f32
+  if (_sim_f32 if f32 else _sim) is not None:
+    return _sim_f32 if f32 else _sim
   spec = importlib.util.spec_from_file_location('hipsim_build', os.path.join(ROOT, 'tools', 'hipsim', 'build.py'))
   mod = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(mod)
-  lib = C.CDLL(mod.build(verbose=False))
+  lib = C.CDLL(mod.build(verbose=False, f32=f32))
   lib.mnr_last_error.restype = C.c_char_p
   lib.hipsim_error.restype = C.c_char_p
   lib.hipsim_reset.argtypes = [C.c_int, C.c_long]
@@ -30,7 +32,10 @@ def load_sim():
     if fn is not None:
       fn.argtypes = argtypes
       fn.restype = restype
-  _sim = lib
+  if f32:
+    _sim_f32 = lib
+  else:
+    _sim = lib
   return lib
 
 
@@ -129,20 +134,24 @@ class simulated_device:
     missing = [n for n in L._PROTOS if not hasattr(self.lib, n)]
     if missing:
       raise RuntimeError(f'simulator build lacks {missing}')
-    self.saved = (L._lib, ops._stream, ops._on_device)
+    self.lib_f32 = load_sim(f32=True)
+    self.saved = (L._lib, ops._stream, ops._on_device, L._lib_f32)
     L._lib = self.lib
+    L._lib_f32 = self.lib_f32
     ops._stream = lambda: None
     ops._on_device = lambda t: True
     self.lib.hipsim_reset(0, 0)
+    self.lib_f32.hipsim_reset(0, 0)
     return self
 
   def check(self):
-    if self.lib.hipsim_failed():
-      raise RuntimeError('hipsim: ' + self.lib.hipsim_error().decode())
+    for lib in (self.lib, self.lib_f32):
+      if lib.hipsim_failed():
+        raise RuntimeError('hipsim: ' + lib.hipsim_error().decode())
 
   def __exit__(self, *exc):
     from multinerf_amd import ops
-    L._lib, ops._stream, ops._on_device = self.saved
+    L._lib, ops._stream, ops._on_device, L._lib_f32 = self.saved
     self.lib.mnr_gemm_nt_set_persistent(1)
     self.lib.mnr_gemm_nt_set_wres(1)
     return False

@@ -49,7 +49,7 @@ def _run(use_chain, cfg, flat, batch, noise, monkeypatch):
 def test_fused_chain_equals_per_layer_path(W, bindings, B, monkeypatch):
   cfg = configs.load_preset('360', bindings)
   m0 = models.Model(config=cfg).build('cuda')
-  assert m0.prop_plan.W == W and models.Model._chain_ok(m0.prop_plan)
+  assert m0.prop_plan.W == W and m0._chain_ok(m0.prop_plan)
   om, on, op = helpers.oracle_hparams(m0)
   params = omodels.init_params(om, on, op, seed=5)
   g = torch.Generator().manual_seed(6)
@@ -124,7 +124,7 @@ def test_fused_trunk_with_skip_equals_per_layer_path(preset, bindings, B, monkey
   skips = [i for i, (_, c) in enumerate(plan.trunk) if c]
   if len(skips) != 1:
     pytest.skip(f'{len(skips)} skip layers')
-  assert models.Model._chain_ok(plan) and plan.has_rgb
+  assert m0._chain_ok(plan) and plan.has_rgb
   om, on, op = helpers.oracle_hparams(m0)
   params = omodels.init_params(om, on, op, seed=5)
   g = torch.Generator().manual_seed(6)
@@ -204,7 +204,7 @@ def test_chain_with_in_kernel_ipe_equals_feature_matrix_path(bindings, B, n):
   cfg = configs.load_preset('360', ['NerfMLP.net_width = 128'] + bindings)
   model = models.Model(config=cfg).build('cuda')
   plan = model.prop_plan
-  assert models.Model._ipe_chain_ok(plan)
+  assert model._ipe_chain_ok(plan)
   hp, W, D = plan.hp, plan.W, len(plan.trunk)
   flat = model.init_flat_params(seed=3)
   g = torch.Generator().manual_seed(4)

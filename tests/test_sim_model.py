@@ -382,3 +382,53 @@ def test_gradients_through_the_sampling_on_the_simulator(name, extra, B):
     rel = ((gs[False][b:e] - gs[True][b:e]).norm() / gs[True][b:e].norm()).item()
     print(f'{name}: |g(stop_level_grad = False) - g(True)| / |g(True)| on {mod} = {rel:.3f}')
     assert rel > 0.02, (mod, rel)
+
+
+# ----------------------------------------------------------------------------- Model(dense_precision='fp32')
+
+F32_CASES = [CASES[0], CASES[1], CASES[2], CASES[5], CASES[7], SAMPLING_GRAD_CASES[0], SAMPLING_GRAD_CASES[1], SAMPLING_GRAD_CASES[3]]
+
+
+@pytest.mark.parametrize('name,extra,B', F32_CASES)
+def test_fp32_dense_mode_matches_the_float64_oracle(name, extra, B):
+  """models.Model.dense_precision = 'fp32' (the fp32-Dense debug build, csrc/common.h MNR_DENSE_F32 + csrc/dense_f32.inc): the
+  same host code and the same kernel sources with float storage and plain-FMA Dense layers (reference models.py:436-437 on its
+  jax-cpu path, math.py:21-23).  With the bf16 rounding of the Dense operands gone, forward outputs and the gradient of every
+  module are held against the oracle evaluated in FLOAT64 on the same float32 inputs: 2e-4 relative L2 per module, or 1.5 x the
+  distance of the fp32 oracle from the float64 one where fp32 arithmetic itself costs more than that (360.gin's contraction at
+  twelve degrees).  The bf16 product is held to 4e-2 ... 4e-1 on the same quantities (its tolerance model: _run above)."""
+  with S.simulated_device() as sim:
+    cfg = configs.load_preset(name, list(extra))
+    _, _, (om, on, op), params, _, batch = _setup(name, extra, B)
+    model = models.Model(config=cfg, dense_precision='fp32').build('cpu')
+    assert model._adt_is_f32() and not model._chain_ok(model.prop_plan)
+    flat = model.flat_from_tree(params)
+    noise = helpers.make_noise(model, B)
+    tf = 0.4
+    p64, b64, n64 = helpers.to_float64(params), helpers.to_float64(batch), helpers.to_float64(noise)
+    r_64, h_64 = omodels.model_apply(om, on, op, p64, b64.rays, tf, True, zero_glo=False, noise=n64)
+    rend, hist = model.apply({'flat': flat}, None, batch.rays, tf, True, zero_glo=False, noise=noise)
+    sim.check()
+    for lv in range(model.num_levels):
+      assert (hist[lv]['sdist'].double() - h_64[lv]['sdist']).abs().max().item() <= 1e-5, lv
+      assert (hist[lv]['weights'].double() - h_64[lv]['weights']).abs().max().item() <= 5e-5, lv
+    assert (rend[-1]['rgb'].double() - r_64[-1]['rgb']).abs().max().item() <= 5e-5
+    stats_64, grads_64 = helpers.oracle_train_step_f64(params, om, on, op, cfg, batch, tf, noise)
+    _, _, _, grads_32 = otrain.train_step(params, otrain.init_opt_state(params), om, on, op, cfg, batch, tf, noise=noise)
+    g_64 = helpers.flat_from_tree_f64(model, grads_64)
+    g_32 = model.flat_from_tree(grads_32, device='cpu').double()
+    state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+    _, stats, _ = train_utils.create_train_step(model, cfg)(0, state, batch, None, tf, 0.0, noise=noise, return_grads=True)
+    sim.check()
+    s = stats.materialize()
+    assert abs(s['loss'] - float(stats_64['loss'])) <= 2e-5 * abs(float(stats_64['loss'])) + 1e-7
+    g = stats['_grads'].double()
+    for mod, b, e in model.modules:
+      a, r, r32 = g[b:e], g_64[b:e], g_32[b:e]
+      if r.norm() < 1e-12:
+        assert a.norm() < 1e-6, mod
+        continue
+      rel = ((a - r).norm() / r.norm()).item()
+      cost32 = ((r32 - r).norm() / r.norm()).item()
+      print(f'F32 {name} {mod}: |kernel_fp32 - oracle_fp64| {rel:.3e} (|oracle_fp32 - oracle_fp64| {cost32:.3e})')
+      assert rel <= max(2e-4, 1.5 * cost32), (mod, rel, cost32)
