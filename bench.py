@@ -100,7 +100,8 @@ def main():
   # torch-only preflight in a child process before this process creates a HIP context (multinerf_amd/preflight.py): a box
   # whose first host -> device copy aborts is then on record as `BOX_FAULT: ...` instead of a core dump of the benchmark
   pre = None
-  if int(os.environ.get('LOCAL_RANK', '0')) == 0 and os.environ.get('MNR_SKIP_PREFLIGHT') != '1':
+  # (on EVERY local rank: the HSA_ENABLE_SDMA=0 workaround lives in the environment of the process that found it needed)
+  if os.environ.get('MNR_SKIP_PREFLIGHT') != '1':
     from multinerf_amd import preflight
     pre = preflight.check(verbose=False)
     if not pre['ok']:

@@ -309,7 +309,8 @@ typedef struct {
   /* Pairing with the dX GEMM that reads the same B (= dY) matrix (Model backward, one layer): m_interleave = 1 hands the
    * M-splits the 256-row M-tiles block-cyclically (split s takes M-tiles s, s + splits, ...) so that every split walks M from
    * top to bottom at the pace of a persistent NT launch running next to it; max_wgs > 0 caps the grid (the two launches then
-   * share the chip).  Performance only. */
+   * share the chip).  Performance only: where M / 256 is not a multiple of the split count the launcher picks
+   * (shape- and CU-count-dependent), m_interleave is dropped and the splits are contiguous. */
   int m_interleave, max_wgs;
   /* B given by its factors instead of as a matrix (then B may be NULL; row-major A, K and N multiples of 256):
    *   B[m, n] = bit n of rank1_bits[m, :] ? bf16(rank1_g[m] * rank1_w[n]) : 0

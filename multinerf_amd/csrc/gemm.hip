@@ -610,11 +610,12 @@ static int tn_launch(const mnr_gemm_tn_args* a, int target_wgs, void* stream) {
   // (every workgroup ends with an atomic epilogue of its whole fp32 tile: a split must be long enough to pay for it)
   constexpr int min_steps = 4;
   while (splits > unit && (total_steps + splits - 1) / splits < min_steps) splits -= unit;
-  if (a->m_interleave) {
-    // block-cyclic M-tiles: every split gets the same whole number of 256-row M-tiles (4 steps of 64 rows)
-    MNR_CHECK_ARG(total_steps % (4 * splits) == 0, "mnr_gemm_tn_bf16: m_interleave needs M / 256 = %d to be a multiple of the %d splits",
-                  total_steps / 4, splits);
-  }
+  // block-cyclic M-tiles (m_interleave) need every split to get the same whole number of 256-row M-tiles (4 steps of 64 rows).  The
+  // split count depends on the shape and on the CU count (8 at W = 1024 on 256 CUs, 16 at 768, up to 32 at 512), so a caller cannot
+  // know it: where it does not divide, the launch runs with contiguous splits (the flag is performance only, include/mnerf.h).
+  mnr_gemm_tn_args local = *a;
+  if (local.m_interleave && total_steps % (4 * splits) != 0) local.m_interleave = 0;
+  a = &local;
   const int steps_per_split = (total_steps + splits - 1) / splits;
   const int64_t grid = (int64_t)splits * tiles;
   // LDS: a panel operand's stage image carries 128 bytes of padding per 1-KiB block (gemm_tn_body.inc)

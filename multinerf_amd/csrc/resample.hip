@@ -490,8 +490,11 @@ extern "C" int mnr_max_dilate_weights(int64_t B, int n, const float* t, const fl
 //     attains it), sort + clip (each dilated fence-post is one of t[i], t[i] - d, t[i+1] + d, or a clipped constant)
 // to g_sdist_prev [B, n_prev+1] and g_w_prev [B, n_prev].  The indices (which bin, which maximum, which source of a sorted
 // fence-post) are piecewise constant and carry no gradient, as in the reference's autodiff.  One deliberate deviation: where
-// a bin's weight + padding is exactly 0 its logit is -inf, its softmax weight 0, and autodiff yields 0 * inf = NaN (which the
-// reference's train_step then turns into a zero update through nan_to_num, train_utils.py:326-328); here that product is 0.
+// a bin's weight + padding is exactly 0 its logit is -inf, its softmax weight 0, and autodiff yields 0 * inf = NaN for that
+// bin's weight gradient; the NaN then propagates to every parameter-gradient element that weight depends on, and the reference's
+// train_step applies nan_to_num ELEMENT-WISE (train_utils.py:326-328): those elements become 0, the others stay.  Here that
+// product is 0, i.e. the gradient of the function that is evaluated; with resample_padding = 0 the two training trajectories
+// differ (the reference is effectively undefined there: models.Model.build warns once).
 //
 // 16 lanes per ray as in the forward kernel: element-wise passes are split over the lanes, the three scatters / scans
 // (sample -> bracketing bins, suffix sum, window maximum -> bin) run on the ray's first lane (deterministic order).

@@ -170,10 +170,11 @@ class MLP:
       bad.append('net_width must be positive')
     # (a net_width that is not a multiple of 128, e.g. configs/debug.gin's PropMLP.net_width = 64, runs on kernels of the next
     # multiple of 128 with structurally zero padding: Model.build / Model._to_exec)
-    if not self.disable_rgb and (self.bottleneck_width <= 0 or self.bottleneck_width % 64 != 0):
-      bad.append('bottleneck_width must be a positive multiple of 64')
-    if not self.disable_rgb and self.net_width_viewdirs % 128 != 0:
-      bad.append('net_width_viewdirs not a multiple of 128')
+    # (bottleneck_width / net_width_viewdirs off the kernels' tile, models.py:345-347: zero-padded execution layout as well)
+    if not self.disable_rgb and self.bottleneck_width <= 0:
+      bad.append('bottleneck_width must be positive')
+    if not self.disable_rgb and self.net_width_viewdirs <= 0:
+      bad.append('net_width_viewdirs must be positive')
     if self.num_rgb_channels != 3:
       bad.append('num_rgb_channels != 3')
     return bad
@@ -202,6 +203,8 @@ class DenseSpec:
   fan_out: int
   kernel_off: int = 0  # offsets into the flat fp32 parameter vector
   bias_off: int = 0
+  in_segs: Tuple[int, ...] = ()   # widths of the concatenated blocks its input rows are made of (trunk | features | ...): what
+                                  # Model.build maps between the callers' layout and a zero-padded execution layout
 
 
 class MLPPlan:
@@ -222,25 +225,27 @@ class MLPPlan:
     self.dense: List[DenseSpec] = []
     k = 0
 
-    def add(fi, fo):
+    def add(segs, fo):
+      """A Dense whose input is the concatenation of blocks of the widths `segs`."""
       nonlocal k
-      d = DenseSpec(f'Dense_{k}', fi, fo)
+      segs = tuple(int(w) for w in segs if w > 0)
+      d = DenseSpec(f'Dense_{k}', sum(segs), fo, in_segs=segs)
       k += 1
       self.dense.append(d)
       return d
 
     # trunk (models.py:455-459)
     self.trunk: List[Tuple[DenseSpec, bool]] = []   # (spec, input_is_concat_with_features)
-    width, concat = self.F, False
+    concat = False
     first = True
     for i in range(hp.net_depth):
-      fan_in = self.F if first else (self.W + (self.F if concat else 0))
-      self.trunk.append((add(fan_in, self.W), (not first) and concat))
+      self.trunk.append((add((self.F,) if first else ((self.W, self.F) if concat else (self.W,)), self.W), (not first) and concat))
       first = False
       concat = (i % hp.skip_layer == 0 and i > 0)
     self.x_concat = concat                     # trunk output carries the features too (depth ending on a skip)
     self.x_width = self.W + (self.F if concat else 0)
-    self.density = add(self.x_width, 1)        # models.py:460
+    x_segs = (self.W, self.F) if concat else (self.W,)
+    self.density = add(x_segs, 1)              # models.py:460
     self.ref = hp.is_ref() and self.use_viewdirs           # (without view directions the reference skips the branch: models.py:512)
     self.features = hp.ref_features() if self.ref else 0   # MNR_REF_* bits
     self.pn = hp.enable_pred_normals and not self.ref      # predicted normals without the rest of the Ref-NeRF head
@@ -253,16 +258,16 @@ class MLPPlan:
     self.gradpred = self.diffuse = self.tint = self.rough = None
     self.glo = 0
     if hp.enable_pred_normals:
-      self.gradpred = add(self.x_width, 3)                           # models.py:495
+      self.gradpred = add(x_segs, 3)                                 # models.py:495
     if self.has_rgb:
       if self.use_viewdirs:
         if hp.use_diffuse_color:
-          self.diffuse = add(self.x_width, hp.num_rgb_channels)      # models.py:515
+          self.diffuse = add(x_segs, hp.num_rgb_channels)            # models.py:515
         if hp.use_specular_tint:
-          self.tint = add(self.x_width, 3)                           # models.py:518
+          self.tint = add(x_segs, 3)                                 # models.py:518
         if hp.enable_pred_roughness:
-          self.rough = add(self.x_width, 1)                          # models.py:521
-        self.bottleneck = add(self.x_width, hp.bottleneck_width)     # models.py:527
+          self.rough = add(x_segs, 1)                                # models.py:521
+        self.bottleneck = add(x_segs, hp.bottleneck_width)           # models.py:527
         if hp.use_directional_enc:
           from multinerf_amd import ref_utils
           self.dir_enc_dim = 2 * len(ref_utils.ide_tables(hp.deg_view)[0])   # IDE: real + imaginary parts
@@ -272,20 +277,20 @@ class MLPPlan:
         self.glo_col = hp.bottleneck_width + self.dir_enc_dim + (1 if hp.use_n_dot_v else 0)   # models.py:565-568
         self.vi_width = self.glo_col + num_glo_features
         self.ldVI = _rup(self.vi_width, 128)
+        vi_segs = (hp.bottleneck_width, self.glo_col - hp.bottleneck_width, num_glo_features)
         WV = hp.net_width_viewdirs
         concat, first = False, True
         for i in range(hp.net_depth_viewdirs):                       # models.py:576-580
-          fan_in = self.vi_width if first else (WV + (self.vi_width if concat else 0))
-          self.view.append((add(fan_in, WV), (not first) and concat))
+          self.view.append((add(vi_segs if first else (((WV,) + vi_segs) if concat else (WV,)), WV), (not first) and concat))
           first = False
           concat = (i % hp.skip_layer_dir == 0 and i > 0)
         self.v_concat = concat
-        rgb_in = WV + (self.vi_width if concat else 0)
+        rgb_segs = ((WV,) + vi_segs) if concat else (WV,)
         if hp.net_depth_viewdirs == 0:
-          rgb_in = self.vi_width
+          rgb_segs = vi_segs
       else:
-        rgb_in = self.x_width
-      self.rgb = add(rgb_in, hp.num_rgb_channels)                    # models.py:585
+        rgb_segs = x_segs
+      self.rgb = add(rgb_segs, hp.num_rgb_channels)                  # models.py:585
       if self.use_viewdirs:
         # merged head: (Dense, first column) -- bottleneck first, then the scalar / 3-vector heads
         bw = hp.bottleneck_width
@@ -403,6 +408,12 @@ class Model:
     bad = self.hip_supported()
     if bad:
       raise NotImplementedError('not yet implemented on the HIP path: ' + '; '.join(bad))
+    if not self.stop_level_grad and self.resample_padding == 0 and (self.dilation_bias > 0 or self.dilation_multiplier > 0):
+      import warnings
+      warnings.warn('Model.stop_level_grad = False with resample_padding = 0: where two dilated fence-posts are clipped to the same '
+                    'domain end a bin has weight 0 and the reference\'s own autodiff yields NaN gradient elements there (which its '
+                    'train_step zeroes element-wise, train_utils.py:326-328); this path differentiates the function that is evaluated '
+                    '(that bin is a constant), so the two trajectories differ.', stacklevel=2)
     self.device = torch.device(device)
 
     def layout(nerf_hp, prop_hp):
@@ -433,7 +444,14 @@ class Model:
     # rows / columns are structurally zero (`_to_exec` scatters the parameters into it before a pass, `true_grads` gathers the
     # gradient back: zero weights and biases give zero activations behind the ReLU and zero gradients; behind another
     # activation the padded units are non-zero but feed zero rows of the next kernel, and their gradients are dropped).
-    pad = lambda hp: hp if hp.net_width % 128 == 0 else dataclasses.replace(hp, net_width=_rup(hp.net_width, 128))
+    def pad(hp):
+      """The hyper-parameters the kernels run: trunk and view-MLP widths on the 128-column GEMM tile, the bottleneck on its
+      64-column K granule (models.py:345-347,526-527,577 take any width)."""
+      w = dict(net_width=_rup(hp.net_width, 128))
+      if not hp.disable_rgb and self.use_viewdirs:
+        w.update(bottleneck_width=_rup(hp.bottleneck_width, 64), net_width_viewdirs=_rup(hp.net_width_viewdirs, 128))
+      return hp if all(getattr(hp, k) == v for k, v in w.items()) else dataclasses.replace(hp, **w)
+
     self._tplans, self.modules, self.glo_off_true, self.expo_off_true, self.num_params = layout(self.nerf_hp, self.prop_hp)
     nerf_x = pad(self.nerf_hp)
     prop_x = nerf_x if self.single_mlp else pad(self.prop_hp)
@@ -444,13 +462,16 @@ class Model:
       self._plans, _, self.glo_off, self.expo_off, self.num_params_exec = layout(nerf_x, prop_x)
       idx = torch.empty(self.num_params, dtype=torch.int64)
       for pt, px in zip(self._tplans, self._plans):
-        shift = px.W - pt.W
         for dt, dx in zip(pt.dense, px.dense):
-          rows = torch.arange(dt.fan_in)
-          # input rows: the trunk's own columns first; what follows them in a concatenated input (the features) moves up
-          reads_trunk = dt.fan_in == pt.W or dt.fan_in == pt.W + pt.F
-          if reads_trunk and dx.fan_in != dt.fan_in:
-            rows = torch.where(rows < pt.W, rows, rows + shift)
+          # input rows: block by block of the concatenated input (a padded block's extra rows sit behind its own rows, and what
+          # follows it moves up); output columns keep their index
+          assert len(dt.in_segs) == len(dx.in_segs)
+          rows, ot, ox = [], 0, 0
+          for wt, wx in zip(dt.in_segs, dx.in_segs):
+            assert wx >= wt
+            rows.append(ox + torch.arange(wt))
+            ot, ox = ot + wt, ox + wx
+          rows = torch.cat(rows)
           cols = torch.arange(dt.fan_out)
           idx[dt.kernel_off:dt.kernel_off + dt.fan_in * dt.fan_out] = (dx.kernel_off + rows[:, None] * dx.fan_out + cols[None, :]).reshape(-1)
           idx[dt.bias_off:dt.bias_off + dt.fan_out] = dx.bias_off + cols
@@ -887,14 +908,18 @@ class Model:
                           out=feat)
       bnoise = None
       if randomized and plan.has_rgb and plan.use_viewdirs and hp.bottleneck_noise > 0:      # models.py:530-533
-        bw_ = hp.bottleneck_width
+        bw_ = hp.bottleneck_width                                  # (the execution layout's; bw_t: the configuration's)
+        bw_t = self._tplans[self._plans.index(plan)].hp.bottleneck_width
         if noise is not None and 'bottleneck_noise' in noise:
-          bnoise = noise['bottleneck_noise'][i_level].to(dev).reshape(-1, n, bw_).float()
+          bnoise = noise['bottleneck_noise'][i_level].to(dev).reshape(-1, n, bw_t).float()
           if bnoise.shape[0] != Bp:
-            bnoise = torch.cat([bnoise, bnoise[-1:].expand(Bp - bnoise.shape[0], n, bw_)], 0)
-          bnoise = bnoise.reshape(M, bw_).contiguous()
+            bnoise = torch.cat([bnoise, bnoise[-1:].expand(Bp - bnoise.shape[0], n, bw_t)], 0)
+          bnoise = bnoise.reshape(M, bw_t)
         else:
-          bnoise = torch.randn((M, bw_), generator=gen, device=dev, dtype=f32)
+          bnoise = torch.randn((M, bw_t), generator=gen, device=dev, dtype=f32)
+        if bw_ != bw_t:                                             # padded bottleneck columns (they feed zero kernel rows): no noise
+          bnoise = torch.cat([bnoise, bnoise.new_zeros((M, bw_ - bw_t))], 1)
+        bnoise = bnoise.contiguous()
       if ipe_in_chain:
         mlp_out = self._chain_forward_ipe(plan, flat, tdist, R, radii, M, tag)
       else:
@@ -1569,57 +1594,72 @@ class Model:
       if getattr(self, '_dw_stream', None) is None:
         self._dw_stream = torch.cuda.Stream(device=self.device)
         self._half_cus = max(8, torch.cuda.get_device_properties(self.device).multi_processor_count // 2 // 8 * 8)
+        self._pair_events = {}
       dw_done = None
-    for i in reversed(range(len(plan.trunk))):
-      d, concat = plan.trunk[i]
-      e = plan.packed[('trunk', i)]
-      if t_extras is not None:
-        ops.add_cols_bf16(dy, t_extras[i], dy, W)        # the tangent network's act'' term of this layer's pre-activation
-      if pair and i > 0:
-        # dW_i on the side stream, dX_i on this one, half the chip each, both ascending through M
-        ready = torch.cuda.Event()
-        ready.record(cur_s)
-        self._dw_stream.wait_event(ready)
-        with torch.cuda.stream(self._dw_stream):
+
+    def pair_event(kind, i):
+      """One cached event per (kind, trunk layer): nothing is allocated per step."""
+      ev = self._pair_events.get((kind, i))
+      if ev is None:
+        ev = self._pair_events[(kind, i)] = torch.cuda.Event()
+      return ev
+
+    try:
+      for i in reversed(range(len(plan.trunk))):
+        d, concat = plan.trunk[i]
+        e = plan.packed[('trunk', i)]
+        if t_extras is not None:
+          ops.add_cols_bf16(dy, t_extras[i], dy, W)        # the tangent network's act'' term of this layer's pre-activation
+        if pair and i > 0:
+          # dW_i on the side stream, dX_i on this one, half the chip each, both ascending through M
+          ready = pair_event('ready', i)
+          ready.record(cur_s)
+          self._dw_stream.wait_event(ready)
+          with torch.cuda.stream(self._dw_stream):
+            ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W,
+                        bias_out=gslice(d.bias_off, W), bias_n_valid=W, m_interleave=True, max_wgs=self._half_cus, **tn_a, **tn_b)
+            if concat:
+              ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
+                          lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W, **tn_b)
+            done = pair_event('done', i)
+            done.record(self._dw_stream)
+          if concat:
+            feat_grad(i, dy, dy_panel=panel)
+          if dw_done is not None:
+            cur_s.wait_event(dw_done)                      # dX_i overwrites the buffer dW_{i+1} read its dY from
+          Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
+          other = dy_buf(i - 1)
+          ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, max_wgs=self._half_cus,
+                      **mask_kw(i - 1), **lay_ac)
+          dw_done = done
+          dy = other
+          continue
+        if pair and dw_done is not None:
+          cur_s.wait_event(dw_done)
+          dw_done = None
+        if i == 0:
+          ops.gemm_tn(feat, dy, gslice(d.kernel_off, plan.F * W), M=M, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
+                      ldc=W, k_valid=plan.F, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_b)
+        else:
           ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W,
-                      bias_out=gslice(d.bias_off, W), bias_n_valid=W, m_interleave=True, max_wgs=self._half_cus, **tn_a, **tn_b)
+                      bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_a, **tn_b)
           if concat:
             ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
                         lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W, **tn_b)
-          done = torch.cuda.Event()
-          done.record(self._dw_stream)
-        if concat:
+        if i == 0 or concat:
           feat_grad(i, dy, dy_panel=panel)
-        if dw_done is not None:
-          cur_s.wait_event(dw_done)                      # dX_i overwrites the buffer dW_{i+1} read its dY from
-        Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
-        other = dy_buf(i - 1)
-        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, max_wgs=self._half_cus,
-                    **mask_kw(i - 1), **lay_ac)
-        dw_done = done
-        dy = other
-        continue
+        if i > 0:
+          Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
+          other = dy_buf(i - 1)
+          ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, walk_descending=bool(i & 1),
+                      **mask_kw(i - 1), **lay_ac)
+          act_vjp(mlp['zs'][i - 1] if not relu else None, other)
+          dy = other
+    finally:
+      # whatever path leaves the loop: the side stream's writes into `grads` (fp32 atomics of the last dW launch) are ordered
+      # against what the caller enqueues next on this stream (the gradient all-reduce, clip + Adam)
       if pair and dw_done is not None:
         cur_s.wait_event(dw_done)
-        dw_done = None
-      if i == 0:
-        ops.gemm_tn(feat, dy, gslice(d.kernel_off, plan.F * W), M=M, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
-                    ldc=W, k_valid=plan.F, n_valid=W, bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_b)
-      else:
-        ops.gemm_tn(acts[i - 1], dy, gslice(d.kernel_off, W * W), M=M, K=W, N=W, lda=W, ldb=W, ldc=W,
-                    bias_out=gslice(d.bias_off, W), bias_n_valid=W, **tn_a, **tn_b)
-        if concat:
-          ops.gemm_tn(feat, dy, gslice(d.kernel_off + W * W, plan.F * W), M=M, K=plan.ldF, N=W,
-                      lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W, **tn_b)
-      if i == 0 or concat:
-        feat_grad(i, dy, dy_panel=panel)
-      if i > 0:
-        Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
-        other = dy_buf(i - 1)
-        ops.gemm_nt(dy, Bw, M=M, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W, walk_descending=bool(i & 1),
-                    **mask_kw(i - 1), **lay_ac)
-        act_vjp(mlp['zs'][i - 1] if not relu else None, other)
-        dy = other
 
   @_in_library
   def backward_prop_levels(self, lvs, flat, grads, g_weights, losses):

@@ -304,12 +304,31 @@ class _DenseCursor:
 
 
 def mlp_apply(mlp: MLP, p, gaussians, viewdirs=None, imageplane=None, glo_vec=None,
-              exposure=None, density_noise=None, bottleneck_noise=None, dense_dtype=None):
-  """MLP.__call__ -- returns the same dict as models.py:604-612."""
+              exposure=None, density_noise=None, bottleneck_noise=None, dense_dtype=None, relu_sides=None):
+  """MLP.__call__ -- returns the same dict as models.py:604-612.
+
+  `relu_sides` (test hook, not a reference argument; ReLU networks only): {'masks': [bool tensor per activated Dense layer, in
+  call order], 'stats': dict}.  Layer k then computes z * masks[k] instead of relu(z): the SIDE of every ReLU kink is taken
+  from another evaluation of the same network (the fp32-Dense kernels', tests/helpers.py) instead of from sign(z).  The two
+  differ only where |z| is within that evaluation's rounding of 0, where both sides are valid subgradients; `stats` receives
+  the number of units, the number of disagreements with sign(z) and the largest |z| among them, which the caller bounds."""
   mlp.check()
   dense = _DenseCursor(p, dense_dtype)
   basis = mlp.pos_basis_t(gaussians[0].dtype)
   act = _ACT[mlp.net_activation]
+  if relu_sides is not None and mlp.net_activation == 'relu':
+    sides = iter(relu_sides['masks'])
+    st = relu_sides.setdefault('stats', {})
+
+    def act(z):                                            # noqa: F811
+      m = next(sides).reshape(z.shape)
+      own = z.detach() > 0
+      dis = own != m
+      st['units'] = st.get('units', 0) + z.numel()
+      st['disagree'] = st.get('disagree', 0) + int(dis.sum())
+      if dis.any():
+        st['max_abs_z'] = max(st.get('max_abs_z', 0.0), float(z.detach().abs()[dis].max()))
+      return z * m.to(z.dtype)
 
   def predict_density(means, covs):
     """models.py:441-465."""
@@ -421,7 +440,7 @@ def mlp_apply(mlp: MLP, p, gaussians, viewdirs=None, imageplane=None, glo_vec=No
 
 
 def model_apply(model: Model, nerf_mlp: MLP, prop_mlp: Optional[MLP], params, rays,
-                train_frac, compute_extras, zero_glo=True, noise=None, dense_dtype=None):
+                train_frac, compute_extras, zero_glo=True, noise=None, dense_dtype=None, relu_sides=None):
   """Returns (renderings, ray_history) exactly as models.py:312.
 
   `rays` is any object with the utils.Rays fields (utils.py:44-57) as torch
@@ -513,7 +532,8 @@ def model_apply(model: Model, nerf_mlp: MLP, prop_mlp: Optional[MLP], params, ra
         imageplane=rays.imageplane,
         glo_vec=None if is_prop else glo_vec,
         exposure=rays.exposure_values,
-        density_noise=dn, bottleneck_noise=bn, dense_dtype=dense_dtype)
+        density_noise=dn, bottleneck_noise=bn, dense_dtype=dense_dtype,
+        relu_sides=None if relu_sides is None else relu_sides[i_level])     # (test hook, see mlp_apply)
 
     weights = render.compute_alpha_weights(
         ray_results['density'], tdist, rays.directions,

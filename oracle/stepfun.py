@@ -192,8 +192,9 @@ def resample_logits(sdist, weights, anneal, resample_padding, differentiable=Fal
   if differentiable:
     # (closed bins are constants: their weight is replaced by 1 INSIDE the log so that autograd's 0 * d log(0) is 0, not NaN.
     # A dilated histogram has such bins whenever two fence-posts are clipped to the same domain end, their weight is p * 0 = 0,
-    # and with resample_padding = 0 the reference's own autodiff yields 0 * inf = NaN there, which its train_step then zeroes
-    # with the rest of the gradient (train_utils.py:326-328); the complex-step golden through the reference's code, like this
+    # and with resample_padding = 0 the reference's own autodiff yields 0 * inf = NaN there; the NaN propagates to every
+    # parameter-gradient element that weight depends on and the reference's train_step replaces those elements by 0
+    # (nan_to_num, element-wise, train_utils.py:326-328); the complex-step golden through the reference's code, like this
     # form and like the HIP kernel, gives the derivative of the function that is actually evaluated.)
     open_ = sdist[..., 1:] > sdist[..., :-1]
     w = torch.where(open_, weights + resample_padding, torch.ones_like(weights))

@@ -192,14 +192,14 @@ def clip_gradients(grad, config):
   return out
 
 
-def loss_fn(params, model, nerf_mlp, prop_mlp, config, batch, train_frac, noise, dense_dtype=None):
+def loss_fn(params, model, nerf_mlp, prop_mlp, config, batch, train_frac, noise, dense_dtype=None, relu_sides=None):
   """The closure of train_utils.py:265-314."""
   rays = batch.rays
   compute_extras = config.compute_disp_metrics or config.compute_normal_metrics
   renderings, ray_history = models.model_apply(
       model, nerf_mlp, prop_mlp, params, rays, train_frac=train_frac,
       compute_extras=compute_extras, zero_glo=False,
-      noise=noise if config.randomized else None, dense_dtype=dense_dtype)
+      noise=noise if config.randomized else None, dense_dtype=dense_dtype, relu_sides=relu_sides)
 
   losses = {}
   data_loss, stats = compute_data_loss(batch, renderings, rays, config)
@@ -252,14 +252,15 @@ def adam_update(params, grads, opt_state, config):
 
 
 def train_step(params, opt_state, model, nerf_mlp, prop_mlp, config, batch, train_frac,
-               noise=None, grad_allreduce=None, dense_dtype=None):
+               noise=None, grad_allreduce=None, dense_dtype=None, relu_sides=None):
   """train_utils.py:239-339.  Returns (new_params, new_opt_state, stats, grads).
+  (`relu_sides`: test hook, oracle.models.mlp_apply.)
 
   `grad_allreduce(tree)` stands in for jax.lax.pmean (train_utils.py:319-321).
   """
   leaves = tree_map(lambda p: p.detach().clone().requires_grad_(True), params)
   loss, stats, _ = loss_fn(leaves, model, nerf_mlp, prop_mlp, config, batch, train_frac,
-                           noise, dense_dtype=dense_dtype)
+                           noise, dense_dtype=dense_dtype, relu_sides=relu_sides)
   flat = [v for _, v in tree_leaves(leaves)]
   gflat = torch.autograd.grad(loss, flat, allow_unused=True)
   gflat = [torch.zeros_like(p) if g is None else g for g, p in zip(gflat, flat)]

@@ -48,7 +48,7 @@ def _route_gpu_tests_to_the_simulator():
 # full-size cases), periphery after it, the long equal-step training runs last -- a late environmental failure under `-x`
 # then costs the least evidence (round 4's driver run died in the alphabetically first file, tests/test_gpu_camera.py,
 # at its first host -> device copy, with 0 of 219 tests run).
-_GPU_FILE_ORDER = ['test_gpu_kernels', 'test_gpu_chain', 'test_gpu_model', 'test_gpu_zz_fullsize', 'test_gpu_sampling_grad',
+_GPU_FILE_ORDER = ['test_gpu_kernels', 'test_gpu_chain', 'test_gpu_model', 'test_gpu_zz_fullsize', 'test_gpu_sampling_grad', 'test_gpu_fp32_mode',
                    'test_gpu_refnerf', 'test_gpu_camera', 'test_gpu_scripts', 'test_gpu_convergence']
 
 

@@ -215,6 +215,10 @@ CASES = [
     # a trunk too wide for the fused chain (512, as 360.gin's 1024): per-layer GEMMs on 256x256 tiles, the density head's weight
     # gradient as a vector column of the bottleneck's dW GEMM (gemm_tn_gcol_kernel)
     ('360', ['NerfMLP.net_width = 512', 'PropMLP.net_width = 128'], 16),
+    # ... at a ray count whose 24 M-tiles pass models._PAIR_DXDW's gate but do not divide among the 32 M-splits the weight-gradient
+    # launcher picks for a 512-wide layer on half the chip: the block-cyclic split order (mnr_gemm_tn_args.m_interleave, performance
+    # only) is then dropped by the library instead of failing the step
+    ('360', ['NerfMLP.net_width = 512', 'PropMLP.net_width = 128'], 192),
     # density-gradient normals under warp_fn = contract (models.py:445-446 applies the warp INSIDE predict_density, so
     # value_and_grad, :478-481, differentiates through it; refused until round 5): Ref-NeRF on a contracted scene, and the
     # normals alone with the orientation loss on them
@@ -236,6 +240,12 @@ CASES = [
     # ... and widths that are multiples of 64 only, the proposal MLP behind a non-ReLU activation (its padded units are then
     # non-zero, feed zero kernel rows, and their gradients are dropped)
     ('blender_256', ['PropMLP.net_width = 192', 'PropMLP.net_activation = @jax.nn.softplus', 'NerfMLP.net_width = 320'], 16),
+    # bottleneck_width / net_width_viewdirs off the kernels' tile (models.py:345-347,526-527,577 take any width; refused until
+    # round 6): the same zero-padded execution layout; a view MLP deep enough for its skip concat, whose input rows move with
+    # the padded bottleneck; and the Ref-NeRF head, whose side columns sit behind the bottleneck's
+    ('blender_256', ['NerfMLP.bottleneck_width = 96', 'NerfMLP.net_width_viewdirs = 72', 'NerfMLP.net_depth_viewdirs = 4',
+                     'NerfMLP.skip_layer_dir = 2'], 16),
+    ('blender_refnerf', ['NerfMLP.bottleneck_width = 40', 'NerfMLP.net_width_viewdirs = 200'], 8),
 ]
 
 

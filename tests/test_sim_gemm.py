@@ -381,8 +381,11 @@ def test_tn_block_cyclic_m_splits(sim, layouts):
     np.testing.assert_allclose(b.numpy(), refb.numpy(), rtol=1e-5, atol=1e-3)
     if gcol is not None:
       np.testing.assert_allclose(gout.numpy(), (A.float().T @ gcol.float()).numpy(), rtol=1e-4, atol=1e-2)
-  with pytest.raises(RuntimeError, match='m_interleave needs'):
-    S.sim_gemm_tn(sim, A[:768], B[:768], torch.zeros((K, N)), m_interleave=True, max_wgs=16)     # 3 M-tiles on 8 splits
+  # 3 M-tiles do not divide among the 8 splits the launcher picks for this shape: the flag is performance only and the launch
+  # runs with contiguous splits (the split count depends on the width and the CU count, a caller cannot gate on it)
+  C3 = torch.zeros((K, N))
+  S.sim_gemm_tn(sim, A[:768], B[:768], C3, m_interleave=True, max_wgs=16)
+  np.testing.assert_allclose(C3.numpy(), (A[:768].float().T @ B[:768].float()).numpy(), rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize('late_dma', [0, 1])
