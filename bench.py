@@ -251,6 +251,26 @@ def main():
                              'algorithmic_train_mflop_per_ray': train_b / 1e6,
                              'whole_step_frac_of_mfma_peak': train_b * Bb / dt / 2.5e15}
     del model_b, state_b, step_b, batch_b
+    # (iii) the per-rank shards of BASELINE configs 3 and 5 on ONE GPU: configs/360.gin at 65536 / 8 = 8192 rays, configs/llff_raw.gin
+    # at 16384 / 4 = 4096 rays.  No N > 1 node is available to the builder, so these bound strong-scaling efficiency before any
+    # xGMI cost: a rank that runs its shard at x of the 16384-ray rate cannot scale better than x.
+    def shard_rate(preset, rays, unit_rays):
+      cfg_s = configs.load_preset(preset, [])
+      cfg_s.batch_size = rays
+      model_s, state_s, _, step_s, _ = train_utils.setup_model(cfg_s, 0, device=dev)
+      b_s = synthetic.synthetic_rays(rays, seed=20200823 + rank, near=cfg_s.near, far=cfg_s.far).map(lambda t: t.to(dev))
+      if cfg_s.rawnerf_mode:
+        b_s.rays.exposure_idx = torch.randint(0, 5, (rays, 1), generator=gen, device=dev).to(torch.int32)
+        b_s.rays.exposure_values = 0.5 + torch.rand((rays, 1), generator=gen, device=dev)
+        b_s.rays.lossmult = (torch.rand((rays, 3), generator=gen, device=dev) > 0.4).float()
+      st = [state_s]
+      def run_s():
+        st[0], _, _ = step_s(gen, st[0], b_s, None, train_frac, 0.0)
+      dt_s = timed(run_s, 3, 10)
+      return {'value': rays * world / dt_s, 'unit': 'rays/s', 'ms_per_step': 1e3 * dt_s, 'rays_per_gpu': rays, 'of_ranks': unit_rays // rays}
+    aux['shard_360_8192'] = shard_rate('360', 8192, 65536)
+    aux['shard_360_8192']['fraction_of_the_16384_ray_rate'] = aux['shard_360_8192']['value'] / (B * world / (elapsed / args.steps)) if B == 16384 else None
+    aux['shard_llff_raw_4096'] = shard_rate('llff_raw', 4096, 16384)
 
   # HBM bytes of the GEMM kernels per train step from the PMC passes of the last profiled build (same command,
   # same workload); null for any other workload.  tools/profile_round.sh regenerates the inputs.

@@ -31,7 +31,18 @@ PRESETS = {
                                   "Config.weight_decay_mults = {'NerfMLP_0': 3e-4, 'PropMLP_0': 1e-4}"]),
     # one shared MLP (llff_raw): nothing is final before the last level, single all-reduce at the end
     'single_mlp': ('llff_raw', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32']),
+    # Model.stop_level_grad = False (models.py:198-201): the levels' backward passes depend on each other (last level first, its
+    # sampling gradient into the previous one), PropMLP_0's gradient is final only at the very end and NerfMLP_0's early
+    # all-reduce would run next to nothing: the overlap must switch itself off (ONE all-reduce at the end)
+    'through_the_sampling': ('blender_256', ['NerfMLP.net_width = 128', 'PropMLP.net_width = 128', 'Model.num_prop_samples = 32',
+                                             'Model.num_nerf_samples = 32', 'Model.stop_level_grad = False',
+                                             'Model.resample_padding = 0.01']),
+    # a trunk width on the zero-padded execution layout (configs/debug.gin's 64-wide proposal MLP): the gradient the ranks reduce
+    # is the callers' layout, gathered after the backward pass, so nothing is final early either
+    'padded_width': ('blender_256', ['NerfMLP.net_width = 128', 'PropMLP.net_width = 64', 'Model.num_prop_samples = 32',
+                                     'Model.num_nerf_samples = 32']),
 }
+EARLY_REDUCES = {'blender_256': 1, 'glo_decay': 2, 'single_mlp': 0, 'through_the_sampling': 0, 'padded_width': 0}
 B = 8
 
 
@@ -67,8 +78,15 @@ def _step(rank, world, case):
       per = B // world
       noise = {k: {lv: t[rank * per:(rank + 1) * per] for lv, t in d.items()} for k, d in noise.items()}
     state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
-    state2, stats, _ = train_utils.create_train_step(model, cfg)(0, state, batch, None, 0.5, 0.0, noise=noise, return_grads=True)
+    early, real = [], mdist.all_reduce_sum_async
+    mdist.all_reduce_sum_async = lambda t: (early.append(t.numel()), real(t))[1]       # (count the early, overlapped reduces)
+    try:
+      state2, stats, _ = train_utils.create_train_step(model, cfg)(0, state, batch, None, 0.5, 0.0, noise=noise, return_grads=True)
+    finally:
+      mdist.all_reduce_sum_async = real
     sim.check()
+    if world > 1:
+      assert len(early) == EARLY_REDUCES[case], (case, early)
     return stats['_grads'].clone(), state2.params['flat'].clone(), stats.materialize()['loss']
 
 
