@@ -148,6 +148,16 @@ int mnr_cast_rays_ipe_bwd(const mnr_ipe_cfg* cfg, int64_t B, int n, const float*
                           const float* basis, const uint16_t* g_feat_a, const uint16_t* g_feat_b, int ld_feat,
                           float* g_t0, float* g_t1, void* stream);
 
+/* VJP of mnr_cast_rays_ipe_tangent w.r.t. the interval ends: Model.stop_level_grad = False next to density-gradient normals
+ * (models.py:198-201 with :478-492: the normals are a derivative of predict_density AT the sample's Gaussian, so they depend on
+ * the sample positions as well).  g_T_a (and optionally g_T_b, summed) bf16 [3*B*n, ld_feat] = d loss / d (tangent rows) (the
+ * tangent network's dX GEMMs of the trunk layers that read the features); g_t0, g_t1 fp32 [B*n] are ACCUMULATED into (call
+ * after mnr_cast_rays_ipe_bwd).  With cfg->warp_contract the contraction's third derivative enters (forward-mode duals). */
+int mnr_cast_rays_ipe_tangent_bwd(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist,
+                                  const float* origins, const float* directions, const float* radii,
+                                  const float* basis, const uint16_t* g_T_a, const uint16_t* g_T_b, int ld_feat,
+                                  float* g_t0, float* g_t1, void* stream);
+
 /* coord.pos_enc(viewdirs, 0, deg_view, append_identity=True) per ray, written
  * (bf16) into columns [col0, col0+3+6*deg_view) of every one of the ray's n
  * rows of `dst` [B*n, ld]; columns up to col_end are zero-filled

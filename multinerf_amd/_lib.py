@@ -165,6 +165,7 @@ _PROTOS = {
     'mnr_cast_rays_ipe_f32': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp], i32),
     'mnr_cast_rays_ipe_tangent': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, i32, vp], i32),
     'mnr_cast_rays_ipe_bwd': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp], i32),
+    'mnr_cast_rays_ipe_tangent_bwd': ([C.POINTER(IpeCfg), i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp], i32),
     'mnr_sdist_bwd': ([C.POINTER(SdistBwdArgs), vp], i32),
     'mnr_viewdir_enc_fill': ([i64, i32, vp, i32, vp, i32, i32, i32, vp], i32),
     'mnr_pixels_to_rays': ([i64, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp], i32),

@@ -734,3 +734,294 @@ extern "C" int mnr_cast_rays_ipe_bwd(const mnr_ipe_cfg* cfg, int64_t B, int n, c
   MNR_CHECK_LAUNCH();
   return MNR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// VJP of cast_rays_ipe_kernel<.., TANGENT> with respect to the interval ends: Model.stop_level_grad = False NEXT TO
+// density-gradient normals (models.py:198-201 with :478-492).  The normals are -l2_normalize(d raw_density / d mean), computed in
+// forward mode through the tangent network, whose input rows
+//   T_sin[c] = att 2^l cos(lm 2^l) dlm_c - 1/2 4^l att sin(lm 2^l) dlv_c,   T_cos[c] = -att 2^l sin(.) dlm_c - 1/2 4^l att cos(.) dlv_c
+// (c = x, y, z; per basis direction k and degree l; lm = p_k . mean', lv = p_k^T cov' p_k, att = exp(-1/2 4^l lv), dlm_c = p_k . dz[c],
+// dlv_c = p_k^T dC[c] p_k with dz / dC the contraction's tangents, fe_contract_tangent) depend on the sample's (t0, t1) as well.
+//
+// Input: g_T [3 M, ld] = d loss / d (tangent rows) (the tangent network's dX GEMM of trunk layer 0, plus that of the skip
+// layer's feature segment in g_T_b).  Output: g_t0, g_t1 [M] += d loss / d (t0, t1)  (ACCUMULATED onto mnr_cast_rays_ipe_bwd's).
+//
+// Reverse mode down to the eight scalars (lm, lv, dlm_c, dlv_c) of a (sample, direction), forward mode below them:
+//   phase 1: one thread per sample: the Gaussian and the contraction's tangents (the forward pass's own code)
+//   phase 2: one thread per (sample, k): sin / cos / attenuation once more, and with S = sin, C = cos, a = att, sc = 2^l, hv = -1/2 4^l
+//              d T_sin[c] / d lm = -a sc^2 S dlm_c + hv a sc C dlv_c      d T_cos[c] / d lm = -a sc^2 C dlm_c - hv a sc S dlv_c
+//              d T_x[c] / d lv = hv T_x[c]      d T_sin[c] / d dlm_c = a sc C   d T_cos[c] / d dlm_c = -a sc S
+//              d T_sin[c] / d dlv_c = hv a S    d T_cos[c] / d dlv_c = hv a C
+//   phase 3: one thread per sample: g_mean' = sum_k g_lm p_k, G_cov' = sum_k g_lv p_k p_k^T, g_dz[c] = sum_k g_dlm[c] p_k,
+//            G_dC[c] = sum_k g_dlv[c] p_k p_k^T, then the Gaussian AND the contraction's tangents on dual numbers in (t0, t1)
+//            (fe_gaussian_dual, fe_contract_tangent_dual: the same closed forms carrying (value, d/dt0, d/dt1), so the
+//            contraction's THIRD derivative never has to be written down) and the inner products with those duals.
+
+// fe_contract_tangent on dual numbers.
+__device__ __forceinline__ void fe_contract_tangent_dual(const mnr_ipe_cfg& c, float t0v, float t1v, const float* o, const float* d,
+                                                         float radius, FeD2 (&dz)[3][3], FeD2 (&dC)[3][6]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dz[k][i] = fe_d2((i == k) ? 1.0f : 0.0f);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) dC[k][e] = fe_d2(0.0f);
+  }
+  if (!c.warp_contract) return;
+  const FeD2 t0 = {t0v, 1.0f, 0.0f}, t1 = {t1v, 0.0f, 1.0f};
+  FeD2 t_mean, t_var, r_var;
+  if (c.ray_shape == 0) {
+    const FeD2 mu = (t0 + t1) / 2.0f;
+    const FeD2 hw = (t1 - t0) / 2.0f;
+    const FeD2 denom = fe_max_const(MNR_F32_EPS, 3.0f * (mu * mu) + hw * hw);
+    const FeD2 hw2 = hw * hw, hw4 = hw2 * hw2;
+    t_mean = mu + (2.0f * (mu * hw2)) / denom;
+    t_var = hw2 / 3.0f - ((4.0f / 15.0f) * (hw4 * (12.0f * (mu * mu) - hw2))) / (denom * denom);
+    r_var = (mu * mu) / 4.0f + (5.0f / 12.0f) * hw2 - ((4.0f / 15.0f) * hw4) / denom;
+    r_var = r_var * (radius * radius);
+  } else {
+    t_mean = (t0 + t1) / 2.0f;
+    r_var = fe_d2(radius * radius / 4.0f);
+    t_var = ((t1 - t0) * (t1 - t0)) / 12.0f;
+  }
+  if (c.disable_integration) {
+    t_var = fe_d2(0.0f);
+    r_var = fe_d2(0.0f);
+  }
+  const float dmag = fmaxf(1e-10f, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  FeD2 x[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) x[i] = o[i] + d[i] * t_mean;
+  const FeD2 m = fe_max_const(MNR_F32_EPS, x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  if (m.v <= 1.0f) return;
+  const FeD2 sq = fe_sqrt(m);
+  const FeD2 s = (2.0f * sq - 1.0f) / m;
+  const FeD2 m2 = m * m;
+  const FeD2 cc = (2.0f * (1.0f - sq)) / m2;
+  const FeD2 ccp = (3.0f * sq - 4.0f) / (m2 * m);                  // d cc / d m
+  const FeD2 j2x = (2.0f * cc) / sq;
+  const FeD2 j2xp = (2.0f * ccp - cc / m) / sq;                    // d (2 cc / sqrt(m)) / d m
+  const float oo = o[0] * o[0] + o[1] * o[1] + o[2] * o[2];
+  const float od = o[0] * d[0] + o[1] * d[1] + o[2] * d[2];
+  const FeD2 xd = x[0] * d[0] + x[1] * d[1] + x[2] * d[2];
+  const FeD2 brk = (m - (2.0f * (1.0f - sq)) * (oo + t_mean * od)) / m2;
+  FeD2 u[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) u[i] = brk * d[i] + (cc * xd) * o[i];
+  const FeD2 ku = t_var - r_var / dmag;
+  const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const FeD2 xk = x[k];
+    FeD2 du[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      FeD2 lin = xk * d[i] + d[k] * x[i];
+      if (i == k) lin = lin + xd;
+      du[i] = cc * lin + (2.0f * ccp) * (xk * xd) * x[i];
+      dz[k][i] = cc * (xk * x[i]);
+      if (i == k) dz[k][i] = dz[k][i] + s;
+    }
+    const FeD2 ds = cc * xk;
+    const FeD2 dj = (2.0f * j2xp) * xk;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int i = ii[e], j = jj[e];
+      const FeD2 v = ku * (du[i] * u[j] + u[i] * du[j]);
+      FeD2 w = dj * (x[i] * x[j]);
+      if (i == k) w = w + j2x * x[j];
+      if (j == k) w = w + j2x * x[i];
+      if (i == j) w = w + (2.0f * s) * ds;
+      dC[k][e] = v + r_var * w;
+    }
+  }
+}
+
+#define FE_TB_SPB 32                                    // samples per block of the tangent VJP (8 partial sums per (sample, direction))
+
+__global__ __launch_bounds__(FE_THREADS) void cast_rays_ipe_tangent_bwd_kernel(
+    mnr_ipe_cfg c, int64_t total, int n, const float* __restrict__ tdist, const float* __restrict__ origins,
+    const float* __restrict__ directions, const float* __restrict__ radii, const float* __restrict__ basis,
+    const bf16* __restrict__ g_T_a, const bf16* __restrict__ g_T_b, int ld_feat, float* __restrict__ g_t0, float* __restrict__ g_t1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int K = c.basis_k;
+  const int L = c.max_deg - c.min_deg;
+  // LDS: samples [spb] FeSample | tangents [spb] FeTangent | basis [K*3] | partials [spb][K][8]
+  FeSample* gs = (FeSample*)smem;
+  FeTangent* gt = (FeTangent*)(gs + FE_TB_SPB);
+  float* bs = (float*)(gt + FE_TB_SPB);
+  float* part = bs + ((K * 3 + 3) & ~3);
+  const int64_t s0 = (int64_t)blockIdx.x * FE_TB_SPB;
+  const int ns = (int)min((int64_t)FE_TB_SPB, total - s0);
+  for (int i = threadIdx.x; i < K * 3; i += FE_THREADS) bs[i] = basis[i];
+  if (threadIdx.x < ns) {
+    const int64_t s = s0 + threadIdx.x;
+    const int64_t ray = s / n;
+    const int j = (int)(s % n);
+    const float t0 = tdist[ray * (n + 1) + j], t1 = tdist[ray * (n + 1) + j + 1];
+    float o[3], d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      o[i] = origins[ray * 3 + i];
+      d[i] = directions[ray * 3 + i];
+    }
+    FeSample g;
+    fe_gaussian(c, t0, t1, o, d, radii[ray], g);
+    gs[threadIdx.x] = g;
+    FeTangent T;
+    fe_contract_tangent(c, t0, t1, o, d, radii[ray], T);
+    gt[threadIdx.x] = T;
+  }
+  __syncthreads();
+  const int half = K * L;
+  for (int pair = threadIdx.x; pair < ns * K; pair += FE_THREADS) {
+    const int si = pair / K;
+    const int k = pair - si * K;
+    const FeSample g = gs[si];
+    const FeTangent& T = gt[si];
+    const float px = bs[k * 3 + 0], py = bs[k * 3 + 1], pz = bs[k * 3 + 2];
+    const float lm = g.mean[0] * px + g.mean[1] * py + g.mean[2] * pz;
+    const float cx = g.cov[0] * px + g.cov[1] * py + g.cov[2] * pz;
+    const float cy = g.cov[1] * px + g.cov[3] * py + g.cov[4] * pz;
+    const float cz = g.cov[2] * px + g.cov[4] * py + g.cov[5] * pz;
+    const float lv = px * cx + py * cy + pz * cz;
+    const float vscale = -0.5f * 1.44269504088896340736f * lv;
+    float dlm[3], dlv[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      dlm[cc] = px * T.dz[cc][0] + py * T.dz[cc][1] + pz * T.dz[cc][2];
+      const float* C6 = T.dC[cc];
+      dlv[cc] = px * (C6[0] * px + C6[1] * py + C6[2] * pz) + py * (C6[1] * px + C6[3] * py + C6[4] * pz) +
+                pz * (C6[2] * px + C6[4] * py + C6[5] * pz);
+    }
+    float sc = ldexpf(1.0f, c.min_deg);
+    float sn = 0.0f, cs = 1.0f, att = 1.0f;
+    float g_lm = 0.0f, g_lv = 0.0f, g_dlm[3] = {0.0f, 0.0f, 0.0f}, g_dlv[3] = {0.0f, 0.0f, 0.0f};
+    for (int l = 0; l < L; ++l) {
+      if ((l & 3) == 0) {
+        fe_sincos_wrapped(fe_wrap_100pi(lm * sc), &sn, &cs);
+        att = exp2f(vscale * sc * sc);
+      }
+      const float hv = -0.5f * sc * sc;
+      const float aS = att * sn, aC = att * cs;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const size_t row = ((size_t)cc * total + s0 + si) * ld_feat + (size_t)l * K + k;
+        float gsn = (float)g_T_a[row], gcs = (float)g_T_a[row + half];
+        if (g_T_b) {
+          gsn += (float)g_T_b[row];
+          gcs += (float)g_T_b[row + half];
+        }
+        const float Tsn = aC * sc * dlm[cc] + hv * aS * dlv[cc];
+        const float Tcs = -aS * sc * dlm[cc] + hv * aC * dlv[cc];
+        g_lm += gsn * (-aS * sc * sc * dlm[cc] + hv * aC * sc * dlv[cc]) + gcs * (-aC * sc * sc * dlm[cc] - hv * aS * sc * dlv[cc]);
+        g_lv += hv * (gsn * Tsn + gcs * Tcs);
+        g_dlm[cc] += sc * (gsn * aC - gcs * aS);
+        g_dlv[cc] += hv * (gsn * aS + gcs * aC);
+      }
+      const float s2 = 2.0f * sn * cs;
+      cs = 1.0f - 2.0f * sn * sn;
+      sn = s2;
+      const float a2 = att * att;
+      att = a2 * a2;
+      sc *= 2.0f;
+    }
+    float* pp = part + (size_t)pair * 8;
+    pp[0] = g_lm;
+    pp[1] = g_lv;
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      pp[2 + cc] = g_dlm[cc];
+      pp[5 + cc] = g_dlv[cc];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < ns) {
+    const int si = threadIdx.x;
+    float gm[3] = {0.0f, 0.0f, 0.0f}, G[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float gz[3][3], GC[3][6];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) gz[cc][i] = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) GC[cc][e] = 0.0f;
+    }
+    for (int k = 0; k < K; ++k) {
+      const float p[3] = {bs[k * 3 + 0], bs[k * 3 + 1], bs[k * 3 + 2]};
+      const float pp6[6] = {p[0] * p[0], p[0] * p[1], p[0] * p[2], p[1] * p[1], p[1] * p[2], p[2] * p[2]};
+      const float* pr = part + (size_t)(si * K + k) * 8;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) gm[i] += pr[0] * p[i];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) G[e] += pr[1] * pp6[e];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gz[cc][i] += pr[2 + cc] * p[i];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) GC[cc][e] += pr[5 + cc] * pp6[e];
+      }
+    }
+    const int64_t s = s0 + si;
+    const int64_t ray = s / n;
+    const int j = (int)(s % n);
+    const float t0 = tdist[ray * (n + 1) + j], t1 = tdist[ray * (n + 1) + j + 1];
+    float o[3], d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      o[i] = origins[ray * 3 + i];
+      d[i] = directions[ray * 3 + i];
+    }
+    FeD2 mean[3], cov[6];
+    fe_gaussian_dual(c, t0, t1, o, d, radii[ray], mean, cov);
+    FeD2 dz[3][3], dC[3][6];
+    fe_contract_tangent_dual(c, t0, t1, o, d, radii[ray], dz, dC);
+    const float wgt[6] = {1.0f, 2.0f, 2.0f, 1.0f, 2.0f, 1.0f};      // the symmetric matrices' off-diagonal entries count twice
+    float ga = 0.0f, gb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      ga += gm[i] * mean[i].a;
+      gb += gm[i] * mean[i].b;
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      ga += wgt[e] * G[e] * cov[e].a;
+      gb += wgt[e] * G[e] * cov[e].b;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        ga += gz[cc][i] * dz[cc][i].a;
+        gb += gz[cc][i] * dz[cc][i].b;
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        ga += wgt[e] * GC[cc][e] * dC[cc][e].a;
+        gb += wgt[e] * GC[cc][e] * dC[cc][e].b;
+      }
+    }
+    g_t0[s] += ga;
+    g_t1[s] += gb;
+  }
+}
+
+extern "C" int mnr_cast_rays_ipe_tangent_bwd(const mnr_ipe_cfg* cfg, int64_t B, int n, const float* tdist, const float* origins,
+                                             const float* directions, const float* radii, const float* basis, const uint16_t* g_T_a,
+                                             const uint16_t* g_T_b, int ld_feat, float* g_t0, float* g_t1, void* stream) {
+  MNR_CHECK_ARG(cfg && B > 0 && n > 0 && tdist && origins && directions && radii && basis && g_T_a && g_t0 && g_t1,
+                "mnr_cast_rays_ipe_tangent_bwd: null argument");
+  MNR_CHECK_ARG(cfg->ray_shape == 0 || cfg->ray_shape == 1, "ray_shape must be 'cone' or 'cylinder'");
+  const int K = cfg->basis_k, L = cfg->max_deg - cfg->min_deg;
+  MNR_CHECK_ARG(K >= 1 && K <= 128 && L >= 1 && L <= 32, "mnr_cast_rays_ipe_tangent_bwd: basis_k=%d / degrees=%d out of range", K, L);
+  MNR_CHECK_ARG(ld_feat >= 2 * K * L, "mnr_cast_rays_ipe_tangent_bwd: ld_feat=%d must be >= %d", ld_feat, 2 * K * L);
+  const size_t lds = (size_t)FE_TB_SPB * (sizeof(FeSample) + sizeof(FeTangent)) + (size_t)((K * 3 + 3) & ~3) * 4 +
+                     (size_t)FE_TB_SPB * K * 8 * 4;
+  const int64_t total = B * n;
+  hipLaunchKernelGGL(cast_rays_ipe_tangent_bwd_kernel, dim3(mnr_cdiv(total, FE_TB_SPB)), dim3(FE_THREADS), lds, (hipStream_t)stream,
+                     *cfg, total, n, tdist, origins, directions, radii, basis, (const bf16*)g_T_a, (const bf16*)g_T_b, ld_feat, g_t0,
+                     g_t1);
+  MNR_CHECK_LAUNCH();
+  return MNR_OK;
+}

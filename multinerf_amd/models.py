@@ -380,10 +380,8 @@ class Model:
     bad = []
     for name, hp in (('NerfMLP', self.nerf_hp), ('PropMLP', self.prop_hp)):
       bad += [f'{name}: {b}' for b in hp.hip_supported()]
-    if not self.stop_level_grad and any(not hp.disable_density_normals for hp in (self.nerf_hp, self.prop_hp)):
-      # the density-gradient normals are a function of the sample positions as well (the tangent network's input rows):
-      # their VJP with respect to the interval ends is not built
-      bad.append('stop_level_grad=False with density-gradient normals')
+    # (stop_level_grad = False next to density-gradient normals, which are a function of the sample positions as well, models.py:
+    # 198-201 with :478-492: the tangent rows' VJP with respect to the interval ends is mnr_cast_rays_ipe_tangent_bwd, round 6)
     if not self.use_viewdirs and any(hp.enable_pred_normals or not hp.disable_density_normals or hp.is_ref()
                                      for hp in (self.nerf_hp, self.prop_hp) if not hp.disable_rgb):
       bad.append('normals (the Ref-NeRF head or one of its fields) without view directions')
@@ -1309,14 +1307,15 @@ class Model:
 
   @_in_library
   def backward_level(self, lv, flat, grads, g_rgb_out, g_weights, g_expo=None, g_normals=None, g_npred=None, losses=None,
-                     g_x_out=None, g_feat_out=None):
+                     g_x_out=None, g_feat_out=None, g_tfeat_out=None):
     """VJP of one level w.r.t. the parameters: compositing -> heads -> trunk.
     grads: flat fp32 gradient vector (accumulated into).  g_normals / g_npred [M,3]: from the Ref-NeRF
     normal losses (train_utils.py:162-197).  losses: this level's data / interlevel / distortion losses, evaluated
     and differentiated inside the compositing VJP's launch (ops.composite_bwd).
     stop_level_grad = False (models.py:198-201): g_x_out [B, n] receives d loss / d (sigma * delta) of the compositing, and
     the list g_feat_out the bf16 [M, ldF] matrices whose sum is d loss / d features (one per trunk layer that reads the
-    features: layer 0 and the skip layer)."""
+    features: layer 0 and the skip layer); the list g_tfeat_out the [3 M, ldF] matrices whose sum is d loss / d (tangent feature
+    rows) of the density-gradient normals' forward-mode network (`_tangent_backward`)."""
     plan: MLPPlan = lv['plan']
     hp = plan.hp
     M, n, tag = lv['M'], lv['n'], lv['tag']
@@ -1567,7 +1566,7 @@ class Model:
     feat = lv['feat']
     t_extras = None
     if g_raw_grad is not None:
-      t_extras = self._tangent_backward(plan, flat, grads, mlp, feat, M, g_raw_grad, slot)
+      t_extras = self._tangent_backward(plan, flat, grads, mlp, feat, M, g_raw_grad, slot, g_tfeat_out)
     if mlp.get('chain_trunk'):
       # fused dX chain from the dY_last the head GEMMs left in dA; then dW_i = [x_{i-1} | feat]^T dY_i per layer
       dYs = [self._buf(('bwd', slot, 'dYc', W, i), (M, W), bf16) for i in range(D - 1)] + [None]
@@ -1704,7 +1703,7 @@ class Model:
         ops.gemm_tn(feat, dYs[i], grads[o:o + plan.F * W], M=Mall, K=plan.ldF, N=W, lda=plan.ldF, ldb=W, ldc=W,
                     k_valid=plan.F, n_valid=W)
 
-  def _tangent_backward(self, plan, flat, grads, mlp, feat, M, g_raw_grad, slot):
+  def _tangent_backward(self, plan, flat, grads, mlp, feat, M, g_raw_grad, slot, g_tfeat_out=None):
     """Backward pass through the tangent network T_l = bits_l * (T_{l-1} W_l), raw_grad = T_last w_density
     (the "double backward" of the density-gradient normals): the network is linear in each W_l with
     fixed masks, so dW_l += T_{l-1}^T G_l and G_{l-1} = bits_{l-1} * (G_l W_l^T) on 3*M rows."""
@@ -1732,6 +1731,13 @@ class Model:
       e = plan.packed[('trunk', i)]
       if not relu:
         ops.act_tangent_bwd(plan.hp.net_activation, mlp['zs'][i], mlp['T_pre'][i], gy, extras[i])     # gy: d loss / d T_i -> d loss / d U_i
+      if g_tfeat_out is not None and (i == 0 or concat):
+        # stop_level_grad = False: the tangent feature rows depend on the sample positions: d loss / d T_feat through this layer's
+        # feature rows, G_i @ kernel_i[feature rows]^T -> [3 M, ldF] (the backward image `bf` of `feat_grad`)
+        gT = self._buf(('bwd', slot, 'g_tfeat', len(g_tfeat_out)), (M3, plan.ldF), bf16)
+        ops.gemm_nt(gy, self._w(plan, e['bf_off'], plan.ldF, e['bf_ld']), M=M3, N=plan.ldF, K1=e['bf_ld'], Cb=gT, ldcb=plan.ldF,
+                    nb=plan.ldF)
+        g_tfeat_out.append(gT)
       if i == 0:
         ops.gemm_tn(T_feat, gy, gslice(d.kernel_off, plan.F * W), M=M3, K=plan.ldF, N=W, lda=plan.ldF, ldb=W,
                     ldc=W, k_valid=plan.F, n_valid=W)

@@ -292,6 +292,25 @@ def cast_rays_ipe_bwd(tdist, origins, directions, radii, basis, g_feat_a, g_feat
   return g_t0, g_t1
 
 
+def cast_rays_ipe_tangent_bwd(tdist, origins, directions, radii, basis, g_T_a, g_T_b, g_t0, g_t1, *, ray_shape, warp_contract, min_deg,
+                              max_deg, disable_integration=False):
+  """VJP of `cast_rays_ipe_tangent` w.r.t. the interval ends: g_T_a (+ g_T_b) bf16 [3*B*n, ld] -> g_t0, g_t1 fp32 [B*n] += ..."""
+  for x, nm in ((tdist, 'tdist'), (origins, 'origins'), (directions, 'directions'), (radii, 'radii'), (basis, 'basis'),
+                (g_t0, 'g_t0'), (g_t1, 'g_t1')):
+    _chk(x, f32, nm)
+  _chk(g_T_a, bf16, 'g_T_a')
+  _chk(g_T_b, bf16, 'g_T_b', allow_none=True)
+  B, n1 = tdist.shape
+  n = n1 - 1
+  ld = g_T_a.stride(0)
+  assert g_T_a.shape[0] == 3 * B * n and (g_T_b is None or (g_T_b.shape[0] == 3 * B * n and g_T_b.stride(0) == ld))
+  assert g_t0.numel() == B * n and g_t1.numel() == B * n
+  cfg = _ipe_cfg(ray_shape, warp_contract, disable_integration, basis, min_deg, max_deg)
+  L.check(lib().mnr_cast_rays_ipe_tangent_bwd(C.byref(cfg), B, n, _ptr(tdist), _ptr(origins), _ptr(directions), _ptr(radii),
+                                              _ptr(basis), _ptr(g_T_a), _ptr(g_T_b), ld, _ptr(g_t0), _ptr(g_t1), _stream()))
+  return g_t0, g_t1
+
+
 def sdist_bwd(sdist, near, far, raydist_fn, *, B_valid=None, g_x=None, raw_density=None, density_noise=None, density_noise_std=0.0,
               density_bias=0.0, density_act='softplus', dirs=None, g_t0=None, g_t1=None, distortion_mult=0.0, weights=None,
               g_sdist_in=None, out=None):

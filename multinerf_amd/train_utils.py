@@ -246,8 +246,10 @@ def create_train_step(model: models.Model, config, dataset=None):
         through = li >= 1                                # level 0 resamples a constant histogram: nothing upstream of it
         g_x = model._buf(('train', 'g_x', li), (Bp_, n_), f32) if through else None
         g_feat = [] if through else None
+        g_tfeat = [] if (through and plan.tangent) else None     # (density-gradient normals: a function of the sample positions too)
         model.backward_level(lv, flat, grads, None, g_w[li], g_expo, g_nrm[li], g_npr[li],
-                             losses=dict(B_valid=B0, data=data_spec[li], weights=w_spec[li]), g_x_out=g_x, g_feat_out=g_feat)
+                             losses=dict(B_valid=B0, data=data_spec[li], weights=w_spec[li]), g_x_out=g_x, g_feat_out=g_feat,
+                             g_tfeat_out=g_tfeat)
         if not through:
           break
         while len(g_feat) > 2:                           # more than one skip layer: fold the extra matrices into the first
@@ -259,6 +261,15 @@ def create_train_step(model: models.Model, config, dataset=None):
             ray_shape=model.ray_shape, warp_contract=(hp.warp_fn == 'contract'), min_deg=hp.min_deg_point,
             max_deg=hp.max_deg_point, disable_integration=model.disable_integration,
             g_t0=model._buf(('train', 'g_t0', li), (Bp_ * n_,), f32), g_t1=model._buf(('train', 'g_t1', li), (Bp_ * n_,), f32))
+        if g_tfeat:
+          # ... and through the tangent rows of the density-gradient normals (mnr_cast_rays_ipe_tangent_bwd accumulates)
+          while len(g_tfeat) > 2:
+            extra = g_tfeat.pop()
+            ops.add_cols_bf16(g_tfeat[0], extra, g_tfeat[0], plan.ldF)
+          ops.cast_rays_ipe_tangent_bwd(
+              lv['tdist'], R.origins, R.directions, lv['radii'], plan.basis_dev, g_tfeat[0], g_tfeat[1] if len(g_tfeat) > 1 else None,
+              g_t0, g_t1, ray_shape=model.ray_shape, warp_contract=(hp.warp_fn == 'contract'), min_deg=hp.min_deg_point,
+              max_deg=hp.max_deg_point, disable_integration=model.disable_integration)
         ccfg = lv['ccfg']
         fine = li == nlev - 1
         g_s = ops.sdist_bwd(

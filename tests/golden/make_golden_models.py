@@ -104,6 +104,9 @@ CASES.update({
     # (:478-481) differentiates through track_linearize(contract) -- Ref-NeRF on an unbounded scene (jax.linearize under an
     # outer complex step: see `linearize` below)
     'refnerf_contract': ('blender_refnerf', _RB + ['NerfMLP.warp_fn = @coord.contract'], 3, True, 0.5),
+    # gradients through the sampling NEXT TO density-gradient normals (Ref-NeRF, one shared MLP): the normals are a function of
+    # the sample positions too (models.py:478-492 differentiates predict_density at means that depend on the distances)
+    'refnerf_sampling_grad': ('blender_refnerf', _RB + ['Model.stop_level_grad = False', 'Model.resample_padding = 0.01'], 3, True, 0.5),
     # the complete head on predicted normals only (no density gradient: no vmap(value_and_grad) in the forward pass)
     'refnerf_pred_normals_head': ('blender_refnerf', _RB + _NO_PN_LOSS + ['NerfMLP.disable_density_normals = True',
                                                               'Config.compute_normal_metrics = False'], 3, True, 0.5),
@@ -611,7 +614,21 @@ def run_case(case, rmodels, ref_callables, rnd_state, Key):
       est = []
       for h in (1e-6, 2e-6):
         est.append((8 * (at(h) - at(-h)) - (at(2 * h) - at(-2 * h))) / (12 * h))
-      assert abs(est[0] - est[1]) <= 1e-6 * max(1.0, abs(est[0])), (case, d, est)
+      ok = abs(est[0] - est[1]) <= 1e-6 * max(1.0, abs(est[0]))
+      if not ok and not bindings['Model'].get('stop_level_grad', True):
+        # with the sampling on the path as well the loss has a kink wherever a sample crosses a bin edge (see the branch above):
+        # smaller stencils, and a direction whose stencils all straddle a kink is stored as NaN (two of three must survive)
+        for h in (1e-7, 2e-7):
+          est.append((8 * (at(h) - at(-h)) - (at(2 * h) - at(-2 * h))) / (12 * h))
+        ok = abs(est[2] - est[3]) <= 2e-6 * max(1.0, abs(est[2]))
+        est[0] = est[2]
+        fd_agree.append(ok)
+        if not ok:
+          est[0] = float('nan')
+      else:
+        assert ok, (case, d, est)
+        if not bindings['Model'].get('stop_level_grad', True):
+          fd_agree.append(True)
       dl = est[0]
       _StopGradient.mode = 'real'
     g[f'{case}/dloss{d}'] = np.array(float(np.real(dl)))

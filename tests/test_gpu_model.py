@@ -467,10 +467,13 @@ def test_unsupported_features_fail_loudly():
   cfg = configs.load_preset('360', ['NerfMLP.net_activation = "tanh"'])       # not an activation the reference registers
   with pytest.raises(NotImplementedError, match='net_activation'):
     models.Model(config=cfg).build('cuda')
-  # Model.stop_level_grad = False is on the HIP path since round 5 (tests/test_gpu_sampling_grad.py), except next to the
-  # density-gradient normals, which are a function of the sample positions too
-  cfg = configs.load_preset('blender_refnerf', ['Model.stop_level_grad = False'])
-  with pytest.raises(NotImplementedError, match='stop_level_grad=False with density-gradient normals'):
+  # Model.stop_level_grad = False is on the HIP path since round 5 (tests/test_gpu_sampling_grad.py); since round 6 also next to the
+  # density-gradient normals, which are a function of the sample positions too (mnr_cast_rays_ipe_tangent_bwd)
+  cfg = configs.load_preset('blender_refnerf', ['Model.stop_level_grad = False', 'Model.resample_padding = 0.01'])
+  models.Model(config=cfg).build('cuda')
+  # widths are free (zero-padded execution layout); a width of zero is not a network
+  cfg = configs.load_preset('blender_256', ['NerfMLP.bottleneck_width = 0'])
+  with pytest.raises(NotImplementedError, match='bottleneck_width must be positive'):
     models.Model(config=cfg).build('cuda')
 
 

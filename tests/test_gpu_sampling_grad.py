@@ -201,6 +201,67 @@ def test_cast_rays_ipe_bwd_is_the_oracles_autograd(name, ray_shape, contract, ba
   _rays_close(got, t2.grad, tol, 1e-6, f'g_tdist, one source [{name}]')
 
 
+@pytest.mark.parametrize('name,ray_shape,contract,basis,min_deg,max_deg,far,ndc,no_int', IPE_CASES)
+def test_cast_rays_ipe_tangent_bwd_is_the_oracles_autograd(name, ray_shape, contract, basis, min_deg, max_deg, far, ndc, no_int):
+  """mnr_cast_rays_ipe_tangent_bwd: the tangent rows T_c = d features / d mean_c (the input of the density-gradient normals' forward-mode
+  network, models.py:478-492; the covariance an input held fixed, the contraction inside, :445-446) differentiated with respect to the
+  interval ends, against reverse-over-forward autodiff of the oracle's featurisation in float64."""
+  if not torch.cuda.is_available():
+    pytest.skip('no GPU')
+  from multinerf_amd import geopoly
+  from oracle import coord as ocoord
+  from oracle import render as orender
+  B, n = 12, 8
+  o, d, radii, tdist = _ray_case(B, n, seed=41 + len(name), far_samples=far, ndc=ndc)
+  if name == '360-near':
+    tdist = (tdist * 0.5 - 0.6).float().double()
+  P = torch.as_tensor(geopoly.generate_basis(*basis), dtype=torch.float64)
+  K, L = P.shape[0], max_deg - min_deg
+  F = 2 * K * L
+  ld = (F + 127) // 128 * 128
+  M = B * n
+  gen = torch.Generator().manual_seed(7)
+  # upstream gradients shrinking with the degree, as a trained network's first layer does to them: T's entries grow like 4^l
+  scale = torch.cat([2.0 ** -(2.0 * torch.arange(L, dtype=torch.float64).repeat_interleave(K))] * 2)
+  mk = lambda: torch.cat([(torch.randn((3 * M, F), generator=gen, dtype=torch.float64) * scale), torch.zeros((3 * M, ld - F), dtype=torch.float64)], 1).to(torch.bfloat16)
+  gA, gB = mk(), mk()
+
+  def loss_of(t, G):
+    means, covs = orender.cast_rays(t, o, d, radii, ray_shape, diag=False)
+    if no_int:
+      covs = torch.zeros_like(covs)
+
+    def feat_of(mu):
+      m2, c2 = (ocoord.track_linearize(ocoord.contract, mu, covs) if contract else (mu, covs))
+      lm, lv = ocoord.lift_and_diagonalize(m2, c2, P.t())
+      return ocoord.integrated_pos_enc(lm, lv, min_deg, max_deg).reshape(M, F)
+
+    total = 0.0
+    for c in range(3):
+      e = torch.zeros_like(means)
+      e[..., c] = 1.0
+      _, Tc = torch.autograd.functional.jvp(feat_of, means, e, create_graph=True)
+      total = total + (Tc * G[c * M:(c + 1) * M, :F]).sum()
+    return total
+
+  f32c = lambda x: dev(x.float().contiguous())
+  for G, gb in (((gA.double() + gB.double()), gB), (gA.double(), None)):
+    t = tdist.clone().requires_grad_(True)
+    loss_of(t, G).backward()
+    want = t.grad
+    g_t0 = dev(torch.zeros(M, dtype=torch.float32))
+    g_t1 = dev(torch.zeros(M, dtype=torch.float32))
+    ops.cast_rays_ipe_tangent_bwd(f32c(tdist), f32c(o), f32c(d), f32c(radii.reshape(-1)), f32c(P), dev(gA), None if gb is None else dev(gb),
+                                  g_t0, g_t1, ray_shape=ray_shape, warp_contract=contract, min_deg=min_deg, max_deg=max_deg,
+                                  disable_integration=no_int)
+    torch.cuda.synchronize()
+    got = torch.zeros((B, n + 1), dtype=torch.float64)
+    got[:, :n] += g_t0.view(B, n).double().cpu()
+    got[:, 1:] += g_t1.view(B, n).double().cpu()
+    tol = 3e-3 if max_deg <= 12 else 2e-2
+    _rays_close(got, want, tol, 1e-6, f'g_tdist through the tangent rows [{name}]')
+
+
 # ----------------------------------------------------------------------------- compositing / distortion -> sample distances
 
 
@@ -283,6 +344,8 @@ COMPOSED = [
     ('360', '360', [], 16, False),
     # llff_raw.gin: one shared 256-wide MLP on the fused chain (skip concat), cylinders, no dilation
     ('llff_raw', 'llff_raw', ['Model.num_prop_samples = 64', 'Model.num_nerf_samples = 64'], 8, True),
+    # blender_refnerf.gin AS IS apart from the switch: next to density-gradient normals (the tangent rows' VJP, round 6)
+    ('blender_refnerf', 'blender_refnerf', ['Model.resample_padding = 0.01'], 8, True),
 ]
 
 

@@ -365,6 +365,13 @@ SAMPLING_GRAD_CASES = [
     # llff_raw.gin: ONE shared MLP with a skip concat on the fused chain, cylinders, no dilation, per-sample jitter
     ('llff_raw', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32',
                   'Model.stop_level_grad = False'], 4),
+    # blender_refnerf.gin: the sampling gradient NEXT TO density-gradient normals (models.py:198-201 with :478-492): the normals are a
+    # derivative of predict_density at the sample's Gaussian, so the tangent network's input rows depend on the sample positions
+    # too (mnr_cast_rays_ipe_tangent_bwd; golden `refnerf_sampling_grad` from the reference's own models.py); ... under the contraction
+    ('blender_refnerf', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32',
+                         'Model.stop_level_grad = False', 'Model.resample_padding = 0.01'], 4),
+    ('blender_refnerf', ['NerfMLP.net_width = 128', 'Model.num_prop_samples = 32', 'Model.num_nerf_samples = 32',
+                         'Model.stop_level_grad = False', 'Model.resample_padding = 0.01', 'NerfMLP.warp_fn = @coord.contract'], 4),
 ]
 
 
@@ -393,7 +400,7 @@ def test_gradients_through_the_sampling_on_the_simulator(name, extra, B):
 
 # ----------------------------------------------------------------------------- Model(dense_precision='fp32')
 
-F32_CASES = [CASES[0], CASES[1], CASES[2], CASES[5], CASES[7], CASES[8], CASES[9], SAMPLING_GRAD_CASES[0], SAMPLING_GRAD_CASES[1], SAMPLING_GRAD_CASES[3]]
+F32_CASES = [CASES[0], CASES[1], CASES[2], CASES[5], CASES[7], CASES[8], CASES[9], SAMPLING_GRAD_CASES[0], SAMPLING_GRAD_CASES[1], SAMPLING_GRAD_CASES[3], SAMPLING_GRAD_CASES[4], SAMPLING_GRAD_CASES[5]]
 
 
 @pytest.mark.parametrize('name,extra,B', F32_CASES)

@@ -7,6 +7,7 @@ number of train steps inside the profiled command is read off the dispatch count
 module and step: two at 360.gin), or given as a fourth argument after the module count.
 """
 import json
+import os
 import re
 import sys
 
@@ -41,7 +42,8 @@ def main():
   out = {
       # the build these counters were read on (bench.py reports the figure only for that build)
       'lib_digest': open(stamp).read().strip() if os.path.exists(stamp) else None,
-      'source': f'{sys.argv[1]} + {sys.argv[2]} (separate rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1; tools/profile_round.sh)',
+      # (the tracked copies: gpurun_out/ is scratch and git-ignored, the same files are committed under profiles/)
+      'source': f'profiles/{os.path.basename(sys.argv[1])} + profiles/{os.path.basename(sys.argv[2])} (separate rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1; tools/final_lean.sh)',
       'train_steps_in_profile': steps,
       'mfma_kernels': list(MFMA),
       'gemm_fetch_kib_reported': f,
