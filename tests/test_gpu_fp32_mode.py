@@ -11,10 +11,13 @@ float32 inputs (the oracle is pinned to the reference's own code in float64, tes
 
   forward    sdist 3e-5, weights 1e-4, rgb 1e-4 (absolute)
   gradients  relative L2 per top-level module <= max(GRAD_TOL = 2e-4, 2 x |oracle_fp32 - oracle_fp64|): where fp32 arithmetic
-             itself costs more than 3e-4 (the plain fp32 ORACLE sits 2e-3 from its float64 self on 360.gin's contracted scene)
-             the kernels must be about as close to float64 as the fp32 oracle is; both distances are printed.  A ReLU unit whose
-             pre-activation is within fp32 rounding of 0 may take the other side of the kink: tests/helpers.py
-             check_fp32_mode_gradient recognises that signature (one column of one layer) and reports it as KINK_FLIP.
+             itself costs more than 2e-4 the kernels must be about as close to float64 as the fp32 oracle is; both distances
+             are printed.
+  ReLU kinks fp32 cannot promise the SIGN of a pre-activation that is within its evaluation noise of 0, and a unit that takes the
+             other side for one sample is not a 1e-7 error but a different (equally valid) subgradient: one such unit moves a
+             small-batch gradient by 1e-3, and a few per million units do (counted and printed).  Both oracles therefore take the
+             kernels' side of every kink (oracle.models.mlp_apply `relu_sides`, tests/helpers.py kernel_relu_sides), and the test
+             asserts that float64's own sign disagrees on at most 5e-5 of the units, all with |z| < 5e-3 (typical |z| ~ 1).
 
 The same cases as the bf16 product's: tests/test_gpu_model.CASES, configs/360.gin AS IS at full width, and the composed
 stop_level_grad = False cases incl. 360.gin AS IS, which the bf16 product can only hold to the oracle's own bf16 cost (0.41).

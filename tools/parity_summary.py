@@ -36,3 +36,37 @@ print('|---|---|---|')
 for n, d in sorted(mx.items()):
   print(f"| `{n}` | {d['sdist']:.1e} / {d['weights']:.1e} / {d['rgb']:.1e} / {d['grad']:.1e} | "
         f"{d['sdist32']:.1e} / {d['weights32']:.1e} / {d['rgb32']:.1e} / {d['grad32']:.1e} |")
+
+# ---- the fp32-Dense debug mode (tests/test_gpu_fp32_mode.py prints `F32MODE <preset>[...]` lines): maxima per preset against the
+# oracle in float64, with the plain fp32 oracle's own distance from float64 next to them
+f32 = collections.defaultdict(lambda: collections.defaultdict(float))
+sides = [0, 0, 0.0]
+for line in open(sys.argv[1], errors='replace'):
+  m = re.search(r'F32MODE (sampling )?(\w+).* level (\d+): \|sdist - oracle_fp64\| (\S+), \|weights - oracle_fp64\| (\S+)', line)
+  if m:
+    k = ('sampling ' if m.group(1) else '') + m.group(2)
+    f32[k]['sdist'] = max(f32[k]['sdist'], float(m.group(4)))
+    f32[k]['weights'] = max(f32[k]['weights'], float(m.group(5)))
+    continue
+  m = re.search(r'F32MODE (sampling )?(\w+).*: \|rgb - oracle_fp64\| (\S+)', line)
+  if m:
+    k = ('sampling ' if m.group(1) else '') + m.group(2)
+    f32[k]['rgb'] = max(f32[k]['rgb'], float(m.group(3)))
+    continue
+  m = re.search(r'F32MODE (sampling )?(\w+).* (\w+): gradient \|kernel_fp32 - oracle_fp64\| (\S+) \(\|oracle_fp32 - oracle_fp64\| (\S+)\)', line)
+  if m:
+    k = ('sampling ' if m.group(1) else '') + m.group(2)
+    f32[k]['grad'] = max(f32[k]['grad'], float(m.group(4)))
+    f32[k]['cost32'] = max(f32[k]['cost32'], float(m.group(5)))
+    f32[k]['n'] += 1
+    continue
+  m = re.search(r'RELU_SIDES: (\d+) of (\d+) units .* \|z\| among them (\S+)\)', line)
+  if m:
+    sides = [sides[0] + int(m.group(1)), sides[1] + int(m.group(2)), max(sides[2], float(m.group(3)))]
+if f32:
+  print()
+  print('| fp32-Dense mode, preset (max over its cases) | sdist / weights / rgb vs float64 oracle | gradient, relative L2 per module vs float64 oracle | the plain fp32 oracle vs its float64 self |')
+  print('|---|---|---|---|')
+  for n, d in sorted(f32.items()):
+    print(f"| `{n}` ({int(d['n'])} module gradients) | {d['sdist']:.1e} / {d['weights']:.1e} / {d['rgb']:.1e} | {d['grad']:.1e} | {d['cost32']:.1e} |")
+  print(f'\nReLU kinks: {sides[0]} of {sides[1]} units took the other side in fp32 (largest float64 |z| among them {sides[2]:.1e}).')
