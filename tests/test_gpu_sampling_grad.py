@@ -258,7 +258,7 @@ def test_cast_rays_ipe_tangent_bwd_is_the_oracles_autograd(name, ray_shape, cont
     got = torch.zeros((B, n + 1), dtype=torch.float64)
     got[:, :n] += g_t0.view(B, n).double().cpu()
     got[:, 1:] += g_t1.view(B, n).double().cpu()
-    tol = 3e-3 if max_deg <= 12 else 2e-2
+    tol = 1e-3 if max_deg <= 12 else 5e-3                                     # (measured on the MI355X: <= 5e-5)
     _rays_close(got, want, tol, 1e-6, f'g_tdist through the tangent rows [{name}]')
 
 
@@ -378,6 +378,9 @@ def test_train_step_through_the_sampling_matches_the_oracle(name, preset, bindin
     batch.rays.exposure_values = 0.5 + torch.rand((B, 1), generator=g)
     batch.rays.lossmult = (torch.rand((B, 3), generator=g) > 0.4).float()
     batch.rgb = batch.rgb * 0.3
+  if cfg.compute_normal_metrics:
+    batch.alphas = torch.rand((B,), generator=g)
+    batch.normals = torch.randn((B, 3), generator=g)
   noise = helpers.make_noise(model, B)
   tf = 0.4
   st = otrain.init_opt_state(params)

@@ -14,7 +14,7 @@ import shutil
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VALIDATED = os.path.join(ROOT, 'profiles', 'r5_validated_isa.json')
+VALIDATED = os.path.join(ROOT, 'profiles', 'r6_validated_isa.json')
 
 pytestmark = pytest.mark.skipif(not os.path.exists('/opt/rocm/bin/hipcc') and not shutil.which('hipcc'), reason='needs hipcc')
 
@@ -176,9 +176,9 @@ def test_fused_chain_weight_chunks_are_prefetched_not_waited_for_on_the_spot(rep
 
 
 def test_shipped_kernels_are_the_ones_validated_on_the_gpu(report):
-  """profiles/r5_validated_isa.json holds digests of the device code of every kernel as it ran the round-5 GPU suite and
-  bench.  Host-side or simulator work must not change them; an intended kernel change re-validates on the GPU and rewrites
-  the file (python tools/isa_report.py --write-digests profiles/r5_validated_isa.json)."""
+  """profiles/r6_validated_isa.json holds digests of the device code of every kernel as it ran the round-6 GPU suite and
+  bench (every kernel of round 5 unchanged, profiles/r5_validated_isa.json, plus cast_rays_ipe_tangent_bwd_kernel).  Host-side or simulator work must not change them; an intended kernel change re-validates on the GPU and rewrites
+  the file (python tools/isa_report.py --write-digests profiles/r6_validated_isa.json)."""
   mod, _ = report
   want = json.load(open(VALIDATED))['kernels']
   got = mod.all_digests()

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Round-end evidence on a short lease (bash tools/final_lean.sh <tag>): the driver's two commands verbatim, the two PMC passes
 # bench.py's roofline.traffic needs for this build's digest, one bench.py line, kernel stats: most important first.
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
-python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $OUT/${TAG}_driver_pytest.log 2>&1; echo "rc=$?" >> $OUT/${TAG}_driver_pytest.log
+python3 -m pytest tests/ -x -q -s -m gpu -p no:cacheprovider > $OUT/${TAG}_driver_pytest.log 2>&1; echo "rc=$?" >> $OUT/${TAG}_driver_pytest.log
 python3 -c 'import sys; sys.path.insert(0,"."); import __graft_entry__ as e; e.smoke()' > $OUT/${TAG}_driver_smoke.log 2>&1; echo "rc=$?" >> $OUT/${TAG}_driver_smoke.log
 tail -3 $OUT/${TAG}_driver_pytest.log; tail -4 $OUT/${TAG}_driver_smoke.log
 export TMPDIR=/tmp
