@@ -71,6 +71,11 @@ _RANK1_LAST = True    # the proposal MLP's last dY built inside its weight-gradi
 # reads of dY is served by the Infinity Cache instead of HBM: 532.4 / 533.8 k -> 538.1 / 538.1 k rays/s on one box, gradients equal
 # up to the atomics' order (profiles/r5_ab.md (d); pacing the two launches against each other returned nothing and is gone)
 _PAIR_DXDW = True
+# The density-gradient normals' tangent network (3 M rows per level) on the fused masked-linear chain: T_l = bits_l * (T_{l-1} W_l)
+# forward and G_{l-1} = bits_{l-1} * (G_l W_l^T) backward are both what mlp_chain_bwd_kernel computes (a Dense chain without bias
+# whose ReLU is a given 1-bit mask), so every run of trunk layers that does not read the features is ONE launch per direction
+# instead of one GEMM per layer: the rows are written once (the weight-gradient GEMMs need them) and never read back in between
+_TANGENT_CHAIN = True
 
 
 # =============================================================================
@@ -1103,8 +1108,37 @@ class Model:
     T_acts, T_pre = [], []
     t = None
     relu = hp.net_activation == 'relu'
-    for i, (d, concat) in enumerate(plan.trunk):
+    D = len(plan.trunk)
+    # (training only: the chain writes every layer's rows, which the weight-gradient GEMMs want anyway; inference ping-pongs two buffers)
+    chain = bool(_TANGENT_CHAIN and keep and relu and self._chain_ok(plan) and all(b is not None for b in bits))
+    i = 0
+    while i < D:
+      d, concat = plan.trunk[i]
       e2 = plan.packed[('trunk', i)]
+      run = 0
+      if chain and i >= 1 and not concat:
+        while i + run < D and not plan.trunk[i + run][1]:
+          run += 1
+      if run >= 1:
+        # layers i .. i + run - 1 as one masked-linear chain per direction c (rows c M .. (c + 1) M share the primal masks):
+        # mnr_mlp_chain_bwd with the FORWARD images as its operands walks "down" from its input; chain position j holds layer
+        # i + run - j: dY_in = T_{i-1}, Bw[j] = Bt of that layer, bits[j - 1] its mask, dY[j - 1] its result
+        outs = [self._buf((tag, 'T_act', i + k), (3 * M, plan.W), bf16) for k in range(run)]
+        Bws, cbits = [None] * (run + 1), [None] * (run + 1)
+        for j in range(1, run + 1):
+          l = i + run - j
+          el = plan.packed[('trunk', l)]
+          Bws[j] = self._w(plan, el['f_off'], el['n_pad'], el['f_ld'])[:plan.W]
+          cbits[j - 1] = bits[l]
+        cbits[run] = bits[i]                                  # (unused with dY_in; the launcher wants a pointer)
+        for c in range(3):
+          rows = slice(c * M, (c + 1) * M)
+          dYs = [outs[run - 1 - jj][rows] for jj in range(run)] + [None]
+          ops.mlp_chain_bwd(None, None, cbits, Bws, dYs, M=M, W=plan.W, dY_in=t[rows])
+        T_acts += outs
+        t = outs[-1]
+        i += run
+        continue
       tout = self._buf((tag, 'T_act', i if keep else i % 2), (3 * M, plan.W), bf16)
       Bt2 = self._w(plan, e2['f_off'], e2['n_pad'], e2['f_ld'])
       # ReLU: T_i = mask_i * (T_{i-1} W_i), the mask applied in the GEMM's epilogue.  Any other activation: the GEMM leaves the
@@ -1122,6 +1156,7 @@ class Model:
         T_pre.append(dst)
       T_acts.append(tout)
       t = tout
+      i += 1
     raw_grad = self._buf((tag, 'raw_grad'), (3, M), f32)
     ed = plan.packed['density']
     ops.gemm_nt(t, self._w(plan, ed['f_off'], ed['n_pad'], ed['f_ld']), M=3 * M, N=ed['n_pad'], K1=plan.W,
@@ -1726,9 +1761,21 @@ class Model:
                        M=M3, K=W, Cn=1, dX=gA, lddx=W, relu_mask=False, dW=gslice(d.kernel_off, W), db=None,
                        bits=bits[-1] if relu else None, bits_row_mod=M if relu else 0)
     gy, other = gA, gB
+    D = len(plan.trunk)
+    Gs = None
+    if _TANGENT_CHAIN and relu and D >= 2 and self._chain_ok(plan) and all(b is not None for b in bits):
+      # every G_i in one masked-linear chain launch per direction (`_TANGENT_CHAIN`), kept for the weight-gradient GEMMs below
+      Gs = [self._buf(('bwd', slot, 'gT', W, i), (M3, W), bf16) for i in range(D - 1)] + [gA]
+      Bws = [None] + [self._w(plan, plan.packed[('trunk', i)]['b_off'], _rup(W, 128), plan.packed[('trunk', i)]['b_ld'])
+                      for i in range(1, D)]
+      for c in range(3):
+        rows = slice(c * M, (c + 1) * M)
+        ops.mlp_chain_bwd(None, None, bits, Bws, [g[rows] for g in Gs[:-1]] + [None], M=M, W=W, dY_in=gA[rows])
     for i in reversed(range(len(plan.trunk))):
       d, concat = plan.trunk[i]
       e = plan.packed[('trunk', i)]
+      if Gs is not None:
+        gy = Gs[i]
       if not relu:
         ops.act_tangent_bwd(plan.hp.net_activation, mlp['zs'][i], mlp['T_pre'][i], gy, extras[i])     # gy: d loss / d T_i -> d loss / d U_i
       if g_tfeat_out is not None and (i == 0 or concat):
@@ -1746,10 +1793,11 @@ class Model:
         if concat:
           ops.gemm_tn(T_feat, gy, gslice(d.kernel_off + W * W, plan.F * W), M=M3, K=plan.ldF, N=W,
                       lda=plan.ldF, ldb=W, ldc=W, k_valid=plan.F, n_valid=W)
-        Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
-        ops.gemm_nt(gy, Bw, M=M3, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W,
-                    **(dict(bits_in=bits[i - 1], bits_row_mod=M) if relu else {}))
-        gy, other = other, gy
+        if Gs is None:
+          Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
+          ops.gemm_nt(gy, Bw, M=M3, N=_rup(W, 128), K1=e['b_ld'], Cb=other, ldcb=W, nb=W,
+                      **(dict(bits_in=bits[i - 1], bits_row_mod=M) if relu else {}))
+          gy, other = other, gy
     return extras
 
 

@@ -439,3 +439,34 @@ def test_fp32_dense_mode_matches_the_float64_oracle(name, extra, B):
     g_32 = model.flat_from_tree(grads_32, device='cpu').double()
     assert abs(s['loss'] - float(stats_64['loss'])) <= 2e-5 * abs(float(stats_64['loss'])) + 1e-7
     helpers.check_fp32_mode_gradient(model, stats['_grads'], g_64, g_32, name)
+
+
+def test_tangent_network_on_the_masked_linear_chain_equals_the_per_layer_gemms(monkeypatch):
+  """models._TANGENT_CHAIN: the density-gradient normals' tangent network (forward T_l = bits_l * (T_{l-1} W_l) and backward
+  G_{l-1} = bits_{l-1} * (G_l W_l^T), 3 M rows) through mnr_mlp_chain_bwd, one launch per direction and run of layers, against
+  one masked GEMM per layer: the same products, bf16 roundings at the same places, only the order of the fp32 sums differs."""
+  from multinerf_amd import models as M_
+  name, extra, B = CASES[1]                        # blender_refnerf: 8-layer trunk with a skip concat into layer 5
+  out = {}
+  with S.simulated_device() as sim:
+    for on in (True, False):
+      monkeypatch.setattr(M_, '_TANGENT_CHAIN', on)
+      calls = []
+      real = ops.mlp_chain_bwd
+      monkeypatch.setattr(ops, 'mlp_chain_bwd', lambda *a, **k: (calls.append(k.get('dY_in') is not None), real(*a, **k))[1])
+      cfg, model, _, params, flat, batch = _setup(name, extra, B)
+      noise = helpers.make_noise(model, B)
+      state, _ = train_utils.create_optimizer(cfg, {'flat': flat.clone(), 'params': None})
+      _, stats, _ = train_utils.create_train_step(model, cfg)(0, state, batch, None, 0.4, 0.0, noise=noise, return_grads=True)
+      monkeypatch.setattr(ops, 'mlp_chain_bwd', real)
+      sim.check()
+      out[on] = (stats['_grads'].double().clone(), stats.materialize()['loss'], sum(calls))
+  # per level: forward runs (layers 1-4, layers 6-7) x 3 directions + backward 3 directions; the primal trunk's own dX chain
+  # is there in both arms (one call per level)
+  assert out[True][2] - out[False][2] == 2 * (2 * 3 + 3), (out[True][2], out[False][2])
+  assert abs(out[True][1] - out[False][1]) <= 2e-3 * abs(out[False][1])
+  for mod, b, e in model.modules:
+    a, r = out[True][0][b:e], out[False][0][b:e]
+    rel = ((a - r).norm() / r.norm()).item()
+    print(f'{mod}: tangent chain vs per-layer GEMMs rel {rel:.2e}')
+    assert rel < 2e-2, (mod, rel)
