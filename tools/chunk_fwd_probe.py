@@ -48,17 +48,17 @@ def chunked(chunk, with_bits=True):
       layer(l, r0, r0 + chunk, with_bits=with_bits)
 
 
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+streams = [torch.cuda.Stream() for _ in range(4)]
 
 
-def chunked_two_streams(chunk, half):
+def chunked_two_streams(chunk, half, ns=2):
   cur = torch.cuda.current_stream()
   ev = torch.cuda.Event()
   ev.record(cur)
   for s in streams:
     s.wait_event(ev)
   for i, r0 in enumerate(range(0, M, chunk)):
-    with torch.cuda.stream(streams[i & 1]):
+    with torch.cuda.stream(streams[i % ns]):
       for l in range(D):
         layer(l, r0, r0 + chunk, max_wgs=half)
   for s in streams:
@@ -92,6 +92,12 @@ for chunk in (65536, 32768):
   t = timed(lambda: chunked_two_streams(chunk, 128))
   same = all(torch.equal(a.view(torch.int16), r.view(torch.int16)) for a, r in zip(acts, ref))
   print(f'chunks of {chunk:6d} rows, two streams x 128 workgroups: {t:9.1f} us  {"bitwise equal" if same else "MISMATCH"}', flush=True)
+for chunk in (131072, 65536, 32768):
+  for ns in (2, 3, 4):
+    t = timed(lambda: chunked_two_streams(chunk, 0, ns))
+    same = all(torch.equal(a.view(torch.int16), r.view(torch.int16)) for a, r in zip(acts, ref))
+    print(f'chunks of {chunk:6d} rows, {ns} streams x full grids: {t:9.1f} us  {"bitwise equal" if same else "MISMATCH"}', flush=True)
+print(f'whole-batch launches again:                {timed(whole):9.1f} us', flush=True)
 print(f'whole-batch, no mask output:               {timed(lambda: whole(False)):9.1f} us', flush=True)
 for chunk in (65536, 32768):
   print(f'chunks of {chunk:6d} rows, no mask output:     {timed(lambda: chunked(chunk, False)):9.1f} us', flush=True)
