@@ -101,7 +101,7 @@ def _setup(name, extra, B, seed=3):
 VARIANTS = [(1, 1, 0, 0), (-8, 2, 1, 5), (0, 0, 1, 2)]
 
 
-@pytest.mark.parametrize('name,extra,B', CASES)
+@pytest.mark.parametrize('name,extra,B', CASES[:9])                      # (CASES[9]: fp32 mode only, below; CPU-suite time)
 def test_forward_and_train_step_on_the_simulator(name, extra, B):
   _run(name, extra, B, VARIANTS[0])
 
@@ -375,7 +375,7 @@ SAMPLING_GRAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize('name,extra,B', SAMPLING_GRAD_CASES)
+@pytest.mark.parametrize('name,extra,B', SAMPLING_GRAD_CASES[:5])       # (the last case: fp32 mode only, below; CPU-suite time)
 def test_gradients_through_the_sampling_on_the_simulator(name, extra, B):
   """Model.stop_level_grad = False (models.py:56,198-201) end to end: forward, losses and the gradient of every module against
   the oracle, whose differentiated sampling path is pinned by the reference's own code (golden `blender_sampling_grad`); and
@@ -400,7 +400,7 @@ def test_gradients_through_the_sampling_on_the_simulator(name, extra, B):
 
 # ----------------------------------------------------------------------------- Model(dense_precision='fp32')
 
-F32_CASES = [CASES[0], CASES[1], CASES[2], CASES[5], CASES[7], CASES[8], CASES[9], SAMPLING_GRAD_CASES[0], SAMPLING_GRAD_CASES[1], SAMPLING_GRAD_CASES[3], SAMPLING_GRAD_CASES[4], SAMPLING_GRAD_CASES[5]]
+F32_CASES = [CASES[0], CASES[1], CASES[5], CASES[8], CASES[9], SAMPLING_GRAD_CASES[1], SAMPLING_GRAD_CASES[4], SAMPLING_GRAD_CASES[5]]
 
 
 @pytest.mark.parametrize('name,extra,B', F32_CASES)
