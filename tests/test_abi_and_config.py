@@ -41,6 +41,26 @@ def test_library_exports_every_header_symbol():
   assert lib.mnr_abi_version() == 20
 
 
+def test_fp32_dense_debug_build_exports_the_same_abi():
+  """libmnerf_hip_f32.so (multinerf_amd/build.py, -DMNR_DENSE_F32: the parity tests' precision arm) exports every entry point of
+  include/mnerf.h except the fused chain's (layout-specific MFMA files, which the host never calls in that mode), and the
+  package reaches it only inside `_lib.dense_f32()`."""
+  import ctypes
+  if not os.path.exists(_lib.LIB_F32_PATH):
+    import __graft_entry__
+    __graft_entry__.build()
+  f32 = ctypes.CDLL(_lib.LIB_F32_PATH)
+  for n in _lib._PROTOS:
+    assert hasattr(f32, n) == (n not in _lib.F32_ABSENT), n
+  assert f32.mnr_abi_version() == 20
+  assert not _lib.f32_active()
+  with _lib.dense_f32():
+    assert _lib.f32_active()
+    with _lib.dense_f32(False):
+      assert _lib.f32_active()
+  assert not _lib.f32_active()
+
+
 def test_ops_refuse_cpu_tensors():
   from multinerf_amd import ops
   with pytest.raises(ValueError, match='device tensor'):
