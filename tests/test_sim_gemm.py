@@ -366,7 +366,7 @@ def test_tn_block_cyclic_m_splits(sim, layouts):
   operands, the bias gradient and the extra column along."""
   ap, bp = layouts
   g = torch.Generator().manual_seed(11)
-  M, K, N = 4096, 256, 512
+  M, K, N = 2048, 256, 512
   A = torch.randn((M, K), generator=g).bfloat16()
   B = torch.randn((M, N), generator=g).bfloat16()
   gcol = torch.randn(M, generator=g).bfloat16() if (ap, bp) == (1, 0) else None
