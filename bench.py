@@ -95,6 +95,7 @@ def main():
   ap.add_argument('--no_aux', action='store_true', help='skip the secondary measurements (4096x192 north-star shape, render)')
   ap.add_argument('--pair_dxdw', type=int, default=-1, help='A/B: models._PAIR_DXDW (1 on, 0 off; default: the module\'s own setting)')
   ap.add_argument('--tangent_chain', type=int, default=-1, help='A/B: models._TANGENT_CHAIN (1 on, 0 off; default: the module\'s own setting)')
+  ap.add_argument('--head_k32', type=int, default=-1, help='A/B: models._HEAD_K32')
   ap.add_argument('--rank1_last', type=int, default=-1, help='A/B: models._RANK1_LAST (1 on, 0 off; default: the module\'s own setting)')
   args = ap.parse_args()
 
@@ -115,6 +116,8 @@ def main():
     models._PAIR_DXDW = bool(args.pair_dxdw)
   if args.rank1_last >= 0:
     models._RANK1_LAST = bool(args.rank1_last)
+  if args.head_k32 >= 0:
+    models._HEAD_K32 = bool(args.head_k32)
   if args.tangent_chain >= 0:
     models._TANGENT_CHAIN = bool(args.tangent_chain)
   mdist.init_from_env()
@@ -318,7 +321,7 @@ def main():
             'train_frac': train_frac,
             'params': model.num_params, 'workspace_GiB': round(model.workspace_bytes() / 2 ** 30, 2),
             'backward_streams': mstreams.describe_env() if not model.single_mlp else {'side_stream': False},
-            'pair_dxdw': bool(models._PAIR_DXDW), 'rank1_last': bool(models._RANK1_LAST), 'tangent_chain': bool(models._TANGENT_CHAIN),
+            'pair_dxdw': bool(models._PAIR_DXDW), 'rank1_last': bool(models._RANK1_LAST), 'tangent_chain': bool(models._TANGENT_CHAIN), 'head_k32': bool(models._HEAD_K32),
             'algorithmic_train_mflop_per_ray': train_flops / 1e6,
             'algorithmic_fwd_mflop_per_ray': fwd_flops / 1e6,
             'whole_step_tflops_per_gpu': train_flops * B / (ms_per_step * 1e-3) / 1e12,

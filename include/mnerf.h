@@ -195,7 +195,7 @@ int mnr_glo_bwd(int64_t B, int n, int G, const float* g_a, const float* g_b, con
  * bf16 operands, fp32 accumulation on the MFMA units.
  * ------------------------------------------------------------------------- */
 typedef struct {
-  /* A = [A1 | A2] : [M, K1+K2] bf16; K1,K2 multiples of 64; A2 may be NULL (K2=0).
+  /* A = [A1 | A2] : [M, K1+K2] bf16; K1,K2 multiples of 64 (of 32 with c_layout = PANEL); A2 may be NULL (K2=0).
    * The second segment is the skip concat of models.py:458-459. */
   const uint16_t* A1; int lda1; int K1;
   const uint16_t* A2; int lda2; int K2;

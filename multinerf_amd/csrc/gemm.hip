@@ -487,8 +487,10 @@ extern "C" int mnr_gemm_nt_bf16(const mnr_gemm_nt_args* a, void* stream) {
                 "mnr_gemm_nt_bf16: unknown layout %d / %d", a->a1_layout, a->c_layout);
   MNR_CHECK_ARG(a->M > 0 && a->M % 128 == 0, "mnr_gemm_nt_bf16: M=%lld must be a positive multiple of 128", (long long)a->M);
   MNR_CHECK_ARG(a->N > 0 && a->N % 128 == 0, "mnr_gemm_nt_bf16: N=%d must be a positive multiple of 128", a->N);
-  MNR_CHECK_ARG(a->K1 > 0 && a->K1 % 64 == 0 && a->K2 >= 0 && a->K2 % 64 == 0,
-                "mnr_gemm_nt_bf16: K1=%d, K2=%d must be multiples of 64", a->K1, a->K2);
+  // (a panel-layout result runs the BK = 32 kernel of gemm_blk.hip: multiples of 32 there, e.g. the merged head's dX at K = 288)
+  const int kgran = a->c_layout == MNR_LAYOUT_PANEL ? 32 : 64;
+  MNR_CHECK_ARG(a->K1 > 0 && a->K1 % kgran == 0 && a->K2 >= 0 && a->K2 % kgran == 0,
+                "mnr_gemm_nt_bf16: K1=%d, K2=%d must be multiples of %d", a->K1, a->K2, kgran);
   MNR_CHECK_ARG(a->A1 && a->Bt && (a->K2 == 0 || a->A2), "mnr_gemm_nt_bf16: null operand");
   MNR_CHECK_ARG(a->lda1 % 8 == 0 && a->ldb % 8 == 0 && (a->K2 == 0 || a->lda2 % 8 == 0),
                 "mnr_gemm_nt_bf16: leading dimensions must be multiples of 8 elements (16 B)");

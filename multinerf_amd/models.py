@@ -76,6 +76,7 @@ _PAIR_DXDW = True
 # whose ReLU is a given 1-bit mask), so every run of trunk layers that does not read the features is ONE launch per direction
 # instead of one GEMM per layer: the rows are written once (the weight-gradient GEMMs need them) and never read back in between
 _TANGENT_CHAIN = True
+_HEAD_K32 = True      # the merged head's dX GEMM into a panel trunk at K = the head's columns rounded to 32 (288 at 360.gin), not 64 (320)
 
 
 # =============================================================================
@@ -1560,7 +1561,7 @@ class Model:
           ops.scatter_add(tmpb, nh, 0, c0, 1, d.fan_out, gslice(d.bias_off, d.fan_out), d.fan_out)
       Bw = self._w(plan, e['b_off'], _rup(W, 128), e['b_ld'])
       # (K = the head's columns rounded to the GEMM's 64-column K granule, not to the buffers' 128: 320 instead of 384 at 360.gin)
-      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=_rup(plan.head_cols, 64), Cb=dA, ldcb=W, nb=W,
+      ops.gemm_nt(dHB, Bw, M=M, N=_rup(W, 128), K1=_rup(plan.head_cols, 32 if (panel and _HEAD_K32) else 64), Cb=dA, ldcb=W, nb=W,
                   **mask_kw(len(acts) - 1), **lay_c)
       act_vjp(mlp['zs'][-1] if not relu else None, dA)
     else:
